@@ -1,0 +1,351 @@
+"""CPU ORACLE for the STRAPS regressor + SMPL hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (straps-3dhumanshapepose_amd/) never does and fails loudly without its HIP
+library.  Everything here is a plain functional restatement (torch-CPU fp32 ops, numpy fp64 for
+the SMPL cross-check) of what the reference computes, written from the reference's behaviour; each
+function cites the reference file:line it follows (paths relative to /root/reference).
+
+Pinning status
+  * encoder / IEF / regressor / rot6d / projections / visibility / heatmaps / loss / cam+proxy
+    augmentation: PINNED -- tests/test_oracle_golden.py checks every function below against golden
+    vectors produced by importing the reference itself (oracle/make_golden.py, run in the authoring
+    container, fixtures in tests/golden/).
+  * SMPL forward (smpl_forward, batch_rodrigues): PARITY UNPINNED against the third-party `smplx`
+    package (un-vendored, unpinned in requirements.txt:6, not installable here, no SMPL model file).
+    It restates the published LBS algorithm (SMPL paper eq. 2-6 with smplx conventions, SURVEY.md
+    section 8a S0-S8) and is pinned only by analytic invariants + fp64/fp32 agreement
+    (tests/test_oracle_smpl_invariants.py).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# constants of the contract (config.py:13-14,27-32)
+# --------------------------------------------------------------------------------------------
+FOCAL_LENGTH = 5000.0
+REGRESSOR_IMG_WH = 256
+ALL_JOINTS_TO_COCO_MAP = [24, 26, 25, 28, 27, 16, 17, 18, 19, 20, 21, 1, 2, 4, 5, 7, 8]
+ALL_JOINTS_TO_H36M_MAP = list(range(73, 90))
+H36M_TO_J14 = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10]
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# (block kind, blocks per stage) -- models/resnet.py:228-258
+_RESNET_SPECS = {18: ('basic', [2, 2, 2, 2]), 50: ('bottleneck', [3, 4, 6, 3])}
+
+
+# --------------------------------------------------------------------------------------------
+# encoder  (models/resnet.py)
+# --------------------------------------------------------------------------------------------
+def _bn(x, sd, name, training):
+    """nn.BatchNorm2d semantics (models/resnet.py:47,147): eval -> running stats; train -> biased
+    batch variance for normalisation, unbiased one folded into running_var with momentum 0.1,
+    num_batches_tracked += 1.  Running buffers in `sd` are updated in place when training."""
+    if training:
+        sd[name + '.num_batches_tracked'] += 1
+    return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'],
+                        sd[name + '.weight'], sd[name + '.bias'], training, BN_MOMENTUM, BN_EPS)
+
+
+def resnet_forward(x, sd, layers=18, training=False, prefix='image_encoder.', taps=None):
+    """ResNet.forward (models/resnet.py:201-216) without the FC head.
+
+    x: float32 [B,C,256,256] NCHW.  sd: state dict (reference key names).  Returns [B,512|2048].
+    `taps` (optional dict) receives named intermediate activations for layer-wise checks.
+    Stem: conv7x7/s2/p3 -> BN -> ReLU -> maxpool3x3/s2/p1 (:145-149); stages (:150-156) of
+    BasicBlock (:61-77) or Bottleneck (:101-121); GAP + flatten (:213-214).
+    """
+    kind, counts = _RESNET_SPECS[layers]
+    p = prefix
+    y = F.conv2d(x, sd[p + 'conv1.weight'], None, 2, 3)
+    y = F.relu(_bn(y, sd, p + 'bn1', training))
+    if taps is not None:
+        taps['stem'] = y
+    y = F.max_pool2d(y, 3, 2, 1)
+    if taps is not None:
+        taps['pool'] = y
+    for li, nblk in enumerate(counts):
+        for bi in range(nblk):
+            q = '%slayer%d.%d.' % (p, li + 1, bi)
+            stride = 2 if (li > 0 and bi == 0) else 1
+            idt = y
+            if kind == 'basic':
+                o = F.conv2d(y, sd[q + 'conv1.weight'], None, stride, 1)
+                o = F.relu(_bn(o, sd, q + 'bn1', training))
+                o = F.conv2d(o, sd[q + 'conv2.weight'], None, 1, 1)
+                o = _bn(o, sd, q + 'bn2', training)
+            else:
+                o = F.conv2d(y, sd[q + 'conv1.weight'], None, 1, 0)
+                o = F.relu(_bn(o, sd, q + 'bn1', training))
+                o = F.conv2d(o, sd[q + 'conv2.weight'], None, stride, 1)
+                o = F.relu(_bn(o, sd, q + 'bn2', training))
+                o = F.conv2d(o, sd[q + 'conv3.weight'], None, 1, 0)
+                o = _bn(o, sd, q + 'bn3', training)
+            if (q + 'downsample.0.weight') in sd:
+                idt = F.conv2d(y, sd[q + 'downsample.0.weight'], None, stride, 0)
+                idt = _bn(idt, sd, q + 'downsample.1', training)
+            y = F.relu(o + idt)
+        if taps is not None:
+            taps['layer%d' % (li + 1)] = y
+    return y.mean(dim=(2, 3))
+
+
+# --------------------------------------------------------------------------------------------
+# IEF regressor  (models/ief_module.py, models/regressor.py)
+# --------------------------------------------------------------------------------------------
+def ief_init_estimate(mean_pose6d, mean_shape):
+    """load_mean_params_6d_pose (models/ief_module.py:33-46): [0.9,0,0] + pose6d[144] + shape[10]."""
+    v = np.zeros(157, dtype=np.float64)
+    v[3:147] = np.asarray(mean_pose6d, dtype=np.float64).reshape(144)
+    v[147:] = np.asarray(mean_shape, dtype=np.float64).reshape(10)
+    v[0] = 0.9
+    return torch.from_numpy(v.astype(np.float32))
+
+
+def ief_forward(feat, sd, init_estimate, iterations=3, prefix='ief_module.'):
+    """IEFModule.forward (models/ief_module.py:48-64).  est += fc3(relu(fc2(relu(fc1([feat,est])))))
+    `iterations` times; returns (cam[B,3], pose[B,144], shape[B,10]) and the full [B,157]."""
+    p = prefix
+    est = init_estimate.to(feat.dtype).repeat(feat.shape[0], 1)
+    for _ in range(iterations):
+        s = torch.cat([feat, est], dim=1)
+        h = F.relu(F.linear(s, sd[p + 'fc1.weight'], sd[p + 'fc1.bias']))
+        h = F.relu(F.linear(h, sd[p + 'fc2.weight'], sd[p + 'fc2.bias']))
+        est = est + F.linear(h, sd[p + 'fc3.weight'], sd[p + 'fc3.bias'])
+    return est[:, :3], est[:, 3:147], est[:, 147:], est
+
+
+def regressor_forward(x, sd, init_estimate, layers=18, iterations=3, training=False):
+    """SingleInputRegressor.forward (models/regressor.py:43-47)."""
+    feat = resnet_forward(x, sd, layers, training)
+    return ief_forward(feat, sd, init_estimate, iterations)
+
+
+# --------------------------------------------------------------------------------------------
+# pose representation  (utils/rigid_transform_utils.py:27-41)
+# --------------------------------------------------------------------------------------------
+def rot6d_to_rotmat(x):
+    """x[...,6] viewed as [-1,3,2] (interleaved a1x,a2x,a1y,a2y,a1z,a2z); Gram-Schmidt; columns
+    (b1,b2,b3).  F.normalize eps 1e-12.  Returns [-1,3,3]."""
+    x = x.reshape(-1, 3, 2)
+    a1, a2 = x[:, :, 0], x[:, :, 1]
+    b1 = a1 / a1.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    u = a2 - (b1 * a2).sum(dim=1, keepdim=True) * b1
+    b2 = u / u.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    b3 = torch.linalg.cross(b1, b2, dim=1)
+    return torch.stack((b1, b2, b3), dim=-1)
+
+
+def batch_rodrigues(rot_vecs):
+    """smplx.lbs.batch_rodrigues [memory; SURVEY 8a S3]: angle = ||r + 1e-8||, K = skew(r/angle),
+    R = I + sin K + (1-cos) K^2.  rot_vecs [N,3] -> [N,3,3]."""
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    d = rot_vecs / angle
+    c = torch.cos(angle)[:, :, None]
+    s = torch.sin(angle)[:, :, None]
+    rx, ry, rz = d[:, 0], d[:, 1], d[:, 2]
+    z = torch.zeros_like(rx)
+    K = torch.stack([z, -rz, ry, rz, z, -rx, -ry, rx, z], dim=1).view(-1, 3, 3)
+    eye = torch.eye(3, dtype=rot_vecs.dtype).unsqueeze(0)
+    return eye + s * K + (1 - c) * torch.bmm(K, K)
+
+
+# --------------------------------------------------------------------------------------------
+# SMPL forward  (models/smpl_official.py:27-41 -> smplx.SMPL.forward -> smplx.lbs.lbs)
+# --------------------------------------------------------------------------------------------
+def smpl_forward(model, betas, rotmats=None, full_pose_aa=None, dtype=torch.float32):
+    """Restatement of the published LBS pipeline.  PARITY UNPINNED vs smplx.
+
+    model: dict of numpy arrays (see straps package `synthetic_smpl_model` / `load_smpl_model`):
+       v_template[6890,3] shapedirs[6890,3,10] posedirs[207,20670] J_regressor[24,6890]
+       weights[6890,24] parents[24] extra_vertex_ids[21] J_regressor_extra[9,6890]
+       J_regressor_cocoplus[19,6890] J_regressor_h36m[17,6890]
+    betas [B,10]; rotmats [B,24,3,3] (pose2rot=False) or full_pose_aa [B,72] (pose2rot=True).
+    Returns (vertices[B,6890,3], joints[B,90,3]) with joint order 24 SMPL + 21 picked vertices +
+    9 extra + 19 cocoplus + 17 h36m (models/smpl_official.py:30-34).
+    """
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype)
+    vt, sdirs, pdirs = t(model['v_template']), t(model['shapedirs']), t(model['posedirs'])
+    Jr, W = t(model['J_regressor']), t(model['weights'])
+    parents = [int(p) for p in model['parents']]
+    betas = betas.to(dtype)
+    B = betas.shape[0]
+    if rotmats is None:
+        rotmats = batch_rodrigues(full_pose_aa.to(dtype).reshape(-1, 3)).view(B, 24, 3, 3)
+    rotmats = rotmats.to(dtype)
+    # S1 shape blend, S2 joint regression
+    v_shaped = vt[None] + torch.einsum('bl,mkl->bmk', betas, sdirs)
+    J = torch.einsum('bik,ji->bjk', v_shaped, Jr)
+    # S4 pose-corrective blend
+    eye = torch.eye(3, dtype=dtype)
+    pose_feature = (rotmats[:, 1:] - eye).reshape(B, 207)
+    v_posed = v_shaped + (pose_feature @ pdirs).view(B, -1, 3)
+    # S5 kinematic chain (batch_rigid_transform)
+    rel = J.clone()
+    rel[:, 1:] = J[:, 1:] - J[:, parents[1:]]
+    L = torch.zeros(B, 24, 4, 4, dtype=dtype)
+    L[:, :, :3, :3] = rotmats
+    L[:, :, :3, 3] = rel
+    L[:, :, 3, 3] = 1
+    G = [L[:, 0]]
+    for i in range(1, 24):
+        G.append(G[parents[i]] @ L[:, i])
+    G = torch.stack(G, dim=1)
+    J_posed = G[:, :, :3, 3].clone()
+    Jh = torch.cat([J, torch.zeros(B, 24, 1, dtype=dtype)], dim=2)[..., None]      # [B,24,4,1]
+    A = G.clone()
+    A[:, :, :, 3:] = G[:, :, :, 3:] - G @ Jh                                         # remove rest pose
+    # S6 skinning
+    T = (W @ A.view(B, 24, 16)).view(B, -1, 4, 4)
+    vh = torch.cat([v_posed, torch.ones(B, v_posed.shape[1], 1, dtype=dtype)], dim=2)
+    verts = (T @ vh[..., None])[:, :, :3, 0]
+    # S7 vertex joint selector, S8 extra regressors
+    picked = verts[:, [int(i) for i in model['extra_vertex_ids']]]
+    extra = [torch.einsum('bik,ji->bjk', verts, t(model[k]))
+             for k in ('J_regressor_extra', 'J_regressor_cocoplus', 'J_regressor_h36m')]
+    joints = torch.cat([J_posed, picked] + extra, dim=1)
+    return verts, joints
+
+
+# --------------------------------------------------------------------------------------------
+# projections / visibility  (utils/cam_utils.py, utils/joints2d_utils.py)
+# --------------------------------------------------------------------------------------------
+def orthographic_project(points3d, cam):
+    """orthographic_project_torch (utils/cam_utils.py:5-26): u=s(x+tx), v=s(y+ty), cam=[s,tx,ty]."""
+    s, tx, ty = cam[:, 0:1], cam[:, 1:2], cam[:, 2:3]
+    return torch.stack([s * (points3d[:, :, 0] + tx), s * (points3d[:, :, 1] + ty)], dim=-1)
+
+
+def intrinsics_matrix(w=REGRESSOR_IMG_WH, h=REGRESSOR_IMG_WH, f=FOCAL_LENGTH):
+    """get_intrinsics_matrix (utils/cam_utils.py:29-37)."""
+    return np.array([[f, 0., w / 2.0], [0., f, h / 2.0], [0., 0., 1.]])
+
+
+def perspective_project(points, rotation, translation, cam_K):
+    """perspective_project_torch (utils/cam_utils.py:40-71): p=R x+t; p/=p_z; K p; drop z."""
+    p = torch.einsum('bij,bkj->bki', rotation, points) + translation[:, None]
+    p = p / p[:, :, -1:]
+    return torch.einsum('bij,bkj->bki', cam_K, p)[:, :, :-1]
+
+
+def check_joints2d_visibility(joints2d, img_wh=REGRESSOR_IMG_WH):
+    """check_joints2d_visibility_torch (utils/joints2d_utils.py:23-32): strict > / <, so 0 and
+    img_wh themselves count as visible."""
+    x, y = joints2d[:, :, 0], joints2d[:, :, 1]
+    return ~((x > img_wh) | (y > img_wh) | (x < 0) | (y < 0))
+
+
+# --------------------------------------------------------------------------------------------
+# input construction  (utils/label_conversions.py:48-55, 90-127)
+# --------------------------------------------------------------------------------------------
+def multiclass_to_binary(seg):
+    """convert_multiclass_to_binary_labels_torch (utils/label_conversions.py:48-55)."""
+    return (seg != 0).to(seg.dtype)
+
+
+def joints2d_to_heatmaps(joints2d, img_wh=REGRESSOR_IMG_WH, std=4):
+    """convert_2Djoints_to_gaussian_heatmaps_torch (utils/label_conversions.py:90-127).
+
+    joints are truncated toward zero (.int() :97); the 16x16 patch is exp(-(gx^2+gy^2)/32) on
+    linspace(-8,8,16)^2 (no exact centre sample); it is pasted at rows [y-8, min(255,y+8)),
+    cols [x-8, min(255,x+8)) -- row/col 255 never written; a joint is drawn only if
+    -8 < x,y < 263 (:111).  NB the meshgrid at :105 is 'ij' so gaussian[r,c] = g(lin[r])*g(lin[c])
+    is symmetric -- no transpose issue.  Pure-loop restatement (B*17 small).
+    """
+    size = 2 * std
+    jr = joints2d.to(torch.int32)
+    B, N = jr.shape[:2]
+    lin = torch.linspace(-size, size, 2 * size)
+    gx, gy = torch.meshgrid(lin, lin, indexing='ij')
+    d = torch.sqrt(gx * gx + gy * gy)
+    gaussian = torch.exp(-(d ** 2 / (2.0 * std ** 2)))
+    out = torch.zeros(B, N, img_wh, img_wh, dtype=torch.float32)
+    for b in range(B):
+        for j in range(N):
+            x, y = int(jr[b, j, 0]), int(jr[b, j, 1])
+            if not (x > -size and y > -size and x < img_wh - 1 + size and y < img_wh - 1 + size):
+                continue
+            hx0, hx1 = max(0, x - size), min(img_wh - 1, x + size)
+            hy0, hy1 = max(0, y - size), min(img_wh - 1, y + size)
+            gx0, gx1 = max(0, size - x), min(2 * size, 2 * size - (size + x - (img_wh - 1)))
+            gy0, gy1 = max(0, size - y), min(2 * size, 2 * size - (size + y - (img_wh - 1)))
+            out[b, j, hy0:hy1, hx0:hx1] = gaussian[gy0:gy1, gx0:gx1]
+    return out
+
+
+def build_proxy_input(seg, joints2d):
+    """train loop :178-182 -- binary silhouette (ch 0) + 17 heatmaps -> [B,18,256,256]."""
+    return torch.cat([multiclass_to_binary(seg).unsqueeze(1), joints2d_to_heatmaps(joints2d)], dim=1)
+
+
+# --------------------------------------------------------------------------------------------
+# loss  (losses/multi_task_loss.py:76-119)
+# --------------------------------------------------------------------------------------------
+LOSS_TASKS = ('verts', 'joints2D', 'joints3D', 'shape_params', 'pose_params')
+
+
+def init_log_vars(init_loss_weights=None, eps=1e-6):
+    """losses/multi_task_loss.py:30-44: s = -log(w + eps) (0 when no weights given)."""
+    if init_loss_weights is None:
+        return {k: 0.0 for k in LOSS_TASKS}
+    return {k: float(-np.log(init_loss_weights[k] + eps)) for k in LOSS_TASKS}
+
+
+def multi_task_loss(labels, outputs, log_vars, losses_on=LOSS_TASKS, img_wh=REGRESSOR_IMG_WH):
+    """HomoscedasticUncertaintyWeightedMultiTaskLoss.forward, reduction='mean'.
+    total = sum_task mse_task * exp(-s_task) + s_task; joints2D rows masked by labels['vis'] and the
+    label normalised 2x/256-1 (:87-93).  log_vars: {task: 0-dim tensor}.  Returns (total, dict)."""
+    total = 0.
+    parts = {}
+
+    def add(name, mse):
+        nonlocal total
+        s = log_vars[name]
+        total = total + mse * torch.exp(-s) + s
+        parts[name] = mse * torch.exp(-s)
+
+    if 'verts' in losses_on:
+        add('verts', F.mse_loss(outputs['verts'], labels['verts']))
+    if 'joints2D' in losses_on:
+        lab, pred = labels['joints2D'], outputs['joints2D']
+        if 'vis' in labels:
+            lab, pred = lab[labels['vis'], :], pred[labels['vis'], :]
+        lab = (2.0 * lab) / img_wh - 1.0
+        add('joints2D', F.mse_loss(pred, lab))
+    if 'joints3D' in losses_on:
+        add('joints3D', F.mse_loss(outputs['joints3D'], labels['joints3D']))
+    if 'shape_params' in losses_on:
+        add('shape_params', F.mse_loss(outputs['shape_params'], labels['shape_params']))
+    if 'pose_params' in losses_on:
+        add('pose_params', F.mse_loss(outputs['pose_params_rot_matrices'],
+                                      labels['pose_params_rot_matrices']))
+    return total, parts
+
+
+# --------------------------------------------------------------------------------------------
+# whole forward used by smoke()/bench cpu_baseline: proxy -> (cam,pose,shape) -> verts/joints
+# --------------------------------------------------------------------------------------------
+def predict_forward(x, sd, init_estimate, smpl_model, layers=18, iterations=3):
+    """predict/predict_3D.py:129-149: regressor -> rot6d -> SMPL(pose2rot=False) -> joints."""
+    cam, pose, shape, _ = regressor_forward(x, sd, init_estimate, layers, iterations, False)
+    R = rot6d_to_rotmat(pose.contiguous()).view(-1, 24, 3, 3)
+    verts, joints = smpl_forward(smpl_model, shape, rotmats=R)
+    return cam, pose, shape, verts, joints
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (run_train.py:200-201): no weight decay, no amsgrad.
+    In place on the given lists of tensors; `step` is the 1-based step count."""
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
