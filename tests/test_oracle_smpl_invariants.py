@@ -87,6 +87,7 @@ def test_rodrigues_is_rotation():
     aa = torch.from_numpy(det_uniform((50, 3), 8, -3, 3)).double()
     aa[0] = 0
     R = O.batch_rodrigues(aa)
-    assert float((R.transpose(1, 2) @ R - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-12
-    assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-12
+    # the +1e-8 inside the norm (smplx convention) makes the axis unit only to ~1e-8
+    assert float((R.transpose(1, 2) @ R - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-6
+    assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-6
     assert float((R[0] - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-7
