@@ -5,5 +5,10 @@ arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI in inclu
 (loaded with ctypes, see hipabi.py).  There is NO CPU fallback: calling a module without the HIP
 library / a GPU raises.
 """
-from . import config  # noqa: F401
+from . import config, hipabi  # noqa: F401
 from .synthetic_smpl import synthetic_smpl_model, synthetic_mean_params, load_smpl_model  # noqa: F401
+from .resnet import ResNet, resnet18, resnet50  # noqa: F401
+from .ief_module import IEFModule  # noqa: F401
+from .regressor import SingleInputRegressor  # noqa: F401
+from .smpl import SMPL, ModelOutput, pack_smpl_model  # noqa: F401
+from .rigid_transform_utils import rot6d_to_rotmat, batch_rodrigues  # noqa: F401

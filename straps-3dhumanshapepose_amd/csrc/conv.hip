@@ -1,0 +1,249 @@
+// conv.hip -- implicit-GEMM convolution over NHWC fp32 on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+// (replaces nn.Conv2d 3x3 / 1x1 + the BN/ReLU/residual passes of models/resnet.py:61-77, 101-121).
+//
+//   GEMM view:  M = B*Ho*Wo output pixels,  N = Cout,  K = R*S*Cin  (tap-major, channel-minor).
+//   A operand = im2col rows gathered on the fly (each 32-channel K chunk of one tap is 128
+//   contiguous bytes of one input pixel -> 8 lanes x float4), B operand = weights repacked KRSC.
+//   Both are staged global -> registers -> LDS (issue-early / write-late, double-buffered LDS,
+//   one barrier per K chunk) and read back as ds_read_b128 fragments: row stride 36 floats
+//   (= 4 * odd) makes both the b128 writes and the b128 fragment reads bank-conflict free.
+//   K is permuted inside each group of 8 (lane half h takes k = 8g+4h..+3) so one b128 read feeds
+//   four MFMAs; A and B use the same permutation so the contraction is unchanged.
+//   Epilogue (C layout: lane = output channel, reg = pixel row): BN scale/shift, residual, ReLU
+//   fused in eval mode; raw output + per-channel (sum, sumsq) partials in training mode.
+//   Block ids are remapped so that consecutive tiles (same A rows / neighbouring halos) share an
+//   XCD's L2.
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    float* stats;
+    int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, relu;
+    int M, MT, NT;
+};
+
+constexpr int LS = 36;   // LDS row stride in floats (32 data + 4 pad)
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+    constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 32, NI = WTN / 32;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM][LS]
+    float* Bs = smem + 2 * BM * LS;   // [2][BN][LS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % p.NT, mt = bid / p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int lr = tid >> 3, lc = tid & 7;
+
+    // per-thread im2col row descriptors (AP rows of the A tile)
+    int a_hi0[AP], a_wi0[AP];
+    long long a_base[AP];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int m = m0 + lr + 32 * q;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            a_hi0[q] = ho * p.stride - p.pad;
+            a_wi0[q] = wo * p.stride - p.pad;
+            a_base[q] = (long long)b * p.H * p.W * p.Cin + lc * 4;
+        } else {
+            a_hi0[q] = -(1 << 28);
+            a_wi0[q] = 0;
+            a_base[q] = 0;
+        }
+    }
+    const long long RS = (long long)p.R * p.S;
+    const float* wrow[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) wrow[q] = p.w + (long long)(n0 + lr + 32 * q) * RS * p.Cin + lc * 4;
+
+    const int cchunks = p.Cin >> 5;
+    const int nchunks = p.R * p.S * cchunks;
+
+    f32x4 ra[AP], rb[BP];
+    auto load_tile = [&](int q) {
+        const int tap = q / cchunks;
+        const int c0 = (q - tap * cchunks) << 5;
+        const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + a_base[i] + ((long long)hi * p.W + wi) * p.Cin + c0);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (long long)tap * p.Cin + c0);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(As + (buf * BM + lr + 32 * i) * LS + lc * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lr + 32 * i) * LS + lc * 4) = rb[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LS + (lane >> 5) * 4;
+    for (int q = 0; q < nchunks; ++q) {
+        const int buf = q & 1;
+        if (q + 1 < nchunks) load_tile(q + 1);
+        const float* Ab = As + (buf * BM + wm * WTM) * LS + frag_off;
+        const float* Bb = Bs + (buf * BN + wn * WTN) * LS + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LS + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LS + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
+        }
+        if (q + 1 < nchunks) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    float s1[NI], s2[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + i * 32 + mfma_row(r, lane);
+                if (m < p.M) {
+                    float v = acc[i][j][r];
+                    t1 += v;
+                    t2 = fmaf(v, v, t2);
+                    const long long o = (long long)m * p.Cout + n;
+                    if (p.scale) v = fmaf(v, sc, sh);
+                    if (p.res) v += p.res[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[o] = v;
+                }
+            }
+        }
+        s1[j] = t1;
+        s2[j] = t2;
+    }
+    if (p.stats) {
+        // lanes l and l+32 hold the same channel; the two M-waves are combined through LDS
+        __syncthreads();   // all fragment reads of the last chunk are done: LDS is free
+        float* red = smem;   // [2 (wm)][BN][2]
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float u1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+            const float u2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+            if (lane < 32) {
+                const int c = wn * WTN + j * 32 + lane;
+                red[(wm * BN + c) * 2 + 0] = u1;
+                red[(wm * BN + c) * 2 + 1] = u2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float* o = p.stats + ((long long)mt * p.Cout + n0 + tid) * 2;
+            o[0] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+            o[1] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+        }
+    }
+}
+
+inline void pick_tile(int cfg, long long M, int cout, int& bm, int& bn) {
+    if (cfg == 1) { bm = 128; bn = 128; }
+    else if (cfg == 2) { bm = 128; bn = 64; }
+    else if (cfg == 3) { bm = 64; bn = 64; }
+    else {
+        // auto: largest tile that still gives >= 2 workgroups per CU (512 blocks)
+        bm = 128; bn = (cout % 128 == 0) ? 128 : 64;
+        if (((M + 127) / 128) * (cout / bn) < 512 && bn == 128) bn = 64;
+        if (((M + 127) / 128) * (cout / bn) < 512) bm = 64;
+    }
+    if (cout % bn != 0) bn = 64;
+}
+
+template <int BM, int BN>
+int launch(const ConvP& p0, hipStream_t st) {
+    ConvP p = p0;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = p.Cout / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { straps_set_error("conv_igemm_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3(p.MT * p.NT), dim3(256), lds, st, p);
+    STRAPS_CHECK_LAUNCH("conv_igemm_kernel");
+    return STRAPS_OK;
+}
+
+}  // namespace
+
+extern "C" int straps_conv_stat_blocks(int batch, int ho, int wo, int cout, int tile_cfg) {
+    int bm, bn;
+    const long long M = (long long)batch * ho * wo;
+    pick_tile(tile_cfg, M, cout, bm, bn);
+    return (int)((M + bm - 1) / bm);
+}
+
+extern "C" int straps_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* residual, int relu,
+                               float* y, float* stats_partial, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
+                               int pad, int tile_cfg, void* stream) {
+    STRAPS_REQUIRE(x && w && y, "straps_conv_fwd: null pointer");
+    STRAPS_REQUIRE(batch > 0 && h > 0 && wdt > 0, "straps_conv_fwd: empty input %dx%dx%d", batch, h, wdt);
+    STRAPS_REQUIRE(cin % 32 == 0 && cout % 64 == 0, "straps_conv_fwd: need cin%%32==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
+    STRAPS_REQUIRE(kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "straps_conv_fwd: bad filter geometry");
+    STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_conv_fwd: scale and shift must be given together");
+    ConvP p;
+    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
+    p.B = batch; p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.R = kh; p.S = kw; p.stride = stride; p.pad = pad;
+    p.Ho = (h + 2 * pad - kh) / stride + 1;
+    p.Wo = (wdt + 2 * pad - kw) / stride + 1;
+    p.relu = relu;
+    const long long M = (long long)batch * p.Ho * p.Wo;
+    STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 40), "straps_conv_fwd: problem too large");
+    p.M = (int)M;
+    int bm, bn;
+    pick_tile(tile_cfg, M, cout, bm, bn);
+    hipStream_t st = (hipStream_t)stream;
+    if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
+    if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
+    return launch<64, 64>(p, st);
+}

@@ -1,0 +1,198 @@
+// elementwise.hip -- HBM-bound helpers of the encoder: weight repacking, BatchNorm fold / statistics /
+// apply, max-pool, global average pool.  All NHWC fp32, float4 per lane, grid-stride where large.
+#include "common.h"
+
+namespace {
+
+// OIHW -> KRSC: dst[((o*R + r)*S + s)*C + c] = src[((o*C + c)*R + r)*S + s]
+__global__ __launch_bounds__(256) void pack_krsc_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int C, int R, int S) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)O * C * R * S;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int s = (int)(t % S); t /= S;
+    const int r = (int)(t % R);
+    const int o = (int)(t / R);
+    dst[i] = src[(((long long)o * C + c) * R + r) * S + s];
+}
+
+// OIHW -> [C][R][S][O] with flipped taps: dst[((c*R + r)*S + s)*O + o] = src[o][c][R-1-r][S-1-s]
+__global__ __launch_bounds__(256) void pack_crsk_flip_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int C, int R, int S) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)O * C * R * S;
+    if (i >= n) return;
+    const int o = (int)(i % O);
+    long long t = i / O;
+    const int s = (int)(t % S); t /= S;
+    const int r = (int)(t % R);
+    const int c = (int)(t / R);
+    dst[i] = src[(((long long)o * C + c) * R + (R - 1 - r)) * S + (S - 1 - s)];
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = g[c] / sqrtf(var[c] + eps);
+    scale[c] = sc;
+    shift[c] = b[c] - mean[c] * sc;
+}
+
+// MaxPool 3x3 / s2 / p1 over NHWC, one float4 of channels per thread
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C,
+                                                      int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const long long n = (long long)B * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long long)b * H + hi) * W + wi) * C + c4 * 4);
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+    }
+}
+
+// global average pool: one thread per (b, c), coalesced across c
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * C) return;
+    const int c = (int)(i % C);
+    const long long b = i / C;
+    const float* p = x + b * HW * C + c;
+    float s = 0.f;
+    for (int k = 0; k < HW; ++k) s += p[(long long)k * C];
+    y[i] = s / (float)HW;
+}
+
+// one wave per channel: fixed-order fp64 sum of the per-block (sum, sumsq) partials
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                               float* __restrict__ scale, float* __restrict__ shift,
+                                                               float* __restrict__ smean, float* __restrict__ sinv) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < nblocks; k += 64) {
+        s1 += (double)part[((long long)k * C + c) * 2 + 0];
+        s2 += (double)part[((long long)k * C + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float inv = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * inv;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        if (smean) smean[c] = (float)mean;
+        if (sinv) sinv[c] = inv;
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ res, int relu,
+                                                       float* __restrict__ y, long long n4, int C4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        v = v * sc + sh;
+        if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+inline unsigned capped_grid(long long n) {
+    long long g = (n + 255) / 256;
+    return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int straps_pack_conv_weight(const float* w_oihw, float* w_krsc, int cout, int cin, int kh, int kw, void* stream) {
+    STRAPS_REQUIRE(w_oihw && w_krsc && cout > 0 && cin > 0 && kh > 0 && kw > 0, "straps_pack_conv_weight: bad arguments");
+    const long long n = (long long)cout * cin * kh * kw;
+    hipLaunchKernelGGL(pack_krsc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, w_krsc, cout, cin, kh, kw);
+    STRAPS_CHECK_LAUNCH("pack_krsc_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_pack_conv_weight_dgrad(const float* w_oihw, float* w_crsk, int cout, int cin, int kh, int kw, void* stream) {
+    STRAPS_REQUIRE(w_oihw && w_crsk && cout > 0 && cin > 0 && kh > 0 && kw > 0, "straps_pack_conv_weight_dgrad: bad arguments");
+    const long long n = (long long)cout * cin * kh * kw;
+    hipLaunchKernelGGL(pack_crsk_flip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, w_crsk, cout, cin, kh, kw);
+    STRAPS_CHECK_LAUNCH("pack_crsk_flip_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                              float* shift, int c, void* stream) {
+    STRAPS_REQUIRE(gamma && beta && mean && var && scale && shift && c > 0, "straps_bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, scale, shift, c);
+    STRAPS_CHECK_LAUNCH("bn_fold_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_maxpool_fwd(const float* x, float* y, int batch, int h, int w, int c, void* stream) {
+    STRAPS_REQUIRE(x && y && batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0, "straps_maxpool_fwd: bad arguments (c%%4 must be 0)");
+    const int Ho = (h + 2 - 3) / 2 + 1, Wo = (w + 2 - 3) / 2 + 1;
+    const long long n = (long long)batch * Ho * Wo * (c >> 2);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, batch, h, w, c, Ho, Wo);
+    STRAPS_CHECK_LAUNCH("maxpool_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_gap_fwd(const float* x, float* y, int batch, int hw, int c, void* stream) {
+    STRAPS_REQUIRE(x && y && batch > 0 && hw > 0 && c > 0, "straps_gap_fwd: bad arguments");
+    const long long n = (long long)batch * c;
+    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, batch, hw, c);
+    STRAPS_CHECK_LAUNCH("gap_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_stats_finalize(const float* stats_partial, int nblocks, int c, long long count, const float* gamma,
+                                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                        float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    STRAPS_REQUIRE(stats_partial && gamma && beta && scale && shift && nblocks > 0 && c > 0 && count > 0, "straps_bn_stats_finalize: bad arguments");
+    STRAPS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "straps_bn_stats_finalize: running stats must be given together");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, stats_partial, nblocks, c, (double)count, gamma, beta,
+                       eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    STRAPS_CHECK_LAUNCH("bn_stats_finalize_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
+                               long long rows, int c, void* stream) {
+    STRAPS_REQUIRE(x && scale && shift && y && rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_apply: bad arguments (c%%4 must be 0)");
+    const long long n4 = rows * (c >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, n4, c >> 2);
+    STRAPS_CHECK_LAUNCH("bn_apply_kernel");
+    return STRAPS_OK;
+}

@@ -1,0 +1,173 @@
+// stem.hip -- conv 7x7 / stride 2 / pad 3 straight from the NCHW network input (models/resnet.py:145)
+//
+// The 18-channel 256x256 proxy representation is the only tensor that crosses the boundary in
+// NCHW, and the stem is 29 % of resnet18's MACs.  Each workgroup produces a 4-row x 32-column tile
+// of output pixels for all 64 output channels:
+//   * the (2*4+5) x (2*32+5) input halo patch of every channel is loaded ONCE with row-contiguous
+//     (coalesced) reads into LDS (C*13*72 floats = 67 KB at C = 18),
+//   * the GEMM K index runs over (c, r, s) = C*49 taps in natural order -- a small LDS table maps
+//     k -> patch offset, so no K padding per filter row is wasted on the slow fp32 MFMA,
+//   * A fragments (pixels) are gathered from the patch with stride-2 ds_read_b32, B fragments
+//     (weights, prepacked in fragment order by straps_pack_stem_weight) stream from L2 as
+//     coalesced float4,
+//   * epilogue writes NHWC (lane = channel) with BN scale/shift + ReLU fused (eval) or raw output
+//     plus per-channel (sum, sumsq) partials (training).
+#include "common.h"
+
+namespace {
+
+constexpr int PH = 13, PW = 72;
+constexpr int TY = 4, TX = 32;
+
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wfrag,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                   float* __restrict__ y, float* __restrict__ stats, int B, int C, int H, int W,
+                                                   int Ho, int Wo, int tiles_x, int tiles_y, int K, int Kp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                                        // [C][PH][PW]
+    int* koff = reinterpret_cast<int*>(smem + C * PH * PW);     // [Kp]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int b = bid / (tiles_x * tiles_y);
+    bid -= b * tiles_x * tiles_y;
+    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
+    const int y0 = ty * TY, x0 = tx * TX;
+    const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
+
+    const int npatch = C * PH * PW;
+    for (int idx = tid; idx < npatch; idx += 256) {
+        const int col = idx % PW;
+        const int rc = idx / PW;
+        const int row = rc % PH, c = rc / PH;
+        const int hi = hi0 + row, wi = wi0 + col;
+        float v = 0.f;
+        if (col < 2 * TX + 5 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+            v = x[(((long long)b * C + c) * H + hi) * W + wi];
+        patch[idx] = v;
+    }
+    for (int k = tid; k < Kp; k += 256) {
+        int o = 0;
+        if (k < K) {
+            const int c = k / 49, rs = k - c * 49;
+            const int r = rs / 7, s = rs - r * 7;
+            o = (c * PH + r) * PW + s;
+        }
+        koff[k] = o;
+    }
+    __syncthreads();
+
+    const int i = lane & 31, h = lane >> 5;
+    const float* pbase = patch + (2 * wave) * PW + 2 * i;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wfrag) + lane;
+    const int G = Kp >> 3;
+    f32x4 b0 = wp[0], b1 = wp[64];
+    for (int g = 0; g < G; ++g) {
+        f32x4 nb0 = b0, nb1 = b1;
+        if (g + 1 < G) { nb0 = wp[(g + 1) * 128]; nb1 = wp[(g + 1) * 128 + 64]; }
+        const int4 ko = *reinterpret_cast<const int4*>(koff + 8 * g + 4 * h);
+        const float a0 = pbase[ko.x], a1 = pbase[ko.y], a2 = pbase[ko.z], a3 = pbase[ko.w];
+        acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
+        acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
+        acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
+        acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
+        b0 = nb0; b1 = nb1;
+    }
+
+    const int yo = y0 + wave;
+    float s1[2], s2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + i;
+        const float sc = scale ? scale[n] : 1.f;
+        const float sh = shift ? shift[n] : 0.f;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int xo = x0 + mfma_row(r, lane);
+            if (xo < Wo && yo < Ho) {
+                float v = nt == 0 ? acc0[r] : acc1[r];
+                t1 += v;
+                t2 = fmaf(v, v, t2);
+                if (scale) v = fmaf(v, sc, sh);
+                if (relu) v = fmaxf(v, 0.f);
+                y[(((long long)b * Ho + yo) * Wo + xo) * 64 + n] = v;
+            }
+        }
+        s1[nt] = t1;
+        s2[nt] = t2;
+    }
+    if (stats) {
+        __syncthreads();
+        float* red = smem;   // [4 waves][64][2]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float u1 = s1[nt] + __shfl_xor(s1[nt], 32, 64);
+            const float u2 = s2[nt] + __shfl_xor(s2[nt], 32, 64);
+            if (lane < 32) {
+                red[(wave * 64 + nt * 32 + lane) * 2 + 0] = u1;
+                red[(wave * 64 + nt * 32 + lane) * 2 + 1] = u2;
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int c = tid >> 1, q = tid & 1;
+            stats[((long long)blockIdx.x * 64 + c) * 2 + q] =
+                (red[(0 * 64 + c) * 2 + q] + red[(1 * 64 + c) * 2 + q]) + (red[(2 * 64 + c) * 2 + q] + red[(3 * 64 + c) * 2 + q]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_stem_kernel(const float* __restrict__ w, float* __restrict__ wf, int C, int K, int Kp) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over [G][2][64][4]
+    if (idx >= (long long)(Kp >> 3) * 512) return;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63), nt = (int)((idx >> 8) & 1), g = (int)(idx >> 9);
+    const int k = 8 * g + 4 * (lane >> 5) + e;
+    const int n = nt * 32 + (lane & 31);
+    wf[idx] = (k < K) ? w[(long long)n * K + k] : 0.f;   // OIHW row n is already (c,r,s)-ordered
+}
+
+}  // namespace
+
+extern "C" size_t straps_stem_weight_floats(int cin) { return (size_t)((cin * 49 + 7) / 8) * 512; }
+
+extern "C" int straps_pack_stem_weight(const float* w_oihw, float* w_frag, int cin, void* stream) {
+    STRAPS_REQUIRE(w_oihw && w_frag && cin > 0, "straps_pack_stem_weight: bad arguments");
+    const int K = cin * 49, Kp = (K + 7) / 8 * 8;
+    const long long n = (long long)(Kp >> 3) * 512;
+    hipLaunchKernelGGL(pack_stem_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, w_frag, cin, K, Kp);
+    STRAPS_CHECK_LAUNCH("pack_stem_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_stem_stat_blocks(int batch, int h, int w) {
+    const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
+    return batch * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX);
+}
+
+extern "C" int straps_stem_fwd(const float* x, const float* w_frag, const float* scale, const float* shift, int relu, float* y,
+                               float* stats_partial, int batch, int cin, int h, int w, void* stream) {
+    STRAPS_REQUIRE(x && w_frag && y, "straps_stem_fwd: null pointer");
+    STRAPS_REQUIRE(batch > 0 && cin > 0 && h >= 7 && w >= 7, "straps_stem_fwd: bad shape B=%d C=%d H=%d W=%d", batch, cin, h, w);
+    STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_stem_fwd: scale and shift must be given together");
+    const int K = cin * 49, Kp = (K + 7) / 8 * 8;
+    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + (size_t)Kp * sizeof(int);
+    STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_fwd: %d input channels need %zu B of LDS (max 160 KiB)", cin, lds);
+    const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
+    const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { straps_set_error("stem_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
+        lds_set = lds;
+    }
+    const long long nblk = (long long)batch * tiles_x * tiles_y;
+    STRAPS_REQUIRE(nblk < (1LL << 31), "straps_stem_fwd: grid too large");
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, x, w_frag, scale, shift, relu, y,
+                       stats_partial, batch, cin, h, w, Ho, Wo, tiles_x, tiles_y, K, Kp);
+    STRAPS_CHECK_LAUNCH("stem_kernel");
+    return STRAPS_OK;
+}

@@ -1,0 +1,131 @@
+"""Executor of the encoder forward on the HIP kernels (replaces ResNet.forward, reference
+models/resnet.py:201-216).  NHWC fp32 activations; one C-ABI call per fused stage.
+
+eval  : conv -> (folded BN scale/shift, residual, ReLU) fused in the conv epilogue.
+train : conv emits raw output + per-block (sum, sumsq) partials -> straps_bn_stats_finalize
+        (batch mean / biased var, running-stat update with the unbiased var) -> straps_bn_apply.
+"""
+import torch
+
+from . import hipabi
+
+
+def _conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+class _Ctx:
+    """per-forward scratch: library handle, stream, device, training flag, optional tape for backward."""
+
+    def __init__(self, device, training, tape=None):
+        self.L = hipabi.lib()
+        self.device = device
+        self.training = training
+        self.tape = tape
+
+    def empty(self, *shape):
+        return torch.empty(*shape, device=self.device, dtype=torch.float32)
+
+
+def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec):
+    C = bn.weight.shape[0]
+    L = ctx.L
+    ss = ctx.empty(4, C)          # scale, shift, save_mean, save_invstd
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    hipabi.check(L.straps_bn_stats_finalize(hipabi.ptr(part), nblk, C, rows, hipabi.ptr(bn.weight), hipabi.ptr(bn.bias), bn.eps,
+                                            mom, hipabi.ptr(bn.running_mean if track else None),
+                                            hipabi.ptr(bn.running_var if track else None), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]),
+                                            hipabi.ptr(ss[2]), hipabi.ptr(ss[3]), hipabi.stream_ptr()), 'straps_bn_stats_finalize')
+    if track:
+        bn.num_batches_tracked.add_(1)
+    y = torch.empty_like(raw)
+    hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
+                                   hipabi.ptr(y), rows, C, hipabi.stream_ptr()), 'straps_bn_apply')
+    if rec is not None:
+        rec.update(raw=raw, stats=ss, out=y)
+    return y
+
+
+def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
+    """x NHWC [B,H,W,Cin] -> NHWC [B,Ho,Wo,Cout] through conv + BatchNorm (+residual) (+ReLU)."""
+    L = ctx.L
+    Cout, Cin, k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
+    stride, pad = conv.stride[0], conv.padding[0]
+    Ho, Wo = _conv_out(H, k, stride, pad), _conv_out(W, k, stride, pad)
+    wpk = net._packed_weight(conv)
+    y = ctx.empty(B, Ho, Wo, Cout)
+    rec = None
+    if ctx.tape is not None:
+        rec = dict(kind='conv', conv=conv, bn=bn, x=x, geom=(B, H, W, Cin, Cout, k, stride, pad, Ho, Wo), relu=relu,
+                   residual=residual)
+        ctx.tape.append(rec)
+    if not ctx.training:
+        ss = net._folded_bn(bn)
+        hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wpk), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual),
+                                       int(relu), hipabi.ptr(y), None, B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg,
+                                       hipabi.stream_ptr()), 'straps_conv_fwd')
+        return y, Ho, Wo
+    nblk = L.straps_conv_stat_blocks(B, Ho, Wo, Cout, tile_cfg)
+    part = ctx.empty(nblk, Cout, 2)
+    hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wpk), None, None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, H, W,
+                                   Cin, Cout, k, k, stride, pad, tile_cfg, hipabi.stream_ptr()), 'straps_conv_fwd')
+    out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec)
+    return out, Ho, Wo
+
+
+def encoder_forward(net, x, tape=None):
+    """net: resnet.ResNet; x: float32 [B,C,H,W] NCHW on the GPU.  Returns features [B, 512|2048]."""
+    hipabi.require_gpu_tensor(x, 'encoder input', torch.float32)
+    if x.dim() != 4 or x.shape[1] != net.in_channels:
+        raise RuntimeError('encoder expects [B,%d,H,W], got %s' % (net.in_channels, tuple(x.shape)))
+    hipabi.require_gpu_tensor(net.conv1.weight, 'encoder parameters (call .to(device))')
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    ctx = _Ctx(x.device, net.training, tape)
+    L = ctx.L
+    # ---- stem: conv7x7/s2 + BN + ReLU (models/resnet.py:145-148) ----
+    Ho, Wo = _conv_out(H, 7, 2, 3), _conv_out(W, 7, 2, 3)
+    wfrag = net._packed_weight(net.conv1, stem=True)
+    y = ctx.empty(B, Ho, Wo, 64)
+    rec = None
+    if tape is not None:
+        rec = dict(kind='stem', conv=net.conv1, bn=net.bn1, x=x, geom=(B, C, H, W, Ho, Wo), relu=True, residual=None)
+        tape.append(rec)
+    if not net.training:
+        ss = net._folded_bn(net.bn1)
+        hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), 1, hipabi.ptr(y),
+                                       None, B, C, H, W, hipabi.stream_ptr()), 'straps_stem_fwd')
+    else:
+        nblk = L.straps_stem_stat_blocks(B, H, W)
+        part = ctx.empty(nblk, 64, 2)
+        hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, C, H, W,
+                                       hipabi.stream_ptr()), 'straps_stem_fwd')
+        y = _bn_train_finish(ctx, net.bn1, y, part, nblk, B * Ho * Wo, None, True, rec)
+    # ---- maxpool 3x3/s2/p1 (:149) ----
+    H, W = Ho, Wo
+    Hp, Wp = _conv_out(H, 3, 2, 1), _conv_out(W, 3, 2, 1)
+    p = ctx.empty(B, Hp, Wp, 64)
+    hipabi.check(L.straps_maxpool_fwd(hipabi.ptr(y), hipabi.ptr(p), B, H, W, 64, hipabi.stream_ptr()), 'straps_maxpool_fwd')
+    if tape is not None:
+        tape.append(dict(kind='maxpool', x=y, out=p, geom=(B, H, W, 64, Hp, Wp)))
+    y, H, W = p, Hp, Wp
+    # ---- residual stages (:150-156) ----
+    for li in range(1, 5):
+        for unit in getattr(net, 'layer%d' % li):
+            idt = y
+            if unit.downsample is not None:
+                idt, _, _ = conv_bn(ctx, net, y, B, H, W, unit.downsample[0], unit.downsample[1], relu=False)
+            pairs = unit.conv_bn_pairs()
+            t, h, w = y, H, W
+            for ci, (conv, bn) in enumerate(pairs):
+                last = ci == len(pairs) - 1
+                t, h, w = conv_bn(ctx, net, t, B, h, w, conv, bn, relu=True, residual=idt if last else None)
+            y, H, W = t, h, w
+    # ---- global average pool + flatten (:213-214) ----
+    Cf = y.shape[3]
+    feat = ctx.empty(B, Cf)
+    hipabi.check(L.straps_gap_fwd(hipabi.ptr(y), hipabi.ptr(feat), B, H * W, Cf, hipabi.stream_ptr()), 'straps_gap_fwd')
+    if tape is not None:
+        tape.append(dict(kind='gap', x=y, geom=(B, H * W, Cf)))
+    return feat

@@ -1,0 +1,125 @@
+"""ctypes binding of libstraps_hip.so (the C ABI declared in include/straps_hip.h).
+
+No torch types cross this boundary: tensors are handed over as raw device pointers + sizes and
+the current HIP stream handle.  There is deliberately NO fallback: if the library is not built or
+no GPU is visible, every product entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
+SOURCES = ['abi.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'stem.hip', 'smpl.hip',
+           'backward.hip', 'train.hip']
+
+_lib = None
+
+
+def _existing_sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.isfile(os.path.join(CSRC, s))]
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into csrc/libstraps_hip.so (in-tree, so the .so travels
+    with the repo snapshot).  hipcc cross-compiles without a GPU."""
+    srcs = _existing_sources()
+    deps = srcs + [os.path.join(CSRC, 'common.h'), HEADER]
+    if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+class SmplModelStruct(C.Structure):
+    """mirror of straps_smpl_model_t"""
+    _fields_ = [('blend_frag', C.c_void_p), ('j_template', C.c_void_p), ('j_shapedirs', C.c_void_p),
+                ('parents', C.c_void_p), ('depth', C.c_void_p), ('max_depth', C.c_int32), ('skin_k', C.c_int32),
+                ('skin_w', C.c_void_p), ('skin_j', C.c_void_p), ('jr_ptr', C.c_void_p), ('jr_code', C.c_void_p),
+                ('jr_w', C.c_void_p), ('pick_ids', C.c_void_p)]
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    'straps_abi_version': (_I, []),
+    'straps_last_error': (C.c_char_p, []),
+    'straps_device_count': (_I, []),
+    'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'straps_stem_weight_floats': (_Z, [_I]),
+    'straps_pack_stem_weight': (_I, [_P, _P, _I, _P]),
+    'straps_bn_fold': (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    'straps_stem_stat_blocks': (_I, [_I, _I, _I]),
+    'straps_stem_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I]),
+    'straps_conv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'straps_maxpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'straps_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),
+    'straps_bn_stats_finalize': (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    'straps_bn_apply': (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _P]),
+    'straps_linear_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'straps_pad_copy': (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    'straps_broadcast_rows': (_I, [_P, _I, _P, _I, _I, _P]),
+    'straps_rot6d_fwd': (_I, [_P, _L, _I, _P, _L, _P]),
+    'straps_rodrigues_fwd': (_I, [_P, _P, _L, _P]),
+    'straps_smpl_workspace_bytes': (_Z, [_L, _I]),
+    'straps_smpl_fwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _L, _I, _P]),
+}
+
+
+def load(path=None):
+    """dlopen the library and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.isfile(p):
+        raise RuntimeError('libstraps_hip.so is not built (%s missing): run `python -c "import __graft_entry__ as g; '
+                           'g.build()"` -- this package has no CPU fallback' % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name):
+            continue                      # symbols of later sources may be absent in partial builds
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def lib():
+    return load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (code %d): %s' % (what, rc, lib().straps_last_error().decode()))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a GPU tensor: the STRAPS hot path runs only through the HIP library '
+                           '(no CPU fallback)' % name)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError('%s must have dtype %s (got %s)' % (name, dtype, t.dtype))
+    return t

@@ -1,0 +1,109 @@
+"""Iterative-error-feedback regressor -- drop-in for reference models/ief_module.py:8-64.
+
+fc1/fc2/fc3 are nn.Linear PARAMETER CONTAINERS (same state-dict keys, incl. the duplicate
+`ief_layers.{0,2,4}.*` aliases the reference produces by registering the same modules twice,
+models/ief_module.py:24-28).  forward() runs straps_linear_fwd (fp32 MFMA) through the C ABI:
+
+    c1  = feat @ W1[:, :F]^T + b1                      (once: the feature half of fc1)
+    est = init ; repeat `iterations` times:
+        h1  = relu(c1 + est @ W1[:, F:]^T)             (== fc1([feat, est]))
+        h2  = relu(h1 @ W2^T + b2)
+        est = est + h2 @ W3^T + b3                     (in place, like :57)
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import config, hipabi
+
+EST_LD = 160     # estimate row stride: 157 padded to a multiple of 8 (zero padding)
+
+
+class IEFModule(nn.Module):
+    def __init__(self, fc_layers_neurons, in_features, num_output_params, iterations=3, mean_params=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features + num_output_params, fc_layers_neurons[0])
+        self.fc2 = nn.Linear(fc_layers_neurons[0], fc_layers_neurons[1])
+        self.fc3 = nn.Linear(fc_layers_neurons[1], num_output_params)
+        self.relu = nn.ReLU(inplace=True)
+        for fc in (self.fc1, self.fc2, self.fc3):
+            nn.init.zeros_(fc.bias)
+        self.ief_layers = nn.Sequential(self.fc1, self.relu, self.fc2, self.relu, self.fc3)
+        self.iterations = iterations
+        self.in_features, self.num_output_params = in_features, num_output_params
+        if num_output_params > EST_LD:
+            raise ValueError('IEF estimate wider than %d is not supported' % EST_LD)
+        if mean_params is None:
+            mean_params = np.load(config.SMPL_MEAN_PARAMS_PATH)          # FileNotFoundError like the reference
+        self.initial_params_estimate = self.load_mean_params_6d_pose(mean_params)
+        self._cache = {}
+
+    @staticmethod
+    def load_mean_params_6d_pose(mean_smpl):
+        """models/ief_module.py:33-46: [s, tx, ty] = [0.9, 0, 0] then mean 6D pose (144) and shape (10).
+        Accepts the npz path, an NpzFile or a dict with 'pose' and 'shape'."""
+        if isinstance(mean_smpl, str):
+            mean_smpl = np.load(mean_smpl)
+        v = np.zeros(3 + 24 * 6 + 10)
+        v[3:] = np.concatenate((np.asarray(mean_smpl['pose']).reshape(-1), np.asarray(mean_smpl['shape']).reshape(-1)))
+        v[0] = 0.9
+        return torch.from_numpy(v.astype(np.float32)).float()
+
+    def _packed(self, device):
+        ps = [self.fc1.weight, self.fc2.weight, self.fc3.weight]
+        sig = tuple((t.data_ptr(), t._version) for t in ps) + (str(device),)
+        if self._cache.get('sig') != sig:
+            L = hipabi.lib()
+            F, H1, H2, P = self.in_features, self.fc1.out_features, self.fc2.out_features, self.num_output_params
+            assert F % 8 == 0 and H1 % 32 == 0 and H2 % 32 == 0, 'IEF widths must be multiples of 32 (features of 8)'
+            w1f = torch.empty(H1, F, device=device)
+            w1e = torch.empty(H1, EST_LD, device=device)
+            w3 = torch.empty((P + 31) // 32 * 32, H2, device=device)
+            st = hipabi.stream_ptr()
+            hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc1.weight), F + P, 0, H1, F, hipabi.ptr(w1f), F, H1, st), 'straps_pad_copy')
+            hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc1.weight), F + P, F, H1, P, hipabi.ptr(w1e), EST_LD, H1, st), 'straps_pad_copy')
+            hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc3.weight), H2, 0, P, H2, hipabi.ptr(w3), H2, w3.shape[0], st), 'straps_pad_copy')
+            self._cache = {'sig': sig, 'w1f': w1f, 'w1e': w1e, 'w3': w3,
+                           'init': self.initial_params_estimate.to(device).contiguous()}
+        return self._cache
+
+    def forward_estimate(self, img_features, tape=None):
+        """[B,F] GPU features -> the full estimate buffer [B,160] (columns >= 157 are zero)."""
+        hipabi.require_gpu_tensor(img_features, 'IEF input features', torch.float32)
+        hipabi.require_gpu_tensor(self.fc1.weight, 'IEF parameters (call .to(device))')
+        feat = img_features.detach().contiguous()
+        B, F = feat.shape
+        if F != self.in_features:
+            raise RuntimeError('IEFModule expects %d features, got %d' % (self.in_features, F))
+        pk = self._packed(feat.device)
+        L, st = hipabi.lib(), hipabi.stream_ptr()
+        H1, H2, P = self.fc1.out_features, self.fc2.out_features, self.num_output_params
+        dev = feat.device
+        c1 = torch.empty(B, H1, device=dev)
+        est = torch.empty(B, EST_LD, device=dev)
+        hipabi.check(L.straps_broadcast_rows(hipabi.ptr(pk['init']), P, hipabi.ptr(est), EST_LD, B, st), 'straps_broadcast_rows')
+        hipabi.check(L.straps_linear_fwd(hipabi.ptr(feat), F, hipabi.ptr(pk['w1f']), F, hipabi.ptr(self.fc1.bias), None,
+                                         hipabi.ptr(c1), H1, B, H1, F, 0, st), 'straps_linear_fwd(fc1 features)')
+        for it in range(self.iterations):
+            h1 = torch.empty(B, H1, device=dev)
+            h2 = torch.empty(B, H2, device=dev)
+            est_in = est.clone() if tape is not None else est
+            hipabi.check(L.straps_linear_fwd(hipabi.ptr(est_in), EST_LD, hipabi.ptr(pk['w1e']), EST_LD, None, hipabi.ptr(c1),
+                                             hipabi.ptr(h1), H1, B, H1, EST_LD, 1, st), 'straps_linear_fwd(fc1 estimate)')
+            hipabi.check(L.straps_linear_fwd(hipabi.ptr(h1), H1, self.fc2.weight.data_ptr(), H1, hipabi.ptr(self.fc2.bias), None,
+                                             hipabi.ptr(h2), H2, B, H2, H1, 1, st), 'straps_linear_fwd(fc2)')
+            hipabi.check(L.straps_linear_fwd(hipabi.ptr(h2), H2, hipabi.ptr(pk['w3']), H2, hipabi.ptr(self.fc3.bias), hipabi.ptr(est),
+                                             hipabi.ptr(est), EST_LD, B, P, H2, 0, st), 'straps_linear_fwd(fc3)')
+            if tape is not None:
+                tape.append(dict(est_in=est_in, h1=h1, h2=h2))
+        return est
+
+    def forward(self, img_features):
+        if torch.is_grad_enabled() and (img_features.requires_grad or self.fc1.weight.requires_grad):
+            from .autograd_ops import ief_autograd
+            est = ief_autograd(self, img_features)
+        else:
+            est = self.forward_estimate(img_features)
+        P = self.num_output_params
+        # three views of one buffer, pose non-contiguous -- exactly what the reference returns (:60-62)
+        return est[:, :3], est[:, 3:3 + 24 * 6], est[:, 3 + 24 * 6:P]

@@ -1,0 +1,135 @@
+"""ResNet-18/50 proxy-representation encoder -- drop-in for reference models/resnet.py (class
+ResNet without the FC head, factories resnet18/resnet50).
+
+The nn.Conv2d / nn.BatchNorm2d objects below are PARAMETER CONTAINERS only: they give the module
+the reference's state-dict keys (`conv1.weight`, `layer2.0.downsample.1.running_var`, ...), its
+parameter iteration order and its seeded initialisation, but their own forward is never called.
+`ResNet.forward` runs the HIP pipeline (stem kernel from NCHW, implicit-GEMM convs over NHWC with
+BatchNorm/ReLU/residual fused in the epilogue, max-pool, global average pool) through the C ABI.
+"""
+import torch
+import torch.nn as nn
+
+from . import hipabi
+
+BN_EPS = 1e-5
+
+
+class ResidualUnit(nn.Module):
+    """One residual block.  kind 'basic': 3x3(s) - 3x3 (models/resnet.py:39-77); kind 'bottleneck':
+    1x1 - 3x3(s) - 1x1 with 4x expansion (:80-121).  A 1x1(s)+BN projection on the skip path when the
+    shape changes (:183-187)."""
+
+    def __init__(self, kind, inplanes, planes, stride, project):
+        super().__init__()
+        self.kind, self.stride = kind, stride
+        out_planes = planes * (4 if kind == 'bottleneck' else 1)
+        # the reference builds the projection BEFORE the block's own convs (models/resnet.py:183-190);
+        # constructing in that order keeps seeded construction bit-identical.
+        proj = None
+        if project:
+            proj = nn.Sequential(nn.Conv2d(inplanes, out_planes, 1, stride, bias=False), nn.BatchNorm2d(out_planes))
+        if kind == 'basic':
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+        else:
+            self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, out_planes, 1, bias=False)
+            self.bn3 = nn.BatchNorm2d(out_planes)
+        self.downsample = proj            # registered last, like the reference's attribute order
+        self.out_planes = out_planes
+
+    def conv_bn_pairs(self):
+        names = ['1', '2'] + (['3'] if self.kind == 'bottleneck' else [])
+        return [(getattr(self, 'conv' + n), getattr(self, 'bn' + n)) for n in names]
+
+
+class ResNet(nn.Module):
+    def __init__(self, kind, counts, in_channels, zero_init_residual=False):
+        super().__init__()
+        self.kind, self.in_channels = kind, in_channels
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        expansion = 4 if kind == 'bottleneck' else 1
+        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), counts)):
+            units = []
+            for bi in range(n):
+                stride = 2 if (li > 0 and bi == 0) else 1
+                project = bi == 0 and (stride != 1 or inplanes != planes * expansion)
+                units.append(ResidualUnit(kind, inplanes, planes, stride, project))
+                inplanes = planes * expansion
+            setattr(self, 'layer%d' % (li + 1), nn.Sequential(*units))
+        self.num_features = inplanes
+        # models/resnet.py:160-165: kaiming-normal(fan_out, relu) convs, BN gamma=1 beta=0, in modules() order
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, ResidualUnit):
+                    nn.init.constant_((m.bn3 if m.kind == 'bottleneck' else m.bn2).weight, 0)
+        self._cache = {}
+
+    # ---- packed-weight / folded-BN caches, refreshed when a parameter's version changes ----
+    def _cached(self, key, tensors, make):
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            hit = (sig, make())
+            self._cache[key] = hit
+        return hit[1]
+
+    def _packed_weight(self, conv, stem=False):
+        w = conv.weight
+        L = hipabi.lib()
+
+        def make():
+            wd = w.detach().contiguous()
+            if stem:
+                out = torch.empty(L.straps_stem_weight_floats(wd.shape[1]), device=wd.device, dtype=torch.float32)
+                hipabi.check(L.straps_pack_stem_weight(hipabi.ptr(wd), hipabi.ptr(out), wd.shape[1], hipabi.stream_ptr()),
+                             'straps_pack_stem_weight')
+            else:
+                out = torch.empty(wd.numel(), device=wd.device, dtype=torch.float32)
+                hipabi.check(L.straps_pack_conv_weight(hipabi.ptr(wd), hipabi.ptr(out), wd.shape[0], wd.shape[1], wd.shape[2],
+                                                       wd.shape[3], hipabi.stream_ptr()), 'straps_pack_conv_weight')
+            return out
+        return self._cached(('w', id(conv)), [w], make)
+
+    def _folded_bn(self, bn):
+        def make():
+            C = bn.weight.shape[0]
+            ss = torch.empty(2, C, device=bn.weight.device, dtype=torch.float32)
+            hipabi.check(hipabi.lib().straps_bn_fold(hipabi.ptr(bn.weight), hipabi.ptr(bn.bias), hipabi.ptr(bn.running_mean),
+                                                     hipabi.ptr(bn.running_var), bn.eps, hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), C,
+                                                     hipabi.stream_ptr()), 'straps_bn_fold')
+            return ss
+        return self._cached(('bn', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make)
+
+    def forward(self, x):
+        from .encoder_exec import encoder_forward
+        return encoder_forward(self, x)
+
+
+def resnet18(in_channels, pretrained=False, progress=True, **kwargs):
+    """models/resnet.py:228-236.  `pretrained` weights cannot be fetched (no torchvision head, no
+    network); the reference always passes False on this path (models/regressor.py:30)."""
+    if pretrained:
+        raise NotImplementedError('pretrained ImageNet weights are not available in this build')
+    return ResNet('basic', [2, 2, 2, 2], in_channels, **kwargs)
+
+
+def resnet50(in_channels, pretrained=False, progress=True, **kwargs):
+    """models/resnet.py:250-258."""
+    if pretrained:
+        raise NotImplementedError('pretrained ImageNet weights are not available in this build')
+    return ResNet('bottleneck', [3, 4, 6, 3], in_channels, **kwargs)

@@ -1,0 +1,46 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/straps_hip.h
+declares (no compute calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+import straps_amd
+from straps_amd import hipabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'straps_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(straps_[a-z0-9_]+)\s*\(', txt)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    hipabi.build()
+    return hipabi.load()
+
+
+def test_header_symbols_exported_and_bound(lib):
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), 'library does not export %s' % n
+        assert n in hipabi.SIGNATURES, 'ctypes binding lacks a prototype for %s' % n
+    for n in hipabi.SIGNATURES:
+        assert n in names, '%s bound in hipabi.py but not declared in straps_hip.h' % n
+
+
+def test_version_and_error_channel(lib):
+    assert lib.straps_abi_version() == 1
+    assert isinstance(lib.straps_last_error(), bytes)
+    # argument validation happens before any HIP call, so it is checkable without a GPU
+    rc = lib.straps_rot6d_fwd(None, 6, 1, None, 1, None)
+    assert rc == 1 and b'null pointer' in lib.straps_last_error()
+    rc = lib.straps_linear_fwd(None, 0, None, 0, None, None, None, 0, 0, 0, 0, 0, None)
+    assert rc == 1
+    assert lib.straps_stem_weight_floats(18) == ((18 * 49 + 7) // 8) * 512
+    assert lib.straps_smpl_workspace_bytes(64, 0) == 64 * (224 + 288 + 54 * 135) * 4
+    assert lib.straps_smpl_workspace_bytes(4096, 0) == 4096 * (224 + 288 + 8 * 135) * 4

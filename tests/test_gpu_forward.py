@@ -1,0 +1,312 @@
+"""GPU parity tests of the forward hot path: every HIP kernel against the CPU oracle (and the
+committed golden vectors), called through the C ABI exactly as the product does.
+
+Tolerances (written where used):
+  * SMPL vertices / joints: <= 1e-4 abs (BASELINE.json north_star) -- measured ~1e-6;
+  * encoder / IEF outputs: fp32 with a different summation order than the oracle's CPU kernels
+    -> <= 2e-4 abs + 2e-4 rel on O(1) activations (measured ~1e-5).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import straps_amd
+import straps_oracle as O
+from detgen import det_uniform, det_state_dict
+from straps_amd import hipabi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+MP = straps_amd.synthetic_mean_params(0)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    hipabi.load()                       # fail loudly if the HIP library is missing
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def smpl_model():
+    return straps_amd.synthetic_smpl_model(0)
+
+
+def _close(a, b, atol, rtol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    worst = float((err - bound).max())
+    assert worst <= 0, '%s: max abs err %.3e (bound violated by %.3e)' % (what, float(err.max()), worst)
+    return float(err.max())
+
+
+# ------------------------------------------------------------------------------------------ SMPL
+@pytest.mark.parametrize('B,chunks', [(1, 0), (5, 0), (37, 8), (70, 54), (64, 3)])
+def test_smpl_forward_vs_oracle(dev, smpl_model, B, chunks):
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    betas = torch.from_numpy(det_uniform((B, 10), 100 + B, -2.5, 2.5))
+    aa = torch.from_numpy(det_uniform((B, 72), 200 + B, -0.9, 0.9))
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+    v, j = smpl.forward_arrays(betas.to(dev), R.to(dev), chunks=chunks)
+    v64, j64 = O.smpl_forward(smpl_model, betas.double(), rotmats=R.double(), dtype=torch.float64)
+    ev = _close(v, v64, 1e-4, 0, 'vertices')       # north_star: <= 1e-4 abs
+    ej = _close(j, j64, 1e-4, 0, 'joints')
+    assert ev < 2e-5 and ej < 2e-5                  # in practice fp32 round-off only
+    # vertices only (config 5 microbench form)
+    v2, none = smpl.forward_arrays(betas.to(dev), R.to(dev), want_joints=False, chunks=chunks)
+    assert none is None and torch.equal(v2, v)
+
+
+def test_smpl_module_call_forms(dev, smpl_model):
+    """the three call forms of the reference (train loop :132, :144, :258)."""
+    B = 4
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    betas = torch.from_numpy(det_uniform((B, 10), 7, -2, 2))
+    aa = torch.from_numpy(det_uniform((B, 72), 8, -0.7, 0.7))
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+    with torch.no_grad():
+        o1 = smpl(body_pose=R[:, 1:].to(dev), global_orient=R[:, 0:1].to(dev), betas=betas.to(dev), pose2rot=False)
+        o2 = smpl(body_pose=aa[:, 3:].to(dev), global_orient=aa[:, :3].to(dev), betas=betas.to(dev))
+        o3 = smpl(betas=betas.to(dev))
+    v1, j1 = O.smpl_forward(smpl_model, betas, rotmats=R)
+    v3, j3 = O.smpl_forward(smpl_model, betas, rotmats=torch.eye(3).expand(B, 24, 3, 3))
+    _close(o1.vertices, v1, 1e-4, 0, 'rotmat form')
+    _close(o2.vertices, v1, 1e-4, 0, 'axis-angle form')
+    _close(o2.joints, j1, 1e-4, 0, 'axis-angle form joints')
+    _close(o3.vertices, v3, 1e-4, 0, 'betas-only form')
+    assert o1.vertices.shape == (B, 6890, 3) and o1.joints.shape == (B, 90, 3)
+    assert o2.full_pose.shape == (B, 72) and o1.betas.shape == (B, 10)
+
+
+def test_smpl_large_batch_properties(dev, smpl_model):
+    """size-independent properties at a batch the oracle cannot do in seconds (4096 bodies, 8 chunks):
+    zero pose == shaped template; a global rotation moves vertices rigidly about the root joint."""
+    B = 4096
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    g = torch.Generator().manual_seed(3)
+    betas = (torch.rand(B, 10, generator=g) * 4 - 2).to(dev)
+    eye = torch.eye(3, device=dev).expand(B, 24, 3, 3).contiguous()
+    v0, j0 = smpl.forward_arrays(betas, eye)
+    vt = torch.tensor(smpl_model['v_template'], device=dev)
+    sdirs = torch.tensor(smpl_model['shapedirs'], device=dev)
+    v_shaped = vt[None] + torch.einsum('bl,vcl->bvc', betas, sdirs)
+    assert float((v0 - v_shaped).abs().max()) < 5e-6
+    aa = (torch.rand(B, 72, generator=g) - 0.5)
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3).to(dev)
+    v1, j1 = smpl.forward_arrays(betas, R)
+    Rg = O.batch_rodrigues(torch.tensor([[0.4, -0.9, 0.2]]))[0].to(dev)
+    R2 = R.clone()
+    R2[:, 0] = Rg @ R[:, 0]
+    v2, j2 = smpl.forward_arrays(betas, R2)
+    root = j1[:, 0:1]
+    assert float((j2[:, 0:1] - root).abs().max()) < 1e-6
+    assert float((v2 - ((v1 - root) @ Rg.T + root)).abs().max()) < 5e-6
+    assert float((j2 - ((j1 - root) @ Rg.T + root)).abs().max()) < 5e-6
+    # picked-vertex joints are exact copies
+    assert torch.equal(j1[:, 24:45], v1[:, smpl_model['extra_vertex_ids'].tolist()])
+    # batch slices are independent of the batch they ride in
+    v_s, j_s = smpl.forward_arrays(betas[1000:1037].contiguous(), R[1000:1037].contiguous())
+    assert torch.equal(v_s, v1[1000:1037]) and float((j_s - j1[1000:1037]).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ pose
+def test_rot6d_and_rodrigues(dev):
+    gold = np.load(os.path.join(GOLD, 'small_golden.npz'))
+    x6 = torch.from_numpy(det_uniform((4, 144), 32, -1.5, 1.5))
+    R = straps_amd.rot6d_to_rotmat(x6.to(dev))
+    assert R.shape == (96, 3, 3)
+    _close(R, torch.from_numpy(gold['rot6d_out']), 2e-6, 0, 'rot6d vs reference golden')
+    # strided view (the IEF estimate's pose slice) gives the same result
+    buf = torch.zeros(4, 160)
+    buf[:, 3:147] = x6
+    R2 = straps_amd.rot6d_to_rotmat(buf.to(dev)[:, 3:147])
+    assert torch.equal(R2, R)
+    z = torch.zeros(2, 6, device=dev)               # degenerate input: F.normalize eps path, no NaN
+    assert torch.isfinite(straps_amd.rot6d_to_rotmat(z)).all()
+    aa = torch.from_numpy(det_uniform((300, 3), 9, -3, 3))
+    aa[0] = 0
+    _close(straps_amd.batch_rodrigues(aa.to(dev)), O.batch_rodrigues(aa.double()), 2e-6, 0, 'rodrigues')
+
+
+# ------------------------------------------------------------------------------------------ conv pieces
+def _run_conv(dev, x_nchw, w, stride, pad, scale=None, shift=None, res_nchw=None, relu=False, cfg=0, stats=False):
+    L = hipabi.lib()
+    B, Cin, H, W = x_nchw.shape
+    Cout, _, k, _ = w.shape
+    x = x_nchw.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.contiguous().to(dev)
+    wp = torch.empty_like(wd)
+    hipabi.check(L.straps_pack_conv_weight(hipabi.ptr(wd), hipabi.ptr(wp), Cout, Cin, k, k, None), 'pack')
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty(B, Ho, Wo, Cout, device=dev)
+    res = res_nchw.permute(0, 2, 3, 1).contiguous().to(dev) if res_nchw is not None else None
+    sc = scale.to(dev) if scale is not None else None
+    sh = shift.to(dev) if shift is not None else None
+    part = None
+    if stats:
+        part = torch.empty(L.straps_conv_stat_blocks(B, Ho, Wo, Cout, cfg), Cout, 2, device=dev)
+    hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wp), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), int(relu),
+                                   hipabi.ptr(y), hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, cfg, None), 'conv')
+    torch.cuda.synchronize()
+    return y.permute(0, 3, 1, 2).cpu(), part
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,k,stride,cfg', [
+    (2, 64, 64, 16, 3, 1, 0), (2, 64, 64, 16, 3, 1, 1), (2, 64, 128, 16, 3, 2, 2), (3, 128, 128, 8, 3, 1, 3),
+    (2, 64, 128, 16, 1, 2, 0), (1, 256, 512, 8, 3, 2, 0), (1, 512, 512, 8, 3, 1, 0), (5, 64, 64, 7, 3, 1, 1),
+    (2, 256, 64, 16, 1, 1, 0)])
+def test_conv_igemm_vs_cpu(dev, B, Cin, Cout, H, k, stride, cfg):
+    """implicit-GEMM conv (all tile configs, ragged M, stride 1/2, 3x3 and 1x1) vs F.conv2d fp64."""
+    pad = 1 if k == 3 else 0
+    x = torch.from_numpy(det_uniform((B, Cin, H, H), 1, -1, 1))
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 2, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    y, part = _run_conv(dev, x, w, stride, pad, cfg=cfg, stats=True)
+    _close(y, ref, 2e-5, 2e-5, 'raw conv')
+    # training-mode statistics partials: per-channel sum / sum of squares of the raw output
+    s = part.double().sum(0).cpu()
+    np.testing.assert_allclose(s[:, 0].numpy(), ref.sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    # fused epilogue: BN scale/shift + residual + ReLU
+    sc = torch.from_numpy(det_uniform((Cout,), 3, 0.5, 1.5))
+    sh = torch.from_numpy(det_uniform((Cout,), 4, -0.5, 0.5))
+    res = torch.from_numpy(det_uniform(tuple(ref.shape), 5, -1, 1))
+    want = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + res.double())
+    y2, _ = _run_conv(dev, x, w, stride, pad, sc, sh, res, True, cfg)
+    _close(y2, want, 3e-5, 3e-5, 'fused epilogue')
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 18, 256, 256), (1, 1, 64, 96), (3, 18, 40, 72)])
+def test_stem_vs_cpu(dev, B, C, H, W):
+    L = hipabi.lib()
+    x = torch.from_numpy(det_uniform((B, C, H, W), 6, 0, 1))
+    w = torch.from_numpy(det_uniform((64, C, 7, 7), 7, -1, 1)) * (2.0 / (C * 49)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    Ho, Wo = ref.shape[2:]
+    xd, wd = x.to(dev), w.to(dev)
+    wf = torch.empty(L.straps_stem_weight_floats(C), device=dev)
+    hipabi.check(L.straps_pack_stem_weight(hipabi.ptr(wd), hipabi.ptr(wf), C, None), 'pack stem')
+    y = torch.empty(B, Ho, Wo, 64, device=dev)
+    part = torch.empty(L.straps_stem_stat_blocks(B, H, W), 64, 2, device=dev)
+    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, C, H, W, None), 'stem')
+    _close(y.permute(0, 3, 1, 2), ref, 2e-5, 2e-5, 'stem raw')
+    s = part.double().sum(0).cpu()
+    np.testing.assert_allclose(s[:, 0].numpy(), ref.sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    sc = torch.from_numpy(det_uniform((64,), 3, 0.5, 1.5))
+    sh = torch.from_numpy(det_uniform((64,), 4, -0.5, 0.5))
+    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), hipabi.ptr(sc.to(dev)), hipabi.ptr(sh.to(dev)), 1, hipabi.ptr(y), None,
+                                   B, C, H, W, None), 'stem fused')
+    want = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    _close(y.permute(0, 3, 1, 2), want, 3e-5, 3e-5, 'stem fused')
+
+
+def test_pool_gap_bn_helpers(dev):
+    L = hipabi.lib()
+    x = torch.from_numpy(det_uniform((3, 64, 17, 22), 8, -1, 1))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    y = torch.empty(3, ref.shape[2], ref.shape[3], 64, device=dev)
+    hipabi.check(L.straps_maxpool_fwd(hipabi.ptr(xn), hipabi.ptr(y), 3, 17, 22, 64, None), 'maxpool')
+    assert torch.equal(y.permute(0, 3, 1, 2).cpu(), ref)                       # max is exact
+    g = torch.empty(3, 64, device=dev)
+    hipabi.check(L.straps_gap_fwd(hipabi.ptr(xn), hipabi.ptr(g), 3, 17 * 22, 64, None), 'gap')
+    _close(g, x.double().mean(dim=(2, 3)), 1e-6, 1e-6, 'gap')
+    # BN training statistics: finalize + apply vs F.batch_norm
+    C, rows = 64, 3 * 17 * 22
+    gamma = torch.from_numpy(det_uniform((C,), 9, 0.5, 1.5))
+    beta = torch.from_numpy(det_uniform((C,), 10, -0.5, 0.5))
+    rm, rv = torch.zeros(C), torch.ones(C)
+    want = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    flat = xn.view(rows, C)
+    part = torch.stack([flat.sum(0), (flat * flat).sum(0)], dim=1)[None].contiguous()      # one "block"
+    ss = torch.empty(4, C, device=dev)
+    rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    hipabi.check(L.straps_bn_stats_finalize(hipabi.ptr(part), 1, C, rows, hipabi.ptr(gamma.to(dev)), hipabi.ptr(beta.to(dev)), 1e-5, 0.1,
+                                            hipabi.ptr(rmd), hipabi.ptr(rvd), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(ss[2]),
+                                            hipabi.ptr(ss[3]), None), 'finalize')
+    out = torch.empty_like(xn)
+    hipabi.check(L.straps_bn_apply(hipabi.ptr(xn), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), None, 0, hipabi.ptr(out), rows, C, None), 'apply')
+    _close(out.permute(0, 3, 1, 2), want, 2e-5, 2e-5, 'bn train apply')
+    _close(rmd, rm, 1e-6, 1e-5, 'running_mean')
+    _close(rvd, rv, 1e-6, 1e-5, 'running_var')
+
+
+# ------------------------------------------------------------------------------------------ IEF / full nets
+def _load_det(reg, layers, dev):
+    man = json.load(open(os.path.join(GOLD, 'state_dict_keys_r%d.json' % layers)))['keys']
+    sd = {k: torch.from_numpy(v) for k, v in det_state_dict(man).items()}
+    reg.load_state_dict(sd, strict=True)
+    return reg.to(dev), sd
+
+
+@pytest.mark.parametrize('layers,F_', [(18, 512), (50, 2048)])
+def test_ief_vs_reference_golden(dev, layers, F_):
+    gold = np.load(os.path.join(GOLD, 'small_golden.npz'))
+    reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+    feat = torch.from_numpy(det_uniform((4, F_), 31, 0.0, 2.0))
+    with torch.no_grad():
+        cam, pose, shape = reg.ief_module(feat.to(dev))
+    assert cam.shape == (4, 3) and pose.shape == (4, 144) and shape.shape == (4, 10)
+    assert not pose.is_contiguous() and cam.data_ptr() == pose.data_ptr() - 12      # views of one buffer (:60-62)
+    _close(torch.cat([cam, pose, shape], 1), torch.from_numpy(gold['ief_r%d_out' % layers]), 2e-5, 2e-5, 'IEF vs golden')
+    # ragged batch (not a multiple of 32) vs oracle
+    feat2 = torch.from_numpy(det_uniform((37, F_), 77, 0.0, 2.0))
+    with torch.no_grad():
+        out = torch.cat(reg.ief_module(feat2.to(dev)), 1)
+        _, _, _, est = O.ief_forward(feat2, sd, O.ief_init_estimate(MP['pose'], MP['shape']), 3)
+    _close(out, est, 2e-5, 2e-5, 'IEF ragged vs oracle')
+
+
+@pytest.mark.parametrize('layers', [18, 50])
+def test_regressor_eval_vs_reference_golden(dev, layers):
+    """whole regressor on the committed golden vectors captured from the reference (eval mode)."""
+    gold = np.load(os.path.join(GOLD, 'encoder_golden.npz'))
+    reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+    reg.eval()
+    x = torch.from_numpy(det_uniform((2, 18, 256, 256), 4242, 0.0, 1.0)).to(dev)
+    with torch.no_grad():
+        feat = reg.image_encoder(x)
+        cam, pose, shape = reg(x)
+    tag = 'r%d_eval_' % layers
+    e1 = _close(feat, torch.from_numpy(gold[tag + 'feat_full']), 2e-4, 2e-4, 'features vs golden')
+    e2 = _close(torch.cat([cam, pose, shape], 1), torch.from_numpy(gold[tag + 'out']), 2e-4, 2e-4, 'outputs vs golden')
+    print('r%d eval: feature err %.2e, output err %.2e' % (layers, e1, e2))
+
+
+@pytest.mark.parametrize('layers', [18, 50])
+def test_regressor_train_mode_forward_vs_reference_golden(dev, layers):
+    """training-mode BatchNorm (batch statistics + running-stat update) vs the reference golden."""
+    gold = np.load(os.path.join(GOLD, 'encoder_golden.npz'))
+    reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+    reg.train()
+    x = torch.from_numpy(det_uniform((2, 18, 256, 256), 4242, 0.0, 1.0)).to(dev)
+    with torch.no_grad():
+        cam, pose, shape = reg(x)
+    tag = 'r%d_train_' % layers
+    _close(torch.cat([cam, pose, shape], 1), torch.from_numpy(gold[tag + 'out']), 5e-4, 5e-4, 'train-mode outputs vs golden')
+    sd2 = reg.state_dict()
+    for bn in ('image_encoder.bn1', 'image_encoder.layer2.0.downsample.1', 'image_encoder.layer4.1.bn2'):
+        _close(sd2[bn + '.running_mean'], torch.from_numpy(gold[tag + bn + '.running_mean']), 1e-5, 1e-4, bn + ' running_mean')
+        _close(sd2[bn + '.running_var'], torch.from_numpy(gold[tag + bn + '.running_var']), 1e-5, 1e-4, bn + ' running_var')
+        assert int(sd2[bn + '.num_batches_tracked']) == 1
+
+
+def test_batch64_forward_consistency(dev):
+    """BASELINE config 2 shape (B=64): batch rows are independent -- the first 3 rows of a 64-batch
+    equal a 3-batch run bit for bit (same tiles, same reduction order) and match the oracle."""
+    reg, sd = _load_det(straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP), 18, dev)
+    reg.eval()
+    x = torch.from_numpy(det_uniform((64, 18, 256, 256), 5151, 0.0, 1.0))
+    with torch.no_grad():
+        big = torch.cat(reg(x.to(dev)), 1)
+        small = torch.cat(reg(x[:3].to(dev)), 1)
+        _, _, _, est = O.regressor_forward(x[:3], sd, O.ief_init_estimate(MP['pose'], MP['shape']), 18, 3, False)
+    _close(big[:3], small, 1e-5, 1e-5, 'batch independence')
+    _close(small, est, 2e-4, 2e-4, 'vs oracle')
+    assert torch.isfinite(big).all()

@@ -1,0 +1,115 @@
+"""CPU: host-side logic of the drop-in modules -- state-dict keys / parameter order / seeded init
+identical to the reference (goldens captured by oracle/make_golden.py), SMPL model packing, and
+the no-CPU-fallback rule."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import straps_amd
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+MP = straps_amd.synthetic_mean_params(0)
+
+
+@pytest.mark.parametrize('layers', [18, 50])
+def test_state_dict_manifest_and_param_order(layers):
+    man = json.load(open(os.path.join(GOLD, 'state_dict_keys_r%d.json' % layers)))
+    m = straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(man['keys'].keys())
+    assert all(list(sd[k].shape) == man['keys'][k] for k in sd)
+    assert [n for n, _ in m.named_parameters()] == man['param_order']
+    assert len(sd) == {18: 132, 50: 330}[layers]
+    # duplicate registration: aliases share storage (models/ief_module.py:24-28)
+    assert sd['ief_module.fc1.weight'].data_ptr() == sd['ief_module.ief_layers.0.weight'].data_ptr()
+
+
+@pytest.mark.parametrize('layers', [18, 50])
+def test_seeded_construction_matches_reference(layers):
+    gold = json.load(open(os.path.join(GOLD, 'init_checksums.json')))['r%d' % layers]
+    torch.manual_seed(1234)
+    m = straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP)
+    sd = m.state_dict()
+    for k, (s, a, head) in gold.items():
+        v = sd[k]
+        assert float(v.double().sum()) == pytest.approx(s, rel=1e-9, abs=1e-9), k
+        assert float(v.double().abs().sum()) == pytest.approx(a, rel=1e-9, abs=1e-9), k
+        assert [float(x) for x in v.reshape(-1)[:3]] == head, k
+
+
+def test_load_state_dict_strict_roundtrip():
+    m = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP)
+    m2 = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP)
+    m2.load_state_dict(m.state_dict(), strict=True)
+    ck = {'epoch': 3, 'best_epoch': 2, 'best_epoch_val_metrics': {'pves_pa': np.float64(0.1)},
+          'model_state_dict': m.state_dict(), 'best_model_state_dict': m.state_dict(),
+          'optimiser_state_dict': torch.optim.Adam(m.parameters(), lr=1e-4).state_dict(), 'criterion_state_dict': {}}
+    keys = json.load(open(os.path.join(GOLD, 'criterion_keys.json')))['checkpoint_keys']
+    assert sorted(ck) == sorted(keys)
+
+
+def test_no_cpu_fallback():
+    m = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='GPU tensor'):
+        m(torch.zeros(1, 18, 256, 256))
+    smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=2)
+    with torch.no_grad(), pytest.raises(RuntimeError, match='GPU tensor'):
+        smpl(betas=torch.zeros(2, 10))
+    with pytest.raises(RuntimeError, match='GPU tensor'):
+        straps_amd.rot6d_to_rotmat(torch.zeros(2, 144))
+
+
+def test_missing_assets_raise_like_reference(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        straps_amd.SingleInputRegressor(18, 18, 3)
+    with pytest.raises(FileNotFoundError):
+        straps_amd.SMPL('additional/smpl', batch_size=1)
+    m = straps_amd.SingleInputRegressor(18, 34, 3, mean_params=MP)     # silently empty, fails late (regressor.py:28-41)
+    with pytest.raises(AttributeError):
+        m(torch.zeros(1, 18, 256, 256))
+
+
+def test_ief_initial_estimate():
+    m = straps_amd.IEFModule([512, 512], 512, 157, mean_params=MP)
+    v = m.initial_params_estimate
+    assert v.shape == (157,) and float(v[0]) == pytest.approx(0.9) and float(v[1]) == 0 and float(v[2]) == 0
+    np.testing.assert_array_equal(v[3:147].numpy(), MP['pose'])
+    np.testing.assert_array_equal(v[147:].numpy(), MP['shape'])
+    assert 'initial_params_estimate' not in m.state_dict()
+
+
+def test_smpl_model_packing_roundtrip():
+    model = straps_amd.synthetic_smpl_model(0)
+    pk = straps_amd.pack_smpl_model(model)
+    frag = pk['blend_frag'].reshape(216, 3, 28, 2, 32, 4)
+    # spot-check the fragment mapping D[8g+4h+e][32t+i][c]
+    for (t, c, g, h, i, e) in [(0, 0, 0, 0, 0, 0), (5, 1, 3, 1, 7, 2), (215, 2, 27, 0, 9, 1), (100, 0, 1, 1, 31, 3)]:
+        k, v = 8 * g + 4 * h + e, 32 * t + i
+        if v >= 6890 or k >= 218:
+            want = 0.0
+        elif k == 0:
+            want = model['v_template'][v, c]
+        elif k <= 10:
+            want = model['shapedirs'][v, c, k - 1]
+        else:
+            want = model['posedirs'][k - 11, v * 3 + c]
+        assert frag[t, c, g, h, i, e] == np.float32(want)
+    assert pk['skin_k'] == 4 and pk['max_depth'] == 8
+    W = np.zeros((6890, 24), np.float32)
+    np.add.at(W, (np.repeat(np.arange(6890), 4), pk['skin_j'][:6890].reshape(-1)), pk['skin_w'][:6890].reshape(-1))
+    np.testing.assert_array_equal(W, model['weights'])
+    # regressor entries reproduce the dense matrices
+    R = np.zeros((45, 6890), np.float32)
+    for q in range(216):
+        rnd = q // 4
+        for e in range(pk['jr_ptr'][q], pk['jr_ptr'][q + 1]):
+            code = int(pk['jr_code'][e])
+            j, vl, tw = code & 255, (code >> 8) & 255, code >> 16
+            assert j % 4 == q % 4
+            R[j, (rnd * 4 + tw) * 32 + vl] = pk['jr_w'][e]
+    want = np.concatenate([model['J_regressor_extra'], model['J_regressor_cocoplus'], model['J_regressor_h36m']])
+    np.testing.assert_array_equal(R, want)
