@@ -200,7 +200,8 @@ def test_stem_vs_cpu(dev, B, C, H, W):
     np.testing.assert_allclose(s[:, 1].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
     sc = torch.from_numpy(det_uniform((64,), 3, 0.5, 1.5))
     sh = torch.from_numpy(det_uniform((64,), 4, -0.5, 0.5))
-    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), hipabi.ptr(sc.to(dev)), hipabi.ptr(sh.to(dev)), 1, hipabi.ptr(y), None,
+    scd, shd = sc.to(dev), sh.to(dev)          # keep the device copies alive across the launch
+    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), hipabi.ptr(scd), hipabi.ptr(shd), 1, hipabi.ptr(y), None,
                                    B, C, H, W, None), 'stem fused')
     want = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
     _close(y.permute(0, 3, 1, 2), want, 3e-5, 3e-5, 'stem fused')
@@ -227,7 +228,8 @@ def test_pool_gap_bn_helpers(dev):
     part = torch.stack([flat.sum(0), (flat * flat).sum(0)], dim=1)[None].contiguous()      # one "block"
     ss = torch.empty(4, C, device=dev)
     rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-    hipabi.check(L.straps_bn_stats_finalize(hipabi.ptr(part), 1, C, rows, hipabi.ptr(gamma.to(dev)), hipabi.ptr(beta.to(dev)), 1e-5, 0.1,
+    gd, bd = gamma.to(dev), beta.to(dev)
+    hipabi.check(L.straps_bn_stats_finalize(hipabi.ptr(part), 1, C, rows, hipabi.ptr(gd), hipabi.ptr(bd), 1e-5, 0.1,
                                             hipabi.ptr(rmd), hipabi.ptr(rvd), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(ss[2]),
                                             hipabi.ptr(ss[3]), None), 'finalize')
     out = torch.empty_like(xn)
