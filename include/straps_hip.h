@@ -157,6 +157,18 @@ typedef struct {
     const int32_t* jr_code;
     const float* jr_w;
     const int32_t* pick_ids;   /* [21] vertex ids appended as joints 24..44                    */
+    /* ---- tables used only by straps_smpl_bwd (may be NULL for forward-only use) ---- */
+    /* transposed blend fragments [tile 216][coord 3][kblock 7][rq 4][lane 64][4]:
+     * element = D[k = 32*kblock + (lane&31)][vertex = 32*tile + row(4*rq+e, lane>>5)][coord],
+     * row(r,h) = (r&3) + 8*(r>>2) + 4*h (the MFMA C-layout row of accumulator register r).    */
+    const float* blend_frag_t;
+    const int32_t* children;   /* [24][3] child joints, -1 padded                              */
+    /* joint-gradient sources per vertex tile: entries of tile t in [jrt_ptr[t], jrt_ptr[t+1]);
+     * jrt_code = (v_local << 8) | src, src 0..20 = picked-vertex joints 24..44 (weight 1),
+     * src 21..65 = regressed joints 45..89.                                                   */
+    const int32_t* jrt_ptr;    /* [216 + 1] */
+    const int32_t* jrt_code;
+    const float* jrt_w;
 } straps_smpl_model_t;
 
 /* bytes of caller-owned scratch for `batch` bodies split into `chunks` vertex chunks           */
@@ -166,6 +178,113 @@ size_t straps_smpl_workspace_bytes(long long batch, int chunks);
 int straps_smpl_fwd(const straps_smpl_model_t* model, const float* betas, const float* rotmats,
                     float* verts, float* joints, void* workspace, long long batch, int chunks,
                     void* stream);
+
+/* gradient of straps_smpl_fwd w.r.t. betas [B,10] and rotmats [B,24,3,3] given dverts [B,6890,3]
+ * and/or djoints [B,90,3] (either may be NULL = zero) -- what autograd does through smplx.lbs for
+ * pred_smpl_output in loss.backward() (train loop :196,:232).                                    */
+size_t straps_smpl_bwd_workspace_bytes(long long batch, int chunks);
+int straps_smpl_bwd(const straps_smpl_model_t* model, const float* betas, const float* rotmats,
+                    const float* dverts, const float* djoints, float* dbetas, float* drotmats,
+                    void* workspace, long long batch, int chunks, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of the encoder / IEF / rot6d -- the work of loss.backward() (train loop :232) that
+ * cuDNN / cuBLAS / ATen kernels do for the reference.
+ * ------------------------------------------------------------------------------------------ */
+/* data gradient of straps_conv_fwd (same geometry arguments as the forward; h,w = forward INPUT
+ * size): dx = conv_transpose(dy, w) (+ addend, e.g. the skip-connection gradient).
+ * w_crsk from straps_pack_conv_weight_dgrad.  cout % 32 == 0, cin % 64 == 0, stride 1 or 2.      */
+int straps_conv_dgrad(const float* dy_nhwc, const float* w_crsk, const float* addend,
+                      float* dx_nhwc, int batch, int h, int w, int cin, int cout, int kh, int kw,
+                      int stride, int pad, int tile_cfg, void* stream);
+/* weight gradient in the parameter's own OIHW layout: dw (+)= sum_pixels dy (x) x.                */
+size_t straps_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int kh,
+                                         int kw, int stride, int pad);
+int straps_conv_wgrad(const float* x_nhwc, const float* dy_nhwc, float* dw_oihw, void* workspace,
+                      int batch, int h, int w, int cin, int cout, int kh, int kw, int stride,
+                      int pad, int accumulate, void* stream);
+/* stem weight gradient straight from the NCHW input (the input itself needs no gradient).        */
+size_t straps_stem_wgrad_workspace_bytes(int batch, int cin, int h, int w);
+int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, void* workspace,
+                      int batch, int cin, int h, int w, int accumulate, void* stream);
+/* training-mode BatchNorm backward with the ReLU mask fused: dz = dy * (yact > 0) (yact NULL = no
+ * ReLU), dgamma/dbeta, draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (optional,
+ * may alias dy) receives dz for the skip connection.                                             */
+int straps_bn_bwd_blocks(long long rows);
+size_t straps_bn_bwd_workspace_bytes(long long rows, int c);
+int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean,
+                  const float* save_invstd, const float* gamma, float* dgamma, float* dbeta,
+                  float* draw, float* dz_out, void* workspace, long long rows, int c,
+                  int accumulate, void* stream);
+/* max-pool forward that also records the arg-max tap (uint8 per element), and its backward.      */
+int straps_maxpool_fwd_idx(const float* x_nhwc, float* y_nhwc, uint8_t* idx, int batch, int h,
+                           int w, int c, void* stream);
+int straps_maxpool_bwd(const float* dy_nhwc, const uint8_t* idx, float* dx_nhwc, int batch, int h,
+                       int w, int c, void* stream);
+int straps_gap_bwd(const float* dfeat, float* dx_nhwc, int batch, int hw, int c, void* stream);
+/* small strided GEMM on the fp32 MFMA: c[m][n] (+)= mask?(sum_k a[m*sam + k*sak] * b[k*sbk + n*sbn])
+ * (linear-layer data / weight gradients of the IEF, models/ief_module.py:16-18).                 */
+int straps_gemm_strided(const float* a, long long sam, long long sak, const float* b,
+                        long long sbk, long long sbn, float* c, int ldc, const float* mask,
+                        int ldmask, int m, int n, int k, int accumulate, void* stream);
+/* out[n] (+)= sum_m x[m][n] * (mask[m][n] > 0)   (bias gradients)                                 */
+int straps_colsum(const float* x, int ldx, const float* mask, int ldmask, float* out, int m, int n,
+                  int accumulate, void* stream);
+/* y[m][n] (+)= x[m][n] * (mask[m][n] > 0)        (ReLU backward on small matrices)                */
+int straps_masked_copy(const float* x, int ldx, const float* mask, int ldmask, float* y, int ldy,
+                       int m, int n, int accumulate, void* stream);
+/* gradient of straps_rot6d_fwd: drot [rows*per_row][3][3] -> dx6 [rows][ldd].                    */
+int straps_rot6d_bwd(const float* x6, long long ld, int per_row, const float* drot, float* dx6,
+                     long long ldd, long long rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Train-step glue: input construction, prediction heads + multi-task loss, Adam.
+ * ------------------------------------------------------------------------------------------ */
+/* utils/label_conversions.py:48-55 + :90-127 + train loop :178-182 in ONE pass: seg [B,H,W] part
+ * ids -> channel 0 = (seg != 0), channels 1..nj = 16x16 truncated Gaussian heat-maps of the
+ * (int-truncated) joints2d [B,nj,2]; writes the NCHW network input [B,1+nj,wh,wh].                */
+int straps_build_proxy_input(const float* seg, const float* joints2d, float* out_nchw, int batch,
+                             int nj, int wh, void* stream);
+/* prediction heads + HomoscedasticUncertaintyWeightedMultiTaskLoss (losses/multi_task_loss.py:76-119,
+ * reduction 'mean') fused with its own backward.  From pred joints [B,90,3], cam [B,3] (row
+ * stride ld_est) it forms joints2D = orthographic projection of the 17 COCO joints
+ * (utils/cam_utils.py:5-26, config.py:27) and joints3D = 14 H36M-LSP joints (config.py:28-32);
+ * visibility of the target 2D joints per utils/joints2d_utils.py:23-32.
+ * loss_out[0] = total, [1..5] = weighted task losses (verts, joints2D, joints3D, shape, pose),
+ * [6..10] = raw MSEs, [11] = number of visible joints.  Gradients: dverts [B,6890,3],
+ * djoints [B,90,3], dest [B,ld_est] (cam cols 0..2, shape cols 147..156, rest zero),
+ * drot [B,24,3,3], dlogvar[5] (order verts, joints2D, joints3D, shape_params, pose_params).        */
+size_t straps_loss_workspace_bytes(long long batch);
+int straps_loss_fwd_bwd(const float* pred_verts, const float* pred_joints, const float* est,
+                        int ld_est, const float* pred_rot, const float* tgt_verts,
+                        const float* tgt_joints2d, const float* tgt_joints3d,
+                        const float* tgt_shape, const float* tgt_rot, const float* log_vars,
+                        float* loss_out, float* dverts, float* djoints, float* dest, float* drot,
+                        float* dlogvar, void* workspace, long long batch, int img_wh, void* stream);
+/* row-masked mean-squared error used by the drop-in criterion module (losses/multi_task_loss.py:78-112):
+ * out3 = {sum of squares, kept element count, mean}; the target is read as tgt*tgt_scale + tgt_shift
+ * (the 2x/256-1 normalisation of :92); row_mask (uint8 per row, may be NULL) is labels['vis'].
+ * workspace: 512 floats.  straps_mse_bwd: grad = coef[0] * (pred - target) on kept rows.             */
+int straps_mse_fwd(const float* pred, const float* tgt, const uint8_t* row_mask, long long rows,
+                   int cols, float tgt_scale, float tgt_shift, float* out3, void* workspace,
+                   void* stream);
+int straps_mse_bwd(const float* pred, const float* tgt, const uint8_t* row_mask, long long rows,
+                   int cols, float tgt_scale, float tgt_shift, const float* coef, float* grad,
+                   void* stream);
+/* random_remove_bodyparts + random_occlude (augmentation/proxy_rep_augmentation.py:52-101) in one
+ * pass over the part-id segmentation [B,wh,wh]: uniforms [B][9] in [0,1) (6 part-removal draws,
+ * 1 occlusion draw, 2 box-centre draws), remove_prob[6] device array.                              */
+int straps_augment_seg(const float* seg, const float* uniforms, const float* remove_prob,
+                       float occlude_prob, int box_dim, float* out, int batch, int wh, void* stream);
+/* STAND-IN for the part-segmentation rasteriser (renderers/nmr_renderer.py; SURVEY 8f row f1, not built):
+ * labels discs around the 17 projected COCO joints (+ a torso box) with the 6 LSP part ids.          */
+int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream);
+/* torch.optim.Adam defaults (run_train.py:200-201) over one flat fp32 buffer:
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).                           */
+int straps_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                     long long n, int step, float lr, float beta1, float beta2, float eps,
+                     float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

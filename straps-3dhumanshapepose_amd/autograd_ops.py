@@ -1,0 +1,262 @@
+"""torch.autograd glue: the drop-in modules stay ordinary autograd citizens (`loss.backward()`,
+`optimiser.step()` of the reference train loop :230-233 work unchanged) while every gradient is
+computed by the HIP kernels behind the C ABI.  Nothing here does arithmetic in torch.
+"""
+import ctypes as C
+
+import torch
+
+from . import hipabi
+from .encoder_exec import encoder_forward
+from .ief_module import EST_LD
+
+
+def _empty_like(t):
+    return torch.empty_like(t, memory_format=torch.contiguous_format)
+
+
+# ------------------------------------------------------------------------------------------ encoder
+def _packed_dgrad_weight(net, conv):
+    w = conv.weight
+
+    def make():
+        wd = w.detach().contiguous()
+        out = torch.empty(wd.numel(), device=wd.device, dtype=torch.float32)
+        hipabi.check(hipabi.lib().straps_pack_conv_weight_dgrad(hipabi.ptr(wd), hipabi.ptr(out), wd.shape[0], wd.shape[1], wd.shape[2],
+                                                                wd.shape[3], hipabi.stream_ptr()), 'straps_pack_conv_weight_dgrad')
+        return out
+    return net._cached(('wd', id(conv)), [w], make)
+
+
+def _bn_bwd(L, rec, dy, masked, want_dz, grads):
+    """BatchNorm(train) + ReLU backward of one tape record; returns (draw, dz|None)."""
+    bn = rec['bn']
+    raw, ss = rec['raw'], rec['stats']
+    rows, Cc = raw.numel() // raw.shape[-1], raw.shape[-1]
+    ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, Cc) // 4, device=raw.device, dtype=torch.float32)
+    dgamma, dbeta = torch.empty_like(bn.weight), torch.empty_like(bn.bias)
+    draw = _empty_like(raw)
+    dz = _empty_like(raw) if want_dz else None
+    hipabi.check(L.straps_bn_bwd(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
+                                 hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw),
+                                 hipabi.ptr(dz), hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
+    grads[bn.weight] = dgamma
+    grads[bn.bias] = dbeta
+    return draw, dz
+
+
+def _conv_wgrad(L, rec, draw, grads):
+    conv = rec['conv']
+    B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
+    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=draw.device, dtype=torch.float32)
+    dw = torch.empty_like(conv.weight)
+    hipabi.check(L.straps_conv_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride,
+                                     pad, 0, hipabi.stream_ptr()), 'straps_conv_wgrad')
+    grads[conv.weight] = dw
+
+
+def _conv_dgrad(L, net, rec, draw, addend):
+    conv = rec['conv']
+    B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
+    dx = torch.empty(B, H, W, Cin, device=draw.device, dtype=torch.float32)
+    hipabi.check(L.straps_conv_dgrad(hipabi.ptr(draw), hipabi.ptr(_packed_dgrad_weight(net, conv)), hipabi.ptr(addend), hipabi.ptr(dx), B, H, W,
+                                     Cin, Cout, k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_dgrad')
+    return dx
+
+
+def encoder_backward(net, tape, dfeat):
+    """tape: dict filled by encoder_forward(net, x, tape) in training mode.  Returns {param: grad}."""
+    L = hipabi.lib()
+    grads = {}
+    rec = tape['gap']
+    B, HW, Cf = rec['geom']
+    dy = _empty_like(rec['x'])
+    hipabi.check(L.straps_gap_bwd(hipabi.ptr(dfeat.contiguous()), hipabi.ptr(dy), B, HW, Cf, hipabi.stream_ptr()), 'straps_gap_bwd')
+    for li in range(4, 0, -1):
+        for unit in reversed(list(getattr(net, 'layer%d' % li))):
+            pairs = unit.conv_bn_pairs()
+            rec = tape[id(pairs[-1][0])]
+            draw, dz = _bn_bwd(L, rec, dy, True, True, grads)          # ReLU(out) mask; dz feeds the skip connection
+            _conv_wgrad(L, rec, draw, grads)
+            if unit.downsample is not None:
+                recd = tape[id(unit.downsample[0])]
+                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads)
+                _conv_wgrad(L, recd, drawd, grads)
+                dskip = _conv_dgrad(L, net, recd, drawd, None)
+            else:
+                dskip = dz
+            for ci in range(len(pairs) - 1, 0, -1):
+                dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None)
+                rec = tape[id(pairs[ci - 1][0])]
+                draw, _ = _bn_bwd(L, rec, dt, True, False, grads)
+                _conv_wgrad(L, rec, draw, grads)
+            dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip)   # + skip gradient fused in the epilogue
+    rec = tape['maxpool']
+    B, H, W, Cc, Hp, Wp = rec['geom']
+    dstem = _empty_like(rec['x'])
+    hipabi.check(L.straps_maxpool_bwd(hipabi.ptr(dy), hipabi.ptr(rec['idx']), hipabi.ptr(dstem), B, H, W, Cc, hipabi.stream_ptr()),
+                 'straps_maxpool_bwd')
+    rec = tape['stem']
+    draw, _ = _bn_bwd(L, rec, dstem, True, False, grads)
+    B, Cin, H, W, Ho, Wo = rec['geom']
+    ws = torch.empty(L.straps_stem_wgrad_workspace_bytes(B, Cin, H, W) // 4, device=draw.device, dtype=torch.float32)
+    dw = torch.empty_like(net.conv1.weight)
+    hipabi.check(L.straps_stem_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, Cin, H, W, 0,
+                                     hipabi.stream_ptr()), 'straps_stem_wgrad')
+    grads[net.conv1.weight] = dw
+    return grads
+
+
+# ------------------------------------------------------------------------------------------ IEF
+def ief_backward(ief, feat, tape, dest):
+    """dest: gradient w.r.t. the final estimate [B,160].  Returns (dfeat, {param: grad})."""
+    L, st = hipabi.lib(), hipabi.stream_ptr()
+    pk = ief._packed(feat.device)
+    B, F = feat.shape
+    H1, H2, P = ief.fc1.out_features, ief.fc2.out_features, ief.num_output_params
+    dev = feat.device
+    z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+    e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    dW3, db3, dW2, db2 = z(P, H2), z(P), z(H2, H1), z(H2)
+    dW1 = z(H1, F + P)
+    dc1 = z(B, H1)
+    dest = dest.contiguous().clone()
+    gemm, colsum = L.straps_gemm_strided, L.straps_colsum
+    for it in reversed(range(len(tape))):
+        rec = tape[it]
+        est_in, h1, h2 = rec['est_in'], rec['h1'], rec['h2']
+        # est_out = est_in + h2 @ W3^T + b3
+        dh2 = e(B, H2)
+        hipabi.check(gemm(hipabi.ptr(dest), EST_LD, 1, hipabi.ptr(ief.fc3.weight), H2, 1, hipabi.ptr(dh2), H2, hipabi.ptr(h2), H2, B, H2, P, 0, st),
+                     'ief d_h2')                                   # masked by relu(h2) > 0  -> d pre-activation of fc2
+        hipabi.check(gemm(hipabi.ptr(dest), 1, EST_LD, hipabi.ptr(h2), H2, 1, hipabi.ptr(dW3), H2, None, 0, P, H2, B, 1, st), 'ief dW3')
+        hipabi.check(colsum(hipabi.ptr(dest), EST_LD, None, 0, hipabi.ptr(db3), B, P, 1, st), 'ief db3')
+        # h2 = relu(h1 @ W2^T + b2): dh2 already masked
+        dh1 = e(B, H1)
+        hipabi.check(gemm(hipabi.ptr(dh2), H2, 1, hipabi.ptr(ief.fc2.weight), H1, 1, hipabi.ptr(dh1), H1, hipabi.ptr(h1), H1, B, H1, H2, 0, st),
+                     'ief d_h1')                                   # masked by relu(h1) > 0
+        hipabi.check(gemm(hipabi.ptr(dh2), 1, H2, hipabi.ptr(h1), H1, 1, hipabi.ptr(dW2), H1, None, 0, H2, H1, B, 1, st), 'ief dW2')
+        hipabi.check(colsum(hipabi.ptr(dh2), H2, None, 0, hipabi.ptr(db2), B, H2, 1, st), 'ief db2')
+        # h1 = relu(c1 + est_in @ W1e^T): dh1 is d pre-activation
+        hipabi.check(L.straps_masked_copy(hipabi.ptr(dh1), H1, None, 0, hipabi.ptr(dc1), H1, B, H1, 1, st), 'ief dc1')
+        hipabi.check(gemm(hipabi.ptr(dh1), H1, 1, hipabi.ptr(pk['w1e']), EST_LD, 1, hipabi.ptr(dest), EST_LD, None, 0, B, P, H1, 1, st),
+                     'ief d_est')                                  # dest += dh1 @ W1e  (est_out = est_in + ...)
+        hipabi.check(gemm(hipabi.ptr(dh1), 1, H1, hipabi.ptr(est_in), EST_LD, 1, C.c_void_p(dW1.data_ptr() + 4 * F), F + P, None, 0, H1, P, B,
+                          1, st), 'ief dW1e')
+    # c1 = feat @ W1f^T + b1
+    dfeat = e(B, F)
+    hipabi.check(gemm(hipabi.ptr(dc1), H1, 1, hipabi.ptr(pk['w1f']), F, 1, hipabi.ptr(dfeat), F, None, 0, B, F, H1, 0, st), 'ief d_feat')
+    hipabi.check(gemm(hipabi.ptr(dc1), 1, H1, hipabi.ptr(feat), F, 1, hipabi.ptr(dW1), F + P, None, 0, H1, F, B, 1, st), 'ief dW1f')
+    db1 = z(H1)
+    hipabi.check(colsum(hipabi.ptr(dc1), H1, None, 0, hipabi.ptr(db1), B, H1, 1, st), 'ief db1')
+    grads = {ief.fc1.weight: dW1, ief.fc1.bias: db1, ief.fc2.weight: dW2, ief.fc2.bias: db2, ief.fc3.weight: dW3, ief.fc3.bias: db3}
+    return dfeat, grads
+
+
+class _RegressorFn(torch.autograd.Function):
+    """input [B,C,H,W] -> estimate buffer [B,160]; parameters are explicit inputs so autograd
+    accumulates their .grad like for any other module."""
+
+    @staticmethod
+    def forward(ctx, reg, x, *params):
+        enc_tape, ief_tape = {}, []
+        with torch.no_grad():
+            feat = encoder_forward(reg.image_encoder, x, enc_tape)
+            est = reg.ief_module.forward_estimate(feat, ief_tape)
+        ctx.reg, ctx.feat, ctx.enc_tape, ctx.ief_tape, ctx.params = reg, feat, enc_tape, ief_tape, params
+        return est
+
+    @staticmethod
+    def backward(ctx, dest):
+        reg = ctx.reg
+        dfeat, g_ief = ief_backward(reg.ief_module, ctx.feat, ctx.ief_tape, dest)
+        g_enc = encoder_backward(reg.image_encoder, ctx.enc_tape, dfeat)
+        g_enc.update(g_ief)
+        out = [g_enc.get(p) if p.requires_grad else None for p in ctx.params]
+        ctx.enc_tape = ctx.ief_tape = None
+        return (None, None) + tuple(out)
+
+
+def regressor_autograd(reg, x):
+    hipabi.require_gpu_tensor(x, 'regressor input', torch.float32)
+    if not reg.training:
+        raise RuntimeError('gradients through the encoder are implemented for training-mode BatchNorm only; call .train() '
+                           '(or torch.no_grad() for inference)')
+    params = list(reg.parameters())
+    est = _RegressorFn.apply(reg, x, *params)
+    P = reg.ief_module.num_output_params
+    return est[:, :3], est[:, 3:3 + 24 * 6], est[:, 3 + 24 * 6:P]
+
+
+class _IefFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ief, feat, *params):
+        tape = []
+        with torch.no_grad():
+            est = ief.forward_estimate(feat, tape)
+        ctx.ief, ctx.feat, ctx.tape, ctx.params = ief, feat.detach().contiguous(), tape, params
+        return est
+
+    @staticmethod
+    def backward(ctx, dest):
+        dfeat, g = ief_backward(ctx.ief, ctx.feat, ctx.tape, dest)
+        return (None, dfeat) + tuple(g.get(p) if p.requires_grad else None for p in ctx.params)
+
+
+def ief_autograd(ief, feat):
+    return _IefFn.apply(ief, feat, *list(ief.parameters()))
+
+
+# ------------------------------------------------------------------------------------------ rot6d / SMPL
+class _Rot6dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from .rigid_transform_utils import _rot6d_fwd
+        ctx.save_for_backward(x)
+        return _rot6d_fwd(x.detach())
+
+    @staticmethod
+    def backward(ctx, dR):
+        (x,) = ctx.saved_tensors
+        xd = x.detach()
+        if xd.dim() == 2 and xd.stride(1) == 1 and xd.shape[1] % 6 == 0 and xd.stride(0) >= xd.shape[1]:
+            rows, per_row, ld = xd.shape[0], xd.shape[1] // 6, xd.stride(0)
+            dx = torch.empty(rows, xd.shape[1], device=xd.device, dtype=torch.float32)
+        else:
+            xd = xd.contiguous().view(-1, 6)
+            rows, per_row, ld = xd.shape[0], 1, 6
+            dx = torch.empty(rows, 6, device=xd.device, dtype=torch.float32)
+        hipabi.check(hipabi.lib().straps_rot6d_bwd(hipabi.ptr(xd), ld, per_row, hipabi.ptr(dR.contiguous()), hipabi.ptr(dx), dx.stride(0), rows,
+                                                   hipabi.stream_ptr()), 'straps_rot6d_bwd')
+        return dx.view(x.shape)
+
+
+def rot6d_autograd(x):
+    return _Rot6dFn.apply(x)
+
+
+class _SmplFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, smpl, betas, rotmats):
+        b, r = betas.detach().float().contiguous(), rotmats.detach().float().contiguous()
+        verts, joints = smpl.forward_arrays(b, r)
+        ctx.smpl, ctx.b, ctx.r = smpl, b, r
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, dverts, djoints):
+        smpl, b, r = ctx.smpl, ctx.b, ctx.r
+        L = hipabi.lib()
+        B = b.shape[0]
+        dbetas = torch.empty_like(b)
+        drot = torch.empty_like(r)
+        ws = torch.empty(L.straps_smpl_bwd_workspace_bytes(B, 0) // 4, device=b.device, dtype=torch.float32)
+        dv = dverts.contiguous() if dverts is not None else None
+        dj = djoints.contiguous() if djoints is not None else None
+        hipabi.check(L.straps_smpl_bwd(C.byref(smpl._model_struct()), hipabi.ptr(b), hipabi.ptr(r), hipabi.ptr(dv), hipabi.ptr(dj),
+                                       hipabi.ptr(dbetas), hipabi.ptr(drot), hipabi.ptr(ws), B, 0, hipabi.stream_ptr()), 'straps_smpl_bwd')
+        return None, dbetas, drot
+
+
+def smpl_forward_autograd(smpl, betas, rotmats):
+    return _SmplFn.apply(smpl, betas, rotmats)

@@ -1,0 +1,747 @@
+// backward.hip -- gradient kernels of the encoder / IEF / rot6d (what autograd + cuDNN/cuBLAS do for the
+// reference's loss.backward(), train/train_synthetic_otf_rendering.py:232).
+//
+//   conv_wgrad_kernel      dW[co][r][s][ci] = sum_m dy[m][co] * x[m@(r,s)][ci]   -- fp32 MFMA, contraction over the
+//                          B*Ho*Wo pixels, split over many workgroups (deterministic partials + fixed-order reduce
+//                          that also transposes KRSC -> OIHW, the layout of the parameter's .grad)
+//   stem_wgrad_kernel      same for the 7x7/s2 stem straight from the NCHW input (LDS halo patch, like stem.hip)
+//   bn_bwd_*               training-mode BatchNorm backward with the ReLU mask fused (two passes: reduce, apply)
+//   maxpool / gap backward
+//   gemm_strided_kernel    small generic C[M,N] (+)= A.B with arbitrary strides (IEF linear dgrad / wgrad)
+//   rot6d_bwd_kernel       Gram-Schmidt backward
+#include "common.h"
+
+namespace {
+
+// =====================================================================================================
+// conv weight gradient
+// =====================================================================================================
+struct WgradP {
+    const float* x;    // [B][H][W][Cin]
+    const float* dy;   // [B][Ho][Wo][Cout]
+    float* part;       // [splits][Cout][R*S][Cin]
+    int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
+    int M, rows_per_split, ct, it;   // ct = Cout/64 tiles, it = Cin/64 tiles
+};
+
+constexpr int WL = 68;   // LDS row stride (floats) of the [32 pixels][64 channels] staging tiles
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+    __shared__ __attribute__((aligned(16))) float Ds[2][32][WL];
+    __shared__ __attribute__((aligned(16))) float Xs[2][32][WL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = blockIdx.x;
+    const int itile = t % p.it; t /= p.it;
+    const int ctile = t % p.ct; t /= p.ct;
+    const int tap = t;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int split = blockIdx.y;
+    const int co0 = ctile * 64, ci0 = itile * 64;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(mbeg + p.rows_per_split, p.M);
+    const int nsteps = (mend - mbeg + 31) >> 5;
+
+    const int lr = tid >> 4, lc = tid & 15;   // 16 rows x 16 float4 per pass, 2 passes
+    const int HoWo = p.Ho * p.Wo;
+    f32x4 rd[2], rx[2];
+    auto load_tile = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = mbeg + st * 32 + lr + 16 * q;
+            f32x4 vd = {0.f, 0.f, 0.f, 0.f}, vx = vd;
+            if (m < mend) {
+                vd = *reinterpret_cast<const f32x4*>(p.dy + (long long)m * p.Cout + co0 + lc * 4);
+                const int b = m / HoWo;
+                const int rem = m - b * HoWo;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    vx = *reinterpret_cast<const f32x4*>(p.x + (((long long)b * p.H + hi) * p.W + wi) * p.Cin + ci0 + lc * 4);
+            }
+            rd[q] = vd;
+            rx[q] = vx;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<f32x4*>(&Ds[buf][lr + 16 * q][lc * 4]) = rd[q];
+            *reinterpret_cast<f32x4*>(&Xs[buf][lr + 16 * q][lc * 4]) = rx[q];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    if (nsteps > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int i = lane & 31, h = lane >> 5;
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) load_tile(st + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = kk * 8 + h * 4 + e;
+                acc = mfma32(Ds[buf][k][wm * 32 + i], Xs[buf][k][wn * 32 + i], acc);
+            }
+        }
+        if (st + 1 < nsteps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // C layout: lane -> ci (col), reg -> co (row).  partial[split][co][tap][ci]
+    const long long RS = (long long)p.R * p.S;
+    float* o = p.part + (long long)split * p.Cout * RS * p.Cin;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int co = co0 + wm * 32 + mfma_row(q, lane);
+        o[((long long)co * RS + tap) * p.Cin + ci0 + wn * 32 + i] = acc[q];
+    }
+}
+
+// dW_oihw[co][ci][r][s] = sum_split part[split][co][tap][ci]   (fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
+                                                           int Cout, int Cin, int RS, int accumulate) {
+    const long long n = (long long)Cout * RS * Cin;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // KRSC index: coalesced partial reads
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(long long)k * n + idx];
+    const int ci = (int)(idx % Cin);
+    long long t = idx / Cin;
+    const int tap = (int)(t % RS);
+    const int co = (int)(t / RS);
+    const long long o = ((long long)co * Cin + ci) * RS + tap;
+    dw[o] = accumulate ? dw[o] + s : s;
+}
+
+// =====================================================================================================
+// stem weight gradient (no data gradient is needed: the network input does not require grad)
+// =====================================================================================================
+constexpr int PH = 13, PW = 72, TY = 4, TX = 32;
+
+// each workgroup walks `tiles_per_block` output tiles (4 rows x 32 cols x 64 channels of dy) and accumulates
+// dW[64][Kp] (Kp = C*49 padded to 32) in registers: wave w owns the K column blocks n with n % 4 == w.
+template <int NB>   // NB = column blocks of 32 per wave (C*49 <= 128*NB)
+__global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ part, int B, int C, int H, int W, int Ho, int Wo,
+                                                            int tiles_x, int tiles_y, int K, int Kp, int tiles_per_block, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                                             // [C][PH][PW]
+    float* dys = patch + C * PH * PW;                                // [128 pixels][64 + 4]
+    int* koff = reinterpret_cast<int*>(dys + 128 * 68);              // [Kp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    for (int k = tid; k < Kp; k += 256) {
+        int o = 0;
+        if (k < K) {
+            const int c = k / 49, rs = k - c * 49;
+            const int r = rs / 7, s = rs - r * 7;
+            o = (c * PH + r) * PW + s;
+        }
+        koff[k] = o;
+    }
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][nb][q] = 0.f;
+
+    const int t0 = blockIdx.x * tiles_per_block;
+    const int t1 = min(t0 + tiles_per_block, ntiles);
+    for (int tile = t0; tile < t1; ++tile) {
+        int bid = tile;
+        const int b = bid / (tiles_x * tiles_y);
+        bid -= b * tiles_x * tiles_y;
+        const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
+        const int y0 = ty * TY, x0 = tx * TX;
+        const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
+        __syncthreads();   // previous tile's LDS reads are done
+        for (int idx = tid; idx < C * PH * PW; idx += 256) {
+            const int col = idx % PW;
+            const int rc = idx / PW;
+            const int row = rc % PH, c = rc / PH;
+            const int hi = hi0 + row, wi = wi0 + col;
+            float v = 0.f;
+            if (col < 2 * TX + 5 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                v = x[(((long long)b * C + c) * H + hi) * W + wi];
+            patch[idx] = v;
+        }
+        for (int idx = tid; idx < 128 * 16; idx += 256) {
+            const int pix = idx >> 4, c4 = idx & 15;
+            const int yo = y0 + (pix >> 5), xo = x0 + (pix & 31);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (yo < Ho && xo < Wo) v = *reinterpret_cast<const f32x4*>(dy + (((long long)b * Ho + yo) * Wo + xo) * 64 + c4 * 4);
+            *reinterpret_cast<f32x4*>(dys + pix * 68 + c4 * 4) = v;
+        }
+        __syncthreads();
+        // contraction over the 128 pixels: A[co][pix] = dys[pix][co], B[pix][k] = patch[koff[k] + 2*py*PW + 2*px]
+#pragma unroll 2
+        for (int g = 0; g < 16; ++g) {           // 16 groups of 8 pixels
+            float a0[4], a1[4];
+            int poff[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pix = g * 8 + h * 4 + e;
+                a0[e] = dys[pix * 68 + i];
+                a1[e] = dys[pix * 68 + 32 + i];
+                poff[e] = (2 * (pix >> 5)) * PW + 2 * (pix & 31);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int kcol = (nb * 4 + wave) * 32 + i;
+                const int ko = kcol < Kp ? koff[kcol] : 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bv = patch[ko + poff[e]];
+                    acc[0][nb] = mfma32(a0[e], bv, acc[0][nb]);
+                    acc[1][nb] = mfma32(a1[e], bv, acc[1][nb]);
+                }
+            }
+        }
+    }
+    // partial[block][co][k]
+    float* o = part + (long long)blockIdx.x * 64 * Kp;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int kcol = (nb * 4 + wave) * 32 + i;
+            if (kcol < Kp) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) o[(long long)(a * 32 + mfma_row(q, lane)) * Kp + kcol] = acc[a][nb][q];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblocks,
+                                                                int K, int Kp, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // over [64][K]
+    if (idx >= 64 * K) return;
+    const int co = idx / K, k = idx - co * K;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[((long long)b * 64 + co) * Kp + k];
+    dw[idx] = accumulate ? dw[idx] + s : s;      // OIHW row co is (c,r,s)-ordered == k
+}
+
+// =====================================================================================================
+// BatchNorm (training) backward with fused ReLU mask
+// =====================================================================================================
+// pass 1: per-block partial sums of dz and dz*xhat, dz = dy * (y > 0 if masked)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
+                                                            const float* __restrict__ raw, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ part, long long rows,
+                                                            int C, int rows_per_block) {
+    __shared__ float red[256][8];
+    const int C4 = C >> 2;
+    const int TC = C4 < 256 ? C4 : 256;       // column groups handled per block pass
+    const int TR = 256 / TC;
+    const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int cb = 0; cb < C4; cb += TC) {
+        const int c4 = cb + tc;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (tr < TR) {
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+            for (long long r = r0 + tr; r < r1; r += TR) {
+                const long long o = r * C + c4 * 4;
+                f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+                if (yact) {
+                    const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
+                }
+                const f32x4 xh = (*reinterpret_cast<const f32x4*>(raw + o) - mu) * is;
+                s1 += g;
+                s2 += g * xh;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][4 + e] = s2[e]; }
+        __syncthreads();
+        if (tr == 0) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = red[tc][e];
+            for (int q = 1; q < TR; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += red[q * TC + tc][e];
+            float* o = part + ((long long)blockIdx.x * C + c4 * 4) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e * 2 + 0] = t[e]; o[e * 2 + 1] = t[4 + e]; }
+        }
+    }
+}
+
+// per channel: dbeta = S1, dgamma = S2; coefficients for the apply pass: k1 = gamma*invstd, m1 = S1/N, m2 = S2/N
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
+                                                             const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ coef, int accumulate) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = lane; k < nblocks; k += 64) {
+        s1 += (double)part[((long long)k * C + c) * 2 + 0];
+        s2 += (double)part[((long long)k * C + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane == 0) {
+        dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+        coef[c] = gamma[c] * invstd[c];
+        coef[C + c] = (float)(s1 / count);
+        coef[2 * C + c] = (float)(s2 / count);
+    }
+}
+
+// pass 2: draw = k1 * (dz - m1 - xhat*m2);  optionally also writes dz (the gradient the skip connection receives)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
+                                                           const float* __restrict__ raw, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           float* __restrict__ draw, float* dz_out, long long n4, int C) {
+    const int C4 = C >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+        if (yact) {
+            const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + idx * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(coef + C + c4 * 4);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4 * 4);
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(raw + idx * 4) - mu) * is;
+        if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = g;
+        *reinterpret_cast<f32x4*>(draw + idx * 4) = k1 * (g - m1 - xh * m2);
+    }
+}
+
+// =====================================================================================================
+// pooling backward
+// =====================================================================================================
+// training-mode max-pool: also records the arg-max tap (first maximum in row-major scan order, like ATen)
+__global__ __launch_bounds__(256) void maxpool_idx_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                                          int B, int H, int W, int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const long long n = (long long)B * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int am[4] = {0, 0, 0, 0};
+        bool first = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long long)b * H + hi) * W + wi) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (first || v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; am[e] = r * 3 + s; }
+                first = false;
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+        *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4((unsigned char)am[0], (unsigned char)am[1], (unsigned char)am[2], (unsigned char)am[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const long long n = (long long)B * H * W * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int wi = (int)(t % W); t /= W;
+        const int hi = (int)(t % H);
+        const int b = (int)(t / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows (ho,wo) with 2*ho-1 <= hi <= 2*ho+1
+        const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;
+        const int wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            const int r = hi - (2 * ho - 1);
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                const int s = wi - (2 * wo - 1);
+                const long long o = (((long long)b * Ho + ho) * Wo + wo) * C + c4 * 4;
+                const uchar4 k = *reinterpret_cast<const uchar4*>(idx + o);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                const int want = r * 3 + s;
+                if (k.x == want) g[0] += d[0];
+                if (k.y == want) g[1] += d[1];
+                if (k.z == want) g[2] += d[2];
+                if (k.w == want) g[3] += d[3];
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ dx, int B, int HW, int C) {
+    const long long n = (long long)B * HW * C;
+    const float inv = 1.0f / (float)HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long b = i / ((long long)HW * C);
+        dx[i] = dfeat[b * C + c] * inv;
+    }
+}
+
+// =====================================================================================================
+// small strided GEMM on the fp32 MFMA:  C[m][n] = (mask? ...)(sum_k A(m,k) * B(k,n)) (+ C)
+// =====================================================================================================
+// A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn].  One 32x32 tile per wave, 4 tiles (along n) per block.
+__global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restrict__ a, long long sam, long long sak,
+                                                           const float* __restrict__ b, long long sbk, long long sbn, float* c,
+                                                           int ldc, const float* __restrict__ mask, int ldmask, int M, int N, int K,
+                                                           int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = (blockIdx.x * 4 + wave) * 32;
+    if (n0 >= N) return;
+    const int mr = min(m0 + i, M - 1), nr = min(n0 + i, N - 1);
+    const float* ap = a + (long long)mr * sam;
+    const float* bp = b + (long long)nr * sbn;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int K8 = K & ~7;
+    for (int k0 = 0; k0 < K8; k0 += 8) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + 4 * h + e;
+            av[e] = ap[(long long)k * sak];
+            bv[e] = bp[(long long)k * sbk];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(av[e], bv[e], acc);
+    }
+    if (K8 < K) {   // ragged tail, zero-filled
+        float av[4], bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = K8 + 4 * h + e;
+            const bool ok = k < K;
+            av[e] = ok ? ap[(long long)k * sak] : 0.f;
+            bv[e] = ok ? bp[(long long)k * sbk] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(av[e], bv[e], acc);
+    }
+    const int n = n0 + i;
+    if (n < N) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + mfma_row(q, lane);
+            if (m < M) {
+                float v = acc[q];
+                if (mask) v = mask[(long long)m * ldmask + n] > 0.f ? v : 0.f;
+                float* o = c + (long long)m * ldc + n;
+                *o = accumulate ? *o + v : v;
+            }
+        }
+    }
+}
+
+// column sums: out[n] (+)= sum_m x[m][n] * (mask[m][n] > 0)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mask, int ldmask,
+                                                     float* __restrict__ out, int M, int N, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float v = x[(long long)m * ldx + n];
+        if (mask) v = mask[(long long)m * ldmask + n] > 0.f ? v : 0.f;
+        s += v;
+    }
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// elementwise: y = x * (mask > 0) (+ y)
+__global__ __launch_bounds__(256) void masked_copy_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mask, int ldm,
+                                                          float* y, int ldy, int M, int N, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    float v = x[(long long)m * ldx + n];
+    if (mask) v = mask[(long long)m * ldm + n] > 0.f ? v : 0.f;
+    float* o = y + (long long)m * ldy + n;
+    *o = accumulate ? *o + v : v;
+}
+
+// =====================================================================================================
+// rot6d backward (utils/rigid_transform_utils.py:27-41 differentiated by hand)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void rot6d_bwd_kernel(const float* __restrict__ x6, long long ld, int per_row,
+                                                        const float* __restrict__ dR, float* __restrict__ dx6, long long ldd,
+                                                        long long n) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const long long row = idx / per_row;
+    const int j = (int)(idx - row * per_row);
+    const float* x = x6 + row * ld + j * 6;
+    const float a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+    const float* g = dR + idx * 9;                 // dL/dR, R columns = (b1,b2,b3)
+    float gb1[3] = {g[0], g[3], g[6]}, gb2[3] = {g[1], g[4], g[7]};
+    const float gb3[3] = {g[2], g[5], g[8]};
+    const float n1r = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    const float n1 = fmaxf(n1r, 1e-12f);
+    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    const float n2r = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const float n2 = fmaxf(n2r, 1e-12f);
+    const float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    // b3 = b1 x b2:  gb1 += b2 x gb3, gb2 += gb3 x b1
+    gb1[0] += b2[1] * gb3[2] - b2[2] * gb3[1];
+    gb1[1] += b2[2] * gb3[0] - b2[0] * gb3[2];
+    gb1[2] += b2[0] * gb3[1] - b2[1] * gb3[0];
+    gb2[0] += gb3[1] * b1[2] - gb3[2] * b1[1];
+    gb2[1] += gb3[2] * b1[0] - gb3[0] * b1[2];
+    gb2[2] += gb3[0] * b1[1] - gb3[1] * b1[0];
+    // b2 = u / max(|u|, eps)
+    float gu[3];
+    if (n2r > 1e-12f) {
+        const float t = b2[0] * gb2[0] + b2[1] * gb2[1] + b2[2] * gb2[2];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gu[e] = (gb2[e] - b2[e] * t) / n2;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gu[e] = gb2[e] / n2;
+    }
+    // u = a2 - d*b1, d = b1.a2
+    const float gd = -(gu[0] * b1[0] + gu[1] * b1[1] + gu[2] * b1[2]);
+    float ga2[3], ga1[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        ga2[e] = gu[e] + gd * b1[e];
+        gb1[e] += -d * gu[e] + gd * a2[e];
+    }
+    // b1 = a1 / max(|a1|, eps)
+    if (n1r > 1e-12f) {
+        const float t = b1[0] * gb1[0] + b1[1] * gb1[1] + b1[2] * gb1[2];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ga1[e] = (gb1[e] - b1[e] * t) / n1;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ga1[e] = gb1[e] / n1;
+    }
+    float* o = dx6 + row * ldd + j * 6;
+    o[0] = ga1[0]; o[1] = ga2[0]; o[2] = ga1[1]; o[3] = ga2[1]; o[4] = ga1[2]; o[5] = ga2[2];
+}
+
+inline unsigned capped_grid(long long n) {
+    long long g = (n + 255) / 256;
+    return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+
+inline int wgrad_splits(long long M, int tiles) {
+    int s = (1536 + tiles - 1) / tiles;
+    const long long max_s = (M + 127) / 128;      // at least 4 K-steps of 32 pixels per split
+    if (s > max_s) s = (int)max_s;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" size_t straps_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    const long long M = (long long)batch * ho * wo;
+    const int tiles = kh * kw * (cout / 64) * (cin / 64);
+    return (size_t)wgrad_splits(M, tiles) * cout * kh * kw * cin * sizeof(float);
+}
+
+extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw, void* workspace, int batch, int h, int w, int cin,
+                                 int cout, int kh, int kw, int stride, int pad, int accumulate, void* stream) {
+    STRAPS_REQUIRE(x && dy && dw_oihw && workspace, "straps_conv_wgrad: null pointer");
+    STRAPS_REQUIRE(cin % 64 == 0 && cout % 64 == 0, "straps_conv_wgrad: need cin%%64==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
+    WgradP p;
+    p.x = x; p.dy = dy; p.part = (float*)workspace;
+    p.B = batch; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.R = kh; p.S = kw; p.stride = stride; p.pad = pad;
+    p.Ho = (h + 2 * pad - kh) / stride + 1;
+    p.Wo = (w + 2 * pad - kw) / stride + 1;
+    const long long M = (long long)batch * p.Ho * p.Wo;
+    STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_wgrad: problem too large");
+    p.M = (int)M;
+    p.ct = cout / 64; p.it = cin / 64;
+    const int tiles = kh * kw * p.ct * p.it;
+    const int splits = wgrad_splits(M, tiles);
+    p.rows_per_split = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
+    STRAPS_CHECK_LAUNCH("conv_wgrad_kernel");
+    const long long n = (long long)cout * kh * kw * cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);
+    STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return STRAPS_OK;
+}
+
+static int stem_wgrad_blocks(int ntiles, int* tpb) {
+    int t = (ntiles + 511) / 512;
+    if (t < 1) t = 1;
+    *tpb = t;
+    return (ntiles + t - 1) / t;
+}
+
+extern "C" size_t straps_stem_wgrad_workspace_bytes(int batch, int cin, int h, int w) {
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const int ntiles = batch * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX);
+    int tpb;
+    const int nblk = stem_wgrad_blocks(ntiles, &tpb);
+    const int Kp = (cin * 49 + 31) / 32 * 32;
+    return (size_t)nblk * 64 * Kp * sizeof(float);
+}
+
+extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, void* workspace, int batch, int cin, int h,
+                                 int w, int accumulate, void* stream) {
+    STRAPS_REQUIRE(x_nchw && dy_nhwc && dw_oihw && workspace, "straps_stem_wgrad: null pointer");
+    const int K = cin * 49, Kp = (K + 31) / 32 * 32;
+    const int ncolblk = Kp / 32;
+    const int NB = (ncolblk + 3) / 4;
+    STRAPS_REQUIRE(NB <= 7, "straps_stem_wgrad: at most 18 input channels supported (got %d)", cin);
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;
+    const int ntiles = batch * tiles_x * tiles_y;
+    int tpb;
+    const int nblk = stem_wgrad_blocks(ntiles, &tpb);
+    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + 128 * 68 * sizeof(float) + (size_t)Kp * sizeof(int);
+    STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_wgrad: LDS budget exceeded");
+    hipStream_t st = (hipStream_t)stream;
+    auto go = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { straps_set_error("stem_wgrad_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, x_nchw, dy_nhwc, (float*)workspace, batch, cin, h, w, Ho, Wo, tiles_x,
+                           tiles_y, K, Kp, tpb, ntiles);
+        return STRAPS_OK;
+    };
+    int rc;
+    if (NB <= 1) rc = go(stem_wgrad_kernel<1>);
+    else if (NB <= 2) rc = go(stem_wgrad_kernel<2>);
+    else if (NB <= 4) rc = go(stem_wgrad_kernel<4>);
+    else rc = go(stem_wgrad_kernel<7>);
+    if (rc != STRAPS_OK) return rc;
+    STRAPS_CHECK_LAUNCH("stem_wgrad_kernel");
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * K + 255) / 256), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk, K, Kp, accumulate);
+    STRAPS_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_bwd_blocks(long long rows) {
+    long long b = (rows + 255) / 256;
+    if (b > 1024) b = 1024;
+    return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
+                             const float* gamma, float* dgamma, float* dbeta, float* draw, float* dz_out, void* workspace, long long rows,
+                             int c, int accumulate, void* stream) {
+    STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && draw && workspace, "straps_bn_bwd: null pointer");
+    STRAPS_REQUIRE(rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd: bad shape rows=%lld c=%d", rows, c);
+    const int C4 = c >> 2;
+    STRAPS_REQUIRE(C4 <= 256 ? (256 % C4 == 0) : (C4 % 256 == 0), "straps_bn_bwd: channel count %d not supported", c);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = straps_bn_bwd_blocks(rows);
+    const int rpb = (int)((rows + nblk - 1) / nblk);
+    float* part = (float*)workspace;                 // [nblk][c][2]
+    float* coef = part + (size_t)nblk * c * 2;       // [3][c]
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, part, rows, c, rpb);
+    STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
+    STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    const long long n4 = rows * C4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coef, draw, dz_out, n4, c);
+    STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" size_t straps_bn_bwd_workspace_bytes(long long rows, int c) {
+    return ((size_t)straps_bn_bwd_blocks(rows) * c * 2 + 3 * (size_t)c) * sizeof(float);
+}
+
+extern "C" int straps_maxpool_fwd_idx(const float* x, float* y, uint8_t* idx, int batch, int h, int w, int c, void* stream) {
+    STRAPS_REQUIRE(x && y && idx && batch > 0 && (c & 3) == 0, "straps_maxpool_fwd_idx: bad arguments");
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const long long n = (long long)batch * Ho * Wo * (c >> 2);
+    hipLaunchKernelGGL(maxpool_idx_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, idx, batch, h, w, c, Ho, Wo);
+    STRAPS_CHECK_LAUNCH("maxpool_idx_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int batch, int h, int w, int c, void* stream) {
+    STRAPS_REQUIRE(dy && idx && dx && batch > 0 && (c & 3) == 0, "straps_maxpool_bwd: bad arguments");
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const long long n = (long long)batch * h * w * (c >> 2);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, batch, h, w, c, Ho, Wo);
+    STRAPS_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_gap_bwd(const float* dfeat, float* dx, int batch, int hw, int c, void* stream) {
+    STRAPS_REQUIRE(dfeat && dx && batch > 0 && hw > 0 && c > 0, "straps_gap_bwd: bad arguments");
+    const long long n = (long long)batch * hw * c;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, dfeat, dx, batch, hw, c);
+    STRAPS_CHECK_LAUNCH("gap_bwd_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_gemm_strided(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn, float* c,
+                                   int ldc, const float* mask, int ldmask, int m, int n, int k, int accumulate, void* stream) {
+    STRAPS_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0, "straps_gemm_strided: bad arguments");
+    dim3 grid((n + 127) / 128, (m + 31) / 32);
+    hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, sam, sak, b, sbk, sbn, c, ldc, mask, ldmask, m, n, k, accumulate);
+    STRAPS_CHECK_LAUNCH("gemm_strided_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_colsum(const float* x, int ldx, const float* mask, int ldmask, float* out, int m, int n, int accumulate, void* stream) {
+    STRAPS_REQUIRE(x && out && m > 0 && n > 0, "straps_colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, mask, ldmask, out, m, n, accumulate);
+    STRAPS_CHECK_LAUNCH("colsum_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_masked_copy(const float* x, int ldx, const float* mask, int ldmask, float* y, int ldy, int m, int n, int accumulate,
+                                  void* stream) {
+    STRAPS_REQUIRE(x && y && m > 0 && n > 0, "straps_masked_copy: bad arguments");
+    const long long t = (long long)m * n;
+    hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, mask, ldmask, y, ldy, m, n, accumulate);
+    STRAPS_CHECK_LAUNCH("masked_copy_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_rot6d_bwd(const float* x6, long long ld, int per_row, const float* drot, float* dx6, long long ldd, long long rows,
+                                void* stream) {
+    STRAPS_REQUIRE(x6 && drot && dx6 && rows > 0 && per_row > 0, "straps_rot6d_bwd: bad arguments");
+    const long long n = rows * per_row;
+    hipLaunchKernelGGL(rot6d_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x6, ld, per_row, drot, dx6, ldd, n);
+    STRAPS_CHECK_LAUNCH("rot6d_bwd_kernel");
+    return STRAPS_OK;
+}

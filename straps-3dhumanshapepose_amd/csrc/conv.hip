@@ -27,6 +27,7 @@ struct ConvP {
     float* stats;
     int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, relu;
     int M, MT, NT;
+    int dil_shift;   // 0 = ordinary conv; 1 = the input is read as if zero-dilated by 2 (data-gradient of a stride-2 conv)
 };
 
 constexpr int LS = 36;   // LDS row stride in floats (32 data + 4 pad)
@@ -81,8 +82,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         const int r = tap / p.S, s = tap - r * p.S;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
+            bool ok = true;
+            if (p.dil_shift) {
+                const int msk = (1 << p.dil_shift) - 1;
+                ok = hi >= 0 && wi >= 0 && ((hi | wi) & msk) == 0;
+                hi >>= p.dil_shift;
+                wi >>= p.dil_shift;
+            }
+            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(p.x + a_base[i] + ((long long)hi * p.W + wi) * p.Cin + c0);
             ra[i] = v;
@@ -237,11 +245,37 @@ extern "C" int straps_conv_fwd(const float* x, const float* w, const float* scal
     p.Ho = (h + 2 * pad - kh) / stride + 1;
     p.Wo = (wdt + 2 * pad - kw) / stride + 1;
     p.relu = relu;
+    p.dil_shift = 0;
     const long long M = (long long)batch * p.Ho * p.Wo;
     STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 40), "straps_conv_fwd: problem too large");
     p.M = (int)M;
     int bm, bn;
     pick_tile(tile_cfg, M, cout, bm, bn);
+    hipStream_t st = (hipStream_t)stream;
+    if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
+    if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
+    return launch<64, 64>(p, st);
+}
+
+// data gradient of straps_conv_fwd: dx[b][hi][wi][ci] = sum_{r,s,co} dy[b][ho][wo][co] * w[co][ci][r][s] over the
+// (ho,wo) with ho*stride + r - pad == hi.  Run as an ordinary implicit GEMM over dy with the rotated / transposed
+// filters from straps_pack_conv_weight_dgrad; a stride-2 forward becomes a zero-dilated read of dy.
+extern "C" int straps_conv_dgrad(const float* dy, const float* w_crsk, const float* addend, float* dx, int batch, int h, int wdt,
+                                 int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg, void* stream) {
+    STRAPS_REQUIRE(dy && w_crsk && dx, "straps_conv_dgrad: null pointer");
+    STRAPS_REQUIRE(cout % 32 == 0 && cin % 64 == 0, "straps_conv_dgrad: need cout%%32==0 and cin%%64==0 (cin=%d cout=%d)", cin, cout);
+    STRAPS_REQUIRE(stride == 1 || stride == 2, "straps_conv_dgrad: stride must be 1 or 2");
+    STRAPS_REQUIRE(kh - 1 - pad >= 0, "straps_conv_dgrad: pad larger than the filter");
+    ConvP p;
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (wdt + 2 * pad - kw) / stride + 1;
+    p.x = dy; p.w = w_crsk; p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
+    p.B = batch; p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.R = kh; p.S = kw; p.stride = 1; p.pad = kh - 1 - pad;
+    p.Ho = h; p.Wo = wdt; p.relu = 0; p.dil_shift = stride == 2 ? 1 : 0;
+    const long long M = (long long)batch * h * wdt;
+    STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_dgrad: problem too large");
+    p.M = (int)M;
+    int bm, bn;
+    pick_tile(tile_cfg, M, cin, bm, bn);
     hipStream_t st = (hipStream_t)stream;
     if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
     if (bm == 128 && bn == 64) return launch<128, 64>(p, st);

@@ -278,6 +278,15 @@ inline int resolve_rpc(long long batch, int chunks) {
 
 }  // namespace
 
+// shared with smpl_bwd.hip (which recomputes F and A before back-propagating)
+int straps_smpl_launch_pose(const straps_smpl_model_t* model, const float* betas, const float* rotmats, float* F, float* Amat,
+                            float* joints, long long batch, hipStream_t st) {
+    const unsigned pose_blocks = (unsigned)((batch * 32 + 255) / 256);
+    hipLaunchKernelGGL(smpl_pose_kernel, dim3(pose_blocks), dim3(256), 0, st, *model, betas, rotmats, F, Amat, joints, batch);
+    STRAPS_CHECK_LAUNCH("smpl_pose_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" size_t straps_smpl_workspace_bytes(long long batch, int chunks) {
     const int rpc = resolve_rpc(batch, chunks);
     const int nch = (NROUNDS + rpc - 1) / rpc;

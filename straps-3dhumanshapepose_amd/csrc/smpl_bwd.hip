@@ -1,0 +1,426 @@
+// smpl_bwd.hip -- gradient of the SMPL forward w.r.t. (betas, rotmats) given dL/dvertices, dL/djoints
+// (what autograd does through smplx.lbs for pred_smpl_output, train/train_synthetic_otf_rendering.py:196-232).
+//
+//   smpl_verts_bwd_kernel : same tiling as the forward (32 bodies x vertex chunk per workgroup, one 32-vertex tile
+//       per wave per round).  Per tile: (1) recompute v_posed with the K=218 MFMA contraction, (2) gather the vertex
+//       gradient (dverts + sparse J-regressor / picked-vertex contributions of djoints) through an LDS-staged tile,
+//       (3) per-vertex skinning backward on the VALU: g_vposed = T_R^T g, dA_j += w_j * g (x) [v_posed;1] (LDS float
+//       adds), (4) second MFMA contraction dF[b][k] += sum_{v,c} D[k][v][c] * g_vposed[b][v][c] with the transposed
+//       blend fragments; per-chunk partials of dF and dA are written out.
+//   smpl_pose_bwd_kernel  : lane = (body, joint): sums the chunk partials, back-propagates through rest-pose removal
+//       and the kinematic chain (children -> parents by depth with wave shuffles), the joint regression and the pose
+//       feature, and emits dbetas [B,10] and drotmats [B,24,3,3].
+#include "common.h"
+
+namespace {
+
+constexpr int KP = STRAPS_SMPL_KP, KG = KP / 8, NT = STRAPS_SMPL_TILES, NV = STRAPS_SMPL_V, NROUNDS = NT / 4;
+constexpr int BT = 32, FS = 228, AS = 292, SS = 97, DS = 289;
+constexpr int NJS = STRAPS_SMPL_NPICK + STRAPS_SMPL_NEXTRA;   // 66 joint-gradient sources (joints 24..89)
+
+__global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_model_t m, const float* __restrict__ F,
+                                                                const float* __restrict__ Amat, const float* __restrict__ dverts,
+                                                                const float* __restrict__ djoints, float* __restrict__ dFp,
+                                                                float* __restrict__ dAp, long long B, int rounds_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Fs = smem;                      // [32][FS]
+    float* As_ = Fs + BT * FS;             // [32][AS]
+    float* dAs = As_ + BT * AS;            // [32][DS]  accumulated with LDS float adds
+    float* stage = dAs + BT * DS;          // [4][32][SS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, bl = lane & 31;
+    const int chunk = blockIdx.x;
+    const long long b0 = (long long)blockIdx.y * BT;
+    const int nb = (int)((B - b0) < BT ? (B - b0) : BT);
+
+    for (int i = tid; i < BT * (KP / 4); i += 256) {
+        const int b = i / (KP / 4), q = i % (KP / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < nb) v = *reinterpret_cast<const f32x4*>(F + (b0 + b) * KP + q * 4);
+        *reinterpret_cast<f32x4*>(Fs + b * FS + q * 4) = v;
+    }
+    for (int i = tid; i < BT * 72; i += 256) {
+        const int b = i / 72, q = i % 72;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < nb) v = *reinterpret_cast<const f32x4*>(Amat + (b0 + b) * 288 + q * 4);
+        *reinterpret_cast<f32x4*>(As_ + b * AS + q * 4) = v;
+    }
+    for (int i = tid; i < BT * DS; i += 256) dAs[i] = 0.f;
+    __syncthreads();
+
+    const int round0 = chunk * rounds_per_chunk;
+    const int round1 = min(round0 + rounds_per_chunk, NROUNDS);
+    const f32x4* __restrict__ blend = reinterpret_cast<const f32x4*>(m.blend_frag);
+    const f32x4* __restrict__ blend_t = reinterpret_cast<const f32x4*>(m.blend_frag_t);
+    float* mystage = stage + wave * BT * SS;
+    const int KW = m.skin_k;
+    const bool vbody = bl < nb;
+
+    f32x16 accF[7];
+#pragma unroll
+    for (int f = 0; f < 7; ++f)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accF[f][q] = 0.f;
+
+    for (int rd = round0; rd < round1; ++rd) {
+        const int tile = rd * 4 + wave;
+        // ---- (1) recompute v_posed for this tile ----
+        f32x16 ax, ay, az;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ax[r] = 0.f; ay[r] = 0.f; az[r] = 0.f; }
+        {
+            const f32x4* px = blend + ((long long)(tile * 3 + 0) * KG) * 64 + lane;
+            const f32x4* py = px + KG * 64;
+            const f32x4* pz = py + KG * 64;
+            const float* frow = Fs + bl * FS + 4 * h;
+            f32x4 cx0 = px[0], cy0 = py[0], cz0 = pz[0];
+#pragma unroll 2
+            for (int g = 0; g < KG; ++g) {
+                f32x4 nx0 = cx0, ny0 = cy0, nz0 = cz0;
+                if (g + 1 < KG) { nx0 = px[(g + 1) * 64]; ny0 = py[(g + 1) * 64]; nz0 = pz[(g + 1) * 64]; }
+                const f32x4 f0 = *reinterpret_cast<const f32x4*>(frow + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ax = mfma32(cx0[e], f0[e], ax);
+                    ay = mfma32(cy0[e], f0[e], ay);
+                    az = mfma32(cz0[e], f0[e], az);
+                }
+                cx0 = nx0; cy0 = ny0; cz0 = nz0;
+            }
+        }
+        // ---- (2) stage dL/dverts of this tile (coalesced rows), then add the joint-gradient contributions ----
+        {
+            const int ncol = min(96, (NV - tile * 32) * 3);
+            for (int i = lane; i < BT * 96; i += 64) {
+                const int b = i / 96, c = i - b * 96;
+                float v = 0.f;
+                if (dverts && b < nb && c < ncol) v = dverts[(b0 + b) * (long long)(NV * 3) + tile * 96 + c];
+                mystage[b * SS + c] = v;
+            }
+        }
+        __syncthreads();
+        if (djoints && h == 0 && vbody) {
+            const float* dj = djoints + (b0 + bl) * (STRAPS_SMPL_NJOINTS_OUT * 3) + 72;   // joints 24..89
+            const int e0 = m.jrt_ptr[tile], e1 = m.jrt_ptr[tile + 1];
+            for (int e = e0; e < e1; ++e) {
+                const int code = m.jrt_code[e];
+                const float w = m.jrt_w[e];
+                float* sv = mystage + bl * SS + (code >> 8) * 3;
+                const float* g = dj + (code & 255) * 3;
+                sv[0] = fmaf(w, g[0], sv[0]); sv[1] = fmaf(w, g[1], sv[1]); sv[2] = fmaf(w, g[2], sv[2]);
+            }
+        }
+        __syncthreads();
+        // ---- (3) skinning backward per (body, vertex) ----
+        {
+            const float* Ab = As_ + bl * AS;
+            float* dAb = dAs + bl * DS;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int vrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int v = tile * 32 + vrow;
+                const float* sv = mystage + bl * SS + vrow * 3;
+                const float gx = sv[0], gy = sv[1], gz = sv[2];
+                const float x = ax[r], y = ay[r], z = az[r];
+                float t00 = 0.f, t01 = 0.f, t02 = 0.f, t10 = 0.f, t11 = 0.f, t12 = 0.f, t20 = 0.f, t21 = 0.f, t22 = 0.f;
+                for (int k = 0; k < KW; ++k) {
+                    const float w = m.skin_w[v * KW + k];
+                    const int jo = m.skin_j[v * KW + k] * 12;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + jo);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + jo + 4);
+                    const f32x4 a2 = *reinterpret_cast<const f32x4*>(Ab + jo + 8);
+                    t00 += w * a0[0]; t01 += w * a0[1]; t02 += w * a0[2];
+                    t10 += w * a1[0]; t11 += w * a1[1]; t12 += w * a1[2];
+                    t20 += w * a2[0]; t21 += w * a2[1]; t22 += w * a2[2];
+                    if (w != 0.f) {
+                        const float wx = w * gx, wy = w * gy, wz = w * gz;
+                        float* d = dAb + jo;
+                        atomicAdd(d + 0, wx * x); atomicAdd(d + 1, wx * y); atomicAdd(d + 2, wx * z); atomicAdd(d + 3, wx);
+                        atomicAdd(d + 4, wy * x); atomicAdd(d + 5, wy * y); atomicAdd(d + 6, wy * z); atomicAdd(d + 7, wy);
+                        atomicAdd(d + 8, wz * x); atomicAdd(d + 9, wz * y); atomicAdd(d + 10, wz * z); atomicAdd(d + 11, wz);
+                    }
+                }
+                // g_vposed = T_R^T g
+                ax[r] = t00 * gx + t10 * gy + t20 * gz;
+                ay[r] = t01 * gx + t11 * gy + t21 * gz;
+                az[r] = t02 * gx + t12 * gy + t22 * gz;
+            }
+        }
+        // ---- (4) dF^T[k][b] += sum_v D[k][v][c] * g_vposed[v][b][c] ----
+        {
+            const f32x4* pt = blend_t + ((long long)tile * 3 * 7 * 4) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int f = 0; f < 7; ++f) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x4 a = pt[((c * 7 + f) * 4 + rq) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = c == 0 ? ax[rq * 4 + e] : (c == 1 ? ay[rq * 4 + e] : az[rq * 4 + e]);
+                            accF[f] = mfma32(a[e], g, accF[f]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- per-chunk partials ----
+    // each wave holds dF sums over ITS tiles: fixed-order tree reduction over the 4 waves through the (now free)
+    // F/A staging area: (0 += 2, 1 += 3) then (0 += 1)
+    {
+        float* red = smem;                                   // 2 x 7168 floats fit in Fs + As_ (16640 floats)
+        if (wave >= 2) {
+#pragma unroll
+            for (int f = 0; f < 7; ++f)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[(wave - 2) * 7168 + (f * 16 + q) * 64 + lane] = accF[f][q];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int f = 0; f < 7; ++f)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) accF[f][q] += red[wave * 7168 + (f * 16 + q) * 64 + lane];
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int f = 0; f < 7; ++f)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) red[(f * 16 + q) * 64 + lane] = accF[f][q];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int f = 0; f < 7; ++f)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) accF[f][q] += red[(f * 16 + q) * 64 + lane];
+        }
+    }
+    if (vbody && wave == 0) {
+        float* o = dFp + ((long long)chunk * B + b0 + bl) * KP;
+#pragma unroll
+        for (int f = 0; f < 7; ++f)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[f * 32 + mfma_row(q, lane)] = accF[f][q];
+    }
+    for (int i = tid; i < BT * 288; i += 256) {
+        const int b = i / 288, r = i - b * 288;
+        if (b < nb) dAp[((long long)chunk * B + b0 + b) * 288 + r] = dAs[b * DS + r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smpl_pose_bwd_kernel(straps_smpl_model_t m, const float* __restrict__ betas,
+                                                            const float* __restrict__ rotmats, const float* __restrict__ dFp,
+                                                            const float* __restrict__ dAp, const float* __restrict__ djoints,
+                                                            float* __restrict__ dbetas, float* __restrict__ drot, long long B,
+                                                            int chunks) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31;
+    const int base = lane & 32;
+    const long long body = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool vb = body < B;
+    const bool vj = j < 24;
+    const long long bb = vb ? body : 0;
+    const int jj = vj ? j : 0;
+
+    float beta[10];
+#pragma unroll
+    for (int l = 0; l < 10; ++l) beta[l] = betas[bb * 10 + l];
+    float R[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) R[e] = rotmats[(bb * 24 + jj) * 9 + e];
+    float J[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = m.j_template[jj * 3 + c];
+#pragma unroll
+        for (int l = 0; l < 10; ++l) s = fmaf(m.j_shapedirs[(jj * 3 + c) * 10 + l], beta[l], s);
+        J[c] = s;
+    }
+    const int par = m.parents[jj];
+    const int dep = vj ? m.depth[jj] : -1;
+    const int src = base + (par < 0 ? 0 : par);
+    float rel[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float jp = __shfl(J[c], src, 64);
+        rel[c] = (jj > 0) ? J[c] - jp : J[c];
+    }
+    // forward chain: G (own global transform) and P (parent's rotation), recomputed
+    float G[12], PR[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        G[r * 4 + 0] = R[r * 3 + 0]; G[r * 4 + 1] = R[r * 3 + 1]; G[r * 4 + 2] = R[r * 3 + 2]; G[r * 4 + 3] = rel[r];
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) PR[e] = (e == 0 || e == 4 || e == 8) ? 1.f : 0.f;
+    for (int d = 1; d <= m.max_depth; ++d) {
+        float P[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) P[e] = __shfl(G[e], src, 64);
+        if (dep == d) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float p0 = P[r * 4 + 0], p1 = P[r * 4 + 1], p2 = P[r * 4 + 2];
+                PR[r * 3 + 0] = p0; PR[r * 3 + 1] = p1; PR[r * 3 + 2] = p2;
+                G[r * 4 + 0] = p0 * R[0] + p1 * R[3] + p2 * R[6];
+                G[r * 4 + 1] = p0 * R[1] + p1 * R[4] + p2 * R[7];
+                G[r * 4 + 2] = p0 * R[2] + p1 * R[5] + p2 * R[8];
+                G[r * 4 + 3] = p0 * rel[0] + p1 * rel[1] + p2 * rel[2] + P[r * 4 + 3];
+            }
+        }
+    }
+    // gradient arriving at A_j (sum of chunk partials) and at the posed joint
+    float gA[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) gA[e] = 0.f;
+    if (vb && vj)
+        for (int c = 0; c < chunks; ++c) {
+            const float* p = dAp + (((long long)c * B + body) * 24 + j) * 12;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) gA[e] += p[e];
+        }
+    float gGR[9], gGt[3], gJ[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float gat = gA[r * 4 + 3];
+        gGR[r * 3 + 0] = gA[r * 4 + 0] - gat * J[0];
+        gGR[r * 3 + 1] = gA[r * 4 + 1] - gat * J[1];
+        gGR[r * 3 + 2] = gA[r * 4 + 2] - gat * J[2];
+        gGt[r] = gat + ((vb && vj && djoints) ? djoints[(body * STRAPS_SMPL_NJOINTS_OUT + j) * 3 + r] : 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gJ[c] = -(G[0 * 4 + c] * gA[3] + G[1 * 4 + c] * gA[7] + G[2 * 4 + c] * gA[11]);
+
+    int child[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) child[c] = m.children[jj * 3 + c];
+    float gR[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) gR[e] = 0.f;
+    for (int d = m.max_depth; d >= 1; --d) {
+        // message of a depth-d joint to its parent: gP_R (9), gP_t (3), -grel (3)
+        float M[15];
+        const bool mine = (dep == d);
+        float grel[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) grel[c] = PR[0 * 3 + c] * gGt[0] + PR[1 * 3 + c] * gGt[1] + PR[2 * 3 + c] * gGt[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                M[r * 3 + c] = mine ? (gGR[r * 3 + 0] * R[c * 3 + 0] + gGR[r * 3 + 1] * R[c * 3 + 1] + gGR[r * 3 + 2] * R[c * 3 + 2] + gGt[r] * rel[c]) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { M[9 + c] = mine ? gGt[c] : 0.f; M[12 + c] = mine ? -grel[c] : 0.f; }
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    gR[r * 3 + c] = PR[0 * 3 + r] * gGR[0 * 3 + c] + PR[1 * 3 + r] * gGR[1 * 3 + c] + PR[2 * 3 + r] * gGR[2 * 3 + c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gJ[c] += grel[c];
+        }
+        // parents gather from their (up to 3) children
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const int ch = child[cc];
+            const int cs = base + (ch < 0 ? 0 : ch);
+            float in[15];
+#pragma unroll
+            for (int e = 0; e < 15; ++e) in[e] = __shfl(M[e], cs, 64);
+            if (vj && ch >= 0) {       // in[] is zero unless that child is at depth d
+#pragma unroll
+                for (int e = 0; e < 9; ++e) gGR[e] += in[e];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { gGt[c] += in[9 + c]; gJ[c] += in[12 + c]; }
+            }
+        }
+    }
+    if (j == 0) {   // root: G = [R | J]
+#pragma unroll
+        for (int e = 0; e < 9; ++e) gR[e] = gGR[e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gJ[c] += gGt[c];
+    }
+    // pose-feature and direct beta gradients from dF (sum of chunk partials)
+    float gbeta_direct = 0.f;
+    if (vb && vj) {
+        for (int c = 0; c < chunks; ++c) {
+            const float* p = dFp + ((long long)c * B + body) * KP;
+            if (j >= 1) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) gR[e] += p[11 + (j - 1) * 9 + e];
+            }
+            if (j < 10) gbeta_direct += p[1 + j];
+        }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) drot[(body * 24 + j) * 9 + e] = gR[e];
+    }
+    // dbeta[l] = dF[1+l] + sum_j sum_c Js[j][c][l] * gJ_j[c]
+#pragma unroll
+    for (int l = 0; l < 10; ++l) {
+        float s = vj ? (m.j_shapedirs[(jj * 3 + 0) * 10 + l] * gJ[0] + m.j_shapedirs[(jj * 3 + 1) * 10 + l] * gJ[1] +
+                        m.j_shapedirs[(jj * 3 + 2) * 10 + l] * gJ[2]) : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float direct = __shfl(gbeta_direct, base + l, 64);
+        if (vb && j == l) dbetas[body * 10 + l] = s + direct;
+    }
+}
+
+inline int resolve_rpc(long long batch, int chunks) {
+    if (chunks <= 0) chunks = (batch >= 1024) ? 8 : 54;
+    if (chunks > NROUNDS) chunks = NROUNDS;
+    return (NROUNDS + chunks - 1) / chunks;
+}
+
+}  // namespace
+
+// forward pose kernel is shared with smpl.hip (recomputes F and A for the backward)
+int straps_smpl_launch_pose(const straps_smpl_model_t* model, const float* betas, const float* rotmats, float* F, float* Amat,
+                            float* joints, long long batch, hipStream_t st);
+
+extern "C" size_t straps_smpl_bwd_workspace_bytes(long long batch, int chunks) {
+    const int rpc = resolve_rpc(batch, chunks);
+    const int nch = (NROUNDS + rpc - 1) / rpc;
+    return (size_t)batch * (size_t)(KP + 288 + nch * (KP + 288)) * sizeof(float);
+}
+
+extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* betas, const float* rotmats, const float* dverts,
+                               const float* djoints, float* dbetas, float* drotmats, void* workspace, long long batch, int chunks,
+                               void* stream) {
+    STRAPS_REQUIRE(model && betas && rotmats && dbetas && drotmats && workspace, "straps_smpl_bwd: null pointer");
+    STRAPS_REQUIRE(model->blend_frag_t && model->children && model->jrt_ptr, "straps_smpl_bwd: model lacks the backward tables");
+    STRAPS_REQUIRE(batch > 0, "straps_smpl_bwd: batch must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const int rpc = resolve_rpc(batch, chunks);
+    const int nch = (NROUNDS + rpc - 1) / rpc;
+    float* F = (float*)workspace;
+    float* Amat = F + batch * KP;
+    float* dFp = Amat + batch * 288;
+    float* dAp = dFp + (long long)nch * batch * KP;
+    int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, nullptr, batch, st);
+    if (rc != STRAPS_OK) return rc;
+    const size_t lds = (size_t)(BT * FS + BT * AS + BT * DS + 4 * BT * SS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)smpl_verts_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { straps_set_error("smpl_verts_bwd_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
+        attr_set = true;
+    }
+    const long long btiles = (batch + BT - 1) / BT;
+    if (btiles > 65535) { straps_set_error("straps_smpl_bwd: batch %lld exceeds one launch; split it", batch); return STRAPS_EUNSUPPORTED; }
+    hipLaunchKernelGGL(smpl_verts_bwd_kernel, dim3(nch, (unsigned)btiles), dim3(256), lds, st, *model, F, Amat, dverts, djoints, dFp, dAp, batch, rpc);
+    STRAPS_CHECK_LAUNCH("smpl_verts_bwd_kernel");
+    hipLaunchKernelGGL(smpl_pose_bwd_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, st, *model, betas, rotmats, dFp, dAp,
+                       djoints, dbetas, drotmats, batch, nch);
+    STRAPS_CHECK_LAUNCH("smpl_pose_bwd_kernel");
+    return STRAPS_OK;
+}

@@ -1,0 +1,410 @@
+// train.hip -- train-step glue kernels: network-input construction, prediction heads + multi-task loss (forward
+// and backward fused), Adam.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// COCO / H36M-LSP joint selections out of the 90-joint superset (reference config.py:27-32)
+__constant__ int c_coco[17] = {24, 26, 25, 28, 27, 16, 17, 18, 19, 20, 21, 1, 2, 4, 5, 7, 8};
+__constant__ int c_h36m14[14] = {73 + 6, 73 + 5, 73 + 4, 73 + 1, 73 + 2, 73 + 3, 73 + 16, 73 + 15, 73 + 14, 73 + 11, 73 + 12, 73 + 13, 73 + 8, 73 + 10};
+
+// =====================================================================================================
+// input construction: binary silhouette + Gaussian joint heat-maps (utils/label_conversions.py:48-55,90-127)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void build_proxy_kernel(const float* __restrict__ seg, const float* __restrict__ j2d,
+                                                          float* __restrict__ out, int B, int NJ, int WH) {
+    const long long n = (long long)B * (NJ + 1) * WH * WH;
+    const int size = 8;
+    const float step = 16.0f / 15.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % WH);
+        long long t = i / WH;
+        const int y = (int)(t % WH); t /= WH;
+        const int ch = (int)(t % (NJ + 1));
+        const int b = (int)(t / (NJ + 1));
+        float v = 0.f;
+        if (ch == 0) {
+            v = seg[((long long)b * WH + y) * WH + x] != 0.f ? 1.f : 0.f;
+        } else {
+            const int jx = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 0];     // truncation toward zero == .int()
+            const int jy = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 1];
+            if (jx > -size && jy > -size && jx < WH - 1 + size && jy < WH - 1 + size) {
+                const int hx0 = max(0, jx - size), hx1 = min(WH - 1, jx + size);
+                const int hy0 = max(0, jy - size), hy1 = min(WH - 1, jy + size);
+                if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1) {
+                    const int gx = x - hx0 + max(0, size - jx), gy = y - hy0 + max(0, size - jy);
+                    // torch.linspace(-8, 8, 16): start + i*step in the first half, end - (15-i)*step in the second
+                    const float lx = gx < 8 ? -8.f + step * gx : 8.f - step * (15 - gx);
+                    const float ly = gy < 8 ? -8.f + step * gy : 8.f - step * (15 - gy);
+                    const float d = sqrtf(lx * lx + ly * ly);
+                    v = expf(-(d * d / 32.f));
+                }
+            }
+        }
+        out[i] = v;
+    }
+}
+
+// =====================================================================================================
+// heads + loss
+// =====================================================================================================
+// ws layout (floats): [0..1023] verts partial sums | [1024 ..) per-body sums [B][8] | then scalars
+constexpr int NVB = 1024;
+
+__global__ __launch_bounds__(256) void loss_verts_partial_kernel(const float* __restrict__ p, const float* __restrict__ t, long long n,
+                                                                 float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = p[i] - t[i];
+        s = fmaf(d, d, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ bool joint_visible(float x, float y, float wh) { return !(x > wh || y > wh || x < 0.f || y < 0.f); }
+
+__global__ __launch_bounds__(256) void loss_heads_kernel(const float* __restrict__ joints, const float* __restrict__ est, int ld_est,
+                                                         const float* __restrict__ prot, const float* __restrict__ tj2d,
+                                                         const float* __restrict__ tj3d, const float* __restrict__ tshape,
+                                                         const float* __restrict__ trot, float* __restrict__ body_sums, long long B,
+                                                         float wh) {
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* J = joints + b * 270;
+    const float* e = est + b * ld_est;
+    const float s = e[0], tx = e[1], ty = e[2];
+    float sq2 = 0.f, nvis = 0.f, sq3 = 0.f, sqs = 0.f, sqr = 0.f;
+    for (int k = 0; k < 17; ++k) {
+        const float lx = tj2d[(b * 17 + k) * 2 + 0], ly = tj2d[(b * 17 + k) * 2 + 1];
+        if (joint_visible(lx, ly, wh)) {
+            const float* pj = J + c_coco[k] * 3;
+            const float u = s * (pj[0] + tx), v = s * (pj[1] + ty);
+            const float du = u - ((2.0f * lx) / wh - 1.0f), dv = v - ((2.0f * ly) / wh - 1.0f);
+            sq2 += du * du + dv * dv;
+            nvis += 1.f;
+        }
+    }
+    for (int k = 0; k < 14; ++k) {
+        const float* pj = J + c_h36m14[k] * 3;
+        const float* tj = tj3d + (b * 14 + k) * 3;
+        for (int c = 0; c < 3; ++c) { const float d = pj[c] - tj[c]; sq3 += d * d; }
+    }
+    for (int l = 0; l < 10; ++l) { const float d = e[147 + l] - tshape[b * 10 + l]; sqs += d * d; }
+    for (int q = 0; q < 216; ++q) { const float d = prot[b * 216 + q] - trot[b * 216 + q]; sqr += d * d; }
+    float* o = body_sums + b * 8;
+    o[0] = sq2; o[1] = nvis; o[2] = sq3; o[3] = sqs; o[4] = sqr;
+}
+
+// single block: fixed-order fp64 sums -> MSEs, weighted losses, d/dlogvar, gradient coefficients
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ vpart, const float* __restrict__ body_sums,
+                                                            const float* __restrict__ log_vars, float* __restrict__ loss_out,
+                                                            float* __restrict__ dlogvar, float* __restrict__ coef, long long B) {
+    __shared__ double red[256][6];
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < NVB; i += 256) a[0] += (double)vpart[i];
+    for (long long b = threadIdx.x; b < B; b += 256) {
+        const float* o = body_sums + b * 8;
+        a[1] += o[0]; a[2] += o[1]; a[3] += o[2]; a[4] += o[3]; a[5] += o[4];
+    }
+    for (int q = 0; q < 6; ++q) red[threadIdx.x][q] = a[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 256; ++i)
+            for (int q = 0; q < 6; ++q) t[q] += red[i][q];
+        const double nvis = t[2];
+        // element counts of the 'mean' reductions: verts B*6890*3, joints2D nvis*2, joints3D B*14*3, shape B*10, pose B*216
+        const double cnt[5] = {(double)B * 20670.0, nvis * 2.0, (double)B * 42.0, (double)B * 10.0, (double)B * 216.0};
+        const double sq[5] = {t[0], t[1], t[3], t[4], t[5]};
+        double total = 0.0;
+        for (int k = 0; k < 5; ++k) {
+            const double mse = sq[k] / cnt[k];            // 0/0 = NaN for no visible joint, like nn.MSELoss on an empty tensor
+            const double s = (double)log_vars[k];
+            const double w = exp(-s);
+            loss_out[1 + k] = (float)(mse * w);
+            loss_out[6 + k] = (float)mse;
+            total += mse * w + s;
+            dlogvar[k] = (float)(-mse * w + 1.0);
+            coef[k] = (float)(2.0 * w / cnt[k]);
+        }
+        loss_out[0] = (float)total;
+        loss_out[11] = (float)nvis;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_verts_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                              const float* __restrict__ coef, float* __restrict__ g, long long n) {
+    const float c = coef[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) g[i] = c * (p[i] - t[i]);
+}
+
+// one wave per body: zero-fill + scatter of the head gradients
+__global__ __launch_bounds__(64) void loss_grad_heads_kernel(const float* __restrict__ joints, const float* __restrict__ est, int ld_est,
+                                                             const float* __restrict__ prot, const float* __restrict__ tj2d,
+                                                             const float* __restrict__ tj3d, const float* __restrict__ tshape,
+                                                             const float* __restrict__ trot, const float* __restrict__ coef,
+                                                             float* __restrict__ djoints, float* __restrict__ dest,
+                                                             float* __restrict__ drot, long long B, float wh) {
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* J = joints + b * 270;
+    const float* e = est + b * ld_est;
+    float* dJ = djoints + b * 270;
+    float* dE = dest + b * ld_est;
+    const float c2 = coef[1], c3 = coef[2], cs = coef[3], cr = coef[4];
+    for (int i = lane; i < 270; i += 64) dJ[i] = 0.f;
+    for (int i = lane; i < ld_est; i += 64) dE[i] = (i >= 147 && i < 157) ? cs * (e[i] - tshape[b * 10 + i - 147]) : 0.f;
+    for (int i = lane; i < 216; i += 64) drot[b * 216 + i] = cr * (prot[b * 216 + i] - trot[b * 216 + i]);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const float s = e[0], tx = e[1], ty = e[2];
+    float gs = 0.f, gtx = 0.f, gty = 0.f;
+    if (lane < 17) {
+        const float lx = tj2d[(b * 17 + lane) * 2 + 0], ly = tj2d[(b * 17 + lane) * 2 + 1];
+        if (joint_visible(lx, ly, wh)) {
+            const float* pj = J + c_coco[lane] * 3;
+            const float u = s * (pj[0] + tx), v = s * (pj[1] + ty);
+            const float du = c2 * (u - ((2.0f * lx) / wh - 1.0f)), dv = c2 * (v - ((2.0f * ly) / wh - 1.0f));
+            dJ[c_coco[lane] * 3 + 0] = du * s;
+            dJ[c_coco[lane] * 3 + 1] = dv * s;
+            gs = du * (pj[0] + tx) + dv * (pj[1] + ty);
+            gtx = du * s;
+            gty = dv * s;
+        }
+    } else if (lane >= 32 && lane < 46) {
+        const int k = lane - 32;
+        const float* pj = J + c_h36m14[k] * 3;
+        const float* tj = tj3d + (b * 14 + k) * 3;
+        for (int c = 0; c < 3; ++c) dJ[c_h36m14[k] * 3 + c] = c3 * (pj[c] - tj[c]);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        gs += __shfl_xor(gs, o, 64);
+        gtx += __shfl_xor(gtx, o, 64);
+        gty += __shfl_xor(gty, o, 64);
+    }
+    if (lane == 0) { dE[0] = gs; dE[1] = gtx; dE[2] = gty; }
+}
+
+// =====================================================================================================
+// Adam
+// =====================================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float b1, float b2, float eps, float step_size,
+                                                   float inv_sqrt_bc2, float gscale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+inline unsigned capped_grid(long long n, int cap = 4096) {
+    long long g = (n + 255) / 256;
+    return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int straps_build_proxy_input(const float* seg, const float* joints2d, float* out_nchw, int batch, int nj, int wh,
+                                        void* stream) {
+    STRAPS_REQUIRE(seg && joints2d && out_nchw && batch > 0 && nj > 0 && wh > 16, "straps_build_proxy_input: bad arguments");
+    const long long n = (long long)batch * (nj + 1) * wh * wh;
+    hipLaunchKernelGGL(build_proxy_kernel, dim3(capped_grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, seg, joints2d, out_nchw, batch, nj, wh);
+    STRAPS_CHECK_LAUNCH("build_proxy_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" size_t straps_loss_workspace_bytes(long long batch) { return (size_t)(NVB + batch * 8 + 16) * sizeof(float); }
+
+extern "C" int straps_loss_fwd_bwd(const float* pred_verts, const float* pred_joints, const float* est, int ld_est, const float* pred_rot,
+                                   const float* tgt_verts, const float* tgt_joints2d, const float* tgt_joints3d, const float* tgt_shape,
+                                   const float* tgt_rot, const float* log_vars, float* loss_out, float* dverts, float* djoints,
+                                   float* dest, float* drot, float* dlogvar, void* workspace, long long batch, int img_wh, void* stream) {
+    STRAPS_REQUIRE(pred_verts && pred_joints && est && pred_rot && tgt_verts && tgt_joints2d && tgt_joints3d && tgt_shape && tgt_rot &&
+                       log_vars && loss_out && workspace,
+                   "straps_loss_fwd_bwd: null pointer");
+    STRAPS_REQUIRE(batch > 0 && ld_est >= 157, "straps_loss_fwd_bwd: bad shape batch=%lld ld_est=%d", batch, ld_est);
+    const bool want_grad = dverts || djoints || dest || drot;
+    STRAPS_REQUIRE(!want_grad || (dverts && djoints && dest && drot && dlogvar), "straps_loss_fwd_bwd: give all gradient outputs or none");
+    hipStream_t st = (hipStream_t)stream;
+    float* vpart = (float*)workspace;
+    float* body = vpart + NVB;
+    float* coef = body + batch * 8;
+    float* dlv = dlogvar ? dlogvar : coef + 8;
+    const long long nv = batch * 20670LL;
+    hipLaunchKernelGGL(loss_verts_partial_kernel, dim3(NVB), dim3(256), 0, st, pred_verts, tgt_verts, nv, vpart);
+    STRAPS_CHECK_LAUNCH("loss_verts_partial_kernel");
+    hipLaunchKernelGGL(loss_heads_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, pred_joints, est, ld_est, pred_rot,
+                       tgt_joints2d, tgt_joints3d, tgt_shape, tgt_rot, body, batch, (float)img_wh);
+    STRAPS_CHECK_LAUNCH("loss_heads_kernel");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, vpart, body, log_vars, loss_out, dlv, coef, batch);
+    STRAPS_CHECK_LAUNCH("loss_finalize_kernel");
+    if (want_grad) {
+        hipLaunchKernelGGL(loss_grad_verts_kernel, dim3(capped_grid(nv)), dim3(256), 0, st, pred_verts, tgt_verts, coef, dverts, nv);
+        STRAPS_CHECK_LAUNCH("loss_grad_verts_kernel");
+        hipLaunchKernelGGL(loss_grad_heads_kernel, dim3((unsigned)batch), dim3(64), 0, st, pred_joints, est, ld_est, pred_rot, tgt_joints2d,
+                           tgt_joints3d, tgt_shape, tgt_rot, coef, djoints, dest, drot, batch, (float)img_wh);
+        STRAPS_CHECK_LAUNCH("loss_grad_heads_kernel");
+    }
+    return STRAPS_OK;
+}
+
+extern "C" int straps_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
+                                float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    STRAPS_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "straps_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, beta1, beta2,
+                       eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    STRAPS_CHECK_LAUNCH("adam_kernel");
+    return STRAPS_OK;
+}
+
+// =====================================================================================================
+// generic (row-masked) MSE used by the drop-in criterion module, and the fused proxy augmentation
+// =====================================================================================================
+namespace {
+
+// out[0] = sum over kept rows of (p - (t*ts + tb))^2, out[1] = number of kept elements
+__global__ __launch_bounds__(256) void mse_sum_kernel(const float* __restrict__ p, const float* __restrict__ t, const uint8_t* __restrict__ mask,
+                                                      long long rows, int cols, float ts, float tb, float* __restrict__ part) {
+    __shared__ float red[4][2];
+    float s = 0.f, c = 0.f;
+    const long long n = rows * cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if (mask && !mask[i / cols]) continue;
+        const float d = p[i] - (t[i] * ts + tb);
+        s = fmaf(d, d, s);
+        c += 1.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        part[blockIdx.x * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+__global__ __launch_bounds__(64) void mse_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) { s += part[i * 2]; c += part[i * 2 + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if (threadIdx.x == 0) { out[0] = (float)s; out[1] = (float)c; out[2] = (float)(s / c); }
+}
+
+// grad[i] = coef[0] * (p - (t*ts + tb)) on kept rows, 0 elsewhere
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ p, const float* __restrict__ t, const uint8_t* __restrict__ mask,
+                                                       long long rows, int cols, float ts, float tb, const float* __restrict__ coef,
+                                                       float* __restrict__ g) {
+    const long long n = rows * cols;
+    const float c = coef[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        g[i] = (mask && !mask[i / cols]) ? 0.f : c * (p[i] - (t[i] * ts + tb));
+}
+
+// seg augmentation (augmentation/proxy_rep_augmentation.py:52-101) folded into the input build: u[b][0..5] < prob[c] removes part
+// class c+1, u[b][6] < occlude_prob zeroes a box centred at (u[b][7], u[b][8]) mapped to [0.35*wh, 0.65*wh].
+__global__ __launch_bounds__(256) void augment_seg_kernel(const float* __restrict__ seg, const float* __restrict__ u,
+                                                          const float* __restrict__ prob, float occl_prob, int box, float* __restrict__ out,
+                                                          int B, int WH) {
+    const long long n = (long long)B * WH * WH;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % WH);
+        const int y = (int)((i / WH) % WH);
+        const int b = (int)(i / ((long long)WH * WH));
+        const float* ub = u + b * 9;
+        float v = seg[i];
+        const int cls = (int)v;
+        if (cls >= 1 && cls <= 6 && ub[cls - 1] < prob[cls - 1]) v = 0.f;
+        if (ub[6] < occl_prob) {
+            // reference: x = (x_h - x_l) * rand + x_l with x_h = c - 0.3*wh/2, x_l = c + 0.3*wh/2; first image axis is rows
+            const float c = WH * 0.5f, lo = c + 0.15f * WH, hi = c - 0.15f * WH;
+            const float cx = (hi - lo) * ub[7] + lo, cy = (hi - lo) * ub[8] + lo;
+            const int r1 = (int)(cx - box * 0.5f), r2 = (int)(cx + box * 0.5f), c1 = (int)(cy - box * 0.5f), c2 = (int)(cy + box * 0.5f);
+            if (y >= r1 && y < r2 && x >= c1 && x < c2) v = 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int straps_mse_fwd(const float* pred, const float* tgt, const uint8_t* row_mask, long long rows, int cols, float tgt_scale,
+                              float tgt_shift, float* out3, void* workspace, void* stream) {
+    STRAPS_REQUIRE(pred && tgt && out3 && workspace && rows > 0 && cols > 0, "straps_mse_fwd: bad arguments");
+    float* part = (float*)workspace;     // 512 floats
+    hipLaunchKernelGGL(mse_sum_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, pred, tgt, row_mask, rows, cols, tgt_scale, tgt_shift, part);
+    STRAPS_CHECK_LAUNCH("mse_sum_kernel");
+    hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, 256, out3);
+    STRAPS_CHECK_LAUNCH("mse_finalize_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_mse_bwd(const float* pred, const float* tgt, const uint8_t* row_mask, long long rows, int cols, float tgt_scale,
+                              float tgt_shift, const float* coef, float* grad, void* stream) {
+    STRAPS_REQUIRE(pred && tgt && coef && grad && rows > 0 && cols > 0, "straps_mse_bwd: bad arguments");
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(capped_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, pred, tgt, row_mask, rows, cols,
+                       tgt_scale, tgt_shift, coef, grad);
+    STRAPS_CHECK_LAUNCH("mse_grad_kernel");
+    return STRAPS_OK;
+}
+
+namespace {
+// STAND-IN for the part-segmentation rasteriser (renderers/nmr_renderer.py, SURVEY 8f row f1, out of scope this round):
+// capsules around the projected 2D joints labelled with the 6 LSP part ids, enough to give the encoder a
+// silhouette-shaped, joint-consistent input of the right statistics.  NOT a renderer.
+__constant__ int c_joint_part[17] = {6, 6, 6, 6, 6, 1, 2, 1, 2, 1, 2, 3, 3, 4, 5, 4, 5};
+__global__ __launch_bounds__(256) void synth_seg_kernel(const float* __restrict__ j2d, float* __restrict__ seg, int B, int WH, float radius) {
+    const long long n = (long long)B * WH * WH;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % WH);
+        const int y = (int)((i / WH) % WH);
+        const int b = (int)(i / ((long long)WH * WH));
+        const float* J = j2d + (long long)b * 34;
+        float best = radius * radius;
+        int part = 0;
+        for (int k = 0; k < 17; ++k) {
+            const float dx = x - J[k * 2], dy = y - J[k * 2 + 1];
+            const float d = dx * dx + dy * dy;
+            if (d < best) { best = d; part = c_joint_part[k]; }
+        }
+        // torso: between shoulders (5,6) and hips (11,12)
+        const float tx0 = fminf(fminf(J[10], J[12]), fminf(J[22], J[24])), tx1 = fmaxf(fmaxf(J[10], J[12]), fmaxf(J[22], J[24]));
+        const float ty0 = fminf(fminf(J[11], J[13]), fminf(J[23], J[25])), ty1 = fmaxf(fmaxf(J[11], J[13]), fmaxf(J[23], J[25]));
+        if (part == 0 && x >= tx0 && x <= tx1 && y >= ty0 && y <= ty1) part = 3;
+        seg[i] = (float)part;
+    }
+}
+}  // namespace
+
+extern "C" int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream) {
+    STRAPS_REQUIRE(joints2d && seg && batch > 0 && wh > 0, "straps_synth_seg: bad arguments");
+    const long long n = (long long)batch * wh * wh;
+    hipLaunchKernelGGL(synth_seg_kernel, dim3(capped_grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, joints2d, seg, batch, wh, radius);
+    STRAPS_CHECK_LAUNCH("synth_seg_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_augment_seg(const float* seg, const float* uniforms, const float* remove_prob, float occlude_prob, int box_dim,
+                                  float* out, int batch, int wh, void* stream) {
+    STRAPS_REQUIRE(seg && uniforms && remove_prob && out && batch > 0 && wh > 0, "straps_augment_seg: bad arguments");
+    const long long n = (long long)batch * wh * wh;
+    hipLaunchKernelGGL(augment_seg_kernel, dim3(capped_grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, seg, uniforms, remove_prob,
+                       occlude_prob, box_dim, out, batch, wh);
+    STRAPS_CHECK_LAUNCH("augment_seg_kernel");
+    return STRAPS_OK;
+}

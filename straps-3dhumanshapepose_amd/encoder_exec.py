@@ -59,7 +59,7 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
     if ctx.tape is not None:
         rec = dict(kind='conv', conv=conv, bn=bn, x=x, geom=(B, H, W, Cin, Cout, k, stride, pad, Ho, Wo), relu=relu,
                    residual=residual)
-        ctx.tape.append(rec)
+        ctx.tape[id(conv)] = rec
     if not ctx.training:
         ss = net._folded_bn(bn)
         hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wpk), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual),
@@ -91,7 +91,7 @@ def encoder_forward(net, x, tape=None):
     rec = None
     if tape is not None:
         rec = dict(kind='stem', conv=net.conv1, bn=net.bn1, x=x, geom=(B, C, H, W, Ho, Wo), relu=True, residual=None)
-        tape.append(rec)
+        tape["stem"] = rec
     if not net.training:
         ss = net._folded_bn(net.bn1)
         hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), 1, hipabi.ptr(y),
@@ -106,9 +106,13 @@ def encoder_forward(net, x, tape=None):
     H, W = Ho, Wo
     Hp, Wp = _conv_out(H, 3, 2, 1), _conv_out(W, 3, 2, 1)
     p = ctx.empty(B, Hp, Wp, 64)
-    hipabi.check(L.straps_maxpool_fwd(hipabi.ptr(y), hipabi.ptr(p), B, H, W, 64, hipabi.stream_ptr()), 'straps_maxpool_fwd')
     if tape is not None:
-        tape.append(dict(kind='maxpool', x=y, out=p, geom=(B, H, W, 64, Hp, Wp)))
+        idx = torch.empty(B, Hp, Wp, 64, device=x.device, dtype=torch.uint8)      # arg-max tap for the backward
+        hipabi.check(L.straps_maxpool_fwd_idx(hipabi.ptr(y), hipabi.ptr(p), hipabi.ptr(idx), B, H, W, 64, hipabi.stream_ptr()),
+                     'straps_maxpool_fwd_idx')
+        tape['maxpool'] = dict(kind='maxpool', x=y, out=p, idx=idx, geom=(B, H, W, 64, Hp, Wp))
+    else:
+        hipabi.check(L.straps_maxpool_fwd(hipabi.ptr(y), hipabi.ptr(p), B, H, W, 64, hipabi.stream_ptr()), 'straps_maxpool_fwd')
     y, H, W = p, Hp, Wp
     # ---- residual stages (:150-156) ----
     for li in range(1, 5):
@@ -127,5 +131,5 @@ def encoder_forward(net, x, tape=None):
     feat = ctx.empty(B, Cf)
     hipabi.check(L.straps_gap_fwd(hipabi.ptr(y), hipabi.ptr(feat), B, H * W, Cf, hipabi.stream_ptr()), 'straps_gap_fwd')
     if tape is not None:
-        tape.append(dict(kind='gap', x=y, geom=(B, H * W, Cf)))
+        tape["gap"] = dict(kind="gap", x=y, geom=(B, H * W, Cf))
     return feat

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
 SOURCES = ['abi.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'stem.hip', 'smpl.hip',
-           'backward.hip', 'train.hip']
+           'smpl_bwd.hip', 'backward.hip', 'train.hip']
 
 _lib = None
 
@@ -42,7 +42,8 @@ class SmplModelStruct(C.Structure):
     _fields_ = [('blend_frag', C.c_void_p), ('j_template', C.c_void_p), ('j_shapedirs', C.c_void_p),
                 ('parents', C.c_void_p), ('depth', C.c_void_p), ('max_depth', C.c_int32), ('skin_k', C.c_int32),
                 ('skin_w', C.c_void_p), ('skin_j', C.c_void_p), ('jr_ptr', C.c_void_p), ('jr_code', C.c_void_p),
-                ('jr_w', C.c_void_p), ('pick_ids', C.c_void_p)]
+                ('jr_w', C.c_void_p), ('pick_ids', C.c_void_p), ('blend_frag_t', C.c_void_p), ('children', C.c_void_p),
+                ('jrt_ptr', C.c_void_p), ('jrt_code', C.c_void_p), ('jrt_w', C.c_void_p)]
 
 
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
@@ -72,6 +73,31 @@ SIGNATURES = {
     'straps_rodrigues_fwd': (_I, [_P, _P, _L, _P]),
     'straps_smpl_workspace_bytes': (_Z, [_L, _I]),
     'straps_smpl_fwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _L, _I, _P]),
+    'straps_smpl_bwd_workspace_bytes': (_Z, [_L, _I]),
+    'straps_smpl_bwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'straps_conv_dgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'straps_conv_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    'straps_conv_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'straps_stem_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I]),
+    'straps_stem_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'straps_bn_bwd_blocks': (_I, [_L]),
+    'straps_bn_bwd_workspace_bytes': (_Z, [_L, _I]),
+    'straps_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'straps_maxpool_fwd_idx': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),
+    'straps_gemm_strided': (_I, [_P, _L, _L, _P, _L, _L, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'straps_colsum': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    'straps_masked_copy': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    'straps_rot6d_bwd': (_I, [_P, _L, _I, _P, _P, _L, _L, _P]),
+    'straps_build_proxy_input': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'straps_loss_workspace_bytes': (_Z, [_L]),
+    'straps_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'straps_adam_step': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
+    'straps_mse_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
+    'straps_mse_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
+    'straps_augment_seg': (_I, [_P, _P, _P, _F, _I, _P, _I, _I, _P]),
+    'straps_synth_seg': (_I, [_P, _P, _I, _I, _F, _P]),
 }
 
 

@@ -62,7 +62,32 @@ def pack_smpl_model(model):
     jr_ptr = np.zeros(54 * 4 + 1, np.int32)
     np.add.at(jr_ptr, q + 1, 1)
     jr_ptr = np.cumsum(jr_ptr).astype(np.int32)
+    # ---- backward tables ----
+    # transposed fragments [t][c][f][rq][h][i][e] <- D[32f+i][32t + row(4rq+e, h)][c], row(r,h) = (r&3)+8(r>>2)+4h
+    r_ = np.arange(16)
+    rows = (r_[None, :] & 3) + 8 * (r_[None, :] >> 2) + 4 * np.arange(2)[:, None]            # [h][r]
+    Dk = D.reshape(7, 32, TILES, 32, 3)                                                          # [f][i][t][vl][c]
+    Dt = Dk[:, :, :, rows, :]                                                                    # [f][i][t][h][r][c]
+    frag_t = Dt.reshape(7, 32, TILES, 2, 4, 4, 3).transpose(2, 6, 0, 4, 3, 1, 5).copy()          # [t][c][f][rq][h][i][e]
+    children = -np.ones((24, 3), np.int32)
+    for j in range(1, 24):
+        slot = int((children[parents[j]] >= 0).sum())
+        assert slot < 3, 'a joint with more than 3 children is not supported'
+        children[parents[j], slot] = j
+    # joint-gradient sources per tile: picked vertices (src 0..20, weight 1) + regressed joints (src 21..65)
+    pj = np.arange(21)
+    pv = np.asarray(model['extra_vertex_ids'], np.int64)
+    src = np.concatenate([pj, 21 + jj])
+    vs = np.concatenate([pv, vv])
+    ws = np.concatenate([np.ones(21, np.float32), R45[jj, vv].astype(np.float32)])
+    o2 = np.lexsort((src, vs))
+    src, vs, ws = src[o2], vs[o2], ws[o2]
+    jrt_ptr = np.zeros(TILES + 1, np.int32)
+    np.add.at(jrt_ptr, vs // 32 + 1, 1)
+    jrt_ptr = np.cumsum(jrt_ptr).astype(np.int32)
     return {
+        'blend_frag_t': frag_t.reshape(-1), 'children': children,
+        'jrt_ptr': jrt_ptr, 'jrt_code': (((vs % 32) << 8) | src).astype(np.int32), 'jrt_w': ws,
         'blend_frag': frag.reshape(-1),
         'j_template': (Jr @ vt).astype(np.float32),
         'j_shapedirs': np.einsum('jv,vcl->jcl', Jr, sd).astype(np.float32),
@@ -111,7 +136,7 @@ class SMPL(nn.Module):
         if self._struct_key != key:
             s = hipabi.SmplModelStruct()
             for f in ('blend_frag', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'jr_ptr',
-                      'jr_code', 'jr_w', 'pick_ids'):
+                      'jr_code', 'jr_w', 'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w'):
                 setattr(s, f, getattr(self, '_k_' + f).data_ptr())
             s.max_depth, s.skin_k = self.max_depth, self.skin_k
             self._struct, self._struct_key = s, key

@@ -1,0 +1,352 @@
+"""GPU parity tests of the gradient kernels (conv dgrad/wgrad, BatchNorm, pooling, IEF, rot6d, SMPL,
+loss, Adam, input construction) against the CPU oracle / autograd of the oracle and against the golden
+vectors captured from the reference (tests/golden/grad_checks_r*.json, small_golden.npz).
+
+Tolerances: gradients are sums over up to 1e6 fp32 products in a different order than the CPU
+kernels -> rel 2e-3 of the tensor's max magnitude unless stated otherwise.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import straps_amd
+import straps_oracle as O
+from detgen import det_uniform, det_state_dict
+from straps_amd import hipabi
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+MP = straps_amd.synthetic_mean_params(0)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    hipabi.load()
+    return torch.device('cuda:0')
+
+
+def _relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def nhwc(t, dev):
+    return t.permute(0, 2, 3, 1).contiguous().to(dev)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,k,stride', [(2, 64, 64, 16, 3, 1), (2, 64, 128, 16, 3, 2), (3, 128, 64, 9, 3, 1), (2, 64, 128, 16, 1, 2),
+                                                   (1, 256, 512, 8, 3, 2), (2, 256, 64, 8, 1, 1), (2, 128, 128, 15, 3, 2)])
+def test_conv_dgrad_wgrad(dev, B, Cin, Cout, H, k, stride):
+    L = hipabi.lib()
+    pad = 1 if k == 3 else 0
+    x = torch.from_numpy(det_uniform((B, Cin, H, H), 1, -1, 1)).double().requires_grad_()
+    w = (torch.from_numpy(det_uniform((Cout, Cin, k, k), 2, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5).double().requires_grad_()
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = torch.from_numpy(det_uniform(tuple(y.shape), 3, -1, 1)).double()
+    y.backward(dy)
+    Ho = y.shape[2]
+    xd, dyd, wd = nhwc(x.detach().float(), dev), nhwc(dy.float(), dev), w.detach().float().to(dev)
+    wpk = torch.empty_like(wd)
+    hipabi.check(L.straps_pack_conv_weight_dgrad(hipabi.ptr(wd), hipabi.ptr(wpk), Cout, Cin, k, k, None), 'pack dgrad')
+    add = torch.from_numpy(det_uniform((B, H, H, Cin), 4, -1, 1)).to(dev)
+    dx = torch.empty(B, H, H, Cin, device=dev)
+    hipabi.check(L.straps_conv_dgrad(hipabi.ptr(dyd), hipabi.ptr(wpk), hipabi.ptr(add), hipabi.ptr(dx), B, H, H, Cin, Cout, k, k, stride, pad, 0, None), 'dgrad')
+    want = x.grad.permute(0, 2, 3, 1) + add.cpu().double()
+    assert _relerr(dx, want) < 2e-5
+    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, k, k, stride, pad) // 4, device=dev)
+    dw = torch.empty_like(wd)
+    hipabi.check(L.straps_conv_wgrad(hipabi.ptr(xd), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws), B, H, H, Cin, Cout, k, k, stride, pad, 0, None), 'wgrad')
+    assert _relerr(dw, w.grad) < 2e-5
+    hipabi.check(L.straps_conv_wgrad(hipabi.ptr(xd), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws), B, H, H, Cin, Cout, k, k, stride, pad, 1, None), 'wgrad acc')
+    assert _relerr(dw, 2 * w.grad) < 2e-5
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 18, 64, 64), (1, 1, 40, 72), (3, 18, 33, 50)])
+def test_stem_wgrad(dev, B, C, H, W):
+    L = hipabi.lib()
+    x = torch.from_numpy(det_uniform((B, C, H, W), 6, 0, 1)).double()
+    w = torch.zeros(64, C, 7, 7, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = torch.from_numpy(det_uniform(tuple(y.shape), 7, -1, 1)).double()
+    y.backward(dy)
+    xd, dyd = x.float().to(dev), nhwc(dy.float(), dev)
+    ws = torch.empty(L.straps_stem_wgrad_workspace_bytes(B, C, H, W) // 4, device=dev)
+    dw = torch.empty(64, C, 7, 7, device=dev)
+    hipabi.check(L.straps_stem_wgrad(hipabi.ptr(xd), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws), B, C, H, W, 0, None), 'stem wgrad')
+    assert _relerr(dw, w.grad) < 2e-5
+
+
+@pytest.mark.parametrize('C,relu', [(64, True), (512, True), (2048, False), (128, False)])
+def test_bn_backward(dev, C, relu):
+    L = hipabi.lib()
+    B, H = 3, 7
+    rows = B * H * H
+    x = torch.from_numpy(det_uniform((B, C, H, H), 8, -1, 1)).double().requires_grad_()
+    g = torch.from_numpy(det_uniform((C,), 9, 0.5, 1.5)).double().requires_grad_()
+    b = torch.from_numpy(det_uniform((C,), 10, -0.5, 0.5)).double().requires_grad_()
+    y = F.batch_norm(x, None, None, g, b, True, 0.1, 1e-5)
+    out = F.relu(y) if relu else y
+    dy = torch.from_numpy(det_uniform(tuple(y.shape), 11, -1, 1)).double()
+    out.backward(dy)
+    xs = x.detach()
+    mean = xs.mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(xs.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    raw, dyd, outd = nhwc(xs.float(), dev), nhwc(dy.float(), dev), nhwc(out.detach().float(), dev)
+    md, isd, gd = mean.float().to(dev), invstd.float().to(dev), g.detach().float().to(dev)
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    draw, dz = torch.empty_like(raw), torch.empty_like(raw)
+    ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, C) // 4, device=dev)
+    hipabi.check(L.straps_bn_bwd(hipabi.ptr(dyd), hipabi.ptr(outd if relu else None), hipabi.ptr(raw), hipabi.ptr(md), hipabi.ptr(isd), hipabi.ptr(gd),
+                                 hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(dz), hipabi.ptr(ws), rows, C, 0, None), 'bn bwd')
+    assert _relerr(draw.permute(0, 3, 1, 2), x.grad) < 5e-5
+    assert _relerr(dg, g.grad) < 5e-5 and _relerr(db, b.grad) < 5e-5
+    mask = (out.detach() > 0).double() if relu else torch.ones_like(dy)
+    assert _relerr(dz.permute(0, 3, 1, 2), dy * mask) < 1e-6
+
+
+def test_maxpool_and_gap_backward(dev):
+    L = hipabi.lib()
+    B, C, H, W = 2, 64, 17, 22
+    # ReLU-like input with many exact ties at zero (the arg-max rule matters)
+    x = F.relu(torch.from_numpy(det_uniform((B, C, H, W), 12, -1, 1))).requires_grad_()
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.from_numpy(det_uniform(tuple(y.shape), 13, -1, 1))
+    y.backward(dy)
+    xd, dyd = nhwc(x.detach(), dev), nhwc(dy, dev)
+    yd = torch.empty(B, y.shape[2], y.shape[3], C, device=dev)
+    idx = torch.empty(B, y.shape[2], y.shape[3], C, device=dev, dtype=torch.uint8)
+    hipabi.check(L.straps_maxpool_fwd_idx(hipabi.ptr(xd), hipabi.ptr(yd), hipabi.ptr(idx), B, H, W, C, None), 'maxpool idx')
+    assert torch.equal(yd.permute(0, 3, 1, 2).cpu(), y.detach())
+    dx = torch.empty_like(xd)
+    hipabi.check(L.straps_maxpool_bwd(hipabi.ptr(dyd), hipabi.ptr(idx), hipabi.ptr(dx), B, H, W, C, None), 'maxpool bwd')
+    assert _relerr(dx.permute(0, 3, 1, 2), x.grad) < 1e-6
+    df = torch.from_numpy(det_uniform((B, C), 14, -1, 1)).to(dev)
+    dg = torch.empty(B, H * W, C, device=dev)
+    hipabi.check(L.straps_gap_bwd(hipabi.ptr(df), hipabi.ptr(dg), B, H * W, C, None), 'gap bwd')
+    assert _relerr(dg, (df / (H * W))[:, None, :].expand(B, H * W, C)) < 1e-6
+
+
+def test_rot6d_backward(dev):
+    x = torch.from_numpy(det_uniform((5, 144), 15, -1.5, 1.5))
+    xo = x.clone().double().requires_grad_()
+    R = O.rot6d_to_rotmat(xo)
+    g = torch.from_numpy(det_uniform((120, 3, 3), 16, -1, 1))
+    R.backward(g.double())
+    xg = x.to(dev).requires_grad_()
+    Rg = straps_amd.rot6d_to_rotmat(xg)
+    Rg.backward(g.to(dev))
+    assert _relerr(xg.grad, xo.grad) < 2e-5
+
+
+def _load_det(reg, layers, dev):
+    man = json.load(open(os.path.join(GOLD, 'state_dict_keys_r%d.json' % layers)))['keys']
+    sd = {k: torch.from_numpy(v) for k, v in det_state_dict(man).items()}
+    reg.load_state_dict(sd, strict=True)
+    return reg.to(dev), sd
+
+
+@pytest.mark.parametrize('layers,F_', [(18, 512), (50, 2048)])
+def test_ief_backward_vs_oracle_autograd(dev, layers, F_):
+    reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+    feat = torch.from_numpy(det_uniform((5, F_), 31, 0.0, 2.0))
+    coef = torch.from_numpy(det_uniform((5, 157), 32, -1, 1))
+    names = ['ief_module.fc%d.%s' % (i, t) for i in (1, 2, 3) for t in ('weight', 'bias')]
+    sdo = {k: v.clone().double() for k, v in sd.items() if k.startswith('ief_module.')}
+    for n in names:
+        sdo[n].requires_grad_()
+    fo = feat.clone().double().requires_grad_()
+    _, _, _, est = O.ief_forward(fo, sdo, O.ief_init_estimate(MP['pose'], MP['shape']).double(), 3)
+    (est * coef.double()).sum().backward()
+    fg = feat.to(dev).requires_grad_()
+    cam, pose, shape = reg.ief_module(fg)
+    (torch.cat([cam, pose, shape], 1) * coef.to(dev)).sum().backward()
+    assert _relerr(fg.grad, fo.grad) < 5e-5
+    for n in names:
+        p = dict(reg.named_parameters())[n]
+        assert _relerr(p.grad, sdo[n].grad) < 5e-5, n
+
+
+@pytest.mark.parametrize('layers', [18, 50])
+def test_regressor_param_grads_vs_reference_golden(dev, layers):
+    """loss.backward() through encoder + IEF (training-mode BatchNorm) against the parameter gradients the
+    reference itself produced (oracle/make_golden.py, grad_checks_r*.json)."""
+    gold = json.load(open(os.path.join(GOLD, 'grad_checks_r%d.json' % layers)))
+    reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+    reg.train()
+    x = torch.from_numpy(det_uniform((2, 18, 256, 256), 4242, 0.0, 1.0)).to(dev)
+    coef = torch.from_numpy(det_uniform((2, 157), 555)).to(dev)
+    cam, pose, shape = reg(x)
+    (torch.cat([cam, pose, shape], 1) * coef).sum().backward()
+    # This B=2 training-mode problem is ill-conditioned: on the CPU the SAME graph in fp64 differs from the reference's
+    # fp32 result by 0.24 % in gradient norm and up to 8 % in single elements (ReLU masks / batch statistics of 2
+    # samples amplify round-off).  Every kernel is checked tightly on its own above; this end-to-end test guards the
+    # wiring: norms within 1 % of the reference golden, direction (cosine) vs the oracle's autograd >= 0.995 (measured: r18 0.99992, r50 0.9989 worst tensor).
+    sdo = {k: v.clone() for k, v in sd.items()}
+    names = [n for n, _ in reg.named_parameters()]
+    for n in names:
+        sdo[n].requires_grad_(True)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    _, _, _, est = O.regressor_forward(x.cpu(), sdo, O.ief_init_estimate(MP['pose'], MP['shape']), layers, 3, training=True)
+    (est * coef.cpu()).sum().backward()
+    worst, worst_cos = 0.0, 1.0
+    for n, p in reg.named_parameters():
+        ref_norm, ref_head = gold[n]
+        assert p.grad is not None, n
+        g = p.grad.cpu().double().reshape(-1)
+        go = sdo[n].grad.double().reshape(-1)
+        err = abs(float(g.norm()) - ref_norm) / max(ref_norm, 1e-12)
+        cos = float((g @ go) / (g.norm() * go.norm()).clamp_min(1e-30))
+        worst, worst_cos = max(worst, err), min(worst_cos, cos)
+        assert err < 1e-2, '%s: grad norm %.6e vs reference %.6e' % (n, float(g.norm()), ref_norm)
+        assert cos > 0.995, '%s: cosine vs oracle autograd %.6f' % (n, cos)
+    print('r%d worst grad-norm rel err %.2e, worst cosine %.6f' % (layers, worst, worst_cos))
+
+
+def test_smpl_backward_vs_oracle_autograd(dev):
+    model = straps_amd.synthetic_smpl_model(0)
+    for B in (3, 37):
+        smpl = straps_amd.SMPL(model, batch_size=B).to(dev)
+        betas = torch.from_numpy(det_uniform((B, 10), 40 + B, -2, 2))
+        aa = torch.from_numpy(det_uniform((B, 72), 41 + B, -0.8, 0.8))
+        R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+        gv = torch.from_numpy(det_uniform((B, 6890, 3), 42, -1, 1))
+        gj = torch.from_numpy(det_uniform((B, 90, 3), 43, -1, 1))
+        bo, Ro = betas.double().requires_grad_(), R.double().requires_grad_()
+        v, j = O.smpl_forward(model, bo, rotmats=Ro, dtype=torch.float64)
+        ((v * gv.double()).sum() + (j * gj.double()).sum()).backward()
+        bg, Rg = betas.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+        out = smpl(body_pose=Rg[:, 1:], global_orient=Rg[:, 0:1], betas=bg, pose2rot=False)
+        ((out.vertices * gv.to(dev)).sum() + (out.joints * gj.to(dev)).sum()).backward()
+        assert _relerr(bg.grad, bo.grad) < 1e-4, 'dbetas B=%d' % B
+        assert _relerr(Rg.grad, Ro.grad) < 1e-4, 'drotmats B=%d' % B
+    # joints-only and verts-only gradients (NULL inputs)
+    bg, Rg = betas.to(dev).requires_grad_(), R.to(dev).requires_grad_()
+    out = smpl(body_pose=Rg[:, 1:], global_orient=Rg[:, 0:1], betas=bg, pose2rot=False)
+    (out.joints * gj.to(dev)).sum().backward()
+    bo.grad = None; Ro.grad = None
+    v, j = O.smpl_forward(model, bo, rotmats=Ro, dtype=torch.float64)
+    (j * gj.double()).sum().backward()
+    assert _relerr(bg.grad, bo.grad) < 1e-4 and _relerr(Rg.grad, Ro.grad) < 1e-4
+
+
+def test_criterion_module_vs_reference_golden(dev):
+    small = np.load(os.path.join(GOLD, 'small_golden.npz'))
+    ck = json.load(open(os.path.join(GOLD, 'criterion_keys.json')))
+    B = 4
+    w = {'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}
+    crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
+                                                                   init_loss_weights=w, reduction='mean').to(dev)
+    assert list(crit.state_dict().keys()) == list(ck['keys'].keys())
+    assert [n for n, _ in crit.named_parameters()] == ck['param_order']
+    for k, v in ck['keys'].items():
+        assert float(crit.state_dict()[k]) == pytest.approx(v, rel=1e-6)
+    lab = {'verts': torch.from_numpy(det_uniform((B, 6890, 3), 40)), 'joints2D': torch.from_numpy(det_uniform((B, 17, 2), 41, -40.0, 300.0)),
+           'joints3D': torch.from_numpy(det_uniform((B, 14, 3), 42)), 'shape_params': torch.from_numpy(det_uniform((B, 10), 43, -2, 2)),
+           'pose_params_rot_matrices': torch.from_numpy(det_uniform((B, 24, 3, 3), 44))}
+    lab['vis'] = O.check_joints2d_visibility(lab['joints2D'])
+    lab = {k: v.to(dev) for k, v in lab.items()}
+    outp = {'verts': torch.from_numpy(det_uniform((B, 6890, 3), 45)), 'joints2D': torch.from_numpy(det_uniform((B, 17, 2), 46)),
+            'joints3D': torch.from_numpy(det_uniform((B, 14, 3), 47)), 'shape_params': torch.from_numpy(det_uniform((B, 10), 48, -2, 2)),
+            'pose_params_rot_matrices': torch.from_numpy(det_uniform((B, 24, 3, 3), 49))}
+    outp = {k: v.to(dev).requires_grad_() for k, v in outp.items()}
+    total, parts = crit(lab, outp)
+    total.backward()
+    assert float(total) == pytest.approx(float(small['loss_total']), rel=2e-5)
+    order = ('verts', 'joints2D', 'joints3D', 'shape_params', 'pose_params')
+    np.testing.assert_allclose([float(parts[k]) for k in order], small['loss_parts'], rtol=2e-5)
+    np.testing.assert_allclose([float(getattr(crit, k + '_log_var').grad) for k in order], small['loss_grad_logvars'], rtol=2e-5)
+    np.testing.assert_allclose(outp['joints2D'].grad.cpu().numpy(), small['loss_grad_j2d'], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(outp['shape_params'].grad.cpu().numpy(), small['loss_grad_shape'], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(outp['verts'].grad.reshape(-1)[:64].cpu().numpy(), small['loss_grad_verts_head'], rtol=1e-4, atol=1e-10)
+    np.testing.assert_allclose(outp['joints3D'].grad.cpu().numpy(), small['loss_grad_j3d'], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(outp['pose_params_rot_matrices'].grad.reshape(-1)[:64].cpu().numpy(), small['loss_grad_pose_head'], rtol=1e-4, atol=1e-10)
+
+
+def test_fused_loss_vs_oracle(dev):
+    """straps_loss_fwd_bwd (heads + 5 losses + gradients in one call) vs the oracle composed with autograd."""
+    L = hipabi.lib()
+    B = 6
+    joints = torch.from_numpy(det_uniform((B, 90, 3), 60, -1, 1))
+    est = torch.zeros(B, 160)
+    est[:, :157] = torch.from_numpy(det_uniform((B, 157), 61, -1, 1))
+    est[:, 0] = est[:, 0].abs() + 0.5
+    prot = torch.from_numpy(det_uniform((B, 24, 3, 3), 62))
+    pverts = torch.from_numpy(det_uniform((B, 6890, 3), 63))
+    tverts = torch.from_numpy(det_uniform((B, 6890, 3), 64))
+    tj2d = torch.from_numpy(det_uniform((B, 17, 2), 65, -40.0, 300.0))
+    tj3d = torch.from_numpy(det_uniform((B, 14, 3), 66))
+    tshape = torch.from_numpy(det_uniform((B, 10), 67, -2, 2))
+    trot = torch.from_numpy(det_uniform((B, 24, 3, 3), 68))
+    lv0 = O.init_log_vars({'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0})
+    order = ('verts', 'joints2D', 'joints3D', 'shape_params', 'pose_params')
+    # oracle with autograd
+    J, E, PR, PV = joints.double().requires_grad_(), est.double().requires_grad_(), prot.double().requires_grad_(), pverts.double().requires_grad_()
+    lv = {k: torch.tensor(lv0[k], dtype=torch.float64, requires_grad=True) for k in order}
+    outp = {'verts': PV, 'joints2D': O.orthographic_project(J[:, O.ALL_JOINTS_TO_COCO_MAP], E[:, :3]),
+            'joints3D': J[:, O.ALL_JOINTS_TO_H36M_MAP][:, O.H36M_TO_J14], 'shape_params': E[:, 147:157], 'pose_params_rot_matrices': PR}
+    lab = {'verts': tverts.double(), 'joints2D': tj2d.double(), 'joints3D': tj3d.double(), 'shape_params': tshape.double(),
+           'pose_params_rot_matrices': trot.double(), 'vis': O.check_joints2d_visibility(tj2d)}
+    total, parts = O.multi_task_loss(lab, outp, lv)
+    total.backward()
+    d = lambda t: t.to(dev).contiguous()
+    tens = [d(pverts), d(joints), d(est), d(prot), d(tverts), d(tj2d), d(tj3d), d(tshape), d(trot)]
+    lvd = torch.tensor([lv0[k] for k in order], dtype=torch.float32, device=dev)
+    loss = torch.empty(12, device=dev)
+    dv, dj, de, dr, dl = torch.empty(B, 6890, 3, device=dev), torch.empty(B, 90, 3, device=dev), torch.empty(B, 160, device=dev), torch.empty(B, 24, 3, 3, device=dev), torch.empty(5, device=dev)
+    ws = torch.empty(L.straps_loss_workspace_bytes(B) // 4, device=dev)
+    hipabi.check(L.straps_loss_fwd_bwd(hipabi.ptr(tens[0]), hipabi.ptr(tens[1]), hipabi.ptr(tens[2]), 160, hipabi.ptr(tens[3]), hipabi.ptr(tens[4]),
+                                       hipabi.ptr(tens[5]), hipabi.ptr(tens[6]), hipabi.ptr(tens[7]), hipabi.ptr(tens[8]), hipabi.ptr(lvd), hipabi.ptr(loss),
+                                       hipabi.ptr(dv), hipabi.ptr(dj), hipabi.ptr(de), hipabi.ptr(dr), hipabi.ptr(dl), hipabi.ptr(ws), B, 256, None), 'loss')
+    lo = loss.cpu()
+    assert float(lo[0]) == pytest.approx(float(total), rel=2e-5)
+    np.testing.assert_allclose(lo[1:6].numpy(), [float(parts[k]) for k in order], rtol=2e-5)
+    assert int(lo[11]) == int(lab['vis'].sum())
+    np.testing.assert_allclose(dl.cpu().numpy(), [float(lv[k].grad) for k in order], rtol=2e-5)
+    assert _relerr(dv, PV.grad) < 1e-5 and _relerr(dj, J.grad) < 1e-5 and _relerr(dr, PR.grad) < 1e-5
+    assert _relerr(de, E.grad) < 1e-5
+
+
+def test_build_proxy_input_vs_reference_golden(dev):
+    small = np.load(os.path.join(GOLD, 'small_golden.npz'))
+    jh = torch.from_numpy(small['heat_in']).to(dev)
+    hm = straps_amd.label_conversions.convert_2Djoints_to_gaussian_heatmaps_torch(jh, 256)
+    flat = hm.reshape(-1).cpu()
+    nz = flat.nonzero().squeeze(1).numpy()
+    assert np.array_equal(nz, small['heat_nz_idx'])
+    np.testing.assert_allclose(flat[nz].numpy(), small['heat_nz_val'], rtol=2e-6, atol=1e-7)
+    seg = (torch.from_numpy(det_uniform((2, 256, 256), 38, 0.0, 1.0)) > 0.7).float() * torch.from_numpy(np.floor(det_uniform((2, 256, 256), 39, 1.0, 6.999)))
+    x = straps_amd.label_conversions.build_proxy_input(seg.to(dev), jh)
+    assert x.shape == (2, 18, 256, 256)
+    assert float(x[:, 0].sum()) == float(small['binary_sum'])
+    assert torch.equal(x[:, 1:], hm)
+
+
+def test_adam_vs_reference_golden(dev):
+    small = np.load(os.path.join(GOLD, 'small_golden.npz'))
+    man = json.load(open(os.path.join(GOLD, 'state_dict_keys_r18.json')))
+    sd = {k: torch.from_numpy(v) for k, v in det_state_dict(man['keys']).items()}
+    ps = [sd[n].clone() for n in man['param_order']] + [torch.zeros(()) for _ in range(5)]
+    grads = [torch.from_numpy(det_uniform(tuple(p.shape), 9000 + i, -1e-2, 1e-2)).reshape(p.shape) for i, p in enumerate(ps)]
+    flat_p = torch.cat([p.reshape(-1) for p in ps]).to(dev)
+    flat_g = torch.cat([g.reshape(-1) for g in grads]).to(dev)
+    before = flat_p.clone()
+    m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+    L = hipabi.lib()
+    for step in (1, 2):
+        hipabi.check(L.straps_adam_step(hipabi.ptr(flat_p), hipabi.ptr(flat_g), hipabi.ptr(m), hipabi.ptr(v), flat_p.numel(), step, 1e-4, 0.9, 0.999, 1e-8, 1.0, None), 'adam')
+    delta = (flat_p - before).cpu().double()
+    off = 0
+    ds, da = [], []
+    for p in ps:
+        n = p.numel()
+        ds.append(float(delta[off:off + n].sum()))
+        da.append(float(delta[off:off + n].abs().sum()))
+        off += n
+    np.testing.assert_allclose(da, small['adam_delta_abs'], rtol=1e-4)
+    np.testing.assert_allclose(ds, small['adam_delta_sum'], rtol=2e-3, atol=1e-6)
