@@ -276,6 +276,11 @@ int straps_mse_bwd(const float* pred, const float* tgt, const uint8_t* row_mask,
  * 1 occlusion draw, 2 box-centre draws), remove_prob[6] device array.                              */
 int straps_augment_seg(const float* seg, const float* uniforms, const float* remove_prob,
                        float occlude_prob, int box_dim, float* out, int batch, int wh, void* stream);
+/* target-side heads of the train step (train loop :138-143): joints3d [B,14,3] = H36M-LSP subset of
+ * joints [B,90,3]; joints2d [B,17,2] = perspective projection of the COCO subset with identity
+ * rotation, translation cam_t [B,3] and intrinsics fx,fy,cx,cy (utils/cam_utils.py:40-71).         */
+int straps_project_targets(const float* joints, const float* cam_t, float fx, float fy, float cx,
+                           float cy, float* joints2d, float* joints3d, long long batch, void* stream);
 /* STAND-IN for the part-segmentation rasteriser (renderers/nmr_renderer.py; SURVEY 8f row f1, not built):
  * labels discs around the 17 projected COCO joints (+ a torso box) with the 6 LSP part ids.          */
 int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream);

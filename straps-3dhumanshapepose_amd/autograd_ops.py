@@ -15,6 +15,20 @@ def _empty_like(t):
     return torch.empty_like(t, memory_format=torch.contiguous_format)
 
 
+class GradSink(dict):
+    """{param: grad}.  `views` (optional) maps a parameter to a preallocated gradient tensor -- e.g. a slice of the
+    flat gradient buffer of train_step.TrainStep -- so kernels write gradients in place (no copies, one all-reduce)."""
+
+    def __init__(self, views=None):
+        super().__init__()
+        self.views = views
+
+    def buf(self, p, zero=False):
+        if self.views is not None and p in self.views:
+            return self.views[p]                      # the owner zeroes the flat buffer once per step
+        return torch.zeros_like(p) if zero else torch.empty_like(p)
+
+
 # ------------------------------------------------------------------------------------------ encoder
 def _packed_dgrad_weight(net, conv):
     w = conv.weight
@@ -34,7 +48,7 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads):
     raw, ss = rec['raw'], rec['stats']
     rows, Cc = raw.numel() // raw.shape[-1], raw.shape[-1]
     ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, Cc) // 4, device=raw.device, dtype=torch.float32)
-    dgamma, dbeta = torch.empty_like(bn.weight), torch.empty_like(bn.bias)
+    dgamma, dbeta = grads.buf(bn.weight), grads.buf(bn.bias)
     draw = _empty_like(raw)
     dz = _empty_like(raw) if want_dz else None
     hipabi.check(L.straps_bn_bwd(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
@@ -49,7 +63,7 @@ def _conv_wgrad(L, rec, draw, grads):
     conv = rec['conv']
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=draw.device, dtype=torch.float32)
-    dw = torch.empty_like(conv.weight)
+    dw = grads.buf(conv.weight)
     hipabi.check(L.straps_conv_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride,
                                      pad, 0, hipabi.stream_ptr()), 'straps_conv_wgrad')
     grads[conv.weight] = dw
@@ -64,10 +78,10 @@ def _conv_dgrad(L, net, rec, draw, addend):
     return dx
 
 
-def encoder_backward(net, tape, dfeat):
+def encoder_backward(net, tape, dfeat, views=None):
     """tape: dict filled by encoder_forward(net, x, tape) in training mode.  Returns {param: grad}."""
     L = hipabi.lib()
-    grads = {}
+    grads = GradSink(views)
     rec = tape['gap']
     B, HW, Cf = rec['geom']
     dy = _empty_like(rec['x'])
@@ -100,7 +114,7 @@ def encoder_backward(net, tape, dfeat):
     draw, _ = _bn_bwd(L, rec, dstem, True, False, grads)
     B, Cin, H, W, Ho, Wo = rec['geom']
     ws = torch.empty(L.straps_stem_wgrad_workspace_bytes(B, Cin, H, W) // 4, device=draw.device, dtype=torch.float32)
-    dw = torch.empty_like(net.conv1.weight)
+    dw = grads.buf(net.conv1.weight)
     hipabi.check(L.straps_stem_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, Cin, H, W, 0,
                                      hipabi.stream_ptr()), 'straps_stem_wgrad')
     grads[net.conv1.weight] = dw
@@ -108,8 +122,9 @@ def encoder_backward(net, tape, dfeat):
 
 
 # ------------------------------------------------------------------------------------------ IEF
-def ief_backward(ief, feat, tape, dest):
+def ief_backward(ief, feat, tape, dest, views=None):
     """dest: gradient w.r.t. the final estimate [B,160].  Returns (dfeat, {param: grad})."""
+    sink = GradSink(views)
     L, st = hipabi.lib(), hipabi.stream_ptr()
     pk = ief._packed(feat.device)
     B, F = feat.shape
@@ -117,8 +132,9 @@ def ief_backward(ief, feat, tape, dest):
     dev = feat.device
     z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
     e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-    dW3, db3, dW2, db2 = z(P, H2), z(P), z(H2, H1), z(H2)
-    dW1 = z(H1, F + P)
+    dW3, db3 = sink.buf(ief.fc3.weight, True), sink.buf(ief.fc3.bias, True)
+    dW2, db2 = sink.buf(ief.fc2.weight, True), sink.buf(ief.fc2.bias, True)
+    dW1 = sink.buf(ief.fc1.weight, True)
     dc1 = z(B, H1)
     dest = dest.contiguous().clone()
     gemm, colsum = L.straps_gemm_strided, L.straps_colsum
@@ -147,7 +163,7 @@ def ief_backward(ief, feat, tape, dest):
     dfeat = e(B, F)
     hipabi.check(gemm(hipabi.ptr(dc1), H1, 1, hipabi.ptr(pk['w1f']), F, 1, hipabi.ptr(dfeat), F, None, 0, B, F, H1, 0, st), 'ief d_feat')
     hipabi.check(gemm(hipabi.ptr(dc1), 1, H1, hipabi.ptr(feat), F, 1, hipabi.ptr(dW1), F + P, None, 0, H1, F, B, 1, st), 'ief dW1f')
-    db1 = z(H1)
+    db1 = sink.buf(ief.fc1.bias, True)
     hipabi.check(colsum(hipabi.ptr(dc1), H1, None, 0, hipabi.ptr(db1), B, H1, 1, st), 'ief db1')
     grads = {ief.fc1.weight: dW1, ief.fc1.bias: db1, ief.fc2.weight: dW2, ief.fc2.bias: db2, ief.fc3.weight: dW3, ief.fc3.bias: db3}
     return dfeat, grads

@@ -391,6 +391,38 @@ __global__ __launch_bounds__(256) void synth_seg_kernel(const float* __restrict_
 }
 }  // namespace
 
+namespace {
+// target-side heads (train loop :138-143): H36M-LSP 3D joints and the perspective projection of the COCO joints
+__global__ __launch_bounds__(256) void project_targets_kernel(const float* __restrict__ joints, const float* __restrict__ cam_t, float fx,
+                                                              float fy, float cx, float cy, float* __restrict__ j2d,
+                                                              float* __restrict__ j3d, long long B) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * 31) return;
+    const long long b = i / 31;
+    const int k = (int)(i - b * 31);
+    const float* J = joints + b * 270;
+    if (k < 17) {
+        const float* p = J + c_coco[k] * 3;
+        const float x = p[0] + cam_t[b * 3 + 0], y = p[1] + cam_t[b * 3 + 1], z = p[2] + cam_t[b * 3 + 2];
+        j2d[(b * 17 + k) * 2 + 0] = fx * (x / z) + cx;      // K [p/p_z] with K = [[fx,0,cx],[0,fy,cy],[0,0,1]]
+        j2d[(b * 17 + k) * 2 + 1] = fy * (y / z) + cy;
+    } else {
+        const float* p = J + c_h36m14[k - 17] * 3;
+        float* o = j3d + (b * 14 + (k - 17)) * 3;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    }
+}
+}  // namespace
+
+extern "C" int straps_project_targets(const float* joints, const float* cam_t, float fx, float fy, float cx, float cy, float* joints2d,
+                                      float* joints3d, long long batch, void* stream) {
+    STRAPS_REQUIRE(joints && cam_t && joints2d && joints3d && batch > 0, "straps_project_targets: bad arguments");
+    hipLaunchKernelGGL(project_targets_kernel, dim3((unsigned)((batch * 31 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, joints, cam_t, fx,
+                       fy, cx, cy, joints2d, joints3d, batch);
+    STRAPS_CHECK_LAUNCH("project_targets_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream) {
     STRAPS_REQUIRE(joints2d && seg && batch > 0 && wh > 0, "straps_synth_seg: bad arguments");
     const long long n = (long long)batch * wh * wh;

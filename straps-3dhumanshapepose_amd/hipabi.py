@@ -98,6 +98,7 @@ SIGNATURES = {
     'straps_mse_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
     'straps_augment_seg': (_I, [_P, _P, _P, _F, _I, _P, _I, _I, _P]),
     'straps_synth_seg': (_I, [_P, _P, _I, _I, _F, _P]),
+    'straps_project_targets': (_I, [_P, _P, _F, _F, _F, _F, _P, _P, _L, _P]),
 }
 
 

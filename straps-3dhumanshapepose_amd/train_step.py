@@ -1,0 +1,200 @@
+"""One synthetic on-the-fly training step on the GPU -- the body of the reference's batch loop
+(train/train_synthetic_otf_rendering.py:112-233), every stage a HIP kernel behind the C ABI:
+
+  [no grad]  G1 augment_smpl (:121-126)  G2 augment_cam_t (:127-129)  SMPL#1 targets (:132-135)
+             P2 perspective projection (:141-143)  SMPL#2 reposed targets (:144)
+             part segmentation (STAND-IN for the NMR rasteriser + cv2 crop, :155-170 -- SURVEY 8f f1/f2)
+             G3 proxy augmentation (:173-175)  G4+G5 network input (:178-182)
+  forward    regressor (training-mode BatchNorm) -> rot6d -> SMPL#3 (:186-199), SMPL#4 reposed (:206)
+  loss       heads (COCO orthographic projection, H36M-LSP joints, visibility) + 5 MSE tasks + gradients
+  backward   SMPL -> rot6d -> IEF -> encoder, gradients written straight into ONE flat fp32 buffer
+  exchange   (world > 1) one sum all-reduce of that buffer over RCCL/xGMI
+  update     Adam over the flat parameter buffer (66|165 regressor tensors + 5 log-variances)
+
+Random draws use torch's device generator (seeded per rank); they are inputs of the step, not part
+of its arithmetic.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import config, hipabi
+from .autograd_ops import encoder_backward, ief_backward
+from .encoder_exec import encoder_forward
+from .ief_module import EST_LD
+from .multi_task_loss import TASKS
+
+REMOVE_PROBS = (0.1, 0.1, 0.1, 0.1, 0.05, 0.05)        # run_train.py:167-168
+H36M14 = [73 + i for i in config.H36M_TO_J14]
+
+
+def flatten_parameters(params, device):
+    """move every parameter into one contiguous fp32 buffer (views keep the modules working) and build
+    the matching flat gradient buffer.  Returns (flat_p, flat_g, {param: grad_view})."""
+    total = sum(p.numel() for p in params)
+    flat_p = torch.empty(total, device=device, dtype=torch.float32)
+    flat_g = torch.zeros(total, device=device, dtype=torch.float32)
+    views, off = {}, 0
+    for p in params:
+        n = p.numel()
+        flat_p[off:off + n].copy_(p.detach().reshape(-1))
+        p.data = flat_p[off:off + n].view(p.shape)
+        views[p] = flat_g[off:off + n].view(p.shape)
+        off += n
+    return flat_p, flat_g, views
+
+
+def allreduce_gradients(flat_g, world_size, group=None):
+    """the step's single exchange: sum all-reduce of the flat gradient buffer (RCCL over xGMI on GPUs,
+    gloo in the CPU tests); the 1/world_size is folded into the Adam kernel's grad_scale."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world_size
+
+
+class TrainStep:
+    def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
+                 mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None):
+        p0 = next(regressor.parameters())
+        hipabi.require_gpu_tensor(p0, 'regressor parameters (call .to(device) first)')
+        self.dev = p0.device
+        self.reg, self.smpl, self.crit = regressor, smpl, criterion
+        self.B, self.lr, self.rank, self.world, self.group = batch_size, lr, rank, world_size, group
+        self.params = list(regressor.parameters()) + list(criterion.parameters())          # run_train.py:200 order
+        self.flat_p, self.flat_g, self.gviews = flatten_parameters(self.params, self.dev)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.steps = 0
+        self.n_reg = sum(p.numel() for p in regressor.parameters())
+        self.logvar_params = [getattr(criterion, n + '_log_var') for n in TASKS]
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(seed + rank)
+        d = self.dev
+        self.mean_shape = torch.zeros(10, device=d) if mean_shape is None else torch.as_tensor(mean_shape, dtype=torch.float32, device=d)
+        self.mean_cam_t = torch.tensor(mean_cam_t, device=d).expand(batch_size, 3).contiguous()
+        K = np.array([[config.FOCAL_LENGTH, 0., config.REGRESSOR_IMG_WH / 2.0], [0., config.FOCAL_LENGTH, config.REGRESSOR_IMG_WH / 2.0],
+                      [0., 0., 1.]], dtype=np.float32)
+        self.cam_K = torch.from_numpy(K).to(d)
+        self.remove_prob = torch.tensor(REMOVE_PROBS, device=d)
+        # stand-in for data/synthetic_training_dataset.py: a resident pool of (pose axis-angle [72]) samples
+        if pose_pool is None:
+            g = torch.Generator().manual_seed(seed)
+            pose_pool = torch.randn(4096, 72, generator=g) * 0.2
+            pose_pool[:, :3] = 0
+            pose_pool[:, 1] = (torch.rand(4096, generator=g) * 2 - 1) * np.pi * 0.5       # global orientation about y
+        self.pose_pool = pose_pool.to(d)
+        self.last = {}
+
+    # ------------------------------------------------------------------ data generation (no grad)
+    def make_batch(self):
+        L, st, d, B = hipabi.lib(), hipabi.stream_ptr(), self.dev, self.B
+        from .rigid_transform_utils import batch_rodrigues
+        idx = torch.randint(0, self.pose_pool.shape[0], (B,), device=d, generator=self.gen)
+        pose = self.pose_pool[idx]
+        # G1: shape ~ mean + N(0, 1.5^2) (run_train.py:133-137), axis-angle -> rotation matrices
+        tgt_shape = self.mean_shape[None] + torch.randn(B, 10, device=d, generator=self.gen) * 1.5
+        tgt_rot = batch_rodrigues(pose.reshape(-1, 3)).view(B, 24, 3, 3)
+        # G2: camera translation (augmentation/cam_augmentation.py:4-14)
+        cam_t = self.mean_cam_t.clone()
+        cam_t[:, :2] += torch.randn(B, 2, device=d, generator=self.gen) * 0.05
+        cam_t[:, 2] += torch.rand(B, device=d, generator=self.gen) * 10.0 - 5.0
+        # SMPL #1 / #2
+        tgt_verts, tgt_joints = self.smpl.forward_arrays(tgt_shape, tgt_rot)
+        eye = torch.eye(3, device=d).expand(B, 24, 3, 3).contiguous()
+        tgt_reposed, _ = self.smpl.forward_arrays(tgt_shape, eye, want_joints=False)
+        # H36M-LSP 3D joints + P2: perspective projection of the COCO joints (utils/cam_utils.py:40-71, cam_R = I)
+        tgt_j3d, tgt_j2d = torch.empty(B, 14, 3, device=d), torch.empty(B, 17, 2, device=d)
+        wh = float(config.REGRESSOR_IMG_WH)
+        hipabi.check(L.straps_project_targets(hipabi.ptr(tgt_joints), hipabi.ptr(cam_t), config.FOCAL_LENGTH, config.FOCAL_LENGTH, wh / 2, wh / 2,
+                                              hipabi.ptr(tgt_j2d), hipabi.ptr(tgt_j3d), B, st), 'straps_project_targets')
+        # stand-in part segmentation, then G3 (+ joints deviation U[-8,8], proxy_rep_augmentation.py:25-49)
+        seg = torch.empty(B, 256, 256, device=d)
+        hipabi.check(L.straps_synth_seg(hipabi.ptr(tgt_j2d), hipabi.ptr(seg), B, 256, 14.0, st), 'straps_synth_seg')
+        u = torch.rand(B, 9, device=d, generator=self.gen)
+        seg_aug = torch.empty_like(seg)
+        hipabi.check(L.straps_augment_seg(hipabi.ptr(seg), hipabi.ptr(u), hipabi.ptr(self.remove_prob), 0.5, 48, hipabi.ptr(seg_aug), B, 256, st),
+                     'straps_augment_seg')
+        j2d_in = tgt_j2d + (torch.rand(B, 17, 2, device=d, generator=self.gen) * 16.0 - 8.0)
+        # G4 + G5
+        x = torch.empty(B, 18, 256, 256, device=d)
+        hipabi.check(L.straps_build_proxy_input(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), B, 17, 256, st), 'straps_build_proxy_input')
+        return dict(input=x, verts=tgt_verts, joints2d=tgt_j2d, joints3d=tgt_j3d, shape=tgt_shape, rot=tgt_rot, reposed=tgt_reposed)
+
+    # ------------------------------------------------------------------ forward + loss + backward
+    def forward_backward(self, batch):
+        L, st, d, B = hipabi.lib(), hipabi.stream_ptr(), self.dev, self.B
+        reg, smpl = self.reg, self.smpl
+        assert reg.training, 'TrainStep needs the regressor in .train() mode'
+        self.flat_g.zero_()
+        enc_tape, ief_tape = {}, []
+        feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape)
+        est = reg.ief_module.forward_estimate(feat, ief_tape)                      # [B,160]
+        pose6d = est[:, 3:147]
+        R = torch.empty(B, 24, 3, 3, device=d)
+        hipabi.check(L.straps_rot6d_fwd(hipabi.ptr(pose6d), EST_LD, 24, hipabi.ptr(R), B, st), 'straps_rot6d_fwd')
+        pred_shape = est[:, 147:157].contiguous()
+        verts, joints = smpl.forward_arrays(pred_shape, R)                         # SMPL #3
+        eye = torch.eye(3, device=d).expand(B, 24, 3, 3).contiguous()
+        reposed, _ = smpl.forward_arrays(pred_shape, eye, want_joints=False)       # SMPL #4 (metrics only, train loop :206)
+        # heads + loss + gradients
+        lv = self.crit.log_var_vector()
+        loss = torch.empty(12, device=d)
+        dverts, djoints = torch.empty_like(verts), torch.empty_like(joints)
+        dest, drot = torch.empty(B, EST_LD, device=d), torch.empty(B, 24, 3, 3, device=d)
+        dlv = torch.empty(5, device=d)
+        ws = torch.empty(L.straps_loss_workspace_bytes(B) // 4, device=d)
+        hipabi.check(L.straps_loss_fwd_bwd(hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(est), EST_LD, hipabi.ptr(R), hipabi.ptr(batch['verts']),
+                                           hipabi.ptr(batch['joints2d']), hipabi.ptr(batch['joints3d']), hipabi.ptr(batch['shape']),
+                                           hipabi.ptr(batch['rot']), hipabi.ptr(lv), hipabi.ptr(loss), hipabi.ptr(dverts), hipabi.ptr(djoints),
+                                           hipabi.ptr(dest), hipabi.ptr(drot), hipabi.ptr(dlv), hipabi.ptr(ws), B, config.REGRESSOR_IMG_WH, st),
+                     'straps_loss_fwd_bwd')
+        # SMPL backward -> (dbetas, drot2)
+        dbetas, drot2 = torch.empty(B, 10, device=d), torch.empty(B, 24, 3, 3, device=d)
+        ws2 = torch.empty(L.straps_smpl_bwd_workspace_bytes(B, 0) // 4, device=d)
+        hipabi.check(L.straps_smpl_bwd(C.byref(smpl._model_struct()), hipabi.ptr(pred_shape), hipabi.ptr(R), hipabi.ptr(dverts), hipabi.ptr(djoints),
+                                       hipabi.ptr(dbetas), hipabi.ptr(drot2), hipabi.ptr(ws2), B, 0, st), 'straps_smpl_bwd')
+        # gather into d(est): shape columns += dbetas; pose columns = rot6d backward of (drot + drot2)
+        hipabi.check(L.straps_masked_copy(hipabi.ptr(drot2), 216, None, 0, hipabi.ptr(drot), 216, B, 216, 1, st), 'drot sum')
+        hipabi.check(L.straps_masked_copy(hipabi.ptr(dbetas), 10, None, 0, C.c_void_p(dest.data_ptr() + 4 * 147), EST_LD, B, 10, 1, st), 'dshape sum')
+        hipabi.check(L.straps_rot6d_bwd(hipabi.ptr(pose6d), EST_LD, 24, hipabi.ptr(drot), C.c_void_p(dest.data_ptr() + 4 * 3), EST_LD, B, st),
+                     'straps_rot6d_bwd')
+        # regressor backward, gradients land in the flat buffer
+        dfeat, _ = ief_backward(reg.ief_module, feat, ief_tape, dest, self.gviews)
+        encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews)
+        for k, p in enumerate(self.logvar_params):
+            if p.requires_grad:
+                self.gviews[p].copy_(dlv[k])
+        self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed)
+        return loss
+
+    def optimise(self):
+        gscale = allreduce_gradients(self.flat_g, self.world, self.group)
+        self.steps += 1
+        hipabi.check(hipabi.lib().straps_adam_step(hipabi.ptr(self.flat_p), hipabi.ptr(self.flat_g), hipabi.ptr(self.exp_avg),
+                                                   hipabi.ptr(self.exp_avg_sq), self.flat_p.numel(), self.steps, self.lr, 0.9, 0.999, 1e-8,
+                                                   gscale, hipabi.stream_ptr()), 'straps_adam_step')
+        # the parameters changed behind torch's back: drop the packed-weight caches
+        self.reg.image_encoder._cache.clear()
+        self.reg.ief_module._cache = {}
+
+    def step(self):
+        """one full training step; returns the 12-float loss record (device tensor, no sync)."""
+        with torch.no_grad():
+            batch = self.make_batch()
+            loss = self.forward_backward(batch)
+            self.optimise()
+        return loss
+
+    def state_dict(self):
+        """optimiser state in torch.optim.Adam's schema (checkpoint key 'optimiser_state_dict')."""
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.steps)), 'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        group = {'lr': self.lr, 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
