@@ -286,10 +286,11 @@ int straps_project_targets(const float* joints, const float* cam_t, float fx, fl
 int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream);
 /* torch.optim.Adam defaults (run_train.py:200-201) over one flat fp32 buffer:
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);
- * grad_scale multiplies g first (1/world_size after a sum all-reduce).                           */
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).  step_dev (optional device
+ * int) overrides `step` so that a captured hipGraph can advance the step count on the device.       */
 int straps_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      long long n, int step, float lr, float beta1, float beta2, float eps,
-                     float grad_scale, void* stream);
+                     float grad_scale, const int* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,18 +1,21 @@
 // conv.hip -- implicit-GEMM convolution over NHWC fp32 on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
-// (replaces nn.Conv2d 3x3 / 1x1 + the BN/ReLU/residual passes of models/resnet.py:61-77, 101-121).
+// (replaces nn.Conv2d 3x3 / 1x1 + the BN/ReLU/residual passes of models/resnet.py:61-77, 101-121, and the
+// data-gradient half of their backward).
 //
-//   GEMM view:  M = B*Ho*Wo output pixels,  N = Cout,  K = R*S*Cin  (tap-major, channel-minor).
-//   A operand = im2col rows gathered on the fly (each 32-channel K chunk of one tap is 128
-//   contiguous bytes of one input pixel -> 8 lanes x float4), B operand = weights repacked KRSC.
-//   Both are staged global -> registers -> LDS (issue-early / write-late, double-buffered LDS,
-//   one barrier per K chunk) and read back as ds_read_b128 fragments: row stride 36 floats
-//   (= 4 * odd) makes both the b128 writes and the b128 fragment reads bank-conflict free.
-//   K is permuted inside each group of 8 (lane half h takes k = 8g+4h..+3) so one b128 read feeds
-//   four MFMAs; A and B use the same permutation so the contraction is unchanged.
-//   Epilogue (C layout: lane = output channel, reg = pixel row): BN scale/shift, residual, ReLU
-//   fused in eval mode; raw output + per-channel (sum, sumsq) partials in training mode.
-//   Block ids are remapped so that consecutive tiles (same A rows / neighbouring halos) share an
-//   XCD's L2.
+//   GEMM view:  M = output pixels,  N = output channels,  K = taps x Cin  (tap-major, channel-minor).
+//   A operand = im2col rows gathered on the fly (each 32-channel K chunk of one tap is 128 contiguous bytes of one
+//   source pixel -> 8 lanes x float4), B operand = weights repacked [n][tap][cin].
+//   Both are staged global -> registers -> LDS (issue-early / write-late, double-buffered LDS, one barrier per K
+//   chunk) and read back as ds_read_b128 fragments: row stride 36 floats (= 4 * odd) makes both the b128 writes and
+//   the b128 fragment reads bank-conflict free.  K is permuted inside each group of 8 (lane half h takes
+//   k = 8g+4h..+3) so one b128 read feeds four MFMAs; A and B use the same permutation.
+//   The taps are a small table (weight tap index, source-row offset, source-col offset), which lets ONE kernel run
+//     * the forward conv (all R*S taps, source pixel = out*stride + tap - pad), and
+//     * the data gradient of a stride-2 conv as four output-parity classes, each with only the taps that hit a
+//       non-zero position of the (conceptually zero-dilated) dy -- no multiply-by-zero MFMA work.
+//   Epilogue (C layout: lane = output channel, reg = pixel row): BN scale/shift, residual/addend, ReLU fused;
+//   raw output + per-channel (sum, sumsq) partials in training mode.
+//   Block ids are remapped so that consecutive tiles (same A rows / neighbouring halos) share an XCD's L2.
 #include "common.h"
 
 namespace {
@@ -25,9 +28,13 @@ struct ConvP {
     const float* res;
     float* y;
     float* stats;
-    int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo, relu;
+    int H, W, Cin, Cout, relu;      // source tensor [B][H][W][Cin]
+    int Mh, Mw;                     // logical output grid enumerated by M = B*Mh*Mw
+    int stride;                     // source pixel of logical (ho,wo) before the tap offset: (ho*stride, wo*stride)
+    int OH, OW, omul, oah, oaw;     // physical output pixel = (b, ho*omul + oah, wo*omul + oaw) in [B][OH][OW][Cout]
     int M, MT, NT;
-    int dil_shift;   // 0 = ordinary conv; 1 = the input is read as if zero-dilated by 2 (data-gradient of a stride-2 conv)
+    int ntaps, wtaps;               // taps used / taps stored per output channel in w
+    int tap_w[9], tap_dh[9], tap_dw[9];
 };
 
 constexpr int LS = 36;   // LDS row stride in floats (32 data + 4 pad)
@@ -50,16 +57,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     // per-thread im2col row descriptors (AP rows of the A tile)
     int a_hi0[AP], a_wi0[AP];
     long long a_base[AP];
-    const int HoWo = p.Ho * p.Wo;
+    const int MhMw = p.Mh * p.Mw;
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
         const int m = m0 + lr + 32 * q;
         if (m < p.M) {
-            const int b = m / HoWo;
-            const int rem = m - b * HoWo;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            a_hi0[q] = ho * p.stride - p.pad;
-            a_wi0[q] = wo * p.stride - p.pad;
+            const int b = m / MhMw;
+            const int rem = m - b * MhMw;
+            const int ho = rem / p.Mw, wo = rem - ho * p.Mw;
+            a_hi0[q] = ho * p.stride;
+            a_wi0[q] = wo * p.stride;
             a_base[q] = (long long)b * p.H * p.W * p.Cin + lc * 4;
         } else {
             a_hi0[q] = -(1 << 28);
@@ -67,36 +74,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
             a_base[q] = 0;
         }
     }
-    const long long RS = (long long)p.R * p.S;
     const float* wrow[BP];
 #pragma unroll
-    for (int q = 0; q < BP; ++q) wrow[q] = p.w + (long long)(n0 + lr + 32 * q) * RS * p.Cin + lc * 4;
+    for (int q = 0; q < BP; ++q) wrow[q] = p.w + (long long)(n0 + lr + 32 * q) * p.wtaps * p.Cin + lc * 4;
 
     const int cchunks = p.Cin >> 5;
-    const int nchunks = p.R * p.S * cchunks;
+    const int nchunks = p.ntaps * cchunks;
 
     f32x4 ra[AP], rb[BP];
     auto load_tile = [&](int q) {
         const int tap = q / cchunks;
         const int c0 = (q - tap * cchunks) << 5;
-        const int r = tap / p.S, s = tap - r * p.S;
+        const int dh = p.tap_dh[tap], dw = p.tap_dw[tap], tw = p.tap_w[tap];
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            int hi = a_hi0[i] + r, wi = a_wi0[i] + s;
-            bool ok = true;
-            if (p.dil_shift) {
-                const int msk = (1 << p.dil_shift) - 1;
-                ok = hi >= 0 && wi >= 0 && ((hi | wi) & msk) == 0;
-                hi >>= p.dil_shift;
-                wi >>= p.dil_shift;
-            }
-            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *reinterpret_cast<const f32x4*>(p.x + a_base[i] + ((long long)hi * p.W + wi) * p.Cin + c0);
             ra[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (long long)tap * p.Cin + c0);
+        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (long long)tw * p.Cin + c0);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -113,8 +112,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    if (nchunks > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
 
     const int frag_off = (lane & 31) * LS + (lane >> 5) * 4;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
 
     // ---------------- epilogue ----------------
+    const bool remap = p.omul != 1 || p.oah != 0 || p.oaw != 0 || p.OH != p.Mh || p.OW != p.Mw;
     float s1[NI], s2[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -158,7 +160,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
                     float v = acc[i][j][r];
                     t1 += v;
                     t2 = fmaf(v, v, t2);
-                    const long long o = (long long)m * p.Cout + n;
+                    long long pix = m;
+                    if (remap) {
+                        const int b = m / MhMw;
+                        const int rem = m - b * MhMw;
+                        const int ho = rem / p.Mw, wo = rem - ho * p.Mw;
+                        pix = ((long long)b * p.OH + ho * p.omul + p.oah) * p.OW + wo * p.omul + p.oaw;
+                    }
+                    const long long o = pix * p.Cout + n;
                     if (p.scale) v = fmaf(v, sc, sh);
                     if (p.res) v += p.res[o];
                     if (p.relu) v = fmaxf(v, 0.f);
@@ -192,16 +201,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
 }
 
+// tile choice from the per-layer sweep (tools/sweep_conv.py, B=64): 128x128 where it still yields >= 2 workgroups
+// per CU (one barrier per 64 MFMAs per wave), otherwise 64x64 whose 4+ resident workgroups per CU hide each
+// other's barrier / LDS-refill bubbles (128x64 never wins).
 inline void pick_tile(int cfg, long long M, int cout, int& bm, int& bn) {
     if (cfg == 1) { bm = 128; bn = 128; }
     else if (cfg == 2) { bm = 128; bn = 64; }
     else if (cfg == 3) { bm = 64; bn = 64; }
-    else {
-        // auto: largest tile that still gives >= 2 workgroups per CU (512 blocks)
-        bm = 128; bn = (cout % 128 == 0) ? 128 : 64;
-        if (((M + 127) / 128) * (cout / bn) < 512 && bn == 128) bn = 64;
-        if (((M + 127) / 128) * (cout / bn) < 512) bm = 64;
-    }
+    else if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= 512) { bm = 128; bn = 128; }
+    else { bm = 64; bn = 64; }
     if (cout % bn != 0) bn = 64;
 }
 
@@ -222,6 +230,14 @@ int launch(const ConvP& p0, hipStream_t st) {
     return STRAPS_OK;
 }
 
+int dispatch(const ConvP& p, int tile_cfg, hipStream_t st) {
+    int bm, bn;
+    pick_tile(tile_cfg, p.M, p.Cout, bm, bn);
+    if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
+    if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
+    return launch<64, 64>(p, st);
+}
+
 }  // namespace
 
 extern "C" int straps_conv_stat_blocks(int batch, int ho, int wo, int cout, int tile_cfg) {
@@ -237,47 +253,69 @@ extern "C" int straps_conv_fwd(const float* x, const float* w, const float* scal
     STRAPS_REQUIRE(x && w && y, "straps_conv_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0 && h > 0 && wdt > 0, "straps_conv_fwd: empty input %dx%dx%d", batch, h, wdt);
     STRAPS_REQUIRE(cin % 32 == 0 && cout % 64 == 0, "straps_conv_fwd: need cin%%32==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
-    STRAPS_REQUIRE(kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "straps_conv_fwd: bad filter geometry");
+    STRAPS_REQUIRE(kh >= 1 && kw >= 1 && kh * kw <= 9 && stride >= 1 && pad >= 0, "straps_conv_fwd: bad filter geometry");
     STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_conv_fwd: scale and shift must be given together");
     ConvP p;
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
-    p.B = batch; p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.R = kh; p.S = kw; p.stride = stride; p.pad = pad;
-    p.Ho = (h + 2 * pad - kh) / stride + 1;
-    p.Wo = (wdt + 2 * pad - kw) / stride + 1;
-    p.relu = relu;
-    p.dil_shift = 0;
-    const long long M = (long long)batch * p.Ho * p.Wo;
-    STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 40), "straps_conv_fwd: problem too large");
+    p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
+    p.Mh = (h + 2 * pad - kh) / stride + 1;
+    p.Mw = (wdt + 2 * pad - kw) / stride + 1;
+    p.OH = p.Mh; p.OW = p.Mw; p.omul = 1; p.oah = 0; p.oaw = 0;
+    p.ntaps = p.wtaps = kh * kw;
+    for (int r = 0; r < kh; ++r)
+        for (int s = 0; s < kw; ++s) { p.tap_w[r * kw + s] = r * kw + s; p.tap_dh[r * kw + s] = r - pad; p.tap_dw[r * kw + s] = s - pad; }
+    const long long M = (long long)batch * p.Mh * p.Mw;
+    STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_fwd: problem too large");
     p.M = (int)M;
-    int bm, bn;
-    pick_tile(tile_cfg, M, cout, bm, bn);
-    hipStream_t st = (hipStream_t)stream;
-    if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
-    if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
-    return launch<64, 64>(p, st);
+    return dispatch(p, tile_cfg, (hipStream_t)stream);
 }
 
 // data gradient of straps_conv_fwd: dx[b][hi][wi][ci] = sum_{r,s,co} dy[b][ho][wo][co] * w[co][ci][r][s] over the
-// (ho,wo) with ho*stride + r - pad == hi.  Run as an ordinary implicit GEMM over dy with the rotated / transposed
-// filters from straps_pack_conv_weight_dgrad; a stride-2 forward becomes a zero-dilated read of dy.
+// (ho,wo) with ho*stride + r - pad == hi.  In terms of the rotated / transposed filters w'[ci][r'][s'][co]
+// (r' = kh-1-r, straps_pack_conv_weight_dgrad) and pad' = kh-1-pad:  source row of tap r' is (hi - pad' + r') / stride
+// when divisible.  stride 1: an ordinary conv over dy.  stride 2: one launch per output-parity class (hi%2, wi%2)
+// carrying exactly the taps whose source position is integral.
 extern "C" int straps_conv_dgrad(const float* dy, const float* w_crsk, const float* addend, float* dx, int batch, int h, int wdt,
                                  int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg, void* stream) {
     STRAPS_REQUIRE(dy && w_crsk && dx, "straps_conv_dgrad: null pointer");
     STRAPS_REQUIRE(cout % 32 == 0 && cin % 64 == 0, "straps_conv_dgrad: need cout%%32==0 and cin%%64==0 (cin=%d cout=%d)", cin, cout);
     STRAPS_REQUIRE(stride == 1 || stride == 2, "straps_conv_dgrad: stride must be 1 or 2");
-    STRAPS_REQUIRE(kh - 1 - pad >= 0, "straps_conv_dgrad: pad larger than the filter");
-    ConvP p;
+    STRAPS_REQUIRE(kh * kw <= 9 && kh - 1 - pad >= 0 && kw - 1 - pad >= 0, "straps_conv_dgrad: unsupported filter geometry");
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (wdt + 2 * pad - kw) / stride + 1;
-    p.x = dy; p.w = w_crsk; p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
-    p.B = batch; p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.R = kh; p.S = kw; p.stride = 1; p.pad = kh - 1 - pad;
-    p.Ho = h; p.Wo = wdt; p.relu = 0; p.dil_shift = stride == 2 ? 1 : 0;
-    const long long M = (long long)batch * h * wdt;
-    STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_dgrad: problem too large");
-    p.M = (int)M;
-    int bm, bn;
-    pick_tile(tile_cfg, M, cin, bm, bn);
+    const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     hipStream_t st = (hipStream_t)stream;
-    if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
-    if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
-    return launch<64, 64>(p, st);
+    ConvP p;
+    p.x = dy; p.w = w_crsk; p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
+    p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
+    p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
+    for (int ph = 0; ph < stride; ++ph) {
+        for (int pw = 0; pw < stride; ++pw) {
+            p.Mh = (h - ph + stride - 1) / stride;
+            p.Mw = (wdt - pw + stride - 1) / stride;
+            if (p.Mh <= 0 || p.Mw <= 0) continue;
+            p.omul = stride; p.oah = ph; p.oaw = pw;
+            p.ntaps = 0;
+            for (int r = 0; r < kh; ++r) {
+                const int nh = ph - padh + r;                 // source row numerator of logical row 0
+                if (((nh % stride) + stride) % stride) continue;
+                for (int s = 0; s < kw; ++s) {
+                    const int nw = pw - padw + s;
+                    if (((nw % stride) + stride) % stride) continue;
+                    p.tap_w[p.ntaps] = r * kw + s;
+                    p.tap_dh[p.ntaps] = (nh - (((nh % stride) + stride) % stride)) / stride;   // exact: nh divisible
+                    p.tap_dw[p.ntaps] = (nw - (((nw % stride) + stride) % stride)) / stride;
+                    // floor division for negative numerators
+                    if (nh < 0) p.tap_dh[p.ntaps] = -((-nh) / stride);
+                    if (nw < 0) p.tap_dw[p.ntaps] = -((-nw) / stride);
+                    ++p.ntaps;
+                }
+            }
+            const long long M = (long long)batch * p.Mh * p.Mw;
+            STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_dgrad: problem too large");
+            p.M = (int)M;
+            const int rc = dispatch(p, tile_cfg, st);
+            if (rc != STRAPS_OK) return rc;
+        }
+    }
+    return STRAPS_OK;
 }

@@ -198,7 +198,12 @@ __global__ __launch_bounds__(64) void loss_grad_heads_kernel(const float* __rest
 // =====================================================================================================
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float b1, float b2, float eps, float step_size,
-                                                   float inv_sqrt_bc2, float gscale) {
+                                                   float inv_sqrt_bc2, float gscale, float lr, const int* __restrict__ step_dev) {
+    if (step_dev) {   // step counter lives on the device (hipGraph replay): bias corrections computed here, in double
+        const double t = (double)step_dev[0];
+        step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -261,12 +266,13 @@ extern "C" int straps_loss_fwd_bwd(const float* pred_verts, const float* pred_jo
 }
 
 extern "C" int straps_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
-                                float beta1, float beta2, float eps, float grad_scale, void* stream) {
-    STRAPS_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "straps_adam_step: bad arguments");
+                                float beta1, float beta2, float eps, float grad_scale, const int* step_dev, void* stream) {
+    STRAPS_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && (step >= 1 || step_dev), "straps_adam_step: bad arguments");
+    if (step < 1) step = 1;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, beta1, beta2,
-                       eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+                       eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, lr, step_dev);
     STRAPS_CHECK_LAUNCH("adam_kernel");
     return STRAPS_OK;
 }

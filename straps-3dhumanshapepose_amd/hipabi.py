@@ -93,7 +93,7 @@ SIGNATURES = {
     'straps_build_proxy_input': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'straps_loss_workspace_bytes': (_Z, [_L]),
     'straps_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
-    'straps_adam_step': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
+    'straps_adam_step': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P]),
     'straps_mse_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
     'straps_mse_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
     'straps_augment_seg': (_I, [_P, _P, _P, _F, _I, _P, _I, _I, _P]),

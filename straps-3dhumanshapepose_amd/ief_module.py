@@ -63,8 +63,13 @@ class IEFModule(nn.Module):
             hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc1.weight), F + P, 0, H1, F, hipabi.ptr(w1f), F, H1, st), 'straps_pad_copy')
             hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc1.weight), F + P, F, H1, P, hipabi.ptr(w1e), EST_LD, H1, st), 'straps_pad_copy')
             hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc3.weight), H2, 0, P, H2, hipabi.ptr(w3), H2, w3.shape[0], st), 'straps_pad_copy')
-            self._cache = {'sig': sig, 'w1f': w1f, 'w1e': w1e, 'w3': w3,
-                           'init': self.initial_params_estimate.to(device).contiguous()}
+            self._cache = {'sig': sig, 'w1f': w1f, 'w1e': w1e, 'w3': w3}
+        # the initial estimate is not a parameter: its device copy outlives weight updates (and is never
+        # re-uploaded inside a captured hipGraph)
+        key = str(device)
+        if getattr(self, '_init_dev', (None, None))[0] != key:
+            self._init_dev = (key, self.initial_params_estimate.to(device).contiguous())
+        self._cache['init'] = self._init_dev[1]
         return self._cache
 
     def forward_estimate(self, img_features, tape=None):

@@ -56,7 +56,9 @@ def allreduce_gradients(flat_g, world_size, group=None):
 
 class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
-                 mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None):
+                 mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False):
+        """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
+        launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches."""
         p0 = next(regressor.parameters())
         hipabi.require_gpu_tensor(p0, 'regressor parameters (call .to(device) first)')
         self.dev = p0.device
@@ -69,8 +71,12 @@ class TrainStep:
         self.steps = 0
         self.n_reg = sum(p.numel() for p in regressor.parameters())
         self.logvar_params = [getattr(criterion, n + '_log_var') for n in TASKS]
-        self.gen = torch.Generator(device=self.dev)
-        self.gen.manual_seed(seed + rank)
+        # random draws come from torch's default device generator (graph-capture safe), seeded per rank
+        with torch.cuda.device(self.dev):
+            torch.cuda.manual_seed(seed + rank)
+        self.gen = None
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=self.dev)     # Adam step count, lives on the device
+        self.use_graph, self.graph, self._warm, self._g_loss = use_graph, None, 0, None
         d = self.dev
         self.mean_shape = torch.zeros(10, device=d) if mean_shape is None else torch.as_tensor(mean_shape, dtype=torch.float32, device=d)
         self.mean_cam_t = torch.tensor(mean_cam_t, device=d).expand(batch_size, 3).contiguous()
@@ -172,9 +178,10 @@ class TrainStep:
     def optimise(self):
         gscale = allreduce_gradients(self.flat_g, self.world, self.group)
         self.steps += 1
+        self.step_t.add_(1)
         hipabi.check(hipabi.lib().straps_adam_step(hipabi.ptr(self.flat_p), hipabi.ptr(self.flat_g), hipabi.ptr(self.exp_avg),
                                                    hipabi.ptr(self.exp_avg_sq), self.flat_p.numel(), self.steps, self.lr, 0.9, 0.999, 1e-8,
-                                                   gscale, hipabi.stream_ptr()), 'straps_adam_step')
+                                                   gscale, hipabi.ptr(self.step_t), hipabi.stream_ptr()), 'straps_adam_step')
         # the parameters changed behind torch's back: drop the packed-weight caches
         self.reg.image_encoder._cache.clear()
         self.reg.ief_module._cache = {}
@@ -182,10 +189,22 @@ class TrainStep:
     def step(self):
         """one full training step; returns the 12-float loss record (device tensor, no sync)."""
         with torch.no_grad():
-            batch = self.make_batch()
-            loss = self.forward_backward(batch)
+            if not self.use_graph or self._warm < 2:
+                self._warm += 1
+                batch = self.make_batch()
+                loss = self.forward_backward(batch)
+                self.optimise()
+                return loss
+            if self.graph is None:
+                # capture with empty weight caches so the repacking kernels are part of the graph
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    batch = self.make_batch()
+                    self._g_loss = self.forward_backward(batch)
+            self.graph.replay()
             self.optimise()
-        return loss
+            return self._g_loss
 
     def state_dict(self):
         """optimiser state in torch.optim.Adam's schema (checkpoint key 'optimiser_state_dict')."""

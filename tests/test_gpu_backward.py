@@ -339,7 +339,7 @@ def test_adam_vs_reference_golden(dev):
     m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
     L = hipabi.lib()
     for step in (1, 2):
-        hipabi.check(L.straps_adam_step(hipabi.ptr(flat_p), hipabi.ptr(flat_g), hipabi.ptr(m), hipabi.ptr(v), flat_p.numel(), step, 1e-4, 0.9, 0.999, 1e-8, 1.0, None), 'adam')
+        hipabi.check(L.straps_adam_step(hipabi.ptr(flat_p), hipabi.ptr(flat_g), hipabi.ptr(m), hipabi.ptr(v), flat_p.numel(), step, 1e-4, 0.9, 0.999, 1e-8, 1.0, None, None), 'adam')
     delta = (flat_p - before).cpu().double()
     off = 0
     ds, da = [], []
