@@ -103,14 +103,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
+// ---- 3x3 / stride 1 / pad 1 weight gradient with an LDS-staged input halo patch ----------------------------------
+// All nine taps of a 64(co) x 64(ci) block are accumulated by ONE workgroup: per 32-pixel chunk (rpc output rows x cw
+// columns, cw = min(Wo,32)) it stages the dy tile [32][64] and the (rpc+2) x (cw+2) x 64 input patch once, then runs
+// 9 taps x 16 = 144 MFMAs per wave between barriers; the nine shifted views are just LDS addresses.  Versus the
+// per-tap kernel above: 1/9 of the dy traffic, ~1/3 of the x traffic, 9x fewer barriers per MFMA.
+struct Wgrad3P {
+    const float* x;
+    const float* dy;
+    float* part;
+    int H, W, Cin, Cout;       // stride 1, pad 1: Ho = H, Wo = W
+    int cw, cw_log2, rpc;      // chunk geometry
+    int chunks_per_row, chunk_rows_per_img, nchunks, chunks_per_split, it;
+};
+
+constexpr int W3L = 68;   // floats per staged pixel (64 channels + 4 pad)
+
+__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int pw = p.cw + 2;
+    const int npatch = (p.rpc + 2) * pw;                 // <= 102 pixels
+    const int buf_floats = (32 + npatch) * W3L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int itile = blockIdx.x % p.it, ctile = blockIdx.x / p.it;
+    const int co0 = ctile * 64, ci0 = itile * 64;
+    const int cbeg = blockIdx.y * p.chunks_per_split;
+    const int cend = min(cbeg + p.chunks_per_split, p.nchunks);
+    const int lp = tid >> 4, lc = tid & 15;              // staging: pixel slot, float4 column
+
+    f32x4 rd[2], rx[7];
+    auto load_chunk = [&](int c) {
+        const int b = c / (p.chunk_rows_per_img * p.chunks_per_row);
+        const int rem = c - b * p.chunk_rows_per_img * p.chunks_per_row;
+        const int cr = rem / p.chunks_per_row, cc = rem - cr * p.chunks_per_row;
+        const int ho0 = cr * p.rpc, wo0 = cc * p.cw;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int px = lp + 16 * q;
+            const int ho = ho0 + (px >> p.cw_log2), wo = wo0 + (px & (p.cw - 1));
+            rd[q] = *reinterpret_cast<const f32x4*>(p.dy + (((long long)b * p.H + ho) * p.W + wo) * p.Cout + co0 + lc * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int pp = lp + 16 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pp < npatch) {
+                const int pr = pp / pw, pc = pp - pr * pw;
+                const int hi = ho0 - 1 + pr, wi = wo0 - 1 + pc;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    v = *reinterpret_cast<const f32x4*>(p.x + (((long long)b * p.H + hi) * p.W + wi) * p.Cin + ci0 + lc * 4);
+            }
+            rx[q] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* D = smem + buf * buf_floats;
+        float* X = D + 32 * W3L;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(D + (lp + 16 * q) * W3L + lc * 4) = rd[q];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int pp = lp + 16 * q;
+            if (pp < npatch) *reinterpret_cast<f32x4*>(X + pp * W3L + lc * 4) = rx[q];
+        }
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    if (cbeg < cend) {
+        load_chunk(cbeg);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int i = lane & 31, h = lane >> 5;
+    for (int c = cbeg; c < cend; ++c) {
+        const int buf = (c - cbeg) & 1;
+        if (c + 1 < cend) load_chunk(c + 1);
+        const float* D = smem + buf * buf_floats + wm * 32 + i;
+        const float* X = smem + buf * buf_floats + 32 * W3L + wn * 32 + i;
+#pragma unroll 2
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int px = kk * 8 + h * 4 + e;
+                const float a = D[px * W3L];
+                const float* xb = X + ((px >> p.cw_log2) * pw + (px & (p.cw - 1))) * W3L;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma32(a, xb[(r * pw + s) * W3L], acc[r * 3 + s]);
+            }
+        }
+        if (c + 1 < cend) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* o = p.part + (long long)blockIdx.y * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + wm * 32 + mfma_row(q, lane);
+            o[((long long)co * 9 + t) * p.Cin + ci0 + wn * 32 + i] = acc[t][q];
+        }
+}
+
 // dW_oihw[co][ci][r][s] = sum_split part[split][co][tap][ci]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
                                                            int Cout, int Cin, int RS, int accumulate) {
+    // 64 consecutive KRSC outputs per workgroup; the 4 waves take interleaved splits (fixed order), combined through LDS
+    __shared__ float red[4][64];
     const long long n = (long long)Cout * RS * Cin;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // KRSC index: coalesced partial reads
-    if (idx >= n) return;
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(long long)k * n + idx];
+    if (idx < n)
+        for (int k = sg; k < splits; k += 4) s += part[(long long)k * n + idx];
+    red[sg][lane] = s;
+    __syncthreads();
+    if (sg != 0 || idx >= n) return;
+    s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     const int ci = (int)(idx % Cin);
     long long t = idx / Cin;
     const int tap = (int)(t % RS);
@@ -122,18 +236,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // =====================================================================================================
 // stem weight gradient (no data gradient is needed: the network input does not require grad)
 // =====================================================================================================
-constexpr int PH = 13, PW = 72, TY = 4, TX = 32;
+// 2-row x 32-column output tiles: patch (2*2+5) x 72 per channel = 46.7 KB at C = 18 -> two workgroups per CU, so one
+// workgroup's patch refill overlaps the other's MFMA phase (the 4-row tile of the forward kernel allowed only one).
+constexpr int TY = 2, TX = 32, PH = 2 * TY + 5, PW = 72, TPIX = TY * TX;
 
 // each workgroup walks `tiles_per_block` output tiles (4 rows x 32 cols x 64 channels of dy) and accumulates
 // dW[64][Kp] (Kp = C*49 padded to 32) in registers: wave w owns the K column blocks n with n % 4 == w.
 template <int NB>   // NB = column blocks of 32 per wave (C*49 <= 128*NB)
-__global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, int B, int C, int H, int W, int Ho, int Wo,
                                                             int tiles_x, int tiles_y, int K, int Kp, int tiles_per_block, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;                                             // [C][PH][PW]
-    float* dys = patch + C * PH * PW;                                // [128 pixels][64 + 4]
-    int* koff = reinterpret_cast<int*>(dys + 128 * 68);              // [Kp]
+    float* dys = patch + C * PH * PW;                                // [TPIX pixels][64 + 4]
+    int* koff = reinterpret_cast<int*>(dys + TPIX * 68);             // [Kp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     for (int k = tid; k < Kp; k += 256) {
@@ -173,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const float* __restr
                 v = x[(((long long)b * C + c) * H + hi) * W + wi];
             patch[idx] = v;
         }
-        for (int idx = tid; idx < 128 * 16; idx += 256) {
+        for (int idx = tid; idx < TPIX * 16; idx += 256) {
             const int pix = idx >> 4, c4 = idx & 15;
             const int yo = y0 + (pix >> 5), xo = x0 + (pix & 31);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -181,9 +297,9 @@ __global__ __launch_bounds__(256, 1) void stem_wgrad_kernel(const float* __restr
             *reinterpret_cast<f32x4*>(dys + pix * 68 + c4 * 4) = v;
         }
         __syncthreads();
-        // contraction over the 128 pixels: A[co][pix] = dys[pix][co], B[pix][k] = patch[koff[k] + 2*py*PW + 2*px]
+        // contraction over the tile's pixels: A[co][pix] = dys[pix][co], B[pix][k] = patch[koff[k] + 2*py*PW + 2*px]
 #pragma unroll 2
-        for (int g = 0; g < 16; ++g) {           // 16 groups of 8 pixels
+        for (int g = 0; g < TPIX / 8; ++g) {     // groups of 8 pixels
             float a0[4], a1[4];
             int poff[4];
 #pragma unroll
@@ -251,7 +367,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         if (tr < TR) {
             const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
             const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-            for (long long r = r0 + tr; r < r1; r += TR) {
+            // 4 rows per trip: 12 independent float4 loads in flight per lane before the first use
+            long long r = r0 + tr;
+            for (; r + 3 * TR < r1; r += 4 * TR) {
+                f32x4 g[4], ya[4], xr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long o = (r + (long long)u * TR) * C + c4 * 4;
+                    g[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                    xr[u] = *reinterpret_cast<const f32x4*>(raw + o);
+                    if (yact) ya[u] = *reinterpret_cast<const f32x4*>(yact + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (yact) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[u][e] = ya[u][e] > 0.f ? g[u][e] : 0.f;
+                    }
+                    s1 += g[u];
+                    s2 += g[u] * ((xr[u] - mu) * is);
+                }
+            }
+            for (; r < r1; r += TR) {
                 const long long o = r * C + c4 * 4;
                 f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
                 if (yact) {
@@ -572,7 +709,33 @@ inline int wgrad_splits(long long M, int tiles) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
+// plan of the halo-patch kernel; returns false when the layer must use the per-tap kernel
+static bool wgrad3_plan(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, Wgrad3P* p, int* splits) {
+    if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1)) return false;
+    if (w < 8 || (w & (w - 1)) != 0) return false;              // chunk columns must tile the row exactly
+    const int cw = w < 32 ? w : 32, rpc = 32 / cw;
+    if (h % rpc != 0) return false;
+    int lg = 0;
+    while ((1 << lg) < cw) ++lg;
+    p->H = h; p->W = w; p->Cin = cin; p->Cout = cout; p->cw = cw; p->cw_log2 = lg; p->rpc = rpc;
+    p->chunks_per_row = w / cw;
+    p->chunk_rows_per_img = h / rpc;
+    p->nchunks = batch * p->chunk_rows_per_img * p->chunks_per_row;
+    p->it = cin / 64;
+    const int tiles = (cout / 64) * (cin / 64);
+    int s = (512 + tiles - 1) / tiles;
+    const int max_s = (p->nchunks + 3) / 4;                     // at least 4 chunks (576 MFMAs per wave) per workgroup
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    p->chunks_per_split = (p->nchunks + s - 1) / s;
+    *splits = (p->nchunks + p->chunks_per_split - 1) / p->chunks_per_split;
+    return true;
+}
+
 extern "C" size_t straps_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+    Wgrad3P p3;
+    int splits3;
+    if (wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) return (size_t)splits3 * cout * 9 * cin * sizeof(float);
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     const long long M = (long long)batch * ho * wo;
     const int tiles = kh * kw * (cout / 64) * (cin / 64);
@@ -583,6 +746,27 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
                                  int cout, int kh, int kw, int stride, int pad, int accumulate, void* stream) {
     STRAPS_REQUIRE(x && dy && dw_oihw && workspace, "straps_conv_wgrad: null pointer");
     STRAPS_REQUIRE(cin % 64 == 0 && cout % 64 == 0, "straps_conv_wgrad: need cin%%64==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
+    {
+        Wgrad3P p3;
+        int splits3;
+        if (wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) {
+            p3.x = x; p3.dy = dy; p3.part = (float*)workspace;
+            const size_t lds = (size_t)2 * (32 + (p3.rpc + 2) * (p3.cw + 2)) * W3L * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+                attr_set = true;
+            }
+            hipStream_t st3 = (hipStream_t)stream;
+            hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((cout / 64) * (cin / 64), splits3), dim3(256), lds, st3, p3);
+            STRAPS_CHECK_LAUNCH("conv_wgrad3x3_kernel");
+            const long long n3 = (long long)cout * 9 * cin;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n3 + 63) / 64)), dim3(256), 0, st3, p3.part, dw_oihw, splits3, cout, cin, 9, accumulate);
+            STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+            return STRAPS_OK;
+        }
+    }
     WgradP p;
     p.x = x; p.dy = dy; p.part = (float*)workspace;
     p.B = batch; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.R = kh; p.S = kw; p.stride = stride; p.pad = pad;
@@ -599,7 +783,7 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
     STRAPS_CHECK_LAUNCH("conv_wgrad_kernel");
     const long long n = (long long)cout * kh * kw * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, p.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);
     STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
     return STRAPS_OK;
 }
@@ -632,7 +816,7 @@ extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, floa
     const int ntiles = batch * tiles_x * tiles_y;
     int tpb;
     const int nblk = stem_wgrad_blocks(ntiles, &tpb);
-    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + 128 * 68 * sizeof(float) + (size_t)Kp * sizeof(int);
+    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + TPIX * 68 * sizeof(float) + (size_t)Kp * sizeof(int);
     STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_wgrad: LDS budget exceeded");
     hipStream_t st = (hipStream_t)stream;
     auto go = [&](auto kern) -> int {
