@@ -31,6 +31,9 @@ extern "C" {
 #define STRAPS_EUNSUPPORTED 3 /* valid request this build does not cover */
 
 int straps_abi_version(void);
+/* calibration: `blocks` x 4 waves each issue 4*iters register-resident fp32 MFMAs (32x32x2);
+ * seed512 = 512 floats, out = blocks*256 floats.  Time it to get the board's sustained MFMA rate. */
+int straps_selftest_mfma_peak(const float* seed512, float* out, int blocks, int iters, void* stream);
 const char* straps_last_error(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int straps_device_count(void);

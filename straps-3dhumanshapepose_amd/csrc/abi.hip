@@ -12,6 +12,34 @@ void straps_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- calibration kernel: register-resident fp32 MFMA stream (what the matrix pipe sustains on THIS board with
+// non-trivial operand data; the roofline "peak" stays the 157.3 TFLOP/s spec, this is the practical ceiling) ----
+__global__ __launch_bounds__(256) void mfma_peak_kernel(const float* __restrict__ seed, float* __restrict__ out, int iters) {
+    f32x16 a0, a1, a2, a3;
+    const float s0 = seed[threadIdx.x], s1 = seed[256 + threadIdx.x];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = s0; a1[r] = s1; a2[r] = -s0; a3[r] = -s1; }
+    float x = s0, y = s1;
+    for (int it = 0; it < iters; ++it) {
+        a0 = mfma32(x, y, a0);
+        a1 = mfma32(y, x, a1);
+        a2 = mfma32(x, x, a2);
+        a3 = mfma32(y, y, a3);
+        x = -x; y = -y;             // keeps the accumulators bounded, operands toggling
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += a0[r] + a1[r] + a2[r] + a3[r];
+    out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
+extern "C" int straps_selftest_mfma_peak(const float* seed512, float* out, int blocks, int iters, void* stream) {
+    STRAPS_REQUIRE(seed512 && out && blocks > 0 && iters > 0, "straps_selftest_mfma_peak: bad arguments");
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seed512, out, iters);
+    STRAPS_CHECK_LAUNCH("mfma_peak_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_abi_version(void) { return STRAPS_ABI_VERSION; }
 extern "C" const char* straps_last_error(void) { return g_err; }
 extern "C" int straps_device_count(void) {

@@ -311,6 +311,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
+                // (the offset is re-read from the LDS table each time on purpose: keeping the 7 offsets in VGPRs pushes
+                //  the kernel past 256 registers = one wave per SIMD, measured 1.73 -> 2.46 ms)
                 const int kcol = (nb * 4 + wave) * 32 + i;
                 const int ko = kcol < Kp ? koff[kcol] : 0;
 #pragma unroll
@@ -558,51 +560,48 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
                                                            const float* __restrict__ b, long long sbk, long long sbn, float* c,
                                                            int ldc, const float* __restrict__ mask, int ldmask, int M, int N, int K,
                                                            int accumulate) {
+    // one 32x32 output tile per workgroup; the K groups of 8 are dealt round-robin to the 4 waves (these GEMMs are
+    // tiny and latency-bound: 4x shorter dependent load chains, two groups of loads in flight per wave), partial
+    // tiles combined through LDS in a fixed order.
+    __shared__ float red[4][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 32, n0 = (blockIdx.x * 4 + wave) * 32;
-    if (n0 >= N) return;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int mr = min(m0 + i, M - 1), nr = min(n0 + i, N - 1);
     const float* ap = a + (long long)mr * sam;
     const float* bp = b + (long long)nr * sbn;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    const int K8 = K & ~7;
-    for (int k0 = 0; k0 < K8; k0 += 8) {
-        float av[4], bv[4];
+    const int G = (K + 7) >> 3;
+    for (int g = wave; g < G; g += 8) {
+        float av[8], bv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = k0 + 4 * h + e;
-            av[e] = ap[(long long)k * sak];
-            bv[e] = bp[(long long)k * sbk];
-        }
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma32(av[e], bv[e], acc);
-    }
-    if (K8 < K) {   // ragged tail, zero-filled
-        float av[4], bv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = K8 + 4 * h + e;
-            const bool ok = k < K;
-            av[e] = ok ? ap[(long long)k * sak] : 0.f;
-            bv[e] = ok ? bp[(long long)k * sbk] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma32(av[e], bv[e], acc);
-    }
-    const int n = n0 + i;
-    if (n < N) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int m = m0 + mfma_row(q, lane);
-            if (m < M) {
-                float v = acc[q];
-                if (mask) v = mask[(long long)m * ldmask + n] > 0.f ? v : 0.f;
-                float* o = c + (long long)m * ldc + n;
-                *o = accumulate ? *o + v : v;
+            for (int e = 0; e < 4; ++e) {
+                const int k = (g + 4 * u) * 8 + 4 * h + e;
+                const bool ok = k < K;
+                av[u * 4 + e] = ok ? ap[(long long)k * sak] : 0.f;
+                bv[u * 4 + e] = ok ? bp[(long long)k * sbk] : 0.f;
             }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = mfma32(av[e], bv[e], acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wave][mfma_row(q, lane)][i] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = threadIdx.x + 256 * q;
+        const int row = idx >> 5, col = idx & 31;
+        const int m = m0 + row, n = n0 + col;
+        if (m < M && n < N) {
+            float v = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+            if (mask) v = mask[(long long)m * ldmask + n] > 0.f ? v : 0.f;
+            float* o = c + (long long)m * ldc + n;
+            *o = accumulate ? *o + v : v;
         }
     }
 }
@@ -899,7 +898,7 @@ extern "C" int straps_gap_bwd(const float* dfeat, float* dx, int batch, int hw, 
 extern "C" int straps_gemm_strided(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn, float* c,
                                    int ldc, const float* mask, int ldmask, int m, int n, int k, int accumulate, void* stream) {
     STRAPS_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0, "straps_gemm_strided: bad arguments");
-    dim3 grid((n + 127) / 128, (m + 31) / 32);
+    dim3 grid((n + 31) / 32, (m + 31) / 32);
     hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, sam, sak, b, sbk, sbn, c, ldc, mask, ldmask, m, n, k, accumulate);
     STRAPS_CHECK_LAUNCH("gemm_strided_kernel");
     return STRAPS_OK;

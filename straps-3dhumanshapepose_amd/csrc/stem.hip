@@ -64,17 +64,25 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wfrag) + lane;
     const int G = Kp >> 3;
+    // software pipeline: the offset table is read two groups ahead and the (dependent) patch gather one group ahead,
+    // so no MFMA of group g waits on an LDS round trip issued in group g
     f32x4 b0 = wp[0], b1 = wp[64];
+    int4 ko_n = *reinterpret_cast<const int4*>(koff + 4 * h);                       // offsets of group 0
+    float a0 = pbase[ko_n.x], a1 = pbase[ko_n.y], a2 = pbase[ko_n.z], a3 = pbase[ko_n.w];
+    ko_n = *reinterpret_cast<const int4*>(koff + (G > 1 ? 8 : 0) + 4 * h);          // offsets of group 1
     for (int g = 0; g < G; ++g) {
         f32x4 nb0 = b0, nb1 = b1;
-        if (g + 1 < G) { nb0 = wp[(g + 1) * 128]; nb1 = wp[(g + 1) * 128 + 64]; }
-        const int4 ko = *reinterpret_cast<const int4*>(koff + 8 * g + 4 * h);
-        const float a0 = pbase[ko.x], a1 = pbase[ko.y], a2 = pbase[ko.z], a3 = pbase[ko.w];
+        float n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+        if (g + 1 < G) {
+            nb0 = wp[(g + 1) * 128]; nb1 = wp[(g + 1) * 128 + 64];
+            n0 = pbase[ko_n.x]; n1 = pbase[ko_n.y]; n2 = pbase[ko_n.z]; n3 = pbase[ko_n.w];
+        }
+        if (g + 2 < G) ko_n = *reinterpret_cast<const int4*>(koff + 8 * (g + 2) + 4 * h);
         acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
         acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
         acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
         acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
-        b0 = nb0; b1 = nb1;
+        b0 = nb0; b1 = nb1; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
     }
 
     const int yo = y0 + wave;

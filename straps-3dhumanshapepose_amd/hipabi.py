@@ -53,6 +53,7 @@ SIGNATURES = {
     'straps_abi_version': (_I, []),
     'straps_last_error': (C.c_char_p, []),
     'straps_device_count': (_I, []),
+    'straps_selftest_mfma_peak': (_I, [_P, _P, _I, _I, _P]),
     'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_stem_weight_floats': (_Z, [_I]),
