@@ -227,6 +227,7 @@ def main():
         # same K steps launched eagerly with HIP-event pairs around the MFMA kernels (roofline section)
         if args.workload == 'train':
             ts.use_graph = False
+            ts.side_stream = None          # one stream: kernels run back to back, so each event pair times ONE kernel alone
         step()
         torch.cuda.synchronize()
         timer.on = True

@@ -29,6 +29,28 @@ class GradSink(dict):
         return torch.zeros_like(p) if zero else torch.empty_like(p)
 
 
+class _SideStream:
+    """runs independent work (the weight gradients) on a second HIP stream so MFMA-bound wgrad kernels overlap the
+    HBM-bound BatchNorm passes and the tails of the data-gradient kernels of the main stream.  Tensors produced on the
+    main stream and consumed on the side stream are kept alive until join()."""
+
+    def __init__(self, stream):
+        self.s, self.keep = stream, []
+
+    def run(self, fn, *tensors):
+        if self.s is None:
+            return fn()
+        self.keep.extend(tensors)
+        self.s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.s):
+            return fn()
+
+    def join(self):
+        if self.s is not None:
+            torch.cuda.current_stream().wait_stream(self.s)
+            self.keep.clear()
+
+
 # ------------------------------------------------------------------------------------------ encoder
 def _packed_dgrad_weight(net, conv):
     w = conv.weight
@@ -78,10 +100,12 @@ def _conv_dgrad(L, net, rec, draw, addend):
     return dx
 
 
-def encoder_backward(net, tape, dfeat, views=None):
-    """tape: dict filled by encoder_forward(net, x, tape) in training mode.  Returns {param: grad}."""
+def encoder_backward(net, tape, dfeat, views=None, side_stream=None):
+    """tape: dict filled by encoder_forward(net, x, tape) in training mode.  Returns {param: grad}.
+    side_stream: optional second torch stream for the weight-gradient kernels (joined before returning)."""
     L = hipabi.lib()
     grads = GradSink(views)
+    side = _SideStream(side_stream)
     rec = tape['gap']
     B, HW, Cf = rec['geom']
     dy = _empty_like(rec['x'])
@@ -91,11 +115,11 @@ def encoder_backward(net, tape, dfeat, views=None):
             pairs = unit.conv_bn_pairs()
             rec = tape[id(pairs[-1][0])]
             draw, dz = _bn_bwd(L, rec, dy, True, True, grads)          # ReLU(out) mask; dz feeds the skip connection
-            _conv_wgrad(L, rec, draw, grads)
+            side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads), draw)
             if unit.downsample is not None:
                 recd = tape[id(unit.downsample[0])]
                 drawd, _ = _bn_bwd(L, recd, dz, False, False, grads)
-                _conv_wgrad(L, recd, drawd, grads)
+                side.run(lambda recd=recd, drawd=drawd: _conv_wgrad(L, recd, drawd, grads), drawd)
                 dskip = _conv_dgrad(L, net, recd, drawd, None)
             else:
                 dskip = dz
@@ -103,7 +127,7 @@ def encoder_backward(net, tape, dfeat, views=None):
                 dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None)
                 rec = tape[id(pairs[ci - 1][0])]
                 draw, _ = _bn_bwd(L, rec, dt, True, False, grads)
-                _conv_wgrad(L, rec, draw, grads)
+                side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads), draw)
             dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip)   # + skip gradient fused in the epilogue
     rec = tape['maxpool']
     B, H, W, Cc, Hp, Wp = rec['geom']
@@ -118,6 +142,7 @@ def encoder_backward(net, tape, dfeat, views=None):
     hipabi.check(L.straps_stem_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, Cin, H, W, 0,
                                      hipabi.stream_ptr()), 'straps_stem_wgrad')
     grads[net.conv1.weight] = dw
+    side.join()
     return grads
 
 

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         if (k < K) {
             const int c = k / 49, rs = k - c * 49;
             const int r = rs / 7, s = rs - r * 7;
-            o = (c * PH + r) * PW + s;
+            o = (c * PH + r) * PW + s + 1;      // +1: patch origin one column left of the receptive field
         }
         koff[k] = o;
     }
@@ -279,15 +279,28 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         const int y0 = ty * TY, x0 = tx * TX;
         const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
         __syncthreads();   // previous tile's LDS reads are done
-        for (int idx = tid; idx < C * PH * PW; idx += 256) {
-            const int col = idx % PW;
-            const int rc = idx / PW;
-            const int row = rc % PH, c = rc / PH;
-            const int hi = hi0 + row, wi = wi0 + col;
-            float v = 0.f;
-            if (col < 2 * TX + 5 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                v = x[(((long long)b * C + c) * H + hi) * W + wi];
-            patch[idx] = v;
+        // patch column p holds input column wi0 - 1 + p (origin shifted one column left: aligned float4 row loads)
+        if ((W & 3) == 0) {
+            for (int idx = tid; idx < C * PH * (PW / 4); idx += 256) {
+                const int q = idx % (PW / 4);
+                const int rc = idx / (PW / 4);
+                const int row = rc % PH, c = rc / PH;
+                const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
+                    v = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
+                *reinterpret_cast<f32x4*>(patch + rc * PW + 4 * q) = v;
+            }
+        } else {
+            for (int idx = tid; idx < C * PH * PW; idx += 256) {
+                const int col = idx % PW;
+                const int rc = idx / PW;
+                const int row = rc % PH, c = rc / PH;
+                const int hi = hi0 + row, wi = wi0 - 1 + col;
+                float v = 0.f;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
+                patch[idx] = v;
+            }
         }
         for (int idx = tid; idx < TPIX * 16; idx += 256) {
             const int pix = idx >> 4, c4 = idx & 15;

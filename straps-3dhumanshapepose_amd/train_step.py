@@ -56,7 +56,7 @@ def allreduce_gradients(flat_g, world_size, group=None):
 
 class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
-                 mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False):
+                 mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=True):
         """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
         launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches."""
         p0 = next(regressor.parameters())
@@ -77,6 +77,7 @@ class TrainStep:
         self.gen = None
         self.step_t = torch.zeros(1, dtype=torch.int32, device=self.dev)     # Adam step count, lives on the device
         self.use_graph, self.graph, self._warm, self._g_loss = use_graph, None, 0, None
+        self.side_stream = torch.cuda.Stream(device=self.dev) if overlap_wgrad else None
         d = self.dev
         self.mean_shape = torch.zeros(10, device=d) if mean_shape is None else torch.as_tensor(mean_shape, dtype=torch.float32, device=d)
         self.mean_cam_t = torch.tensor(mean_cam_t, device=d).expand(batch_size, 3).contiguous()
@@ -168,7 +169,7 @@ class TrainStep:
                      'straps_rot6d_bwd')
         # regressor backward, gradients land in the flat buffer
         dfeat, _ = ief_backward(reg.ief_module, feat, ief_tape, dest, self.gviews)
-        encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews)
+        encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews, self.side_stream)
         for k, p in enumerate(self.logvar_params):
             if p.requires_grad:
                 self.gviews[p].copy_(dlv[k])
