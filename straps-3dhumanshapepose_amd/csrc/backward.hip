@@ -213,24 +213,36 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
 // dW_oihw[co][ci][r][s] = sum_split part[split][co][tap][ci]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
                                                            int Cout, int Cin, int RS, int accumulate) {
-    // 64 consecutive KRSC outputs per workgroup; the 4 waves take interleaved splits (fixed order), combined through LDS
-    __shared__ float red[4][64];
+    // 256 consecutive KRSC outputs per workgroup (float4 per lane: 1 KiB per wave-load); the 4 waves take interleaved
+    // splits, 4 independent loads in flight per lane; fixed summation order; combined through LDS.
+    // n is a multiple of 256 (Cin % 64 == 0, Cout % 64 == 0).
+    __shared__ f32x4 red[4][64];
     const long long n = (long long)Cout * RS * Cin;
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (idx < n)
-        for (int k = sg; k < splits; k += 4) s += part[(long long)k * n + idx];
+    const long long idx = ((long long)blockIdx.x * 64 + lane) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = sg;
+    for (; k + 12 < splits; k += 16) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(part + (long long)k * n + idx);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(part + (long long)(k + 4) * n + idx);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(part + (long long)(k + 8) * n + idx);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(part + (long long)(k + 12) * n + idx);
+        s += (v0 + v1) + (v2 + v3);
+    }
+    for (; k < splits; k += 4) s += *reinterpret_cast<const f32x4*>(part + (long long)k * n + idx);
     red[sg][lane] = s;
     __syncthreads();
-    if (sg != 0 || idx >= n) return;
+    if (sg != 0) return;
     s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    const int ci = (int)(idx % Cin);
+    const int ci = (int)(idx % Cin);           // 4 consecutive ci of one (co, tap)
     long long t = idx / Cin;
     const int tap = (int)(t % RS);
     const int co = (int)(t / RS);
-    const long long o = ((long long)co * Cin + ci) * RS + tap;
-    dw[o] = accumulate ? dw[o] + s : s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long o = ((long long)co * Cin + ci + e) * RS + tap;
+        dw[o] = accumulate ? dw[o] + s[e] : s[e];
+    }
 }
 
 // =====================================================================================================
@@ -774,7 +786,7 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
             hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((cout / 64) * (cin / 64), splits3), dim3(256), lds, st3, p3);
             STRAPS_CHECK_LAUNCH("conv_wgrad3x3_kernel");
             const long long n3 = (long long)cout * 9 * cin;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n3 + 63) / 64)), dim3(256), 0, st3, p3.part, dw_oihw, splits3, cout, cin, 9, accumulate);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n3 / 256)), dim3(256), 0, st3, p3.part, dw_oihw, splits3, cout, cin, 9, accumulate);
             STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
             return STRAPS_OK;
         }
@@ -795,7 +807,7 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
     STRAPS_CHECK_LAUNCH("conv_wgrad_kernel");
     const long long n = (long long)cout * kh * kw * cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, p.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, st, p.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);
     STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
     return STRAPS_OK;
 }

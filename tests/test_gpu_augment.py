@@ -1,0 +1,74 @@
+"""GPU: proxy-representation augmentation kernel (straps_augment_seg) and the target projection kernel against
+plain restatements of the reference semantics (augmentation/proxy_rep_augmentation.py:52-101, utils/cam_utils.py:40-71)
+with the random draws supplied explicitly."""
+import numpy as np
+import pytest
+import torch
+
+import straps_amd
+import straps_oracle as O
+from detgen import det_uniform
+from straps_amd import hipabi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_augment_seg_matches_reference_semantics():
+    dev = torch.device('cuda:0')
+    L = hipabi.load()
+    B, wh, box = 6, 256, 48
+    seg = np.floor(det_uniform((B, wh, wh), 50, 0.0, 6.999)).astype(np.float32)
+    u = det_uniform((B, 9), 51, 0.0, 1.0)
+    u[0, :7] = 0.0           # sample 0: every part removed and occluded
+    u[1, :7] = 0.99          # sample 1: untouched
+    probs = np.array([0.1, 0.1, 0.1, 0.1, 0.05, 0.05], np.float32)
+    # reference semantics with the same uniforms
+    want = seg.copy()
+    for c in range(6):
+        rm = u[:, c] < probs[c]
+        blk = want[rm]
+        blk[blk == c + 1] = 0
+        want[rm] = blk
+    centre = wh / 2
+    hi_, lo_ = centre - 0.3 * wh / 2, centre + 0.3 * wh / 2
+    for i in range(B):
+        if u[i, 6] < 0.5:
+            x = (hi_ - lo_) * u[i, 7] + lo_
+            y = (hi_ - lo_) * u[i, 8] + lo_
+            x1, x2, y1, y2 = int(np.float32(x - box / 2)), int(np.float32(x + box / 2)), int(np.float32(y - box / 2)), int(np.float32(y + box / 2))
+            want[i, x1:x2, y1:y2] = 0
+    segd, ud, pd = torch.from_numpy(seg).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(probs).to(dev)
+    out = torch.empty_like(segd)
+    hipabi.check(L.straps_augment_seg(hipabi.ptr(segd), hipabi.ptr(ud), hipabi.ptr(pd), 0.5, box, hipabi.ptr(out), B, wh, None), 'augment')
+    got = out.cpu().numpy()
+    assert (got != want).mean() < 1e-4          # box edges may differ by float rounding of the centre on a pixel boundary
+    assert np.array_equal(got[1], seg[1]) and got[0].sum() == 0
+    # module-level entry point: inputs untouched, shapes kept
+    params = {'remove_appendages': True, 'deviate_joints2D': True, 'deviate_verts2D': True, 'occlude_seg': True,
+              'remove_appendages_classes': [1, 2, 3, 4, 5, 6], 'remove_appendages_probabilities': [0.1, 0.1, 0.1, 0.1, 0.05, 0.05],
+              'delta_j2d_dev_range': [-8, 8], 'delta_j2d_hip_dev_range': [-8, 8], 'delta_verts2d_dev_range': [-0.01, 0.01],
+              'occlude_probability': 0.5, 'occlude_box_dim': 48}
+    j = torch.from_numpy(det_uniform((B, 17, 2), 52, 20.0, 236.0)).to(dev)
+    j0 = j.clone()
+    s2, j2 = straps_amd.augmentation.augment_proxy_representation(segd, j, params)
+    assert torch.equal(j, j0) and torch.equal(segd.cpu(), torch.from_numpy(seg))
+    assert float((j2 - j0).abs().max()) <= 8.0 and s2.shape == segd.shape
+
+
+def test_project_targets_vs_oracle():
+    dev = torch.device('cuda:0')
+    L = hipabi.load()
+    B = 5
+    joints = torch.from_numpy(det_uniform((B, 90, 3), 53, -1, 1))
+    cam_t = torch.tensor([[0., 0.2, 42.0]]).expand(B, -1) + torch.from_numpy(det_uniform((B, 3), 54, -0.1, 0.1))
+    K = torch.from_numpy(O.intrinsics_matrix().astype(np.float32))[None].expand(B, -1, -1)
+    want2d = O.perspective_project(joints[:, O.ALL_JOINTS_TO_COCO_MAP], torch.eye(3)[None].expand(B, -1, -1), cam_t, K)
+    want3d = joints[:, O.ALL_JOINTS_TO_H36M_MAP][:, O.H36M_TO_J14]
+    j2, j3 = torch.empty(B, 17, 2, device=dev), torch.empty(B, 14, 3, device=dev)
+    jd, cd = joints.to(dev), cam_t.contiguous().to(dev)
+    hipabi.check(L.straps_project_targets(hipabi.ptr(jd), hipabi.ptr(cd), 5000.0, 5000.0, 128.0, 128.0, hipabi.ptr(j2), hipabi.ptr(j3), B, None), 'project')
+    assert float((j2.cpu() - want2d).abs().max()) < 2e-3          # pixels; fp32 division / fma order
+    assert torch.equal(j3.cpu(), want3d)
+    cam = torch.from_numpy(det_uniform((B, 3), 55, 0.5, 1.2)).to(dev)
+    got = straps_amd.cam_utils.orthographic_project_torch(jd[:, :17], cam)
+    assert float((got.cpu() - O.orthographic_project(joints[:, :17], cam.cpu())).abs().max()) < 1e-6
