@@ -201,10 +201,15 @@ def main():
     torch.cuda.synchronize()
     if graph_mode and args.workload != 'train':
         # static inputs: capture the whole forward once, replay it per step (no host launch cost in the timed region)
-        fwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(fwd_graph):
-            step()
-        run = fwd_graph.replay
+        try:
+            fwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fwd_graph, capture_error_mode='thread_local'):
+                step()
+            run = fwd_graph.replay
+        except Exception as e:                 # noqa: BLE001 -- eager launches of the same kernels
+            sys.stderr.write('hipGraph capture failed (%s); timing eager launches\n' % (e,))
+            torch.cuda.synchronize()
+            graph_mode, run = False, step
     else:
         run = step
     run()

@@ -197,12 +197,21 @@ class TrainStep:
                 self.optimise()
                 return loss
             if self.graph is None:
-                # capture with empty weight caches so the repacking kernels are part of the graph
+                # capture with empty weight caches so the repacking kernels are part of the graph.  thread_local error
+                # mode: other threads (e.g. the RCCL watchdog) may touch the HIP runtime while this thread captures.
                 torch.cuda.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    batch = self.make_batch()
-                    self._g_loss = self.forward_backward(batch)
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                        batch = self.make_batch()
+                        self._g_loss = self.forward_backward(batch)
+                    self.graph = g
+                except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, never to another path
+                    import warnings
+                    warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager launches' % (e,))
+                    self.use_graph = False
+                    torch.cuda.synchronize()
+                    return self.step()
             self.graph.replay()
             self.optimise()
             return self._g_loss
