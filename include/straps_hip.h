@@ -287,6 +287,12 @@ int straps_project_targets(const float* joints, const float* cam_t, float fx, fl
 /* STAND-IN for the part-segmentation rasteriser (renderers/nmr_renderer.py; SURVEY 8f row f1, not built):
  * labels discs around the 17 projected COCO joints (+ a torso box) with the 6 LSP part ids.          */
 int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream);
+/* On-device evaluation metrics (metrics/train_loss_and_metrics_tracker.py:127-197 +
+ * utils/eval_utils.py:7-85): for each sample b, out3[b] = { sum_n |p-t|,
+ * sum_n |scale_and_translation_transform(p) - t|, sum_n |procrustes(p) - t| } over npoints 3-D points
+ * (6890 vertices -> PVE / PVE-SC / PVE-PA sums, 14 joints -> MPJPE / -SC / -PA sums).                */
+int straps_point_metrics(const float* pred, const float* target, float* out3, long long batch,
+                         int npoints, void* stream);
 /* torch.optim.Adam defaults (run_train.py:200-201) over one flat fp32 buffer:
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);
  * grad_scale multiplies g first (1/world_size after a sum all-reduce).  step_dev (optional device

@@ -76,3 +76,13 @@ def det_state_dict(shapes, base=0):
         else:                                                 # linear bias
             out[k] = det_uniform(shp, s, -0.01, 0.01)
     return out
+
+
+def det_metrics_case(npts, seed, batch=3):
+    """(pred, target) float32 [batch,npts,3] for the evaluation-metric goldens: the prediction is a rotated, scaled,
+    shifted and noisy copy of the target, so the alignment steps matter."""
+    tv = det_uniform((batch, npts, 3), seed, -1.0, 1.0).astype(np.float64)
+    ang = 0.4
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    pv = 1.1 * tv.dot(Rz.T) + np.array([0.05, -0.02, 0.1]) + 0.03 * det_uniform((batch, npts, 3), seed + 1, -1.0, 1.0)
+    return pv.astype(np.float32), tv.astype(np.float32)

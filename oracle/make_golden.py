@@ -244,6 +244,16 @@ def main():
     small['aug_seg_class_counts'] = np.stack([(nseg == c).sum(dim=(1, 2)).numpy() for c in range(7)], 1)
     small['aug_j2d'] = nj.numpy()
 
+    # ================= G-metrics: PVE / PVE-SC / PVE-PA, MPJPE / -SC / -PA per-sample sums ==
+    from utils.eval_utils import procrustes_analysis_batch, scale_and_translation_transform_batch
+    from detgen import det_metrics_case
+    for tag, npts, seed in (('verts', 6890, 70), ('j14', 14, 72)):
+        pv, tv = det_metrics_case(npts, seed)             # inputs are regenerated by the tests, only the sums are stored
+        raw = np.linalg.norm(pv - tv, axis=-1).sum(1)
+        sc = np.linalg.norm(scale_and_translation_transform_batch(pv, tv) - tv, axis=-1).sum(1)
+        pa = np.linalg.norm(procrustes_analysis_batch(pv, tv) - tv, axis=-1).sum(1)
+        small['metrics_%s_sums' % tag] = np.stack([raw, sc, pa], axis=1)
+
     # ================= G-opt: one Adam step over all 71 tensors =============================
     man = json.load(open(os.path.join(OUT, 'state_dict_keys_r18.json')))['keys']
     m = SingleInputRegressor(18, 18, 3)

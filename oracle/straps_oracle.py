@@ -339,6 +339,47 @@ def predict_forward(x, sd, init_estimate, smpl_model, layers=18, iterations=3):
     return cam, pose, shape, verts, joints
 
 
+# --------------------------------------------------------------------------------------------
+# evaluation metrics  (utils/eval_utils.py:7-85, metrics/train_loss_and_metrics_tracker.py:127-197)
+# --------------------------------------------------------------------------------------------
+def similarity_transform(S1, S2):
+    """compute_similarity_transform (utils/eval_utils.py:7-55) for one sample, points as rows [N,3]:
+    the scaled rotation + translation taking S1 closest to S2 (orthogonal Procrustes, det R = +1)."""
+    X1, X2 = S1.T, S2.T
+    mu1, mu2 = X1.mean(axis=1, keepdims=True), X2.mean(axis=1, keepdims=True)
+    X1c, X2c = X1 - mu1, X2 - mu2
+    var1 = np.sum(X1c ** 2)
+    K = X1c.dot(X2c.T)
+    U, s, Vh = np.linalg.svd(K)
+    V = Vh.T
+    Z = np.eye(3)
+    Z[-1, -1] *= np.sign(np.linalg.det(U.dot(V.T)))
+    R = V.dot(Z.dot(U.T))
+    scale = np.trace(R.dot(K)) / var1
+    t = mu2 - scale * R.dot(mu1)
+    return (scale * R.dot(X1) + t).T
+
+
+def scale_and_translation_transform(P, T):
+    """scale_and_translation_transform_batch (utils/eval_utils.py:66-85), batched [B,N,3]."""
+    Pm = P.mean(axis=1, keepdims=True)
+    Pt = P - Pm
+    Ps = np.sqrt(np.sum(Pt ** 2, axis=(1, 2), keepdims=True) / P.shape[1])
+    Tm = T.mean(axis=1, keepdims=True)
+    Ts = np.sqrt(np.sum((T - Tm) ** 2, axis=(1, 2), keepdims=True) / T.shape[1])
+    return Pt / Ps * Ts + Tm
+
+
+def point_metrics(pred, target):
+    """per-sample sums of point errors [B,3]: raw, scale+translation corrected, Procrustes aligned
+    (the per-batch quantities the tracker adds up, train_loss_and_metrics_tracker.py:127-197)."""
+    pred, target = np.asarray(pred, np.float64), np.asarray(target, np.float64)
+    raw = np.linalg.norm(pred - target, axis=-1).sum(1)
+    sc = np.linalg.norm(scale_and_translation_transform(pred, target) - target, axis=-1).sum(1)
+    pa = np.stack([np.linalg.norm(similarity_transform(pred[i], target[i]) - target[i], axis=-1).sum() for i in range(pred.shape[0])])
+    return np.stack([raw, sc, pa], axis=1)
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
     """torch.optim.Adam defaults (run_train.py:200-201): no weight decay, no amsgrad.
     In place on the given lists of tensors; `step` is the 1-based step count."""

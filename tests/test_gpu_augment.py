@@ -72,3 +72,34 @@ def test_project_targets_vs_oracle():
     cam = torch.from_numpy(det_uniform((B, 3), 55, 0.5, 1.2)).to(dev)
     got = straps_amd.cam_utils.orthographic_project_torch(jd[:, :17], cam)
     assert float((got.cpu() - O.orthographic_project(joints[:, :17], cam.cpu())).abs().max()) < 1e-6
+
+
+def test_point_metrics_vs_reference_golden_and_oracle():
+    """on-device PVE / PVE-SC / PVE-PA (6890 vertices) and MPJPE / -SC / -PA (14 joints) sums."""
+    import os
+    from detgen import det_metrics_case
+    dev = torch.device('cuda:0')
+    small = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'small_golden.npz'))
+    for tag, npts, seed in (('verts', 6890, 70), ('j14', 14, 72)):
+        pv, tv = det_metrics_case(npts, seed)
+        got = straps_amd.metrics.point_error_sums(torch.from_numpy(pv).to(dev), torch.from_numpy(tv).to(dev)).cpu().numpy()
+        np.testing.assert_allclose(got, small['metrics_%s_sums' % tag], rtol=5e-5)
+        np.testing.assert_allclose(got, O.point_metrics(pv, tv), rtol=5e-5)
+    # a reflection-prone case (near-planar points): det(R) must stay +1 like the reference's Z fix
+    pv, tv = det_metrics_case(40, 90)
+    tv[:, :, 2] *= 1e-3
+    pv = tv[:, :, [0, 1, 2]] * np.array([1.0, 1.0, -1.0], np.float32) + 0.01 * pv
+    got = straps_amd.metrics.point_error_sums(torch.from_numpy(pv.astype(np.float32)).to(dev), torch.from_numpy(tv).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(got, O.point_metrics(pv.astype(np.float32), tv), rtol=1e-3)
+    bm = straps_amd.metrics.BatchMetrics(dev)
+    B = 3
+    pd = {'verts': torch.from_numpy(det_metrics_case(6890, 70)[0]).to(dev), 'joints3D': torch.from_numpy(det_metrics_case(14, 72)[0]).to(dev),
+          'joints2D': torch.zeros(B, 17, 2, device=dev), 'shape_params': torch.zeros(B, 10, device=dev),
+          'pose_params_rot_matrices': torch.zeros(B, 24, 3, 3, device=dev)}
+    td = {'verts': torch.from_numpy(det_metrics_case(6890, 70)[1]).to(dev), 'joints3D': torch.from_numpy(det_metrics_case(14, 72)[1]).to(dev),
+          'joints2D': torch.full((B, 17, 2), 128.0, device=dev), 'shape_params': torch.ones(B, 10, device=dev),
+          'pose_params_rot_matrices': torch.zeros(B, 24, 3, 3, device=dev)}
+    bm.update(pd, td)
+    s = bm.summary()
+    assert s['pves_pa'] < s['pves_sc'] < s['pves'] and s['shape_mses'] == pytest.approx(1.0) and s['joints2D_l2es'] == pytest.approx(0.0, abs=1e-6)
+    assert s['pves'] == pytest.approx(float(small['metrics_verts_sums'][:, 0].sum()) / (3 * 6890), rel=1e-4)

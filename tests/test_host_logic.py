@@ -113,3 +113,26 @@ def test_smpl_model_packing_roundtrip():
             R[j, (rnd * 4 + tw) * 32 + vl] = pk['jr_w'][e]
     want = np.concatenate([model['J_regressor_extra'], model['J_regressor_cocoplus'], model['J_regressor_h36m']])
     np.testing.assert_array_equal(R, want)
+
+
+def test_checkpoint_roundtrip_reference_schema(tmp_path):
+    """the .tar dict of train loop :369-377 round-trips, loads with the reference's reader logic and
+    restores a regressor strictly."""
+    from straps_amd import checkpoint_utils as cu
+    m = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP)
+    crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'])
+    opt = torch.optim.Adam(list(m.parameters()) + list(crit.parameters()), lr=1e-4)
+    path = str(tmp_path / 'straps_model_checkpoint_exp001_epoch10.tar')
+    cu.save_checkpoint(path, 10, m, opt, crit, best_epoch=7, best_epoch_val_metrics={'pves_pa': np.float64(0.08), 'mpjpes_pa': np.float64(0.06)})
+    ck = cu.load_checkpoint(path)
+    assert tuple(sorted(ck)) == tuple(sorted(cu.CHECKPOINT_KEYS))
+    cur, best_epoch, best_wts, best_metrics = cu.load_training_info_from_checkpoint(ck, ['pves_pa', 'new_metric'])
+    assert cur == 11 and best_epoch == 7 and best_metrics == {'pves_pa': 0.08, 'new_metric': np.inf}
+    m2 = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP)
+    m2.load_state_dict(ck['best_model_state_dict'], strict=True)            # run_predict.py:15-16
+    crit.load_state_dict(ck['criterion_state_dict'])
+    opt.load_state_dict(ck['optimiser_state_dict'])                           # run_train.py:207-209
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    with pytest.raises(KeyError):
+        torch.save({'epoch': 1}, path)
+        cu.load_checkpoint(path)

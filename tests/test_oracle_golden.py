@@ -176,3 +176,11 @@ def test_adam_two_steps(small):
     da = np.array([float((p - b).double().abs().sum()) for p, b in zip(ps, before)])
     np.testing.assert_allclose(da, small['adam_delta_abs'], rtol=1e-4)
     np.testing.assert_allclose(ds, small['adam_delta_sum'], rtol=1e-3, atol=1e-6)
+
+
+def test_evaluation_metrics(small):
+    """PVE / PVE-SC / PVE-PA and MPJPE sums: oracle restatement vs the reference's utils/eval_utils.py."""
+    from detgen import det_metrics_case
+    for tag, npts, seed in (('verts', 6890, 70), ('j14', 14, 72)):
+        pv, tv = det_metrics_case(npts, seed)
+        np.testing.assert_allclose(O.point_metrics(pv, tv), small['metrics_%s_sums' % tag], rtol=2e-5)
