@@ -287,6 +287,16 @@ int straps_project_targets(const float* joints, const float* cam_t, float fx, fl
 /* STAND-IN for the part-segmentation rasteriser (renderers/nmr_renderer.py; SURVEY 8f row f1, not built):
  * labels discs around the 17 projected COCO joints (+ a torso box) with the 6 LSP part ids.          */
 int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream);
+/* On-device bounding-box crop + nearest-neighbour resize (utils/image_utils.py:44-105,
+ * train loop :161-170): per sample, box of the non-zero pixels of seg [B,wh,wh] -> centre / max(h,w) * scale
+ * (scale = orig_scale_factor + U(delta_scale), centre += U(delta_centre); uniforms [B][3] in [0,1), NULL = no
+ * jitter) -> int16-truncated corners -> crop -> resize to out_wh with cv2.INTER_NEAREST index rule; joints are
+ * shifted by the top-left corner and scaled by out_wh / crop size.  boxes [B][6] receives {r0,c0,r1,c1,shift_r,shift_c}. */
+int straps_crop_resize(const float* seg, const float* joints2d, const float* uniforms,
+                       float orig_scale_factor, float delta_scale_lo, float delta_scale_hi,
+                       float delta_centre_lo, float delta_centre_hi, float* out_seg,
+                       float* out_joints2d, int* boxes, int batch, int wh, int out_wh, int nj,
+                       void* stream);
 /* On-device evaluation metrics (metrics/train_loss_and_metrics_tracker.py:127-197 +
  * utils/eval_utils.py:7-85): for each sample b, out3[b] = { sum_n |p-t|,
  * sum_n |scale_and_translation_transform(p) - t|, sum_n |procrustes(p) - t| } over npoints 3-D points

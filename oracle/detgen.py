@@ -86,3 +86,18 @@ def det_metrics_case(npts, seed, batch=3):
     Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
     pv = 1.1 * tv.dot(Rz.T) + np.array([0.05, -0.02, 0.1]) + 0.03 * det_uniform((batch, npts, 3), seed + 1, -1.0, 1.0)
     return pv.astype(np.float32), tv.astype(np.float32)
+
+
+def det_crop_case(batch=5, wh=256):
+    """(seg [B,wh,wh] part ids, joints2d [B,17,2]) for the crop/resize goldens: a blob per sample, two of them touching
+    the image border so that the corner clamping paths are exercised."""
+    seg = np.zeros((batch, wh, wh), np.float32)
+    boxes = [(60, 200, 80, 170), (0, 140, 30, 120), (100, 256, 90, 256), (20, 60, 10, 250), (120, 135, 120, 131)]
+    for i in range(batch):
+        r0, r1, c0, c1 = boxes[i % len(boxes)]
+        blob = np.floor(det_uniform((r1 - r0, c1 - c0), 300 + i, 0.0, 6.999)).astype(np.float32)
+        seg[i, r0:r1, c0:c1] = blob
+        seg[i, r0, c0] = 1.0
+        seg[i, r1 - 1, c1 - 1] = 2.0
+    joints = det_uniform((batch, 17, 2), 310, 10.0, 246.0).astype(np.float32)
+    return seg, joints

@@ -254,6 +254,19 @@ def main():
         pa = np.linalg.norm(procrustes_analysis_batch(pv, tv) - tv, axis=-1).sum(1)
         small['metrics_%s_sums' % tag] = np.stack([raw, sc, pa], axis=1)
 
+    # ================= G-crop: bounding-box crop (pure numpy half of utils/image_utils.py) ====
+    from utils.image_utils import batch_crop_seg_to_bounding_box
+    from detgen import det_crop_case
+    cseg, cj = det_crop_case()
+    np.random.seed(11)
+    crops, cjs = batch_crop_seg_to_bounding_box(cseg, cj, orig_scale_factor=1.2, delta_scale_range=[-0.2, 0.2], delta_centre_range=[-5, 5])
+    small['crop_shapes'] = np.array([c.shape for c in crops], np.int64)
+    small['crop_joints'] = np.stack(cjs).astype(np.float64)
+    small['crop_sums'] = np.array([float(c.sum()) for c in crops])
+    crops0, cjs0 = batch_crop_seg_to_bounding_box(cseg, cj, orig_scale_factor=1.2)
+    small['crop0_shapes'] = np.array([c.shape for c in crops0], np.int64)
+    small['crop0_joints'] = np.stack(cjs0).astype(np.float64)
+
     # ================= G-opt: one Adam step over all 71 tensors =============================
     man = json.load(open(os.path.join(OUT, 'state_dict_keys_r18.json')))['keys']
     m = SingleInputRegressor(18, 18, 3)

@@ -340,6 +340,56 @@ def predict_forward(x, sd, init_estimate, smpl_model, layers=18, iterations=3):
 
 
 # --------------------------------------------------------------------------------------------
+# bounding-box crop + nearest resize  (utils/image_utils.py:44-105)
+# --------------------------------------------------------------------------------------------
+def crop_boxes(seg, joints2d, uniforms=None, orig_scale_factor=1.2, delta_scale_range=(-0.2, 0.2), delta_centre_range=(-5, 5)):
+    """batch_crop_seg_to_bounding_box (utils/image_utils.py:44-82) with the random draws supplied: uniforms[b] =
+    (scale draw, centre-row draw, centre-col draw) in [0,1).  Returns (boxes [B,4] = r0,c0,r1,c1 after numpy slice
+    clamping, cropped joints [B,J,2])."""
+    B, wh = seg.shape[0], seg.shape[-1]
+    boxes, cj = np.zeros((B, 4), np.int64), np.zeros_like(joints2d, dtype=np.float64)
+    for i in range(B):
+        px = np.argwhere(seg[i] != 0)
+        x1, y1 = np.amin(px, axis=0)
+        x2, y2 = np.amax(px, axis=0)
+        centre = np.array([(x1 + x2) / 2.0, (y1 + y2) / 2.0])
+        height, width = x2 - x1, y2 - y1
+        scale = orig_scale_factor
+        if uniforms is not None:
+            l, h = delta_scale_range
+            scale = orig_scale_factor + ((h - l) * uniforms[i, 0] + l)
+            l, h = delta_centre_range
+            centre = centre + ((h - l) * uniforms[i, 1:3] + l)
+        side = max(height, width) * scale
+        corners = np.array([centre[0] - side / 2.0, centre[1] - side / 2.0, centre[0] + side / 2.0, centre[1] + side / 2.0])
+        tl, br = corners[:2].astype(np.int16), corners[2:].astype(np.int16)
+        tl[tl < 0] = 0
+        br[br < 0] = 0
+        cj[i] = joints2d[i] - tl[::-1]
+        boxes[i] = [tl[0], tl[1], min(int(br[0]), wh), min(int(br[1]), wh)]
+    return boxes, cj
+
+
+def crop_resize(seg, joints2d, uniforms=None, out_wh=REGRESSOR_IMG_WH, **kw):
+    """crop (above) then batch_resize (utils/image_utils.py:85-105).  cv2 is not installed here: INTER_NEAREST is
+    restated from its documented index rule src = floor(dst * src_size / dst_size) (clamped) -- this half is NOT pinned
+    by a reference import."""
+    boxes, cj = crop_boxes(seg, joints2d, uniforms, **kw)
+    B = seg.shape[0]
+    out = np.zeros((B, out_wh, out_wh), seg.dtype)
+    oj = np.zeros_like(cj)
+    for i in range(B):
+        r0, c0, r1, c1 = boxes[i]
+        crop = seg[i, r0:r1, c0:c1]
+        ch, cw = crop.shape
+        ys = np.minimum(np.floor(np.arange(out_wh) * (ch / out_wh)).astype(np.int64), ch - 1)
+        xs = np.minimum(np.floor(np.arange(out_wh) * (cw / out_wh)).astype(np.int64), cw - 1)
+        out[i] = crop[ys][:, xs]
+        oj[i] = cj[i] * np.array([out_wh / float(cw), out_wh / float(ch)])
+    return out, oj, boxes
+
+
+# --------------------------------------------------------------------------------------------
 # evaluation metrics  (utils/eval_utils.py:7-85, metrics/train_loss_and_metrics_tracker.py:127-197)
 # --------------------------------------------------------------------------------------------
 def similarity_transform(S1, S2):

@@ -119,6 +119,11 @@ class TrainStep:
         # stand-in part segmentation, then G3 (+ joints deviation U[-8,8], proxy_rep_augmentation.py:25-49)
         seg = torch.empty(B, 256, 256, device=d)
         hipabi.check(L.straps_synth_seg(hipabi.ptr(tgt_j2d), hipabi.ptr(seg), B, 256, 14.0, st), 'straps_synth_seg')
+        # bounding-box crop with scale / centre jitter + nearest resize back to 256 (train loop :161-170, run_train.py:140-148),
+        # on the device; the 2-D joint targets follow the crop like in the reference
+        from .image_utils import batch_crop_and_resize
+        seg, tgt_j2d, _ = batch_crop_and_resize(seg, tgt_j2d, 256, 1.2, (-0.2, 0.2), (-5.0, 5.0),
+                                                uniforms=torch.rand(B, 3, device=d, generator=self.gen))
         u = torch.rand(B, 9, device=d, generator=self.gen)
         seg_aug = torch.empty_like(seg)
         hipabi.check(L.straps_augment_seg(hipabi.ptr(seg), hipabi.ptr(u), hipabi.ptr(self.remove_prob), 0.5, 48, hipabi.ptr(seg_aug), B, 256, st),

@@ -103,3 +103,28 @@ def test_point_metrics_vs_reference_golden_and_oracle():
     s = bm.summary()
     assert s['pves_pa'] < s['pves_sc'] < s['pves'] and s['shape_mses'] == pytest.approx(1.0) and s['joints2D_l2es'] == pytest.approx(0.0, abs=1e-6)
     assert s['pves'] == pytest.approx(float(small['metrics_verts_sums'][:, 0].sum()) / (3 * 6890), rel=1e-4)
+
+
+def test_crop_resize_vs_oracle_and_reference_boxes():
+    """on-device bbox crop + nearest resize vs the oracle (whose crop half is pinned by the reference golden)."""
+    import os
+    from detgen import det_crop_case
+    dev = torch.device('cuda:0')
+    small = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'small_golden.npz'))
+    seg, j = det_crop_case()
+    np.random.seed(11)
+    u = np.zeros((seg.shape[0], 3), np.float32)
+    for i in range(seg.shape[0]):
+        u[i, 0] = np.random.rand()
+        u[i, 1:3] = np.random.rand(2)
+    for uni in (u, None):
+        kw = dict(delta_scale_range=[-0.2, 0.2], delta_centre_range=[-5, 5], uniforms=torch.from_numpy(u).to(dev)) if uni is not None else {}
+        out, jout, boxes = straps_amd.image_utils.batch_crop_and_resize(torch.from_numpy(seg).to(dev), torch.from_numpy(j).to(dev), 256, 1.2, **kw)
+        want, wj, wb = O.crop_resize(seg, j, uni.astype(np.float64) if uni is not None else None)
+        bx = boxes.cpu().numpy()
+        # float32 uniforms vs the float64 draw: a corner can land on the other side of an integer only within 1e-6 of it
+        assert np.array_equal(bx[:, :4], wb), (bx, wb)
+        shapes = small['crop_shapes'] if uni is not None else small['crop0_shapes']
+        assert np.array_equal(np.stack([bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], 1), shapes)
+        assert np.array_equal(out.cpu().numpy(), want)
+        np.testing.assert_allclose(jout.cpu().numpy(), wj, rtol=1e-5, atol=1e-3)

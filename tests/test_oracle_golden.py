@@ -184,3 +184,24 @@ def test_evaluation_metrics(small):
     for tag, npts, seed in (('verts', 6890, 70), ('j14', 14, 72)):
         pv, tv = det_metrics_case(npts, seed)
         np.testing.assert_allclose(O.point_metrics(pv, tv), small['metrics_%s_sums' % tag], rtol=2e-5)
+
+
+def test_crop_boxes_match_reference(small):
+    """pure-numpy half of utils/image_utils.py (batch_crop_seg_to_bounding_box) with and without jitter; the jitter
+    draws are reproduced from numpy's seeded stream in the reference's call order (rand(), rand(2) per sample)."""
+    from detgen import det_crop_case
+    seg, j = det_crop_case()
+    np.random.seed(11)
+    u = np.zeros((seg.shape[0], 3))
+    for i in range(seg.shape[0]):
+        u[i, 0] = np.random.rand()
+        u[i, 1:3] = np.random.rand(2)
+    boxes, cj = O.crop_boxes(seg, j, u)
+    assert np.array_equal(np.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1), small['crop_shapes'])
+    np.testing.assert_allclose(cj, small['crop_joints'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose([seg[i, b[0]:b[2], b[1]:b[3]].sum() for i, b in enumerate(boxes)], small['crop_sums'])
+    boxes0, cj0 = O.crop_boxes(seg, j, None)
+    assert np.array_equal(np.stack([boxes0[:, 2] - boxes0[:, 0], boxes0[:, 3] - boxes0[:, 1]], 1), small['crop0_shapes'])
+    np.testing.assert_allclose(cj0, small['crop0_joints'], rtol=0, atol=1e-9)
+    out, oj, _ = O.crop_resize(seg, j, u)
+    assert out.shape == (seg.shape[0], 256, 256) and set(np.unique(out)) <= set(range(7))
