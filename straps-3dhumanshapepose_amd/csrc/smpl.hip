@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t 
     float* As_ = Fs + BT * FS;             // [32][AS]
     float* jacc = As_ + BT * AS;           // [32][JS]
     float* stage = jacc + BT * JS;         // [4][32][SS]
+    float* skin_lds = stage + 4 * BT * SS; // [4 waves][256]: per-tile skinning weights + joint offsets
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,6 +161,17 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t 
 
     for (int rd = round0; rd < round1; ++rd) {
         const int tile = rd * 4 + wave;
+        // skinning weights / joint offsets of this tile's 32 vertices -> LDS now, so their L2 latency hides under the
+        // MFMA loop instead of stalling the per-vertex loop (fast path: 4 weights per vertex, the real model's layout)
+        float* skw = skin_lds + wave * 256;                    // [32][4] weights, then [32][4] joint offsets (int bits)
+        if (KW == 4) {
+            const int e2 = lane * 2;
+            const f32x2 w2 = *reinterpret_cast<const f32x2*>(m.skin_w + tile * 128 + e2);
+            const int2 j2 = *reinterpret_cast<const int2*>(m.skin_j + tile * 128 + e2);
+            skw[e2] = w2[0]; skw[e2 + 1] = w2[1];
+            reinterpret_cast<int*>(skw)[128 + e2] = j2.x * 12;
+            reinterpret_cast<int*>(skw)[128 + e2 + 1] = j2.y * 12;
+        }
         // ---------------- blendshape contraction on the fp32 MFMA ----------------
         {
             f32x16 ax, ay, az;
@@ -201,13 +213,26 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t 
                 const int vrow = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int v = tile * 32 + vrow;
                 f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
-                for (int k = 0; k < KW; ++k) {
-                    const float w = m.skin_w[v * KW + k];
-                    const int jo = m.skin_j[v * KW + k] * 12;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + jo);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + jo + 4);
-                    const f32x4 a2 = *reinterpret_cast<const f32x4*>(Ab + jo + 8);
-                    t0 += w * a0; t1 += w * a1; t2 += w * a2;
+                if (KW == 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(skw + vrow * 4);
+                    const int4 j4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(skw) + 128 + vrow * 4);
+                    const int jo[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + jo[k]);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + jo[k] + 4);
+                        const f32x4 a2 = *reinterpret_cast<const f32x4*>(Ab + jo[k] + 8);
+                        t0 += w4[k] * a0; t1 += w4[k] * a1; t2 += w4[k] * a2;
+                    }
+                } else {
+                    for (int k = 0; k < KW; ++k) {
+                        const float w = m.skin_w[v * KW + k];
+                        const int jo = m.skin_j[v * KW + k] * 12;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + jo);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + jo + 4);
+                        const f32x4 a2 = *reinterpret_cast<const f32x4*>(Ab + jo + 8);
+                        t0 += w * a0; t1 += w * a1; t2 += w * a2;
+                    }
                 }
                 const float x = ax[r], y = ay[r], z = az[r];
                 float* so = mystage + bl * SS + vrow * 3;
@@ -308,7 +333,7 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
     const unsigned pose_blocks = (unsigned)((batch * 32 + 255) / 256);
     hipLaunchKernelGGL(smpl_pose_kernel, dim3(pose_blocks), dim3(256), 0, st, *model, betas, rotmats, F, Amat, joints, batch);
     STRAPS_CHECK_LAUNCH("smpl_pose_kernel");
-    const size_t lds = (size_t)(BT * FS + BT * AS + BT * JS + 4 * BT * SS) * sizeof(float);
+    const size_t lds = (size_t)(BT * FS + BT * AS + BT * JS + 4 * BT * SS + 4 * 256) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)smpl_verts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
