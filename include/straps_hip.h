@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STRAPS_ABI_VERSION 1
+#define STRAPS_ABI_VERSION 2
 
 #define STRAPS_OK 0
 #define STRAPS_EINVAL 1       /* bad argument (shape, alignment, null pointer) */
@@ -141,9 +141,11 @@ int straps_rodrigues_fwd(const float* aa, float* rotmats, long long n, void* str
 #define STRAPS_SMPL_NJOINTS_OUT 90
 
 typedef struct {
-    /* blend directions in MFMA A-fragment order: [tile 216][coord 3][kgroup 28][lane 64][4],
+    /* blend directions in MFMA A-fragment order: [tile n_tiles][coord 3][kgroup 28][lane 64][4],
      * element = D[k = 8*g + 4*(lane>>5) + e][vertex = 32*tile + (lane&31)][coord], where D row 0
-     * is v_template, rows 1..10 shapedirs[..., l], rows 11..217 posedirs, rest zero.           */
+     * is v_template, rows 1..10 shapedirs[..., l], rows 11..217 posedirs, rest zero.
+     * Tiles 0..215 are the 6890 mesh vertices; tiles 216..n_tiles-1 hold the VIRTUAL vertices that
+     * carry the 45 sparse-regressed joints (see vj_ptr), zero padded to a multiple of 8 tiles.    */
     const float* blend_frag;
     const float* j_template;   /* [24][3]  J_regressor @ v_template (host fp64)              */
     const float* j_shapedirs;  /* [24][3][10] J_regressor @ shapedirs                          */
@@ -151,14 +153,16 @@ typedef struct {
     const int32_t* depth;      /* [24] depth of each joint in the kinematic tree               */
     int32_t max_depth;
     int32_t skin_k;            /* non-zeros kept per vertex (4 for the real model)              */
-    const float* skin_w;       /* [VPAD][skin_k] */
-    const int32_t* skin_j;     /* [VPAD][skin_k] joint index of each weight                     */
-    /* extra-joint regressors as sparse entries grouped by (round = tile/4, owner = joint%4):
-     * entries of group q = round*4 + owner live in [jr_ptr[q], jr_ptr[q+1]).
-     * jr_code = (tile_in_round << 16) | (v_local << 8) | joint(0..44).                        */
-    const int32_t* jr_ptr;     /* [54*4 + 1] */
-    const int32_t* jr_code;
-    const float* jr_w;
+    const float* skin_w;       /* [32*n_tiles][skin_k] */
+    const int32_t* skin_j;     /* [32*n_tiles][skin_k] joint index of each weight               */
+    /* Extra joints (J_regressor_extra | cocoplus | h36m, 45 rows) without a gather: regrouping
+     *   joint_j = sum_v R[j,v] sum_k w[v,k] A_k.[v_posed_v;1]  by bone k gives one rigidly skinned
+     * virtual vertex per (joint, bone) pair: blend directions sum_v R[j,v] w[v,k] D[:,v] / s and
+     * skinning weight s = sum_v R[j,v] w[v,k] on bone k.  They ride through the same contraction
+     * as extra tiles; joint j is the sum of virtual vertices [vj_ptr[j], vj_ptr[j+1]).           */
+    const int32_t* vj_ptr;     /* [45 + 1] */
+    int32_t n_tiles;           /* 216 + virtual tiles, multiple of 8                            */
+    int32_t reserved0;
     const int32_t* pick_ids;   /* [21] vertex ids appended as joints 24..44                    */
     /* ---- tables used only by straps_smpl_bwd (may be NULL for forward-only use) ---- */
     /* transposed blend fragments [tile 216][coord 3][kblock 7][rq 4][lane 64][4]:
@@ -174,10 +178,10 @@ typedef struct {
     const float* jrt_w;
 } straps_smpl_model_t;
 
-/* bytes of caller-owned scratch for `batch` bodies split into `chunks` vertex chunks           */
-size_t straps_smpl_workspace_bytes(long long batch, int chunks);
+/* bytes of caller-owned scratch for `batch` bodies (depends on the model's virtual-tile count)  */
+size_t straps_smpl_workspace_bytes(const straps_smpl_model_t* model, long long batch);
 /* verts [B][6890][3], joints [B][90][3] (may be NULL: vertices only).  betas [B][10],
- * rotmats [B][24][3][3] row-major.  chunks: 0 = auto (8 for big batches = one per XCD).        */
+ * rotmats [B][24][3][3] row-major.  chunks: split of the n_tiles/8 tile rounds over blocks, 0 = auto.  */
 int straps_smpl_fwd(const straps_smpl_model_t* model, const float* betas, const float* rotmats,
                     float* verts, float* joints, void* workspace, long long batch, int chunks,
                     void* stream);

@@ -9,9 +9,11 @@
 //                           run on the exact-fp32 MFMA (32x32x2), 32 bodies x 32 vertices x 3
 //                           coords per wave tile; linear blend skinning is then done per vertex
 //                           on the VALU straight out of the accumulators (lane = body), staged
-//                           through LDS so the 12-byte vertices leave as coalesced rows; the
-//                           45 regressed joints are accumulated from the staged tile (sparse).
-//   3. smpl_joints_kernel : picked vertices + fixed-order sum of the per-chunk joint partials.
+//                           through a per-wave LDS slice so the 12-byte vertices leave as
+//                           coalesced rows.  8 waves per block, no barrier in the tile loop: the
+//                           second wave of each SIMD skins/stores while the first contracts.
+//   3. smpl_joints_kernel : picked vertices + the 45 sparse-regressed joints, gathered from the
+//                           just-written vertices in a fixed order.
 // Everything is deterministic (no atomics).
 #include "common.h"
 
@@ -19,14 +21,13 @@ namespace {
 
 constexpr int KP = STRAPS_SMPL_KP;        // 224
 constexpr int KG = KP / 8;                // 28 k-groups of 8
-constexpr int NT = STRAPS_SMPL_TILES;     // 216 vertex tiles
+constexpr int NT = STRAPS_SMPL_TILES;     // 216 mesh-vertex tiles (virtual-vertex tiles follow, see straps_hip.h)
 constexpr int NV = STRAPS_SMPL_V;         // 6890
-constexpr int NROUNDS = NT / 4;           // 54 rounds of 4 tiles (one per wave)
+constexpr int NW = 8;                     // waves per block of the vertex kernel (2 per SIMD)
 constexpr int BT = 32;                    // bodies per block
 constexpr int FS = 228;                   // LDS row strides (floats): 4*odd -> conflict-free b128
 constexpr int AS = 292;
-constexpr int SS = 97;                    // stage row stride (odd -> conflict-free b32)
-constexpr int JS = 180;                   // jacc row stride: 45 joints x vec4
+constexpr int HS = 50;                    // half-tile stage row stride: 48 floats + 2 (even: b64 row reads)
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void smpl_pose_kernel(straps_smpl_model_t m, const float* __restrict__ betas,
@@ -117,53 +118,64 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(straps_smpl_model_t m, c
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t m, const float* __restrict__ F,
-                                                            const float* __restrict__ Amat,
-                                                            float* __restrict__ verts, float* __restrict__ partial,
-                                                            long long B, int rounds_per_chunk) {
+// 8 waves per block = 2 per SIMD: while one wave of a SIMD runs its 336-MFMA contraction the other
+// does its skinning / stores on the VALU + LDS, so the two phases overlap in hardware (measured:
+// run back to back by one wave per SIMD they cost ~6 ms + ~6 ms at B = 65536).  No block barrier
+// inside the tile loop: each wave owns its stage slice.
+__global__ __launch_bounds__(NW * 64) void smpl_verts_kernel(straps_smpl_model_t m, const float* __restrict__ F,
+                                                             const float* __restrict__ Amat, float* __restrict__ verts,
+                                                             float* __restrict__ vout, long long B, int btiles,
+                                                             int rounds, int rounds_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Fs = smem;                      // [32][FS]
     float* As_ = Fs + BT * FS;             // [32][AS]
-    float* jacc = As_ + BT * AS;           // [32][JS]
-    float* stage = jacc + BT * JS;         // [4][32][SS]
-    float* skin_lds = stage + 4 * BT * SS; // [4 waves][256]: per-tile skinning weights + joint offsets
+    float* stage = As_ + BT * AS;          // [NW][32][HS]  half a tile (16 vertices) per wave
+    float* skin_lds = stage + NW * BT * HS; // [NW][256]    per-tile skinning weights + joint offsets
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int h = lane >> 5;
     const int bl = lane & 31;              // body within the block tile
-    const int chunk = blockIdx.x;
-    const long long b0 = (long long)blockIdx.y * BT;
+    // chunk-major logical order, contiguous per XCD: an XCD streams one ~2 MB slice of the blend
+    // fragments at a time (L2-resident) while it walks the body tiles
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = logical / btiles;
+    const long long b0 = (long long)(logical - chunk * btiles) * BT;
     const int nb = (int)((B - b0) < BT ? (B - b0) : BT);
 
-    // ---- stage the block's feature rows and joint transforms, zero the joint accumulators ----
-    for (int i = tid; i < BT * (KP / 4); i += 256) {
+    // ---- stage the block's feature rows and joint transforms ----
+    for (int i = tid; i < BT * (KP / 4); i += NW * 64) {
         const int b = i / (KP / 4), q = i % (KP / 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b < nb) v = *reinterpret_cast<const f32x4*>(F + (b0 + b) * KP + q * 4);
         *reinterpret_cast<f32x4*>(Fs + b * FS + q * 4) = v;
     }
-    for (int i = tid; i < BT * 72; i += 256) {
+    for (int i = tid; i < BT * 72; i += NW * 64) {
         const int b = i / 72, q = i % 72;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b < nb) v = *reinterpret_cast<const f32x4*>(Amat + (b0 + b) * 288 + q * 4);
         *reinterpret_cast<f32x4*>(As_ + b * AS + q * 4) = v;
     }
-    for (int i = tid; i < BT * JS; i += 256) jacc[i] = 0.f;
     __syncthreads();
 
     const int round0 = chunk * rounds_per_chunk;
-    const int round1 = min(round0 + rounds_per_chunk, NROUNDS);
+    const int round1 = min(round0 + rounds_per_chunk, rounds);
+    const int vrow_floats = (m.n_tiles - NT) * 96;      // virtual-vertex row of one body
     const f32x4* __restrict__ blend = reinterpret_cast<const f32x4*>(m.blend_frag);
-    float* mystage = stage + wave * BT * SS;
+    float* mystage = stage + wave * BT * HS;
+    float* skw = skin_lds + wave * 256;    // [32][4] weights, then [32][4] joint offsets (int bits)
     const int KW = m.skin_k;
+    const float* Ab = As_ + bl * AS;
+    const float* frow = Fs + bl * FS + 4 * h;
 
+#ifdef SMPL_STAGGER
+    if (wave >= 4) { for (int i = 0; i < SMPL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); }
+#endif
     for (int rd = round0; rd < round1; ++rd) {
-        const int tile = rd * 4 + wave;
+        const int tile = rd * NW + wave;
         // skinning weights / joint offsets of this tile's 32 vertices -> LDS now, so their L2 latency hides under the
         // MFMA loop instead of stalling the per-vertex loop (fast path: 4 weights per vertex, the real model's layout)
-        float* skw = skin_lds + wave * 256;                    // [32][4] weights, then [32][4] joint offsets (int bits)
         if (KW == 4) {
             const int e2 = lane * 2;
             const f32x2 w2 = *reinterpret_cast<const f32x2*>(m.skin_w + tile * 128 + e2);
@@ -173,14 +185,13 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t 
             reinterpret_cast<int*>(skw)[128 + e2 + 1] = j2.y * 12;
         }
         // ---------------- blendshape contraction on the fp32 MFMA ----------------
-        {
-            f32x16 ax, ay, az;
+        f32x16 ax, ay, az;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ax[r] = 0.f; ay[r] = 0.f; az[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { ax[r] = 0.f; ay[r] = 0.f; az[r] = 0.f; }
+        {
             const f32x4* px = blend + ((long long)(tile * 3 + 0) * KG) * 64 + lane;
             const f32x4* py = px + KG * 64;
             const f32x4* pz = py + KG * 64;
-            const float* frow = Fs + bl * FS + 4 * h;
             f32x4 cx0 = px[0], cy0 = py[0], cz0 = pz[0];
             f32x4 cx1 = px[64], cy1 = py[64], cz1 = pz[64];
 #pragma unroll 2
@@ -206,12 +217,15 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t 
                 }
                 cx0 = nx0; cy0 = ny0; cz0 = nz0; cx1 = nx1; cy1 = ny1; cz1 = nz1;
             }
-            // ---------------- linear blend skinning, lane = body, reg = vertex ----------------
-            const float* Ab = As_ + bl * AS;
+        }
+        // ---------------- linear blend skinning, lane = body, reg = vertex; 16 vertices at a time ----------------
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int vrow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int v = tile * 32 + vrow;
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = half * 8 + rr;
+                const int vrow = (r & 3) + 8 * (r >> 2) + 4 * h;          // 0..31 within the tile
+                const int vloc = vrow - 16 * half;                         // 0..15 within the half
                 f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
                 if (KW == 4) {
                     const f32x4 w4 = *reinterpret_cast<const f32x4*>(skw + vrow * 4);
@@ -225,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t 
                         t0 += w4[k] * a0; t1 += w4[k] * a1; t2 += w4[k] * a2;
                     }
                 } else {
+                    const int v = tile * 32 + vrow;
                     for (int k = 0; k < KW; ++k) {
                         const float w = m.skin_w[v * KW + k];
                         const int jo = m.skin_j[v * KW + k] * 12;
@@ -235,50 +250,46 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_kernel(straps_smpl_model_t 
                     }
                 }
                 const float x = ax[r], y = ay[r], z = az[r];
-                float* so = mystage + bl * SS + vrow * 3;
+                float* so = mystage + bl * HS + vloc * 3;
                 so[0] = t0[0] * x + t0[1] * y + t0[2] * z + t0[3];
                 so[1] = t1[0] * x + t1[1] * y + t1[2] * z + t1[3];
                 so[2] = t2[0] * x + t2[1] * y + t2[2] * z + t2[3];
             }
-        }
-        __syncthreads();
-        // ---------------- coalesced row store of this wave's staged tile ----------------
-        {
-            const int ncol = min(96, (NV - tile * 32) * 3);
-            for (int i = lane; i < BT * 96; i += 64) {
-                const int b = i / 96, c = i - b * 96;
-                if (b < nb && c < ncol) verts[(b0 + b) * (long long)(NV * 3) + tile * 96 + c] = mystage[b * SS + c];
+            // the stage slice is private to this wave: wave-level ordering is enough (LDS ops of one wave retire in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---------------- coalesced row store: 32 bodies x 192 contiguous bytes ----------------
+            {
+                // mesh tiles go to verts [B][6890][3]; virtual tiles to the joint scratch [B][32*(n_tiles-216)][3]
+                const bool mesh = tile < NT;
+                const int v0 = (mesh ? tile : tile - NT) * 32 + half * 16;
+                const int npair = mesh ? min(24, max(0, (NV - v0) * 3 / 2)) : 24;   // float2 columns that exist (NV*3 is even)
+                const long long rstride = mesh ? (long long)(NV * 3) : (long long)vrow_floats;
+                float* vbase = (mesh ? verts : vout) + b0 * rstride + (long long)v0 * 3;
+                if (mesh || vout) {
+#pragma unroll 4
+                    for (int i = lane; i < BT * 24; i += 64) {
+                        const int b = i / 24, c = i - b * 24;
+                        if (b < nb && c < npair)
+                            *reinterpret_cast<f32x2*>(vbase + b * rstride + c * 2) =
+                                *reinterpret_cast<const f32x2*>(mystage + b * HS + c * 2);
+                    }
+                }
             }
-        }
-        // ---------------- sparse joint regression: this wave owns joints == wave (mod 4) ----------------
-        if (h == 0) {
-            const int q = rd * 4 + wave;
-            const int e0 = m.jr_ptr[q], e1 = m.jr_ptr[q + 1];
-            for (int e = e0; e < e1; ++e) {
-                const int code = m.jr_code[e];
-                const float w = m.jr_w[e];
-                const float* sv = stage + ((code >> 16) * BT + bl) * SS + ((code >> 8) & 255) * 3;
-                f32x4* acc = reinterpret_cast<f32x4*>(jacc + bl * JS + (code & 255) * 4);
-                f32x4 a = *acc;
-                a[0] = fmaf(w, sv[0], a[0]); a[1] = fmaf(w, sv[1], a[1]); a[2] = fmaf(w, sv[2], a[2]);
-                *acc = a;
-            }
-        }
-        __syncthreads();
-    }
-    if (partial) {
-        for (int i = tid; i < BT * STRAPS_SMPL_NEXTRA * 3; i += 256) {
-            const int b = i / (STRAPS_SMPL_NEXTRA * 3), r = i - b * (STRAPS_SMPL_NEXTRA * 3);
-            if (b < nb)
-                partial[((long long)chunk * B + b0 + b) * (STRAPS_SMPL_NEXTRA * 3) + r] = jacc[b * JS + (r / 3) * 4 + (r % 3)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
+// Output joints 24..89: 21 picked vertices, then the 45 regressed joints = fixed-order sums of their
+// virtual vertices (contiguous in the scratch row).  One thread per output scalar -> deterministic.
 __global__ __launch_bounds__(256) void smpl_joints_kernel(straps_smpl_model_t m, const float* __restrict__ verts,
-                                                          const float* __restrict__ partial, float* __restrict__ joints,
-                                                          long long B, int chunks) {
+                                                          const float* __restrict__ vout, float* __restrict__ joints,
+                                                          long long B) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     constexpr int PER = (STRAPS_SMPL_NPICK + STRAPS_SMPL_NEXTRA) * 3;   // 198
     if (gid >= B * PER) return;
@@ -289,16 +300,21 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(straps_smpl_model_t m,
         v = verts[b * (long long)(NV * 3) + m.pick_ids[r / 3] * 3 + (r % 3)];
     } else {
         const int rr = r - STRAPS_SMPL_NPICK * 3;
+        const int j = rr / 3, c = rr - j * 3;
+        const float* vb = vout + b * (long long)((m.n_tiles - NT) * 96);
+        const int e0 = m.vj_ptr[j], e1 = m.vj_ptr[j + 1];
         v = 0.f;
-        for (int c = 0; c < chunks; ++c) v += partial[((long long)c * B + b) * (STRAPS_SMPL_NEXTRA * 3) + rr];
+        for (int e = e0; e < e1; ++e) v += vb[e * 3 + c];
     }
     joints[b * (STRAPS_SMPL_NJOINTS_OUT * 3) + 72 + r] = v;
 }
 
-inline int resolve_rpc(long long batch, int chunks) {
-    if (chunks <= 0) chunks = (batch >= 1024) ? 8 : 54;
-    if (chunks > NROUNDS) chunks = NROUNDS;
-    return (NROUNDS + chunks - 1) / chunks;
+// rounds (of NW tiles) per block; chunks <= 0 -> auto: big batches take 8 rounds per block so the F / A staging
+// amortises, small ones 1 round so a 64-body step still puts 2 x n_tiles/8 blocks on the chip
+inline int resolve_rpc(int rounds, long long batch, int chunks) {
+    if (chunks <= 0) return (batch >= 1024) ? 8 : 1;
+    if (chunks > rounds) chunks = rounds;
+    return (rounds + chunks - 1) / chunks;
 }
 
 }  // namespace
@@ -312,10 +328,9 @@ int straps_smpl_launch_pose(const straps_smpl_model_t* model, const float* betas
     return STRAPS_OK;
 }
 
-extern "C" size_t straps_smpl_workspace_bytes(long long batch, int chunks) {
-    const int rpc = resolve_rpc(batch, chunks);
-    const int nch = (NROUNDS + rpc - 1) / rpc;
-    return (size_t)batch * (size_t)(KP + 288 + nch * STRAPS_SMPL_NEXTRA * 3) * sizeof(float);
+extern "C" size_t straps_smpl_workspace_bytes(const straps_smpl_model_t* model, long long batch) {
+    if (!model || batch <= 0 || model->n_tiles < NT) return 0;
+    return (size_t)batch * (size_t)(KP + 288 + (model->n_tiles - NT) * 96) * sizeof(float);
 }
 
 extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* betas, const float* rotmats,
@@ -324,16 +339,18 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
     STRAPS_REQUIRE(model && betas && rotmats && verts && workspace, "straps_smpl_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0, "straps_smpl_fwd: batch must be positive (got %lld)", batch);
     STRAPS_REQUIRE(model->skin_k >= 1 && model->skin_k <= 24, "straps_smpl_fwd: skin_k %d out of range", model->skin_k);
+    STRAPS_REQUIRE(model->n_tiles >= NT && model->n_tiles % NW == 0 && model->vj_ptr,
+                   "straps_smpl_fwd: n_tiles %d must be a multiple of %d >= %d with the virtual-vertex table set", model->n_tiles, NW, NT);
     hipStream_t st = (hipStream_t)stream;
-    const int rpc = resolve_rpc(batch, chunks);
-    const int nch = (NROUNDS + rpc - 1) / rpc;
+    const int rounds = (joints ? model->n_tiles : NT) / NW;   // vertices only: the virtual (joint) tiles are skipped
+    const int rpc = resolve_rpc(rounds, batch, chunks);
+    const int nch = (rounds + rpc - 1) / rpc;
     float* F = (float*)workspace;
     float* Amat = F + batch * KP;
-    float* partial = Amat + batch * 288;
-    const unsigned pose_blocks = (unsigned)((batch * 32 + 255) / 256);
-    hipLaunchKernelGGL(smpl_pose_kernel, dim3(pose_blocks), dim3(256), 0, st, *model, betas, rotmats, F, Amat, joints, batch);
-    STRAPS_CHECK_LAUNCH("smpl_pose_kernel");
-    const size_t lds = (size_t)(BT * FS + BT * AS + BT * JS + 4 * BT * SS + 4 * 256) * sizeof(float);
+    float* vout = Amat + batch * 288;
+    int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, joints, batch, st);
+    if (rc != STRAPS_OK) return rc;
+    const size_t lds = (size_t)(BT * FS + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)smpl_verts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -341,16 +358,16 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
         attr_set = true;
     }
     const long long btiles = (batch + BT - 1) / BT;
-    if (btiles > 65535) {
-        straps_set_error("straps_smpl_fwd: batch %lld exceeds one launch (max %d bodies); split it", batch, 65535 * BT);
+    if (btiles * nch > 0x7fffffffLL || btiles > 0x3fffffLL) {
+        straps_set_error("straps_smpl_fwd: batch %lld exceeds one launch; split it", batch);
         return STRAPS_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL(smpl_verts_kernel, dim3(nch, (unsigned)btiles), dim3(256), lds, st, *model, F, Amat, verts,
-                       joints ? partial : nullptr, batch, rpc);
+    hipLaunchKernelGGL(smpl_verts_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
+                       joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);
     STRAPS_CHECK_LAUNCH("smpl_verts_kernel");
     if (joints) {
         const long long n = batch * (STRAPS_SMPL_NPICK + STRAPS_SMPL_NEXTRA) * 3;
-        hipLaunchKernelGGL(smpl_joints_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *model, verts, partial, joints, batch, nch);
+        hipLaunchKernelGGL(smpl_joints_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *model, verts, vout, joints, batch);
         STRAPS_CHECK_LAUNCH("smpl_joints_kernel");
     }
     return STRAPS_OK;

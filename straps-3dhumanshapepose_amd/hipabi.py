@@ -41,8 +41,8 @@ class SmplModelStruct(C.Structure):
     """mirror of straps_smpl_model_t"""
     _fields_ = [('blend_frag', C.c_void_p), ('j_template', C.c_void_p), ('j_shapedirs', C.c_void_p),
                 ('parents', C.c_void_p), ('depth', C.c_void_p), ('max_depth', C.c_int32), ('skin_k', C.c_int32),
-                ('skin_w', C.c_void_p), ('skin_j', C.c_void_p), ('jr_ptr', C.c_void_p), ('jr_code', C.c_void_p),
-                ('jr_w', C.c_void_p), ('pick_ids', C.c_void_p), ('blend_frag_t', C.c_void_p), ('children', C.c_void_p),
+                ('skin_w', C.c_void_p), ('skin_j', C.c_void_p), ('vj_ptr', C.c_void_p), ('n_tiles', C.c_int32),
+                ('reserved0', C.c_int32), ('pick_ids', C.c_void_p), ('blend_frag_t', C.c_void_p), ('children', C.c_void_p),
                 ('jrt_ptr', C.c_void_p), ('jrt_code', C.c_void_p), ('jrt_w', C.c_void_p)]
 
 
@@ -72,7 +72,7 @@ SIGNATURES = {
     'straps_broadcast_rows': (_I, [_P, _I, _P, _I, _I, _P]),
     'straps_rot6d_fwd': (_I, [_P, _L, _I, _P, _L, _P]),
     'straps_rodrigues_fwd': (_I, [_P, _P, _L, _P]),
-    'straps_smpl_workspace_bytes': (_Z, [_L, _I]),
+    'straps_smpl_workspace_bytes': (_Z, [C.POINTER(SmplModelStruct), _L]),
     'straps_smpl_fwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _L, _I, _P]),
     'straps_smpl_bwd_workspace_bytes': (_Z, [_L, _I]),
     'straps_smpl_bwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),

@@ -35,8 +35,47 @@ def pack_smpl_model(model):
     D[0, :V] = vt
     D[1:11, :V] = np.transpose(sd, (2, 0, 1))
     D[11:218, :V] = pd.reshape(207, V, 3)
+    # ---- the 45 sparse-regressed joints as "virtual vertices" (no gather over the written mesh) ----
+    #   joint_j = sum_v R[j,v] sum_k W[v,k] (R_k v_posed_v + t_k) = sum_k ( R_k (F . E_jk) + s_jk t_k ),
+    #   E_jk = sum_v R[j,v] W[v,k] D[:,v],  s_jk = sum_v R[j,v] W[v,k]
+    # i.e. one virtual vertex per (joint, bone) pair with blend directions E_jk / s_jk, skinned rigidly with weight
+    # s_jk on bone k.  A pair whose coefficients cancel (|s| small against sum |c|) is split by sign so s never
+    # vanishes.  Accumulated in fp64 on the host.
+    R45 = np.concatenate([np.asarray(model[n], np.float64) for n in
+                          ('J_regressor_extra', 'J_regressor_cocoplus', 'J_regressor_h36m')], axis=0)
+    assert R45.shape == (45, V)
+    D64 = np.zeros((V, 218, 3), np.float64)
+    D64[:, 0] = vt
+    D64[:, 1:11] = np.transpose(sd, (0, 2, 1))
+    D64[:, 11:] = pd.reshape(207, V, 3).transpose(1, 0, 2)
+    D64 = D64.reshape(V, 218 * 3)
+    W64 = W.astype(np.float64)
+    vdirs, vs_, vk_, vjn = [], [], [], np.zeros(45, np.int64)
+    for j in range(45):
+        cols = np.nonzero(R45[j])[0]
+        if cols.size == 0:
+            continue
+        Cj = R45[j, cols, None] * W64[cols]                                  # [n][24]
+        for kb in np.nonzero(np.any(Cj != 0, axis=0))[0]:
+            c = Cj[:, kb]
+            parts = [c] if abs(c.sum()) >= 0.25 * np.abs(c).sum() else [np.where(c > 0, c, 0.0), np.where(c < 0, c, 0.0)]
+            for cp in parts:
+                s_ = cp.sum()
+                if s_ == 0:
+                    continue
+                vdirs.append((cp @ D64[cols]) / s_)
+                vs_.append(s_)
+                vk_.append(kb)
+                vjn[j] += 1
+    nvirt = len(vs_)
+    vj_ptr = np.concatenate([[0], np.cumsum(vjn)]).astype(np.int32)
+    n_tiles = ((TILES + (nvirt + 31) // 32 + 7) // 8) * 8
+    Dall = np.zeros((KP, n_tiles * 32, 3), np.float32)
+    Dall[:, :VPAD] = D
+    if nvirt:
+        Dall[:218, VPAD:VPAD + nvirt] = np.asarray(vdirs).reshape(nvirt, 218, 3).transpose(1, 0, 2)
     # fragment order [tile][coord][g][h][i][e]  <-  D[8g+4h+e][32t+i][c]
-    frag = D.reshape(28, 2, 4, TILES, 32, 3).transpose(3, 5, 0, 1, 4, 2).copy()
+    frag = Dall.reshape(28, 2, 4, n_tiles, 32, 3).transpose(3, 5, 0, 1, 4, 2).copy()
     parents = np.asarray(model['parents'], np.int32).copy()
     depth = np.zeros(24, np.int32)
     for j in range(1, 24):
@@ -45,23 +84,16 @@ def pack_smpl_model(model):
     nnz = (W != 0).sum(1)
     k = int(max(1, nnz.max()))
     order = np.argsort(-(W != 0).astype(np.int8), axis=1, kind='stable')[:, :k]      # non-zeros first, by joint id
-    sw = np.zeros((VPAD, k), np.float32)
-    sj = np.zeros((VPAD, k), np.int32)
+    sw = np.zeros((n_tiles * 32, k), np.float32)
+    sj = np.zeros((n_tiles * 32, k), np.int32)
     sw[:V] = np.take_along_axis(W, order, axis=1)
     sj[:V] = np.where(sw[:V] != 0, order, 0)
-    # sparse extra regressors grouped by (round = tile//4, owner = joint%4)
-    R45 = np.concatenate([np.asarray(model[n], np.float32) for n in
-                          ('J_regressor_extra', 'J_regressor_cocoplus', 'J_regressor_h36m')], axis=0)
-    assert R45.shape == (45, V)
-    jj, vv = np.nonzero(R45)
-    tile = vv // 32
-    q = (tile // 4) * 4 + (jj % 4)
-    o = np.lexsort((vv, jj, q))
-    jj, vv, q, tile = jj[o], vv[o], q[o], tile[o]
-    code = ((tile % 4) << 16) | ((vv % 32) << 8) | jj
-    jr_ptr = np.zeros(54 * 4 + 1, np.int32)
-    np.add.at(jr_ptr, q + 1, 1)
-    jr_ptr = np.cumsum(jr_ptr).astype(np.int32)
+    if nvirt:
+        sw[VPAD:VPAD + nvirt, 0] = np.asarray(vs_, np.float32)
+        sj[VPAD:VPAD + nvirt, 0] = np.asarray(vk_, np.int32)
+    jj, vv = np.nonzero(R45)                                                 # (backward tables below)
+    o = np.lexsort((vv, jj))
+    jj, vv = jj[o], vv[o]
     # ---- backward tables ----
     # transposed fragments [t][c][f][rq][h][i][e] <- D[32f+i][32t + row(4rq+e, h)][c], row(r,h) = (r&3)+8(r>>2)+4h
     r_ = np.arange(16)
@@ -93,8 +125,7 @@ def pack_smpl_model(model):
         'j_shapedirs': np.einsum('jv,vcl->jcl', Jr, sd).astype(np.float32),
         'parents': parents, 'depth': depth, 'max_depth': int(depth.max()), 'skin_k': k,
         'skin_w': sw, 'skin_j': sj,
-        'jr_ptr': jr_ptr, 'jr_code': np.ascontiguousarray(code.astype(np.int32) if code.size else np.zeros(1, np.int32)),
-        'jr_w': np.ascontiguousarray(R45[jj, vv].astype(np.float32) if jj.size else np.zeros(1, np.float32)),
+        'vj_ptr': vj_ptr, 'n_tiles': int(n_tiles),
         'pick_ids': np.asarray(model['extra_vertex_ids'], np.int32),
     }
 
@@ -111,7 +142,7 @@ class SMPL(nn.Module):
         model = model_path if isinstance(model_path, dict) else load_smpl_model(model_path, gender, extra_regressor_paths)
         self.batch_size = batch_size
         packed = pack_smpl_model(model)
-        self.max_depth, self.skin_k = packed.pop('max_depth'), packed.pop('skin_k')
+        self.max_depth, self.skin_k, self.n_tiles = packed.pop('max_depth'), packed.pop('skin_k'), packed.pop('n_tiles')
         for name, arr in packed.items():
             self.register_buffer('_k_' + name, torch.from_numpy(np.ascontiguousarray(arr)), persistent=False)
         # buffers with the names smplx / the reference expose (state-dict visible, used by callers)
@@ -135,10 +166,10 @@ class SMPL(nn.Module):
         key = self._k_blend_frag.data_ptr()
         if self._struct_key != key:
             s = hipabi.SmplModelStruct()
-            for f in ('blend_frag', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'jr_ptr',
-                      'jr_code', 'jr_w', 'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w'):
+            for f in ('blend_frag', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
+                      'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w'):
                 setattr(s, f, getattr(self, '_k_' + f).data_ptr())
-            s.max_depth, s.skin_k = self.max_depth, self.skin_k
+            s.max_depth, s.skin_k, s.n_tiles = self.max_depth, self.skin_k, self.n_tiles
             self._struct, self._struct_key = s, key
         return self._struct
 
@@ -155,7 +186,7 @@ class SMPL(nn.Module):
         L = hipabi.lib()
         verts = torch.empty(B, V, 3, device=betas.device, dtype=torch.float32)
         joints = torch.empty(B, 90, 3, device=betas.device, dtype=torch.float32) if want_joints else None
-        ws = torch.empty(L.straps_smpl_workspace_bytes(B, chunks) // 4, device=betas.device, dtype=torch.float32)
+        ws = torch.empty(L.straps_smpl_workspace_bytes(C.byref(self._model_struct()), B) // 4, device=betas.device, dtype=torch.float32)
         hipabi.check(L.straps_smpl_fwd(C.byref(self._model_struct()), hipabi.ptr(betas), hipabi.ptr(rotmats),
                                        hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(ws), B, chunks,
                                        hipabi.stream_ptr()), 'straps_smpl_fwd')

@@ -1,5 +1,6 @@
 """CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/straps_hip.h
 declares (no compute calls -- there is no GPU here)."""
+import ctypes as C
 import os
 import re
 
@@ -34,7 +35,6 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_version_and_error_channel(lib):
-    assert lib.straps_abi_version() == 1
     assert isinstance(lib.straps_last_error(), bytes)
     # argument validation happens before any HIP call, so it is checkable without a GPU
     rc = lib.straps_rot6d_fwd(None, 6, 1, None, 1, None)
@@ -42,5 +42,7 @@ def test_version_and_error_channel(lib):
     rc = lib.straps_linear_fwd(None, 0, None, 0, None, None, None, 0, 0, 0, 0, 0, None)
     assert rc == 1
     assert lib.straps_stem_weight_floats(18) == ((18 * 49 + 7) // 8) * 512
-    assert lib.straps_smpl_workspace_bytes(64, 0) == 64 * (224 + 288 + 54 * 135) * 4
-    assert lib.straps_smpl_workspace_bytes(4096, 0) == 4096 * (224 + 288 + 8 * 135) * 4
+    ms = hipabi.SmplModelStruct()
+    ms.n_tiles = 224
+    assert lib.straps_smpl_workspace_bytes(C.byref(ms), 64) == 64 * (224 + 288 + 8 * 96) * 4
+    assert lib.straps_abi_version() == 2

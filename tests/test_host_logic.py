@@ -85,7 +85,7 @@ def test_ief_initial_estimate():
 def test_smpl_model_packing_roundtrip():
     model = straps_amd.synthetic_smpl_model(0)
     pk = straps_amd.pack_smpl_model(model)
-    frag = pk['blend_frag'].reshape(216, 3, 28, 2, 32, 4)
+    frag = pk['blend_frag'].reshape(pk['n_tiles'], 3, 28, 2, 32, 4)
     # spot-check the fragment mapping D[8g+4h+e][32t+i][c]
     for (t, c, g, h, i, e) in [(0, 0, 0, 0, 0, 0), (5, 1, 3, 1, 7, 2), (215, 2, 27, 0, 9, 1), (100, 0, 1, 1, 31, 3)]:
         k, v = 8 * g + 4 * h + e, 32 * t + i
@@ -102,17 +102,25 @@ def test_smpl_model_packing_roundtrip():
     W = np.zeros((6890, 24), np.float32)
     np.add.at(W, (np.repeat(np.arange(6890), 4), pk['skin_j'][:6890].reshape(-1)), pk['skin_w'][:6890].reshape(-1))
     np.testing.assert_array_equal(W, model['weights'])
-    # regressor entries reproduce the dense matrices
-    R = np.zeros((45, 6890), np.float32)
-    for q in range(216):
-        rnd = q // 4
-        for e in range(pk['jr_ptr'][q], pk['jr_ptr'][q + 1]):
-            code = int(pk['jr_code'][e])
-            j, vl, tw = code & 255, (code >> 8) & 255, code >> 16
-            assert j % 4 == q % 4
-            R[j, (rnd * 4 + tw) * 32 + vl] = pk['jr_w'][e]
-    want = np.concatenate([model['J_regressor_extra'], model['J_regressor_cocoplus'], model['J_regressor_h36m']])
-    np.testing.assert_array_equal(R, want)
+    # virtual vertices: skinned with the packed tables they reproduce J_regressor_* @ LBS(vertices) for random
+    # blend features F and random bone transforms A (fp64 emulation of the kernel's arithmetic)
+    nt = pk['n_tiles']
+    assert nt % 8 == 0 and nt >= 216 and pk['vj_ptr'].shape == (46,)
+    nvirt = int(pk['vj_ptr'][-1])
+    assert 0 < nvirt <= (nt - 216) * 32
+    rs = np.random.RandomState(3)
+    F = np.zeros(224)
+    F[0] = 1.0
+    F[1:218] = rs.randn(217) * 0.3
+    A = rs.randn(24, 3, 4)
+    Dk = pk['blend_frag'].reshape(nt, 3, 28, 2, 32, 4).transpose(2, 3, 5, 0, 4, 1).reshape(224, nt * 32, 3).astype(np.float64)
+    vp = np.einsum('k,kvc->vc', F, Dk)                                                   # [nt*32][3]
+    T = np.einsum('vk,vkrc->vrc', pk['skin_w'].astype(np.float64), A[pk['skin_j']])       # [nt*32][3][4]
+    out = np.einsum('vrc,vc->vr', T[:, :, :3], vp) + T[:, :, 3]
+    want = np.concatenate([model['J_regressor_extra'], model['J_regressor_cocoplus'], model['J_regressor_h36m']]).astype(np.float64) @ out[:6890]
+    got = np.stack([out[6912 + pk['vj_ptr'][j]:6912 + pk['vj_ptr'][j + 1]].sum(0) for j in range(45)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * np.abs(want).max())
+    assert np.all(out[6912 + nvirt:] == 0)                                                 # zero padding skins to zero
 
 
 def test_checkpoint_roundtrip_reference_schema(tmp_path):
