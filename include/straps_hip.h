@@ -217,7 +217,7 @@ int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw,
 /* training-mode BatchNorm backward with the ReLU mask fused: dz = dy * (yact > 0) (yact NULL = no
  * ReLU), dgamma/dbeta, draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (optional,
  * may alias dy) receives dz for the skip connection.                                             */
-int straps_bn_bwd_blocks(long long rows);
+int straps_bn_bwd_blocks(long long rows, int c);
 size_t straps_bn_bwd_workspace_bytes(long long rows, int c);
 int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean,
                   const float* save_invstd, const float* gamma, float* dgamma, float* dbeta,

@@ -376,93 +376,82 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
 // =====================================================================================================
 // BatchNorm (training) backward with fused ReLU mask
 // =====================================================================================================
-// pass 1: per-block partial sums of dz and dz*xhat, dz = dy * (y > 0 if masked)
+// pass 1: per-block partial sums of dz and dz*xhat, dz = dy * (y > 0 if masked).  Block (bx, by) owns rows
+// [bx*rows_per_block, ...) x the 64 channels [64*by, 64*by+64): 16 float4 column lanes x 16 row lanes, so a deep layer
+// (few rows, many channels) still fills the chip, and every wave load is 4 full 256-byte row segments.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part, long long rows,
                                                             int C, int rows_per_block) {
     __shared__ float red[256][8];
-    const int C4 = C >> 2;
-    const int TC = C4 < 256 ? C4 : 256;       // column groups handled per block pass
-    const int TR = 256 / TC;
-    const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
+    constexpr int TR = 16;
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c4 = blockIdx.y * 16 + tc;
+    const bool active = c4 * 4 < C;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (int cb = 0; cb < C4; cb += TC) {
-        const int c4 = cb + tc;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-        if (tr < TR) {
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
-            const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-            // 4 rows per trip: 12 independent float4 loads in flight per lane before the first use
-            long long r = r0 + tr;
-            for (; r + 3 * TR < r1; r += 4 * TR) {
-                f32x4 g[4], ya[4], xr[4];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (active) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        // 4 rows per trip: 12 independent float4 loads in flight per lane before the first use
+        long long r = r0 + tr;
+        for (; r + 3 * TR < r1; r += 4 * TR) {
+            f32x4 g[4], ya[4], xr[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long long o = (r + (long long)u * TR) * C + c4 * 4;
-                    g[u] = *reinterpret_cast<const f32x4*>(dy + o);
-                    xr[u] = *reinterpret_cast<const f32x4*>(raw + o);
-                    if (yact) ya[u] = *reinterpret_cast<const f32x4*>(yact + o);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (yact) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g[u][e] = ya[u][e] > 0.f ? g[u][e] : 0.f;
-                    }
-                    s1 += g[u];
-                    s2 += g[u] * ((xr[u] - mu) * is);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const long long o = (r + (long long)u * TR) * C + c4 * 4;
+                g[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                xr[u] = *reinterpret_cast<const f32x4*>(raw + o);
+                if (yact) ya[u] = *reinterpret_cast<const f32x4*>(yact + o);
             }
-            for (; r < r1; r += TR) {
-                const long long o = r * C + c4 * 4;
-                f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 if (yact) {
-                    const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) g[u][e] = ya[u][e] > 0.f ? g[u][e] : 0.f;
                 }
-                const f32x4 xh = (*reinterpret_cast<const f32x4*>(raw + o) - mu) * is;
-                s1 += g;
-                s2 += g * xh;
+                s1 += g[u];
+                s2 += g[u] * ((xr[u] - mu) * is);
             }
         }
-        __syncthreads();
+        for (; r < r1; r += TR) {
+            const long long o = r * C + c4 * 4;
+            f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            if (yact) {
+                const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + o);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][4 + e] = s2[e]; }
-        __syncthreads();
-        if (tr == 0) {
-            float t[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = red[tc][e];
-            for (int q = 1; q < TR; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] += red[q * TC + tc][e];
-            float* o = part + ((long long)blockIdx.x * C + c4 * 4) * 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e * 2 + 0] = t[e]; o[e * 2 + 1] = t[4 + e]; }
+                for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
+            }
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(raw + o) - mu) * is;
+            s1 += g;
+            s2 += g * xh;
         }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][4 + e] = s2[e]; }
+    __syncthreads();
+    if (tr == 0 && active) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = red[tc][e];
+        for (int q = 1; q < TR; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += red[q * 16 + tc][e];
+        float* o = part + ((long long)blockIdx.x * C + c4 * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e * 2 + 0] = t[e]; o[e * 2 + 1] = t[4 + e]; }
     }
 }
 
 // per channel: dbeta = S1, dgamma = S2; coefficients for the apply pass: k1 = gamma*invstd, m1 = S1/N, m2 = S2/N
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ coef, int accumulate) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = lane; k < nblocks; k += 64) {
-        s1 += (double)part[((long long)k * C + c) * 2 + 0];
-        s2 += (double)part[((long long)k * C + c) * 2 + 1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-    }
-    if (lane == 0) {
+    int c;
+    double s1, s2;
+    if (bn_partials_sum4(part, nblocks, C, s1, s2, c)) {
         dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
         dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
         coef[c] = gamma[c] * invstd[c];
@@ -862,9 +851,12 @@ extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, floa
     return STRAPS_OK;
 }
 
-extern "C" int straps_bn_bwd_blocks(long long rows) {
-    long long b = (rows + 255) / 256;
-    if (b > 1024) b = 1024;
+// row blocks of the reduction pass: ~2048 blocks in total over (row blocks x 64-channel column blocks), >= 64 rows each
+extern "C" int straps_bn_bwd_blocks(long long rows, int c) {
+    const int colblocks = (c + 63) / 64;
+    long long b = 2048 / colblocks;
+    const long long cap = (rows + 63) / 64;
+    if (b > cap) b = cap;
     return (int)(b < 1 ? 1 : b);
 }
 
@@ -876,13 +868,13 @@ extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* ra
     const int C4 = c >> 2;
     STRAPS_REQUIRE(C4 <= 256 ? (256 % C4 == 0) : (C4 % 256 == 0), "straps_bn_bwd: channel count %d not supported", c);
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = straps_bn_bwd_blocks(rows);
+    const int nblk = straps_bn_bwd_blocks(rows, c);
     const int rpb = (int)((rows + nblk - 1) / nblk);
     float* part = (float*)workspace;                 // [nblk][c][2]
     float* coef = part + (size_t)nblk * c * 2;       // [3][c]
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, part, rows, c, rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, part, rows, c, rpb);
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(64), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coef, draw, dz_out, n4, c);
@@ -891,7 +883,7 @@ extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* ra
 }
 
 extern "C" size_t straps_bn_bwd_workspace_bytes(long long rows, int c) {
-    return ((size_t)straps_bn_bwd_blocks(rows) * c * 2 + 3 * (size_t)c) * sizeof(float);
+    return ((size_t)straps_bn_bwd_blocks(rows, c) * c * 2 + 3 * (size_t)c) * sizeof(float);
 }
 
 extern "C" int straps_maxpool_fwd_idx(const float* x, float* y, uint8_t* idx, int batch, int h, int w, int c, void* stream) {

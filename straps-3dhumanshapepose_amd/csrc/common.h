@@ -45,4 +45,29 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// BatchNorm finalize helper: fixed-order fp64 sum of the per-block (s1, s2) partials part[k][C][2], k < nblocks, for 4
+// consecutive channels per 256-thread block (grid = ceil(C/4)).  Lane group pl = tid>>2 walks k = pl, pl+64, ... with
+// 32-byte coalesced segments; the 64 group sums are then added in order by the pl == 0 threads, which get `true`.
+__device__ __forceinline__ bool bn_partials_sum4(const float* __restrict__ part, int nblocks, int C, double& s1, double& s2, int& c) {
+    __shared__ double red[256][2];
+    const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    c = blockIdx.x * 4 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = pl; k < nblocks; k += 64) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(part + ((long long)k * C + c) * 2);
+            a1 += (double)v[0];
+            a2 += (double)v[1];
+        }
+    }
+    red[threadIdx.x][0] = a1;
+    red[threadIdx.x][1] = a2;
+    __syncthreads();
+    if (pl != 0 || c >= C) return false;
+    s1 = 0.0; s2 = 0.0;
+    for (int q = 0; q < 64; ++q) { s1 += red[q * 4 + cl][0]; s2 += red[q * 4 + cl][1]; }
+    return true;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

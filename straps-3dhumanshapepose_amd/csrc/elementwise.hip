@@ -80,23 +80,14 @@ __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, f
 }
 
 // one wave per channel: fixed-order fp64 sum of the per-block (sum, sumsq) partials
-__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
                                                                float* __restrict__ scale, float* __restrict__ shift,
                                                                float* __restrict__ smean, float* __restrict__ sinv) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = lane; k < nblocks; k += 64) {
-        s1 += (double)part[((long long)k * C + c) * 2 + 0];
-        s2 += (double)part[((long long)k * C + c) * 2 + 1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-    }
-    if (lane == 0) {
+    int c;
+    double s1, s2;
+    if (bn_partials_sum4(part, nblocks, C, s1, s2, c)) {
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -182,7 +173,7 @@ extern "C" int straps_bn_stats_finalize(const float* stats_partial, int nblocks,
                                         float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
     STRAPS_REQUIRE(stats_partial && gamma && beta && scale && shift && nblocks > 0 && c > 0 && count > 0, "straps_bn_stats_finalize: bad arguments");
     STRAPS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "straps_bn_stats_finalize: running stats must be given together");
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, stats_partial, nblocks, c, (double)count, gamma, beta,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats_partial, nblocks, c, (double)count, gamma, beta,
                        eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
     STRAPS_CHECK_LAUNCH("bn_stats_finalize_kernel");
     return STRAPS_OK;

@@ -81,7 +81,7 @@ SIGNATURES = {
     'straps_conv_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_stem_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     'straps_stem_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    'straps_bn_bwd_blocks': (_I, [_L]),
+    'straps_bn_bwd_blocks': (_I, [_L, _I]),
     'straps_bn_bwd_workspace_bytes': (_Z, [_L, _I]),
     'straps_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'straps_maxpool_fwd_idx': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
