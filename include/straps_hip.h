@@ -288,9 +288,17 @@ int straps_augment_seg(const float* seg, const float* uniforms, const float* rem
  * rotation, translation cam_t [B,3] and intrinsics fx,fy,cx,cy (utils/cam_utils.py:40-71).         */
 int straps_project_targets(const float* joints, const float* cam_t, float fx, float fy, float cx,
                            float cy, float* joints2d, float* joints3d, long long batch, void* stream);
-/* STAND-IN for the part-segmentation rasteriser (renderers/nmr_renderer.py; SURVEY 8f row f1, not built):
- * labels discs around the 17 projected COCO joints (+ a torso box) with the 6 LSP part ids.          */
-int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream);
+/* renderers/nmr_renderer.py:84-100 (NMRRenderer.forward, rend_parts_seg=True; train loop :155): body-part id per pixel.
+ * neural_renderer's 'projection' camera (x_cam = R v + t, pin-hole K, NDC, flipped v axis), pixel-centre sampling,
+ * two-sided faces, nearest depth in (near, far), lower face id on ties, final vertical flip; the texture + cube_parts
+ * decode of get_parts is the per-face table face_parts (0..255).  verts [B][nverts][3], faces [nfaces][3],
+ * cam_K / cam_R [3][3] shared (cam_per_body = 0) or [B][3][3], cam_t [B][3].  parts [B][wh][wh] float part ids
+ * (0 = background) and/or depth [B][wh][wh] (`far` where empty); either may be NULL.  Deterministic.             */
+size_t straps_rasterize_workspace_bytes(long long batch, int nverts, int wh);
+int straps_rasterize_parts(const float* verts, const int32_t* faces, const uint8_t* face_parts,
+                           const float* cam_K, const float* cam_R, const float* cam_t, float* parts,
+                           float* depth, void* workspace, long long batch, int nverts, int nfaces, int wh,
+                           int cam_per_body, float near, float far, void* stream);
 /* On-device bounding-box crop + nearest-neighbour resize (utils/image_utils.py:44-105,
  * train loop :161-170): per sample, box of the non-zero pixels of seg [B,wh,wh] -> centre / max(h,w) * scale
  * (scale = orig_scale_factor + U(delta_scale), centre += U(delta_centre); uniforms [B][3] in [0,1), NULL = no

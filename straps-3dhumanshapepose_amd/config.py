@@ -4,6 +4,9 @@ SMPL_MEAN_PARAMS_PATH = 'additional/neutral_smpl_mean_params_6dpose.npz'
 J_REGRESSOR_EXTRA_PATH = 'additional/J_regressor_extra.npy'
 COCOPLUS_REGRESSOR_PATH = 'additional/cocoplus_regressor.npy'
 H36M_REGRESSOR_PATH = 'additional/J_regressor_h36m.npy'
+SMPL_FACES_PATH = 'additional/smpl_faces.npy'
+VERTEX_TEXTURE_PATH = 'additional/vertex_texture.npy'
+CUBE_PARTS_PATH = 'additional/cube_parts.npy'
 
 FOCAL_LENGTH = 5000.
 REGRESSOR_IMG_WH = 256

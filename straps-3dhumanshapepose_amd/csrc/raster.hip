@@ -1,0 +1,157 @@
+// raster.hip -- body-part segmentation rasteriser: replaces NMRRenderer.forward with
+// rend_parts_seg=True (renderers/nmr_renderer.py:84-100), i.e. the third-party `neural_renderer` z-buffer pass
+// + the get_parts look-up, for the on-the-fly training loop (train loop :155).
+//
+// HBM-bound integer/byte work, no MFMA.  Three launches per call:
+//   1. project kernel  : one thread per (body, vertex): camera transform + pin-hole projection to NDC, exactly
+//                        neural_renderer's `projection` camera mode.
+//   2. face kernel     : 16 lanes per (body, face) share the pixel-centre samples inside the face's bounding box (SMPL
+//                        faces cover a few pixels, so that is 1-2 trips; a stretched face no longer serialises a wave),
+//                        two-sided inside test, perspective-correct depth, 64-bit atomicMin of (depth bits << 32 | face id)
+//                        into the per-body z-buffer.  min over (depth, id) pairs is order-independent -> deterministic,
+//                        ties go to the lower face id like the sequential reference loop.
+//   3. resolve kernel  : z-buffer -> part id per pixel through the per-face part table (the reference decodes a
+//                        rendered texture through cube_parts; with one part per face that is this table), rows flipped
+//                        like the renderer's final image flip.
+// Every arithmetic step is written unfused (fp contract off) in the order oracle/straps_oracle.py::rasterize_parts
+// uses, so the part maps agree bit for bit.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__global__ __launch_bounds__(256) void raster_project_kernel(const float* __restrict__ verts, const float* __restrict__ K,
+                                                             const float* __restrict__ R, const float* __restrict__ t,
+                                                             float* __restrict__ ndc, long long n, int nverts, int cam_per_body,
+                                                             float orig) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long b = i / nverts;
+    const float* Kb = K + (cam_per_body ? b * 9 : 0);
+    const float* Rb = R + (cam_per_body ? b * 9 : 0);
+    const float* tb = t + b * 3;
+    const float x = verts[i * 3 + 0], y = verts[i * 3 + 1], z = verts[i * 3 + 2];
+    const float xc = ((Rb[0] * x + Rb[1] * y) + Rb[2] * z) + tb[0];
+    const float yc = ((Rb[3] * x + Rb[4] * y) + Rb[5] * z) + tb[1];
+    const float zc = ((Rb[6] * x + Rb[7] * y) + Rb[8] * z) + tb[2];
+    const float den = zc + 1e-9f;
+    const float xn = xc / den, yn = yc / den;
+    const float u = (Kb[0] * xn + Kb[1] * yn) + Kb[2];
+    float v = (Kb[3] * xn + Kb[4] * yn) + Kb[5];
+    v = orig - v;
+    const float half = orig / 2.f;
+    ndc[i * 3 + 0] = 2.f * (u - half) / orig;
+    ndc[i * 3 + 1] = 2.f * (v - half) / orig;
+    ndc[i * 3 + 2] = zc;
+}
+
+__device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
+    return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+__global__ __launch_bounds__(256) void raster_face_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
+                                                          unsigned long long* __restrict__ zbuf, long long n, int nverts,
+                                                          int nfaces, int wh, float near, float far) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = gid >> 4;                  // (body, face)
+    const int sub = (int)(gid & 15);               // lane within the face's 16-lane group
+    if (i >= n) return;
+    const long long b = i / nfaces;
+    const int f = (int)(i - b * nfaces);
+    const int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+    if ((unsigned)i0 >= (unsigned)nverts || (unsigned)i1 >= (unsigned)nverts || (unsigned)i2 >= (unsigned)nverts) return;
+    const float* p0 = ndc + (b * nverts + i0) * 3;
+    const float* p1 = ndc + (b * nverts + i1) * 3;
+    const float* p2 = ndc + (b * nverts + i2) * 3;
+    const float x0 = p0[0], y0 = p0[1], z0 = p0[2];
+    const float x1 = p1[0], y1 = p1[1], z1 = p1[2];
+    const float x2 = p2[0], y2 = p2[1], z2 = p2[2];
+    const float area = edge_fn(x0, y0, x1, y1, x2, y2);
+    if (!(fabsf(area) > 1e-12f)) return;                       // degenerate (or NaN) face
+    // pixel-centre sample k sits at (2k + 1 - wh) / wh; conservative bounding box of sample indices
+    const float fw = (float)wh;
+    const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
+    const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+    if (!(xmax >= -1.f && xmin <= 1.f && ymax >= -1.f && ymin <= 1.f)) return;
+    int xa = (int)floorf((fmaxf(xmin, -1.f) * fw + fw - 1.f) * 0.5f), xb = (int)ceilf((fminf(xmax, 1.f) * fw + fw - 1.f) * 0.5f);
+    int ya = (int)floorf((fmaxf(ymin, -1.f) * fw + fw - 1.f) * 0.5f), yb = (int)ceilf((fminf(ymax, 1.f) * fw + fw - 1.f) * 0.5f);
+    xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
+    xb = xb > wh - 1 ? wh - 1 : xb; yb = yb > wh - 1 ? wh - 1 : yb;
+    if (xb < xa || yb < ya) return;
+    unsigned long long* zb = zbuf + b * (long long)wh * wh;
+    const int bw = xb - xa + 1;
+    // the group's 16 lanes take the box samples round-robin in row-major order
+    int xi = xa + sub, yi = ya;
+    while (xi > xb) { xi -= bw; ++yi; }
+    for (; yi <= yb;) {
+        {
+            const float yp = (float)(2 * yi + 1 - wh) / fw;
+            const float xp = (float)(2 * xi + 1 - wh) / fw;
+            const float e0 = edge_fn(x1, y1, x2, y2, xp, yp);     // weight of vertex 0
+            const float e1 = edge_fn(x2, y2, x0, y0, xp, yp);
+            const float e2 = edge_fn(x0, y0, x1, y1, xp, yp);
+            const bool in = (e0 >= 0.f && e1 >= 0.f && e2 >= 0.f) || (e0 <= 0.f && e1 <= 0.f && e2 <= 0.f);
+            if (in) {
+            float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+            w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
+            const float ws = (w0 + w1) + w2;
+            w0 = w0 / ws; w1 = w1 / ws; w2 = w2 / ws;
+            const float zp = 1.f / ((w0 / z0 + w1 / z1) + w2 / z2);
+            if (zp > near && zp < far) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)f;
+                atomicMin(zb + (long long)yi * wh + xi, key);
+            }
+            }
+        }
+        xi += 16;
+        while (xi > xb) { xi -= bw; ++yi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const unsigned long long* __restrict__ zbuf,
+                                                             const uint8_t* __restrict__ face_parts, float* __restrict__ parts,
+                                                             float* __restrict__ depth, long long n, int wh, float far) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long b = i / ((long long)wh * wh);
+    const int rem = (int)(i - b * (long long)wh * wh);
+    const int row = rem / wh, col = rem - row * wh;
+    const unsigned long long key = zbuf[b * (long long)wh * wh + (long long)(wh - 1 - row) * wh + col];   // final vertical flip
+    const bool hit = key != ~0ULL;
+    if (parts) parts[i] = hit ? (float)face_parts[(unsigned)(key & 0xffffffffULL)] : 0.f;
+    if (depth) depth[i] = hit ? __uint_as_float((unsigned)(key >> 32)) : far;
+}
+
+}  // namespace
+
+extern "C" size_t straps_rasterize_workspace_bytes(long long batch, int nverts, int wh) {
+    if (batch <= 0 || nverts <= 0 || wh <= 0) return 0;
+    return (size_t)batch * ((size_t)wh * wh * sizeof(unsigned long long) + (size_t)nverts * 3 * sizeof(float));
+}
+
+extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, const uint8_t* face_parts, const float* cam_K,
+                                      const float* cam_R, const float* cam_t, float* parts, float* depth, void* workspace,
+                                      long long batch, int nverts, int nfaces, int wh, int cam_per_body, float near, float far,
+                                      void* stream) {
+    STRAPS_REQUIRE(verts && faces && face_parts && cam_K && cam_R && cam_t && workspace, "straps_rasterize_parts: null pointer");
+    STRAPS_REQUIRE(parts || depth, "straps_rasterize_parts: neither parts nor depth requested");
+    STRAPS_REQUIRE(batch > 0 && nverts > 0 && nfaces > 0 && wh > 0 && wh <= 4096, "straps_rasterize_parts: bad sizes (batch %lld, %d verts, %d faces, wh %d)",
+                   batch, nverts, nfaces, wh);
+    STRAPS_REQUIRE(far > near && near >= 0.f, "straps_rasterize_parts: need 0 <= near < far");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* zbuf = (unsigned long long*)workspace;
+    float* ndc = (float*)(zbuf + batch * (long long)wh * wh);
+    hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)batch * wh * wh * sizeof(unsigned long long), st);
+    if (e != hipSuccess) { straps_set_error("straps_rasterize_parts: z-buffer clear failed: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+    const long long nv = batch * nverts, nf = batch * nfaces, np = batch * (long long)wh * wh;
+    STRAPS_REQUIRE((nv + 255) / 256 < (1LL << 31) && (nf * 16 + 255) / 256 < (1LL << 31) && (np + 255) / 256 < (1LL << 31), "straps_rasterize_parts: batch too large for one launch");
+    hipLaunchKernelGGL(raster_project_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam_K, cam_R, cam_t, ndc, nv, nverts,
+                       cam_per_body, (float)wh);
+    STRAPS_CHECK_LAUNCH("raster_project_kernel");
+    hipLaunchKernelGGL(raster_face_kernel, dim3((unsigned)((nf * 16 + 255) / 256)), dim3(256), 0, st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far);
+    STRAPS_CHECK_LAUNCH("raster_face_kernel");
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, zbuf, face_parts, parts, depth, np, wh, far);
+    STRAPS_CHECK_LAUNCH("raster_resolve_kernel");
+    return STRAPS_OK;
+}

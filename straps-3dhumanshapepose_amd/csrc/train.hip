@@ -370,34 +370,6 @@ extern "C" int straps_mse_bwd(const float* pred, const float* tgt, const uint8_t
 }
 
 namespace {
-// STAND-IN for the part-segmentation rasteriser (renderers/nmr_renderer.py, SURVEY 8f row f1, out of scope this round):
-// capsules around the projected 2D joints labelled with the 6 LSP part ids, enough to give the encoder a
-// silhouette-shaped, joint-consistent input of the right statistics.  NOT a renderer.
-__constant__ int c_joint_part[17] = {6, 6, 6, 6, 6, 1, 2, 1, 2, 1, 2, 3, 3, 4, 5, 4, 5};
-__global__ __launch_bounds__(256) void synth_seg_kernel(const float* __restrict__ j2d, float* __restrict__ seg, int B, int WH, float radius) {
-    const long long n = (long long)B * WH * WH;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % WH);
-        const int y = (int)((i / WH) % WH);
-        const int b = (int)(i / ((long long)WH * WH));
-        const float* J = j2d + (long long)b * 34;
-        float best = radius * radius;
-        int part = 0;
-        for (int k = 0; k < 17; ++k) {
-            const float dx = x - J[k * 2], dy = y - J[k * 2 + 1];
-            const float d = dx * dx + dy * dy;
-            if (d < best) { best = d; part = c_joint_part[k]; }
-        }
-        // torso: between shoulders (5,6) and hips (11,12)
-        const float tx0 = fminf(fminf(J[10], J[12]), fminf(J[22], J[24])), tx1 = fmaxf(fmaxf(J[10], J[12]), fmaxf(J[22], J[24]));
-        const float ty0 = fminf(fminf(J[11], J[13]), fminf(J[23], J[25])), ty1 = fmaxf(fmaxf(J[11], J[13]), fmaxf(J[23], J[25]));
-        if (part == 0 && x >= tx0 && x <= tx1 && y >= ty0 && y <= ty1) part = 3;
-        seg[i] = (float)part;
-    }
-}
-}  // namespace
-
-namespace {
 // target-side heads (train loop :138-143): H36M-LSP 3D joints and the perspective projection of the COCO joints
 __global__ __launch_bounds__(256) void project_targets_kernel(const float* __restrict__ joints, const float* __restrict__ cam_t, float fx,
                                                               float fy, float cx, float cy, float* __restrict__ j2d,
@@ -426,14 +398,6 @@ extern "C" int straps_project_targets(const float* joints, const float* cam_t, f
     hipLaunchKernelGGL(project_targets_kernel, dim3((unsigned)((batch * 31 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, joints, cam_t, fx,
                        fy, cx, cy, joints2d, joints3d, batch);
     STRAPS_CHECK_LAUNCH("project_targets_kernel");
-    return STRAPS_OK;
-}
-
-extern "C" int straps_synth_seg(const float* joints2d, float* seg, int batch, int wh, float radius, void* stream) {
-    STRAPS_REQUIRE(joints2d && seg && batch > 0 && wh > 0, "straps_synth_seg: bad arguments");
-    const long long n = (long long)batch * wh * wh;
-    hipLaunchKernelGGL(synth_seg_kernel, dim3(capped_grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, joints2d, seg, batch, wh, radius);
-    STRAPS_CHECK_LAUNCH("synth_seg_kernel");
     return STRAPS_OK;
 }
 

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
 SOURCES = ['abi.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'stem.hip', 'smpl.hip',
-           'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip']
+           'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip', 'raster.hip']
 
 _lib = None
 
@@ -98,7 +98,8 @@ SIGNATURES = {
     'straps_mse_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
     'straps_mse_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
     'straps_augment_seg': (_I, [_P, _P, _P, _F, _I, _P, _I, _I, _P]),
-    'straps_synth_seg': (_I, [_P, _P, _I, _I, _F, _P]),
+    'straps_rasterize_workspace_bytes': (_Z, [_L, _I, _I]),
+    'straps_rasterize_parts': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P]),
     'straps_project_targets': (_I, [_P, _P, _F, _F, _F, _F, _P, _P, _L, _P]),
     'straps_point_metrics': (_I, [_P, _P, _P, _L, _I, _P]),
     'straps_crop_resize': (_I, [_P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),

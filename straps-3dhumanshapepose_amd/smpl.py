@@ -141,6 +141,9 @@ class SMPL(nn.Module):
         super().__init__()
         model = model_path if isinstance(model_path, dict) else load_smpl_model(model_path, gender, extra_regressor_paths)
         self.batch_size = batch_size
+        # mesh topology like smplx's `.faces` (numpy); face_parts is this package's per-face body-part table (nmr_renderer.py)
+        self.faces = None if model.get('faces') is None else np.asarray(model['faces'])
+        self.face_parts = None if model.get('face_parts') is None else np.asarray(model['face_parts'])
         packed = pack_smpl_model(model)
         self.max_depth, self.skin_k, self.n_tiles = packed.pop('max_depth'), packed.pop('skin_k'), packed.pop('n_tiles')
         for name, arr in packed.items():

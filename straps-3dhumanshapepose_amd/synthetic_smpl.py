@@ -7,6 +7,7 @@ same tensor shapes, sparsity pattern and magnitudes:
   v_template[6890,3]  shapedirs[6890,3,10]  posedirs[207,20670]  J_regressor[24,6890] (sparse rows)
   weights[6890,24] (<=4 non-zeros per vertex, rows sum to 1)  parents[24]  extra_vertex_ids[21]
   J_regressor_extra[9,6890]  J_regressor_cocoplus[19,6890]  J_regressor_h36m[17,6890]
+  faces[13776,3] (stand-in for additional/smpl_faces.npy)  face_parts[13776] (1..6, stand-in for the part texture)
 
 `load_smpl_model` reads the real files when a user has them (same dict out), so the SMPL module
 is a drop-in for reference `models/smpl_official.py:15-25`.
@@ -20,6 +21,11 @@ NUM_VERTS = 6890
 NUM_JOINTS = 24
 NUM_BETAS = 10
 NUM_POSE_FEATS = 207
+NUM_FACES = 13776
+
+# 6-part convention of renderers/nmr_renderer.py:12-20 (0 background, 1 left arm, 2 right arm, 3 head, 4 left leg,
+# 5 right leg, 6 torso) assigned through each vertex's dominant SMPL joint
+JOINT_TO_PART = np.array([6, 4, 5, 6, 4, 5, 6, 4, 5, 6, 4, 5, 3, 6, 6, 3, 1, 2, 1, 2, 1, 2, 1, 2], dtype=np.uint8)
 
 # kinematic tree of the SMPL body model (published with the model)
 SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
@@ -62,7 +68,17 @@ def _sparse_rows(centres, verts, nnz, seed):
     return out
 
 
+_MODEL_CACHE = {}
+
+
 def synthetic_smpl_model(seed=0):
+    """cached front end of _build_synthetic_smpl_model (fresh array copies per call)."""
+    if seed not in _MODEL_CACHE:
+        _MODEL_CACHE[seed] = _build_synthetic_smpl_model(seed)
+    return {k: v.copy() for k, v in _MODEL_CACHE[seed].items()}
+
+
+def _build_synthetic_smpl_model(seed=0):
     """Seeded SMPL-shaped model (float32 arrays).  Magnitudes follow the real model: template spans
     a ~1.7 m body-sized box, shapedirs ~1e-2 m/unit beta, posedirs ~1e-3 m/unit pose feature."""
     s = 1000 * seed
@@ -81,7 +97,23 @@ def synthetic_smpl_model(seed=0):
     w4 /= w4.sum(axis=1, keepdims=True)
     weights = np.zeros((NUM_VERTS, NUM_JOINTS))
     np.put_along_axis(weights, near, w4, axis=1)
+    # triangles over the point cloud: each vertex with its nearest neighbours (SMPL-sized faces of a few cm), and one
+    # part label per face from its first vertex's dominant joint
+    faces = np.zeros((NUM_FACES, 3), np.int32)
+    for lo in range(0, NUM_VERTS, 1024):
+        blk = verts[lo:lo + 1024]
+        dd = sum((blk[:, c:c + 1] - verts[None, :, c]) ** 2 for c in range(3))         # squared distances
+        cand = np.argpartition(dd, 4, axis=1)[:, :4]                                   # self + 3 nearest, unordered
+        cd = np.take_along_axis(dd, cand, axis=1)
+        nn = np.take_along_axis(cand, np.lexsort((cand, cd), axis=1), axis=1)[:, 1:4]  # by distance, then index
+        idx = np.arange(lo, min(lo + 1024, NUM_VERTS))
+        for k in range(2):
+            rows = 2 * idx + k
+            ok = rows < NUM_FACES
+            faces[rows[ok]] = np.stack([idx[ok], nn[ok, k], nn[ok, k + 1]], axis=1)
+    face_parts = JOINT_TO_PART[np.argmax(weights, axis=1)][faces[:, 0]]
     model = {
+        'faces': faces, 'face_parts': face_parts,
         'v_template': verts,
         'shapedirs': _u((NUM_VERTS, 3, NUM_BETAS), s + 4) * 1e-2,
         'posedirs': _u((NUM_POSE_FEATS, NUM_VERTS * 3), s + 5) * 1e-3,
@@ -144,4 +176,8 @@ def load_smpl_model(model_path, gender='neutral', extra_regressor_paths=None):
     for key, path in zip(('J_regressor_extra', 'J_regressor_cocoplus', 'J_regressor_h36m'),
                          extra_regressor_paths):
         model[key] = np.asarray(raw[key] if key in raw else np.load(path), dtype=np.float32)
+    if 'f' in raw or 'faces' in raw:                          # mesh topology (smplx exposes it as .faces)
+        model['faces'] = np.asarray(raw['faces'] if 'faces' in raw else raw['f']).astype(np.int32)
+    if 'face_parts' in raw:
+        model['face_parts'] = np.asarray(raw['face_parts']).astype(np.uint8)
     return model

@@ -56,7 +56,8 @@ def allreduce_gradients(flat_g, world_size, group=None):
 
 class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
-                 mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=True):
+                 mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=True,
+                 renderer=None):
         """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
         launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches."""
         p0 = next(regressor.parameters())
@@ -85,6 +86,14 @@ class TrainStep:
                       [0., 0., 1.]], dtype=np.float32)
         self.cam_K = torch.from_numpy(K).to(d)
         self.remove_prob = torch.tensor(REMOVE_PROBS, device=d)
+        # part-segmentation renderer of the target meshes (run_train.py:119-124: NMRRenderer(batch, cam_K, cam_R = I, 256, parts))
+        if renderer is None:
+            if smpl.faces is None or smpl.face_parts is None:
+                raise RuntimeError('TrainStep: the SMPL model carries no faces / face_parts; pass renderer=NMRRenderer(...)')
+            from .nmr_renderer import NMRRenderer
+            renderer = NMRRenderer(batch_size, self.cam_K.cpu(), torch.eye(3), config.REGRESSOR_IMG_WH, rend_parts_seg=True,
+                                   faces=smpl.faces, face_parts=smpl.face_parts).to(d)
+        self.renderer = renderer
         # stand-in for data/synthetic_training_dataset.py: a resident pool of (pose axis-angle [72]) samples
         if pose_pool is None:
             g = torch.Generator().manual_seed(seed)
@@ -116,9 +125,9 @@ class TrainStep:
         wh = float(config.REGRESSOR_IMG_WH)
         hipabi.check(L.straps_project_targets(hipabi.ptr(tgt_joints), hipabi.ptr(cam_t), config.FOCAL_LENGTH, config.FOCAL_LENGTH, wh / 2, wh / 2,
                                               hipabi.ptr(tgt_j2d), hipabi.ptr(tgt_j3d), B, st), 'straps_project_targets')
-        # stand-in part segmentation, then G3 (+ joints deviation U[-8,8], proxy_rep_augmentation.py:25-49)
-        seg = torch.empty(B, 256, 256, device=d)
-        hipabi.check(L.straps_synth_seg(hipabi.ptr(tgt_j2d), hipabi.ptr(seg), B, 256, 14.0, st), 'straps_synth_seg')
+        # part segmentation of the target mesh (train loop :155, renderers/nmr_renderer.py), then G3 (+ joints deviation
+        # U[-8,8], proxy_rep_augmentation.py:25-49)
+        seg = self.renderer.render_arrays(tgt_verts, cam_t)
         # bounding-box crop with scale / centre jitter + nearest resize back to 256 (train loop :161-170, run_train.py:140-148),
         # on the device; the 2-D joint targets follow the crop like in the reference
         from .image_utils import batch_crop_and_resize

@@ -13,6 +13,7 @@ from straps_amd import hipabi  # noqa: E402
 L = hipabi.load()
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+NET = sys.argv[2] if len(sys.argv) > 2 else 'r18'
 SHAPES = [('l1 3x3 s1', 64, 64, 64, 3, 1), ('l2.0 3x3 s2', 64, 64, 128, 3, 2), ('l2 3x3 s1', 32, 128, 128, 3, 1), ('l2 ds 1x1 s2', 64, 64, 128, 1, 2),
           ('l3.0 3x3 s2', 32, 128, 256, 3, 2), ('l3 3x3 s1', 16, 256, 256, 3, 1), ('l4.0 3x3 s2', 16, 256, 512, 3, 2), ('l4 3x3 s1', 8, 512, 512, 3, 1)]
 
@@ -29,6 +30,14 @@ def timeit(fn, iters=10):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+R50 = [('l1 1x1 64>64', 64, 64, 64, 1, 1), ('l1 1x1 64>256', 64, 64, 256, 1, 1), ('l1 1x1 256>64', 64, 256, 64, 1, 1),
+       ('l2 1x1 256>128', 64, 256, 128, 1, 1), ('l2 1x1 128>512', 32, 128, 512, 1, 1), ('l2 1x1 512>128', 32, 512, 128, 1, 1),
+       ('l2 ds 256>512 s2', 64, 256, 512, 1, 2), ('l3 1x1 512>256', 32, 512, 256, 1, 1), ('l3 1x1 256>1024', 16, 256, 1024, 1, 1),
+       ('l3 1x1 1024>256', 16, 1024, 256, 1, 1), ('l3 ds 512>1024 s2', 32, 512, 1024, 1, 2), ('l4 1x1 1024>512', 16, 1024, 512, 1, 1),
+       ('l4 1x1 512>2048', 8, 512, 2048, 1, 1), ('l4 1x1 2048>512', 8, 2048, 512, 1, 1), ('l4 ds 1024>2048 s2', 16, 1024, 2048, 1, 2),
+       ('l2 3x3 s2 128', 64, 128, 128, 3, 2), ('l3 3x3 s2 256', 32, 256, 256, 3, 2), ('l4 3x3 s2 512', 16, 512, 512, 3, 2)]
+if NET == 'r50':
+    SHAPES = R50
 for name, H, Cin, Cout, k, stride in SHAPES:
     pad = 1 if k == 3 else 0
     Ho = (H + 2 * pad - k) // stride + 1
@@ -40,7 +49,7 @@ for name, H, Cin, Cout, k, stride in SHAPES:
     y = torch.empty(B, Ho, Ho, Cout, device=dev)
     dx = torch.empty_like(x)
     flops = 2.0 * B * Ho * Ho * Cout * Cin * k * k
-    row = '%-14s M=%7d N=%3d K=%4d |' % (name, B * Ho * Ho, Cout, Cin * k * k)
+    row = '%-18s M=%7d N=%3d K=%4d |' % (name, B * Ho * Ho, Cout, Cin * k * k)
     for cfg in (1, 2, 3):
         if cfg == 1 and Cout % 128:
             row += ' fwd%d   n/a ' % cfg
