@@ -90,9 +90,11 @@ def _build_synthetic_smpl_model(seed=0):
     # skinning weights: 4 nearest joints, positive, normalised (<=4-sparse rows)
     d = np.linalg.norm(verts[:, None, :] - jc[None, :, :], axis=2)                # [V,24]
     near = np.argsort(d, axis=1, kind='stable')[:, :4]
-    w4 = np.exp(-8.0 * np.take_along_axis(d, near, axis=1)) + 1e-3
-    # make roughly a third of the vertices rigidly bound to one joint, like the real model
-    rigid = _u((NUM_VERTS,), s + 3, 0, 1) < 0.33
+    dn = np.take_along_axis(d, near, axis=1)
+    w4 = np.exp(-25.0 * (dn - dn[:, :1])) + 1e-3
+    # roughly a third of the vertices -- those much closer to one joint than to any other -- are rigidly bound to
+    # it, like the real model; spatially coherent, so neighbouring vertices move together under a pose
+    rigid = (dn[:, 1] - dn[:, 0]) > np.quantile(dn[:, 1] - dn[:, 0], 0.67)
     w4[rigid, 1:] = 0.0
     w4 /= w4.sum(axis=1, keepdims=True)
     weights = np.zeros((NUM_VERTS, NUM_JOINTS))
@@ -112,10 +114,17 @@ def _build_synthetic_smpl_model(seed=0):
             ok = rows < NUM_FACES
             faces[rows[ok]] = np.stack([idx[ok], nn[ok, k], nn[ok, k + 1]], axis=1)
     face_parts = JOINT_TO_PART[np.argmax(weights, axis=1)][faces[:, 0]]
+    # shape directions: smooth displacement fields over the body (a few low spatial frequencies, ~1e-2 m per unit
+    # beta like the real model) plus 5 % per-vertex detail, so a shaped mesh keeps SMPL-sized faces
+    freq = _u((NUM_BETAS, 3, 4, 3), s + 13) * np.array([6.0, 3.5, 12.0])              # [l][c][m][xyz] rad / m
+    phase = _u((NUM_BETAS, 3, 4), s + 14) * np.pi
+    amp = _u((NUM_BETAS, 3, 4), s + 15) * 0.5e-2
+    arg = np.einsum('lcmk,vk->vclm', freq, verts) + phase.transpose(1, 0, 2)[None]    # [v][c][l][m]
+    shapedirs = (np.cos(arg) * amp.transpose(1, 0, 2)[None]).sum(-1) + _u((NUM_VERTS, 3, NUM_BETAS), s + 4) * 5e-4
     model = {
         'faces': faces, 'face_parts': face_parts,
         'v_template': verts,
-        'shapedirs': _u((NUM_VERTS, 3, NUM_BETAS), s + 4) * 1e-2,
+        'shapedirs': shapedirs,
         'posedirs': _u((NUM_POSE_FEATS, NUM_VERTS * 3), s + 5) * 1e-3,
         'J_regressor': _sparse_rows(jc, verts, 32, s + 6),
         'weights': weights,

@@ -71,7 +71,7 @@ def test_global_rotation_is_rigid_about_root(model):
     want = (v0 - root) @ Rg.T + root
     # pose-corrective offsets depend only on R[1:], so the rotation is exactly rigid
     assert float((v1 - want).abs().max()) < 5e-7
-    assert float((j1 - ((j0 - root) @ Rg.T + root)).abs().max()) < 1e-10
+    assert float((j1 - ((j0 - root) @ Rg.T + root)).abs().max()) < 5e-9       # J_regressor rows sum to 1 only to fp32 rounding
 
 
 def test_pose2rot_equals_rotmat_path(model):
