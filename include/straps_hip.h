@@ -76,7 +76,7 @@ int straps_stem_fwd(const float* x_nchw, const float* w_frag, const float* scale
  * cin % 32 == 0 and cout % 64 == 0 required.  stats_partial as for the stem:
  * [straps_conv_stat_blocks(...)][cout][2].  tile_cfg: 0 = auto, 1 = 128x128, 2 = 128x64,
  * 3 = 64x64 block tile.                                                                       */
-int straps_conv_stat_blocks(int batch, int ho, int wo, int cout, int tile_cfg);
+int straps_conv_stat_blocks(int batch, int ho, int wo, int cout, int kdim /* kh*kw*cin */, int tile_cfg);
 int straps_conv_fwd(const float* x_nhwc, const float* w_krsc, const float* scale,
                     const float* shift, const float* residual, int relu, float* y_nhwc,
                     float* stats_partial, int batch, int h, int w, int cin, int cout, int kh,
@@ -216,13 +216,16 @@ int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw,
                       int batch, int cin, int h, int w, int accumulate, void* stream);
 /* training-mode BatchNorm backward with the ReLU mask fused: dz = dy * (yact > 0) (yact NULL = no
  * ReLU), dgamma/dbeta, draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (optional,
- * may alias dy) receives dz for the skip connection.                                             */
+ * may alias dy) receives dz for the skip connection.  When the activation was exactly
+ * relu(raw*scale + shift) (no residual), pass yact = NULL and the forward's scale/shift as
+ * mask_scale/mask_shift: the mask is then recomputed from raw with the forward's fmaf (bit-identical,
+ * one tensor read less); both NULL with yact NULL = no ReLU.                                        */
 int straps_bn_bwd_blocks(long long rows, int c);
 size_t straps_bn_bwd_workspace_bytes(long long rows, int c);
 int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean,
-                  const float* save_invstd, const float* gamma, float* dgamma, float* dbeta,
-                  float* draw, float* dz_out, void* workspace, long long rows, int c,
-                  int accumulate, void* stream);
+                  const float* save_invstd, const float* gamma, const float* mask_scale,
+                  const float* mask_shift, float* dgamma, float* dbeta, float* draw, float* dz_out,
+                  void* workspace, long long rows, int c, int accumulate, void* stream);
 /* max-pool forward that also records the arg-max tap (uint8 per element), and its backward.      */
 int straps_maxpool_fwd_idx(const float* x_nhwc, float* y_nhwc, uint8_t* idx, int batch, int h,
                            int w, int c, void* stream);

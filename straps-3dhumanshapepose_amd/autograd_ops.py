@@ -73,8 +73,12 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads):
     dgamma, dbeta = grads.buf(bn.weight), grads.buf(bn.bias)
     draw = _empty_like(raw)
     dz = _empty_like(raw) if want_dz else None
-    hipabi.check(L.straps_bn_bwd(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
-                                 hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw),
+    # ReLU mask: without a residual the activation is relu(raw*scale + shift), so the kernel re-derives it from raw (one
+    # tensor read less); with a residual it has to read the stored activation
+    from_raw = masked and rec.get('residual') is None
+    hipabi.check(L.straps_bn_bwd(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked and not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
+                                 hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
+                                 hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw),
                                  hipabi.ptr(dz), hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
     grads[bn.weight] = dgamma
     grads[bn.bias] = dbeta

@@ -379,9 +379,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
 // pass 1: per-block partial sums of dz and dz*xhat, dz = dy * (y > 0 if masked).  Block (bx, by) owns rows
 // [bx*rows_per_block, ...) x the 64 channels [64*by, 64*by+64): 16 float4 column lanes x 16 row lanes, so a deep layer
 // (few rows, many channels) still fills the chip, and every wave load is 4 full 256-byte row segments.
+// ReLU mask: (yact > 0), or -- when the activation is exactly relu(raw*msc + msh), no residual -- recomputed from raw
+// with the forward's own fmaf (bit-identical to reading yact, one tensor read less).
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, float* __restrict__ part, long long rows,
+                                                            const float* __restrict__ invstd, const float* __restrict__ msc,
+                                                            const float* __restrict__ msh, float* __restrict__ part, long long rows,
                                                             int C, int rows_per_block) {
     __shared__ float red[256][8];
     constexpr int TR = 16;
@@ -394,7 +397,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (active) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-        // 4 rows per trip: 12 independent float4 loads in flight per lane before the first use
+        f32x4 ksc = {0.f, 0.f, 0.f, 0.f}, ksh = ksc;
+        if (msc) { ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4); ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4); }
+        // 4 rows per trip: 8-12 independent float4 loads in flight per lane before the first use
         long long r = r0 + tr;
         for (; r + 3 * TR < r1; r += 4 * TR) {
             f32x4 g[4], ya[4], xr[4];
@@ -410,6 +415,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 if (yact) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[u][e] = ya[u][e] > 0.f ? g[u][e] : 0.f;
+                } else if (msc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[u][e] = fmaf(xr[u][e], ksc[e], ksh[e]) > 0.f ? g[u][e] : 0.f;
                 }
                 s1 += g[u];
                 s2 += g[u] * ((xr[u] - mu) * is);
@@ -418,12 +426,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (; r < r1; r += TR) {
             const long long o = r * C + c4 * 4;
             f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + o);
             if (yact) {
                 const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
+            } else if (msc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = fmaf(xr[e], ksc[e], ksh[e]) > 0.f ? g[e] : 0.f;
             }
-            const f32x4 xh = (*reinterpret_cast<const f32x4*>(raw + o) - mu) * is;
+            const f32x4 xh = (xr - mu) * is;
             s1 += g;
             s2 += g * xh;
         }
@@ -464,22 +476,29 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                            const float* __restrict__ raw, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           const float* __restrict__ msc, const float* __restrict__ msh,
                                                            float* __restrict__ draw, float* dz_out, long long n4, int C) {
     const int C4 = C >> 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
         const int c4 = (int)(idx % C4);
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + idx * 4);
         if (yact) {
             const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + idx * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
+        } else if (msc) {
+            const f32x4 ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4);
+            const f32x4 ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = fmaf(xr[e], ksc[e], ksh[e]) > 0.f ? g[e] : 0.f;
         }
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
         const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
         const f32x4 m1 = *reinterpret_cast<const f32x4*>(coef + C + c4 * 4);
         const f32x4 m2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4 * 4);
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(raw + idx * 4) - mu) * is;
+        const f32x4 xh = (xr - mu) * is;
         if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = g;
         *reinterpret_cast<f32x4*>(draw + idx * 4) = k1 * (g - m1 - xh * m2);
     }
@@ -861,8 +880,8 @@ extern "C" int straps_bn_bwd_blocks(long long rows, int c) {
 }
 
 extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
-                             const float* gamma, float* dgamma, float* dbeta, float* draw, float* dz_out, void* workspace, long long rows,
-                             int c, int accumulate, void* stream) {
+                             const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
+                             float* dz_out, void* workspace, long long rows, int c, int accumulate, void* stream) {
     STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && draw && workspace, "straps_bn_bwd: null pointer");
     STRAPS_REQUIRE(rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd: bad shape rows=%lld c=%d", rows, c);
     const int C4 = c >> 2;
@@ -872,12 +891,12 @@ extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* ra
     const int rpb = (int)((rows + nblk - 1) / nblk);
     float* part = (float*)workspace;                 // [nblk][c][2]
     float* coef = part + (size_t)nblk * c * 2;       // [3][c]
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, part, rows, c, rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb);
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coef, draw, dz_out, n4, c);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coef, mask_scale, mask_shift, draw, dz_out, n4, c);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }

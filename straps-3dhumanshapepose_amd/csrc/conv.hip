@@ -202,13 +202,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 }
 
 // tile choice from the per-layer sweep (tools/sweep_conv.py, B=64): 128x128 where it still yields >= 2 workgroups
-// per CU (one barrier per 64 MFMAs per wave), otherwise 64x64 whose 4+ resident workgroups per CU hide each
-// other's barrier / LDS-refill bubbles (128x64 never wins).
-inline void pick_tile(int cfg, long long M, int cout, int& bm, int& bn) {
+// per CU (one barrier per 64 MFMAs per wave) AND the reduction is long enough (K >= 1024) to amortise its heavier
+// prologue / epilogue, otherwise 64x64 whose 4+ resident workgroups per CU hide each other's barrier / LDS-refill
+// bubbles (128x64 never wins).
+inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
     if (cfg == 1) { bm = 128; bn = 128; }
     else if (cfg == 2) { bm = 128; bn = 64; }
     else if (cfg == 3) { bm = 64; bn = 64; }
-    else if (cout % 128 == 0 && ((M + 127) / 128) * (cout / 128) >= 512) { bm = 128; bn = 128; }
+    else if (cout % 128 == 0 && kdim >= 1024 && ((M + 127) / 128) * (cout / 128) >= 512) { bm = 128; bn = 128; }
     else { bm = 64; bn = 64; }
     if (cout % bn != 0) bn = 64;
 }
@@ -232,7 +233,7 @@ int launch(const ConvP& p0, hipStream_t st) {
 
 int dispatch(const ConvP& p, int tile_cfg, hipStream_t st) {
     int bm, bn;
-    pick_tile(tile_cfg, p.M, p.Cout, bm, bn);
+    pick_tile(tile_cfg, p.M, p.Cout, p.ntaps * p.Cin, bm, bn);
     if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
     if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
     return launch<64, 64>(p, st);
@@ -240,10 +241,10 @@ int dispatch(const ConvP& p, int tile_cfg, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int straps_conv_stat_blocks(int batch, int ho, int wo, int cout, int tile_cfg) {
+extern "C" int straps_conv_stat_blocks(int batch, int ho, int wo, int cout, int kdim, int tile_cfg) {
     int bm, bn;
     const long long M = (long long)batch * ho * wo;
-    pick_tile(tile_cfg, M, cout, bm, bn);
+    pick_tile(tile_cfg, M, cout, kdim, bm, bn);
     return (int)((M + bm - 1) / bm);
 }
 

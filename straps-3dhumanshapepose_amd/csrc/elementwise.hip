@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
-        v = v * sc + sh;
+        // explicit fmaf: the backward pass re-derives the ReLU mask from raw with the same operation (bn_bwd, mask_scale)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaf(v[q], sc[q], sh[q]);
         if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         *reinterpret_cast<f32x4*>(y + i * 4) = v;

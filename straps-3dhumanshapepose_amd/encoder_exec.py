@@ -66,7 +66,7 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
                                        int(relu), hipabi.ptr(y), None, B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg,
                                        hipabi.stream_ptr()), 'straps_conv_fwd')
         return y, Ho, Wo
-    nblk = L.straps_conv_stat_blocks(B, Ho, Wo, Cout, tile_cfg)
+    nblk = L.straps_conv_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
     part = ctx.empty(nblk, Cout, 2)
     hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wpk), None, None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, H, W,
                                    Cin, Cout, k, k, stride, pad, tile_cfg, hipabi.stream_ptr()), 'straps_conv_fwd')

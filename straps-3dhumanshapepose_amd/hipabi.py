@@ -61,7 +61,7 @@ SIGNATURES = {
     'straps_bn_fold': (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     'straps_stem_stat_blocks': (_I, [_I, _I, _I]),
     'straps_stem_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
-    'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I]),
+    'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I, _I]),
     'straps_conv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_maxpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_gap_fwd': (_I, [_P, _P, _I, _I, _I, _P]),
@@ -83,7 +83,7 @@ SIGNATURES = {
     'straps_stem_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'straps_bn_bwd_blocks': (_I, [_L, _I]),
     'straps_bn_bwd_workspace_bytes': (_Z, [_L, _I]),
-    'straps_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'straps_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'straps_maxpool_fwd_idx': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),

@@ -103,11 +103,27 @@ def test_bn_backward(dev, C, relu):
     draw, dz = torch.empty_like(raw), torch.empty_like(raw)
     ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, C) // 4, device=dev)
     hipabi.check(L.straps_bn_bwd(hipabi.ptr(dyd), hipabi.ptr(outd if relu else None), hipabi.ptr(raw), hipabi.ptr(md), hipabi.ptr(isd), hipabi.ptr(gd),
-                                 hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(dz), hipabi.ptr(ws), rows, C, 0, None), 'bn bwd')
+                                 None, None, hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(dz), hipabi.ptr(ws), rows, C, 0, None), 'bn bwd')
     assert _relerr(draw.permute(0, 3, 1, 2), x.grad) < 5e-5
     assert _relerr(dg, g.grad) < 5e-5 and _relerr(db, b.grad) < 5e-5
     mask = (out.detach() > 0).double() if relu else torch.ones_like(dy)
     assert _relerr(dz.permute(0, 3, 1, 2), dy * mask) < 1e-6
+    if relu:
+        # mask re-derived from raw with the forward's scale / shift == mask read from the forward's own activation, bit for bit
+        sc = gd * isd
+        sh = b.detach().float().to(dev) - md * sc
+        act = torch.empty_like(raw)
+        hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), None, 1, hipabi.ptr(act), rows, C, None), 'bn apply')
+        outs = []
+        for kw in ((act, None, None), (None, sc, sh)):
+            dg2, db2, draw2, dz2 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty_like(raw), torch.empty_like(raw)
+            hipabi.check(L.straps_bn_bwd(hipabi.ptr(dyd), hipabi.ptr(kw[0]), hipabi.ptr(raw), hipabi.ptr(md), hipabi.ptr(isd), hipabi.ptr(gd),
+                                         hipabi.ptr(kw[1]), hipabi.ptr(kw[2]), hipabi.ptr(dg2), hipabi.ptr(db2), hipabi.ptr(draw2), hipabi.ptr(dz2),
+                                         hipabi.ptr(ws), rows, C, 0, None), 'bn bwd')
+            outs.append((dg2, db2, draw2, dz2))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+        assert _relerr(outs[1][2].permute(0, 3, 1, 2), x.grad) < 5e-5
 
 
 def test_maxpool_and_gap_backward(dev):

@@ -149,7 +149,7 @@ def _run_conv(dev, x_nchw, w, stride, pad, scale=None, shift=None, res_nchw=None
     sh = shift.to(dev) if shift is not None else None
     part = None
     if stats:
-        part = torch.empty(L.straps_conv_stat_blocks(B, Ho, Wo, Cout, cfg), Cout, 2, device=dev)
+        part = torch.empty(L.straps_conv_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, cfg), Cout, 2, device=dev)
     hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wp), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), int(relu),
                                    hipabi.ptr(y), hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, cfg, None), 'conv')
     torch.cuda.synchronize()

@@ -54,7 +54,7 @@ for name, H, Cin, Cout, k, stride in SHAPES:
         if cfg == 1 and Cout % 128:
             row += ' fwd%d   n/a ' % cfg
             continue
-        part = torch.empty(L.straps_conv_stat_blocks(B, Ho, Ho, Cout, cfg), Cout, 2, device=dev)
+        part = torch.empty(L.straps_conv_stat_blocks(B, Ho, Ho, Cout, k * k * Cin, cfg), Cout, 2, device=dev)
         t = timeit(lambda: L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wp), None, None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, H, H, Cin, Cout, k, k, stride, pad, cfg, None))
         row += ' fwd%d %5.1f' % (cfg, flops / t / 1e12)
     row += ' |'
