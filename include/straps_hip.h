@@ -50,6 +50,18 @@ int straps_pack_conv_weight(const float* w_oihw, float* w_krsc, int cout, int ci
  * (dgrad of a conv is a conv with rotated filters).                                           */
 int straps_pack_conv_weight_dgrad(const float* w_oihw, float* w_crsk, int cout, int cin, int kh,
                                   int kw, void* stream);
+/* both packings of MANY conv layers in one launch (a training step repacks every layer after the
+ * optimiser update: 2 x 19 / 2 x 52 tiny launches otherwise).  descs: DEVICE array of n entries sorted by
+ * `first` (prefix sum of cout*cin*kh*kw); dst_crsk may be NULL (forward only); total = sum of elements. */
+typedef struct {
+    const float* src;          /* OIHW */
+    float* dst_krsc;
+    float* dst_crsk;
+    int32_t o, c, r, s;
+    long long first;
+} straps_pack_desc_t;
+int straps_pack_conv_weights_batched(const straps_pack_desc_t* descs, int n, long long total,
+                                     void* stream);
 
 /* stem weights OIHW [64][cin][7][7] (models/resnet.py:145) -> MFMA fragment order
  * [ceil(cin*49/8)][2][64][4]; straps_stem_weight_floats gives the element count.              */

@@ -30,6 +30,35 @@ __global__ __launch_bounds__(256) void pack_crsk_flip_kernel(const float* __rest
     dst[i] = src[(((long long)o * C + c) * R + (R - 1 - r)) * S + (S - 1 - s)];
 }
 
+// both packings of every layer in one launch: thread i finds its layer by binary search over the element prefix sums
+__global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_desc_t* __restrict__ descs, int n, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    const straps_pack_desc_t d = descs[lo];
+    const long long j = i - d.first;
+    {   // j as KRSC index
+        const int c = (int)(j % d.c);
+        long long t = j / d.c;
+        const int s = (int)(t % d.s); t /= d.s;
+        const int r = (int)(t % d.r);
+        const int o = (int)(t / d.r);
+        d.dst_krsc[j] = d.src[(((long long)o * d.c + c) * d.r + r) * d.s + s];
+    }
+    if (d.dst_crsk) {   // j as flipped CRSK index
+        const int o = (int)(j % d.o);
+        long long t = j / d.o;
+        const int s = (int)(t % d.s); t /= d.s;
+        const int r = (int)(t % d.r);
+        const int c = (int)(t / d.r);
+        d.dst_crsk[j] = d.src[(((long long)o * d.c + c) * d.r + (d.r - 1 - r)) * d.s + (d.s - 1 - s)];
+    }
+}
+
 __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
                                const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,6 +171,13 @@ extern "C" int straps_pack_conv_weight_dgrad(const float* w_oihw, float* w_crsk,
     const long long n = (long long)cout * cin * kh * kw;
     hipLaunchKernelGGL(pack_crsk_flip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, w_crsk, cout, cin, kh, kw);
     STRAPS_CHECK_LAUNCH("pack_crsk_flip_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_pack_conv_weights_batched(const straps_pack_desc_t* descs, int n, long long total, void* stream) {
+    STRAPS_REQUIRE(descs && n > 0 && total > 0, "straps_pack_conv_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, descs, n, total);
+    STRAPS_CHECK_LAUNCH("pack_batched_kernel");
     return STRAPS_OK;
 }
 

@@ -46,6 +46,12 @@ class SmplModelStruct(C.Structure):
                 ('jrt_ptr', C.c_void_p), ('jrt_code', C.c_void_p), ('jrt_w', C.c_void_p)]
 
 
+class PackDesc(C.Structure):
+    """mirror of straps_pack_desc_t"""
+    _fields_ = [('src', C.c_void_p), ('dst_krsc', C.c_void_p), ('dst_crsk', C.c_void_p), ('o', C.c_int32), ('c', C.c_int32),
+                ('r', C.c_int32), ('s', C.c_int32), ('first', C.c_longlong)]
+
+
 _P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
@@ -56,6 +62,7 @@ SIGNATURES = {
     'straps_selftest_mfma_peak': (_I, [_P, _P, _I, _I, _P]),
     'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'straps_pack_conv_weights_batched': (_I, [_P, _I, _L, _P]),
     'straps_stem_weight_floats': (_Z, [_I]),
     'straps_pack_stem_weight': (_I, [_P, _P, _I, _P]),
     'straps_bn_fold': (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),

@@ -105,6 +105,45 @@ class ResNet(nn.Module):
             return out
         return self._cached(('w', id(conv)), [w], make)
 
+    def prepack(self, with_dgrad=True):
+        """(re)pack the weights of every non-stem conv for the forward (KRSC) and data-gradient (flipped CRSK) kernels in
+        ONE launch and seed the caches `_packed_weight` / autograd_ops._packed_dgrad_weight read.  The training step
+        calls this after each optimiser update instead of 2 x (19 | 52) tiny launches."""
+        import ctypes as C
+        import numpy as np
+        convs = [m for m in self.modules() if isinstance(m, nn.Conv2d) and m is not self.conv1]
+        key = tuple(c.weight.data_ptr() for c in convs) + (with_dgrad,)
+        st = getattr(self, '_prepack_state', None)
+        if st is None or st['key'] != key:
+            dev = convs[0].weight.device
+            hipabi.require_gpu_tensor(convs[0].weight, 'conv weights (call .to(device) first)')
+            total = sum(c.weight.numel() for c in convs)
+            krsc = torch.empty(total, device=dev, dtype=torch.float32)
+            crsk = torch.empty(total, device=dev, dtype=torch.float32) if with_dgrad else None
+            descs = (hipabi.PackDesc * len(convs))()
+            off = 0
+            for d, c in zip(descs, convs):
+                w = c.weight
+                if not w.is_contiguous():
+                    raise RuntimeError('prepack: conv weights must be contiguous')
+                d.src, d.dst_krsc = w.data_ptr(), krsc.data_ptr() + 4 * off
+                d.dst_crsk = crsk.data_ptr() + 4 * off if with_dgrad else None
+                d.o, d.c, d.r, d.s, d.first = w.shape[0], w.shape[1], w.shape[2], w.shape[3], off
+                off += w.numel()
+            table = torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()).to(dev)
+            st = dict(key=key, krsc=krsc, crsk=crsk, table=table, total=total, convs=convs)
+            self._prepack_state = st
+        hipabi.check(hipabi.lib().straps_pack_conv_weights_batched(hipabi.ptr(st['table']), len(st['convs']), st['total'],
+                                                                   hipabi.stream_ptr()), 'straps_pack_conv_weights_batched')
+        off = 0
+        for c in st['convs']:
+            w, n = c.weight, c.weight.numel()
+            sig = ((w.data_ptr(), w._version),)
+            self._cache[('w', id(c))] = (sig, st['krsc'][off:off + n])
+            if with_dgrad:
+                self._cache[('wd', id(c))] = (sig, st['crsk'][off:off + n])
+            off += n
+
     def _folded_bn(self, bn):
         def make():
             C = bn.weight.shape[0]

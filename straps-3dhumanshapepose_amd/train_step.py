@@ -150,6 +150,7 @@ class TrainStep:
         assert reg.training, 'TrainStep needs the regressor in .train() mode'
         self.flat_g.zero_()
         enc_tape, ief_tape = {}, []
+        reg.image_encoder.prepack(with_dgrad=True)          # every conv's forward + data-gradient weight layout, one launch
         feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape)
         est = reg.ief_module.forward_estimate(feat, ief_tape)                      # [B,160]
         pose6d = est[:, 3:147]
