@@ -262,8 +262,17 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     float* patch = smem;                                             // [C][PH][PW]
     float* dys = patch + C * PH * PW;                                // [TPIX pixels][64 + 4]
     int* koff = reinterpret_cast<int*>(dys + TPIX * 68);             // [Kp]
+    int* chflag = koff + Kp;                                         // [C] channel's patch holds a non-zero (zero skipping, see stem.hip)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
+    // channels spanned by this wave's K column blocks (a block of 32 taps touches at most 2 channels)
+    int nb_c0[NB], nb_c1[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int k0 = (nb * 4 + wave) * 32;
+        nb_c0[nb] = k0 < K ? k0 / 49 : -1;
+        nb_c1[nb] = k0 < K ? min(k0 + 31, K - 1) / 49 : -1;
+    }
     for (int k = tid; k < Kp; k += 256) {
         int o = 0;
         if (k < K) {
@@ -291,6 +300,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         const int y0 = ty * TY, x0 = tx * TX;
         const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
         __syncthreads();   // previous tile's LDS reads are done
+        if (tid < C) chflag[tid] = 0;
+        __syncthreads();
         // patch column p holds input column wi0 - 1 + p (origin shifted one column left: aligned float4 row loads)
         if ((W & 3) == 0) {
             for (int idx = tid; idx < C * PH * (PW / 4); idx += 256) {
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                 if ((unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
                     v = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
                 *reinterpret_cast<f32x4*>(patch + rc * PW + 4 * q) = v;
+                if (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f) chflag[c] = 1;
             }
         } else {
             for (int idx = tid; idx < C * PH * PW; idx += 256) {
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                 float v = 0.f;
                 if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
                 patch[idx] = v;
+                if (v != 0.f) chflag[c] = 1;
             }
         }
         for (int idx = tid; idx < TPIX * 16; idx += 256) {
@@ -322,6 +335,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             *reinterpret_cast<f32x4*>(dys + pix * 68 + c4 * 4) = v;
         }
         __syncthreads();
+        // column blocks whose channels are all zero in this tile contribute nothing: skipped (wave-uniform)
+        unsigned active = 0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            if (nb_c0[nb] >= 0 && (chflag[nb_c0[nb]] | chflag[nb_c1[nb]])) active |= 1u << nb;
+        if (active == 0) continue;
         // contraction over the tile's pixels: A[co][pix] = dys[pix][co], B[pix][k] = patch[koff[k] + 2*py*PW + 2*px]
 #pragma unroll 2
         for (int g = 0; g < TPIX / 8; ++g) {     // groups of 8 pixels
@@ -336,6 +355,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
+                if (!((active >> nb) & 1u)) continue;
                 // (the offset is re-read from the LDS table each time on purpose: keeping the 7 offsets in VGPRs pushes
                 //  the kernel past 256 registers = one wave per SIMD, measured 1.73 -> 2.46 ms)
                 const int kcol = (nb * 4 + wave) * 32 + i;
@@ -848,7 +868,7 @@ extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, floa
     const int ntiles = batch * tiles_x * tiles_y;
     int tpb;
     const int nblk = stem_wgrad_blocks(ntiles, &tpb);
-    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + TPIX * 68 * sizeof(float) + (size_t)Kp * sizeof(int);
+    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + TPIX * 68 * sizeof(float) + ((size_t)Kp + cin) * sizeof(int);
     STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_wgrad: LDS budget exceeded");
     hipStream_t st = (hipStream_t)stream;
     auto go = [&](auto kern) -> int {

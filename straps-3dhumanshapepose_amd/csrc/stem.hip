@@ -10,6 +10,12 @@
 //   * A fragments (pixels) are gathered from the patch with stride-2 ds_read_b32, B fragments
 //     (weights, prepacked in fragment order by straps_pack_stem_weight) stream from L2 as
 //     coalesced float4,
+//   * ZERO SKIPPING: the proxy representation is a binary silhouette + 17 joint heat-maps whose Gaussians
+//     underflow to exactly 0 about 55 px from the joint, so most (channel, patch row) strips are all zero.
+//     The patch load flags the non-zero strips; each wave (one output row) compacts the 8-tap K groups that
+//     touch a flagged strip of ITS 7 input rows into an LDS list and contracts only those.  A skipped group
+//     would have added 0*w = 0 to every accumulator, so the result is the dense one bit for bit (finite weights);
+//     a dense input simply skips nothing.
 //   * epilogue writes NHWC (lane = channel) with BN scale/shift + ReLU fused (eval) or raw output
 //     plus per-channel (sum, sumsq) partials (training).
 #include "common.h"
@@ -26,6 +32,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;                                        // [C][PH][PW]
     int* koff = reinterpret_cast<int*>(smem + C * PH * PW);     // [Kp]
+    int* rowflag = koff + Kp;                                   // [C*PH]  strip (channel, patch row) holds a non-zero
+    int* glist = rowflag + C * PH;                              // [4 waves][Kp/8] active K groups of each wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -35,6 +43,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     const int y0 = ty * TY, x0 = tx * TX;
     const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
 
+    for (int idx = tid; idx < C * PH; idx += 256) rowflag[idx] = 0;
+    __syncthreads();
     // patch column p holds input column wi0 - 1 + p: the patch origin is shifted one column left so that every row is
     // 18 ALIGNED float4 loads (wi0 - 1 = 2*x0 - 4 is a multiple of 4) instead of 69 scalar ones
     if ((W & 3) == 0) {
@@ -48,6 +58,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             if ((unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
                 v = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
             *reinterpret_cast<f32x4*>(patch + rc * PW + 4 * q) = v;
+            if (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f) rowflag[rc] = 1;      // (NaN counts as non-zero)
         }
     } else {
         const int npatch = C * PH * PW;
@@ -59,6 +70,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             float v = 0.f;
             if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
             patch[idx] = v;
+            if (v != 0.f) rowflag[rc] = 1;
         }
     }
     for (int k = tid; k < Kp; k += 256) {
@@ -79,25 +91,53 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wfrag) + lane;
     const int G = Kp >> 3;
-    // software pipeline: the offset table is read two groups ahead and the (dependent) patch gather one group ahead,
-    // so no MFMA of group g waits on an LDS round trip issued in group g
-    f32x4 b0 = wp[0], b1 = wp[64];
-    int4 ko_n = *reinterpret_cast<const int4*>(koff + 4 * h);                       // offsets of group 0
-    float a0 = pbase[ko_n.x], a1 = pbase[ko_n.y], a2 = pbase[ko_n.z], a3 = pbase[ko_n.w];
-    ko_n = *reinterpret_cast<const int4*>(koff + (G > 1 ? 8 : 0) + 4 * h);          // offsets of group 1
-    for (int g = 0; g < G; ++g) {
-        f32x4 nb0 = b0, nb1 = b1;
-        float n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-        if (g + 1 < G) {
-            nb0 = wp[(g + 1) * 128]; nb1 = wp[(g + 1) * 128 + 64];
-            n0 = pbase[ko_n.x]; n1 = pbase[ko_n.y]; n2 = pbase[ko_n.z]; n3 = pbase[ko_n.w];
+    // ---- this wave's active K groups: group g is needed iff one of its 8 taps reads a flagged strip of rows 2*wave + r ----
+    int* gl = glist + wave * G;
+    int ng = 0;
+    for (int gb = 0; gb < G; gb += 64) {
+        const int g = gb + lane;
+        bool act = false;
+        if (g < G) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * g + e;
+                if (k < K) act = act || rowflag[koff[k] / PW + 2 * wave] != 0;
+            }
         }
-        if (g + 2 < G) ko_n = *reinterpret_cast<const int4*>(koff + 8 * (g + 2) + 4 * h);
-        acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
-        acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
-        acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
-        acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
-        b0 = nb0; b1 = nb1; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        const unsigned long long m = __ballot(act);
+        if (act) gl[ng + __popcll(m & ((1ULL << lane) - 1ULL))] = g;
+        ng += (int)__popcll(m);
+    }
+    // (the list is written and read by this wave only; LDS operations of one wave retire in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // software pipeline over the active groups: the offset table is read two groups ahead and the (dependent) patch
+    // gather one group ahead, so no MFMA of a group waits on an LDS round trip issued in that group
+    if (ng > 0) {
+        int gcur = gl[0];
+        int gnext = gl[ng > 1 ? 1 : 0];
+        f32x4 b0 = wp[gcur * 128], b1 = wp[gcur * 128 + 64];
+        int4 ko_n = *reinterpret_cast<const int4*>(koff + 8 * gcur + 4 * h);
+        float a0 = pbase[ko_n.x], a1 = pbase[ko_n.y], a2 = pbase[ko_n.z], a3 = pbase[ko_n.w];
+        ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
+        for (int j = 0; j < ng; ++j) {
+            f32x4 nb0 = b0, nb1 = b1;
+            float n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+            if (j + 1 < ng) {
+                nb0 = wp[gnext * 128]; nb1 = wp[gnext * 128 + 64];
+                n0 = pbase[ko_n.x]; n1 = pbase[ko_n.y]; n2 = pbase[ko_n.z]; n3 = pbase[ko_n.w];
+            }
+            if (j + 2 < ng) {
+                gnext = gl[j + 2];
+                ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
+            }
+            acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
+            acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
+            acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
+            acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
+            b0 = nb0; b1 = nb1; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        }
     }
 
     const int yo = y0 + wave;
@@ -177,7 +217,7 @@ extern "C" int straps_stem_fwd(const float* x, const float* w_frag, const float*
     STRAPS_REQUIRE(batch > 0 && cin > 0 && h >= 7 && w >= 7, "straps_stem_fwd: bad shape B=%d C=%d H=%d W=%d", batch, cin, h, w);
     STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_stem_fwd: scale and shift must be given together");
     const int K = cin * 49, Kp = (K + 7) / 8 * 8;
-    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + (size_t)Kp * sizeof(int);
+    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + ((size_t)Kp + (size_t)cin * PH + 4 * (size_t)(Kp >> 3)) * sizeof(int);
     STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_fwd: %d input channels need %zu B of LDS (max 160 KiB)", cin, lds);
     const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
     const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;
