@@ -105,11 +105,11 @@ def instrument(timer):
             return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a))
 
         def straps_stem_fwd(self, *a):
-            B, C, H, W = a[7:11]
+            B, C, H, W = a[8:12]
             return timer.wrap('stem_kernel', 2.0 * B * _out(H, 7, 2, 3) * _out(W, 7, 2, 3) * 64 * C * 49, lambda: L.straps_stem_fwd(*a))
 
         def straps_stem_wgrad(self, *a):
-            B, C, H, W = a[4:8]
+            B, C, H, W = a[5:9]
             return timer.wrap('stem_wgrad_kernel', 2.0 * B * _out(H, 7, 2, 3) * _out(W, 7, 2, 3) * 64 * C * 49, lambda: L.straps_stem_wgrad(*a))
 
         def straps_smpl_fwd(self, *a):

@@ -76,11 +76,20 @@ int straps_bn_fold(const float* gamma, const float* beta, const float* mean, con
 /* conv7x7/s2/p3 over the NCHW network input, fused y = relu?(conv*scale+shift) -> NHWC.
  * scale/shift may be NULL (raw conv output, used in training mode).  If stats_partial != NULL it
  * receives per-block per-channel (sum, sum of squares) of the RAW conv output:
- * [straps_stem_stat_blocks()][64][2] floats (training-mode BatchNorm statistics).             */
+ * [straps_stem_stat_blocks()][64][2] floats (training-mode BatchNorm statistics).
+ * ZERO SKIPPING (exact): the proxy input is a silhouette + truncated joint heat-maps, ~98 % exact
+ * zeros.  The kernel contracts only the K groups whose input strips hold a non-zero (a skipped
+ * group adds 0*w = 0), so the result equals the dense one bit for bit for finite weights; a dense
+ * input skips nothing.  nzmask (optional, from straps_stem_nzmask; NULL = probe by loading) lets it
+ * skip even the loads of all-zero 4x8 cells.                                                    */
 int straps_stem_stat_blocks(int batch, int h, int w);
+size_t straps_stem_nzmask_words(int batch, int cin, int h, int w);
+/* one bit per 4-row x 8-column cell of x: mask[B][cin][ceil(h/4)][ceil(w/256)] uint32            */
+int straps_stem_nzmask(const float* x_nchw, uint32_t* mask, int batch, int cin, int h, int w,
+                       void* stream);
 int straps_stem_fwd(const float* x_nchw, const float* w_frag, const float* scale,
-                    const float* shift, int relu, float* y_nhwc, float* stats_partial, int batch,
-                    int cin, int h, int w, void* stream);
+                    const float* shift, int relu, float* y_nhwc, float* stats_partial,
+                    const uint32_t* nzmask, int batch, int cin, int h, int w, void* stream);
 
 /* generic implicit-GEMM convolution over NHWC fp32 (3x3 pad 1 stride 1|2, 1x1 stride 1|2):
  *   y[m][co] = epilogue( sum_{r,s,ci} x[b][ho*stride+r-pad][wo*stride+s-pad][ci] * w[co][r][s][ci] )
@@ -225,7 +234,8 @@ int straps_conv_wgrad(const float* x_nhwc, const float* dy_nhwc, float* dw_oihw,
 /* stem weight gradient straight from the NCHW input (the input itself needs no gradient).        */
 size_t straps_stem_wgrad_workspace_bytes(int batch, int cin, int h, int w);
 int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, void* workspace,
-                      int batch, int cin, int h, int w, int accumulate, void* stream);
+                      const uint32_t* nzmask /* optional, see straps_stem_fwd */, int batch, int cin,
+                      int h, int w, int accumulate, void* stream);
 /* training-mode BatchNorm backward with the ReLU mask fused: dz = dy * (yact > 0) (yact NULL = no
  * ReLU), dgamma/dbeta, draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (optional,
  * may alias dy) receives dz for the skip connection.  When the activation was exactly

@@ -143,8 +143,8 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None):
     B, Cin, H, W, Ho, Wo = rec['geom']
     ws = torch.empty(L.straps_stem_wgrad_workspace_bytes(B, Cin, H, W) // 4, device=draw.device, dtype=torch.float32)
     dw = grads.buf(net.conv1.weight)
-    hipabi.check(L.straps_stem_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, Cin, H, W, 0,
-                                     hipabi.stream_ptr()), 'straps_stem_wgrad')
+    hipabi.check(L.straps_stem_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), hipabi.ptr(rec.get('nzmask')),
+                                     B, Cin, H, W, 0, hipabi.stream_ptr()), 'straps_stem_wgrad')
     grads[net.conv1.weight] = dw
     side.join()
     return grads

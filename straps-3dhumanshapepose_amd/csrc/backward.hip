@@ -248,139 +248,221 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // =====================================================================================================
 // stem weight gradient (no data gradient is needed: the network input does not require grad)
 // =====================================================================================================
-// 2-row x 32-column output tiles: patch (2*2+5) x 72 per channel = 46.7 KB at C = 18 -> two workgroups per CU, so one
-// workgroup's patch refill overlaps the other's MFMA phase (the 4-row tile of the forward kernel allowed only one).
+// The network input is the proxy representation: a silhouette + 17 truncated joint heat-maps, ~98 % exact zeros.  The
+// kernel is organised around that: a workgroup owns ONE GROUP OF 4 INPUT CHANNELS (grid.y) and walks 2-row x 32-column
+// output tiles; a pre-pass over the non-zero bit map of the input (straps_stem_nzmask -> stem_tileact_kernel) tells it --
+// before touching LDS, x or dy -- which of its channels hold anything inside the tile's 9 x 72 input patch: most (tile,
+// group) pairs are skipped outright (a workgroup fetches the activity of 64 tiles with one load), and inside an active
+// pair only the active channels are loaded.
+// A skipped contribution is 0 * dy = 0, so the result equals the dense one bit for bit; a dense input skips nothing.
+// Per group the accumulator is dW[64][4*49 = 196 taps] = 14 MFMA tiles of 32x32 over the 4 waves (64 accumulator
+// registers), so 4-5 workgroups are resident per CU and cover each other's load latency (the all-channel variant needed
+// 472 registers: one wave per SIMD).
 constexpr int TY = 2, TX = 32, PH = 2 * TY + 5, PW = 72, TPIX = TY * TX;
+constexpr int CG = 4, GK = CG * 49, GNB = (GK + 31) / 32, GUNITS = 2 * GNB, UPW = (GUNITS + 3) / 4;   // 196 taps, 7 column blocks, 14 units, 4 per wave
 
-// each workgroup walks `tiles_per_block` output tiles (4 rows x 32 cols x 64 channels of dy) and accumulates
-// dW[64][Kp] (Kp = C*49 padded to 32) in registers: wave w owns the K column blocks n with n % 4 == w.
-template <int NB>   // NB = column blocks of 32 per wave (C*49 <= 128*NB)
+// per (channel group, tile): which of the group's channels have a non-zero inside the tile's 9 x 72 input patch (bit cl)
+__global__ __launch_bounds__(256) void stem_tileact_kernel(const unsigned* __restrict__ nzmask, uint8_t* __restrict__ tact, int C, int H, int W,
+                                                           int tiles_x, int tiles_y, int ntiles, int groups) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ntiles * groups) return;
+    const int grp = idx / ntiles, tile = idx - grp * ntiles;
+    int bid = tile;
+    const int b = bid / (tiles_x * tiles_y);
+    bid -= b * tiles_x * tiles_y;
+    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
+    const int hi0 = 2 * (ty * TY) - 3, wi0 = 2 * (tx * TX) - 3;
+    const int HC = (H + 3) >> 2, WW = (W + 255) >> 8;
+    const int rc0 = max(hi0, 0) >> 2, rc1 = min(hi0 + PH - 1, H - 1) >> 2;
+    const int wa = max(wi0 - 1, 0), wb = min(wi0 - 2 + PW, W - 1);
+    const int c0 = grp * CG, nc = min(CG, C - c0);
+    unsigned chact = 0;
+    for (int cl = 0; cl < nc; ++cl) {
+        unsigned any = 0;
+        for (int rcell = rc0; rcell <= rc1; ++rcell)
+            for (int word = wa >> 8; word <= (wb >> 8); ++word) {
+                const int lo = max(wa, word << 8), hi = min(wb, (word << 8) + 255);
+                const int b0 = (lo >> 3) & 31, b1 = (hi >> 3) & 31;
+                const unsigned bits = (b1 == 31 ? 0xffffffffu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+                any |= nzmask[(((long long)b * C + c0 + cl) * HC + rcell) * WW + word] & bits;
+            }
+        if (any) chact |= 1u << cl;
+    }
+    tact[idx] = (uint8_t)chact;
+}
+
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ part, int B, int C, int H, int W, int Ho, int Wo,
-                                                            int tiles_x, int tiles_y, int K, int Kp, int tiles_per_block, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* patch = smem;                                             // [C][PH][PW]
-    float* dys = patch + C * PH * PW;                                // [TPIX pixels][64 + 4]
-    int* koff = reinterpret_cast<int*>(dys + TPIX * 68);             // [Kp]
-    int* chflag = koff + Kp;                                         // [C] channel's patch holds a non-zero (zero skipping, see stem.hip)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                         float* __restrict__ part, const uint8_t* __restrict__ tact, int B, int C, int H,
+                                                         int W, int Ho, int Wo,
+                                                         int tiles_x, int tiles_y, int Kp, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float patch[2 * CG * PH * PW]; // [buffer][cl][PH][PW]
+    __shared__ __attribute__((aligned(16))) float dys[2 * TPIX * 68];      // [buffer][pixel][64 + 4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    // channels spanned by this wave's K column blocks (a block of 32 taps touches at most 2 channels)
-    int nb_c0[NB], nb_c1[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int k0 = (nb * 4 + wave) * 32;
-        nb_c0[nb] = k0 < K ? k0 / 49 : -1;
-        nb_c1[nb] = k0 < K ? min(k0 + 31, K - 1) / 49 : -1;
-    }
-    for (int k = tid; k < Kp; k += 256) {
-        int o = 0;
-        if (k < K) {
-            const int c = k / 49, rs = k - c * 49;
-            const int r = rs / 7, s = rs - r * 7;
-            o = (c * PH + r) * PW + s + 1;      // +1: patch origin one column left of the receptive field
-        }
-        koff[k] = o;
-    }
-    f32x16 acc[2][NB];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[a][nb][q] = 0.f;
+    const int c0 = blockIdx.y * CG;
+    const int nc = min(CG, C - c0);
+    const int gk = nc * 49;                                                // valid taps of this group
 
-    const int t0 = blockIdx.x * tiles_per_block;
-    const int t1 = min(t0 + tiles_per_block, ntiles);
-    for (int tile = t0; tile < t1; ++tile) {
-        int bid = tile;
-        const int b = bid / (tiles_x * tiles_y);
-        bid -= b * tiles_x * tiles_y;
-        const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
-        const int y0 = ty * TY, x0 = tx * TX;
-        const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
-        __syncthreads();   // previous tile's LDS reads are done
-        if (tid < C) chflag[tid] = 0;
-        __syncthreads();
-        // patch column p holds input column wi0 - 1 + p (origin shifted one column left: aligned float4 row loads)
-        if ((W & 3) == 0) {
-            for (int idx = tid; idx < C * PH * (PW / 4); idx += 256) {
-                const int q = idx % (PW / 4);
-                const int rc = idx / (PW / 4);
-                const int row = rc % PH, c = rc / PH;
-                const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
-                    v = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
-                *reinterpret_cast<f32x4*>(patch + rc * PW + 4 * q) = v;
-                if (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f) chflag[c] = 1;
-            }
-        } else {
-            for (int idx = tid; idx < C * PH * PW; idx += 256) {
-                const int col = idx % PW;
-                const int rc = idx / PW;
-                const int row = rc % PH, c = rc / PH;
-                const int hi = hi0 + row, wi = wi0 - 1 + col;
-                float v = 0.f;
-                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
-                patch[idx] = v;
-                if (v != 0.f) chflag[c] = 1;
-            }
+    // this wave's units u = wave + 4*j = 2*nb + a: (tap column block nb, co half a); patch offset of this lane's tap; channel span
+    int u_a[UPW], u_nb[UPW], u_ko[UPW];
+    unsigned u_span[UPW];
+#pragma unroll
+    for (int j = 0; j < UPW; ++j) {
+        const int u = wave + 4 * j;
+        u_a[j] = u & 1;                     // consecutive column blocks x both co halves land on 4 different waves: the
+        u_nb[j] = u >> 1;                   // 4 units of one active channel (49 taps ~ 1.5 column blocks) run in parallel
+        const int k = u_nb[j] * 32 + i;
+        int o = 0;
+        if (u < GUNITS && k < gk) {
+            const int cl = k / 49, rs = k - cl * 49;
+            const int r = rs / 7, s_ = rs - r * 7;
+            o = (cl * PH + r) * PW + s_ + 1;                               // +1: patch origin one column left of the receptive field
         }
-        for (int idx = tid; idx < TPIX * 16; idx += 256) {
+        u_ko[j] = o;
+        const int k0 = u_nb[j] * 32;
+        u_span[j] = 0;
+        if (u < GUNITS && k0 < gk) {
+            const int cl0 = k0 / 49, cl1 = min(k0 + 31, gk - 1) / 49;
+            u_span[j] = (1u << cl0) | (1u << cl1);
+        }
+    }
+    f32x16 acc[UPW];
+#pragma unroll
+    for (int j = 0; j < UPW; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+    // Strided tile assignment (evens out body vs background tiles).  The activity bytes of 64 tiles are fetched with one
+    // load and only the active tiles are visited -- in ascending order, so the accumulation order is fixed.  The visit is
+    // software-pipelined over a double-buffered LDS: while the MFMAs of tile t run, the global loads of the next active
+    // tile are already in flight (registers), and one barrier per tile is enough (a buffer is rewritten two tiles later,
+    // after every wave has passed the barrier in between).
+    constexpr int PIT = (CG * PH * (PW / 4) + 255) / 256;                  // 3 float4 of the patch per thread
+    constexpr int DIT = TPIX * 16 / 256;                                   // 4 float4 of the dy tile per thread
+    const bool vec = (W & 3) == 0;
+    f32x4 pv[PIT], dv[DIT];
+    auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
+        b = tile / (tiles_x * tiles_y);
+        const int bid = tile - b * tiles_x * tiles_y;
+        const int ty = bid / tiles_x;
+        y0 = ty * TY;
+        x0 = (bid - ty * tiles_x) * TX;
+    };
+    auto issue_loads = [&](int tile, unsigned chact) {                     // global -> registers, nothing waits here
+        int b, y0, x0;
+        tile_origin(tile, b, y0, x0);
+        const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int idx = tid + it * 256;
+            const int q = idx % (PW / 4);
+            const int rc = idx / (PW / 4);
+            const int row = rc % PH, cl = rc / PH;
+            const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;                // patch column p holds input column wi0 - 1 + p
+            pv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (vec && cl < nc && ((chact >> cl) & 1u) && (unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
+                pv[it] = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c0 + cl) * H + hi) * W + wi);
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int idx = tid + it * 256;
             const int pix = idx >> 4, c4 = idx & 15;
             const int yo = y0 + (pix >> 5), xo = x0 + (pix & 31);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (yo < Ho && xo < Wo) v = *reinterpret_cast<const f32x4*>(dy + (((long long)b * Ho + yo) * Wo + xo) * 64 + c4 * 4);
-            *reinterpret_cast<f32x4*>(dys + pix * 68 + c4 * 4) = v;
+            dv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (yo < Ho && xo < Wo) dv[it] = *reinterpret_cast<const f32x4*>(dy + (((long long)b * Ho + yo) * Wo + xo) * 64 + c4 * 4);
         }
-        __syncthreads();
-        // column blocks whose channels are all zero in this tile contribute nothing: skipped (wave-uniform)
-        unsigned active = 0;
+    };
+    auto store_tile = [&](int tile, unsigned chact, float* pb, float* db) {        // registers -> LDS buffer
+        if (vec) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            if (nb_c0[nb] >= 0 && (chflag[nb_c0[nb]] | chflag[nb_c1[nb]])) active |= 1u << nb;
-        if (active == 0) continue;
-        // contraction over the tile's pixels: A[co][pix] = dys[pix][co], B[pix][k] = patch[koff[k] + 2*py*PW + 2*px]
-#pragma unroll 2
-        for (int g = 0; g < TPIX / 8; ++g) {     // groups of 8 pixels
-            float a0[4], a1[4];
-            int poff[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int pix = g * 8 + h * 4 + e;
-                a0[e] = dys[pix * 68 + i];
-                a1[e] = dys[pix * 68 + 32 + i];
-                poff[e] = (2 * (pix >> 5)) * PW + 2 * (pix & 31);
+            for (int it = 0; it < PIT; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < nc * PH * (PW / 4)) *reinterpret_cast<f32x4*>(pb + (idx / (PW / 4)) * PW + 4 * (idx % (PW / 4))) = pv[it];
             }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                if (!((active >> nb) & 1u)) continue;
-                // (the offset is re-read from the LDS table each time on purpose: keeping the 7 offsets in VGPRs pushes
-                //  the kernel past 256 registers = one wave per SIMD, measured 1.73 -> 2.46 ms)
-                const int kcol = (nb * 4 + wave) * 32 + i;
-                const int ko = kcol < Kp ? koff[kcol] : 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float bv = patch[ko + poff[e]];
-                    acc[0][nb] = mfma32(a0[e], bv, acc[0][nb]);
-                    acc[1][nb] = mfma32(a1[e], bv, acc[1][nb]);
-                }
+        } else {                                                           // odd widths: scalar fill, not pipelined
+            int b, y0, x0;
+            tile_origin(tile, b, y0, x0);
+            const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
+            for (int idx = tid; idx < nc * PH * PW; idx += 256) {
+                const int col = idx % PW;
+                const int rc = idx / PW;
+                const int row = rc % PH, cl = rc / PH;
+                const int hi = hi0 + row, wi = wi0 - 1 + col;
+                float v = 0.f;
+                if (((chact >> cl) & 1u) && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c0 + cl) * H + hi) * W + wi];
+                pb[idx] = v;
             }
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int idx = tid + it * 256;
+            *reinterpret_cast<f32x4*>(db + (idx >> 4) * 68 + (idx & 15) * 4) = dv[it];
+        }
+    };
+
+    const uint8_t* myact = tact + (long long)blockIdx.y * ntiles;
+    int buf = 0;
+    for (int base = blockIdx.x; base < ntiles; base += 64 * gridDim.x) {
+        const int mine = base + lane * gridDim.x;
+        const unsigned act = mine < ntiles ? myact[mine] : 0u;
+        unsigned long long todo = __ballot(act != 0u);
+        if (todo) {
+            const int l0 = __ffsll((long long)todo) - 1;
+            issue_loads(base + l0 * gridDim.x, (unsigned)__shfl((int)act, l0, 64));
+        }
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int tile = base + l * gridDim.x;
+            const unsigned chact = (unsigned)__shfl((int)act, l, 64);
+            float* pb = patch + buf * (CG * PH * PW);
+            float* db = dys + buf * (TPIX * 68);
+            store_tile(tile, chact, pb, db);
+            __syncthreads();
+            if (todo) {                                                    // next active tile of this chunk: loads fly during the MFMAs
+                const int ln = __ffsll((long long)todo) - 1;
+                issue_loads(base + ln * gridDim.x, (unsigned)__shfl((int)act, ln, 64));
+            }
+            // contraction over the tile's 64 pixels: A[co][pix] = dys[pix][co], B[pix][k] = patch[koff[k] + 2*py*PW + 2*px].
+            // Unit-outer / pixel-inner and fully unrolled: every LDS operand is base + immediate offset (a unit is skipped
+            // when its taps read only all-zero channels of this tile -- wave-uniform).
+#pragma unroll
+            for (int j = 0; j < UPW; ++j) {
+                if (!(u_span[j] & chact)) continue;
+                const float* ap = db + (h * 4) * 68 + u_a[j] * 32 + i;
+                const float* bp = pb + u_ko[j] + 8 * h;
+                // all 64 operands of the unit are fetched first (the scheduling barrier keeps the compiler from re-serialising
+                // read -> wait -> MFMA pairs through two registers), then the 32-MFMA chain runs without LDS waits
+                float av[32], bv[32];
+#pragma unroll
+                for (int g = 0; g < TPIX / 8; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        av[g * 4 + e] = ap[(g * 8 + e) * 68];
+                        bv[g * 4 + e] = bp[(g >> 2) * 2 * PW + (g & 3) * 16 + 2 * e];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 c = acc[j];
+#pragma unroll
+                for (int t = 0; t < 32; ++t) c = mfma32(av[t], bv[t], c);
+                acc[j] = c;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf ^= 1;
+        }
+        __syncthreads();          // chunk boundary: the next chunk's first store may target the buffer still being read
+    }
+    // partial[block][co][k], k = (c0 + cl)*49 + rs: the group's taps are a contiguous column range
+    float* o = part + (long long)blockIdx.x * 64 * Kp + c0 * 49;
+#pragma unroll
+    for (int j = 0; j < UPW; ++j) {
+        const int kcol = u_nb[j] * 32 + i;
+        if (wave + 4 * j < GUNITS && kcol < gk) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[(long long)(u_a[j] * 32 + mfma_row(q, lane)) * Kp + kcol] = acc[j][q];
         }
     }
-    // partial[block][co][k]
-    float* o = part + (long long)blockIdx.x * 64 * Kp;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int kcol = (nb * 4 + wave) * 32 + i;
-            if (kcol < Kp) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) o[(long long)(a * 32 + mfma_row(q, lane)) * Kp + kcol] = acc[a][nb][q];
-            }
-        }
 }
 
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblocks,
@@ -840,50 +922,46 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
     return STRAPS_OK;
 }
 
-static int stem_wgrad_blocks(int ntiles, int* tpb) {
-    int t = (ntiles + 511) / 512;
-    if (t < 1) t = 1;
-    *tpb = t;
-    return (ntiles + t - 1) / t;
-}
+// row blocks of tiles (grid.x): enough for 4-5 resident workgroups per CU across the channel groups, few enough that the
+// per-block partials stay small
+static int stem_wgrad_blocks(int ntiles) { return ntiles < 256 ? ntiles : 256; }
 
 extern "C" size_t straps_stem_wgrad_workspace_bytes(int batch, int cin, int h, int w) {
     const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
     const int ntiles = batch * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX);
-    int tpb;
-    const int nblk = stem_wgrad_blocks(ntiles, &tpb);
     const int Kp = (cin * 49 + 31) / 32 * 32;
-    return (size_t)nblk * 64 * Kp * sizeof(float);
+    // partials + room for an internally computed non-zero map (used when the caller passes none)
+    const size_t groups = (cin + CG - 1) / CG;
+    return (size_t)stem_wgrad_blocks(ntiles) * 64 * Kp * sizeof(float) + straps_stem_nzmask_words(batch, cin, h, w) * sizeof(uint32_t) +
+           ((groups * ntiles + 3) & ~(size_t)3);
 }
 
-extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, void* workspace, int batch, int cin, int h,
-                                 int w, int accumulate, void* stream) {
+extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw, void* workspace, const uint32_t* nzmask,
+                                 int batch, int cin, int h, int w, int accumulate, void* stream) {
     STRAPS_REQUIRE(x_nchw && dy_nhwc && dw_oihw && workspace, "straps_stem_wgrad: null pointer");
+    STRAPS_REQUIRE(batch > 0 && cin > 0 && h >= 7 && w >= 7, "straps_stem_wgrad: bad shape B=%d C=%d H=%d W=%d", batch, cin, h, w);
     const int K = cin * 49, Kp = (K + 31) / 32 * 32;
-    const int ncolblk = Kp / 32;
-    const int NB = (ncolblk + 3) / 4;
-    STRAPS_REQUIRE(NB <= 7, "straps_stem_wgrad: at most 18 input channels supported (got %d)", cin);
     const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
     const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;
     const int ntiles = batch * tiles_x * tiles_y;
-    int tpb;
-    const int nblk = stem_wgrad_blocks(ntiles, &tpb);
-    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + TPIX * 68 * sizeof(float) + ((size_t)Kp + cin) * sizeof(int);
-    STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_wgrad: LDS budget exceeded");
+    const int nblk = stem_wgrad_blocks(ntiles);
+    const int groups = (cin + CG - 1) / CG;
+    STRAPS_REQUIRE(groups <= 65535, "straps_stem_wgrad: too many input channels (%d)", cin);
     hipStream_t st = (hipStream_t)stream;
-    auto go = [&](auto kern) -> int {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { straps_set_error("stem_wgrad_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, x_nchw, dy_nhwc, (float*)workspace, batch, cin, h, w, Ho, Wo, tiles_x,
-                           tiles_y, K, Kp, tpb, ntiles);
-        return STRAPS_OK;
-    };
-    int rc;
-    if (NB <= 1) rc = go(stem_wgrad_kernel<1>);
-    else if (NB <= 2) rc = go(stem_wgrad_kernel<2>);
-    else if (NB <= 4) rc = go(stem_wgrad_kernel<4>);
-    else rc = go(stem_wgrad_kernel<7>);
-    if (rc != STRAPS_OK) return rc;
+    float* part = (float*)workspace;
+    uint32_t* own = (uint32_t*)(part + (size_t)nblk * 64 * Kp);
+    uint8_t* tact = (uint8_t*)(own + straps_stem_nzmask_words(batch, cin, h, w));
+    if (!nzmask) {
+        const int rc = straps_stem_nzmask(x_nchw, own, batch, cin, h, w, stream);
+        if (rc != STRAPS_OK) return rc;
+        nzmask = own;
+    }
+    // (every (block, group) writes its whole column slice at the end, skipped tiles or not; padded columns are never read)
+    hipLaunchKernelGGL(stem_tileact_kernel, dim3((ntiles * groups + 255) / 256), dim3(256), 0, st, nzmask, tact, cin, h, w, tiles_x, tiles_y, ntiles,
+                       groups);
+    STRAPS_CHECK_LAUNCH("stem_tileact_kernel");
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk, groups), dim3(256), 0, st, x_nchw, dy_nhwc, part, tact, batch, cin, h, w, Ho, Wo,
+                       tiles_x, tiles_y, Kp, ntiles);
     STRAPS_CHECK_LAUNCH("stem_wgrad_kernel");
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * K + 255) / 256), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk, K, Kp, accumulate);
     STRAPS_CHECK_LAUNCH("stem_wgrad_reduce_kernel");

@@ -25,9 +25,50 @@ namespace {
 constexpr int PH = 13, PW = 72;
 constexpr int TY = 4, TX = 32;
 
+// Non-zero map of the input: one bit per 4-row x 8-column cell, [B][C][ceil(H/4)][ceil(W/256)] 32-bit words
+// (bit = (w >> 3) & 31).  With it the stem kernels do not even LOAD the all-zero cells of the proxy representation.
+// One lane per cell (8 float4 loads, row-contiguous across lanes), the 32 bits of a word are gathered with a ballot:
+// no atomics, no clear pass, same cost for dense and sparse inputs.
+__global__ __launch_bounds__(256) void stem_nzmask_kernel(const float* __restrict__ x, unsigned* __restrict__ mask, long long nwords,
+                                                          int H, int W, int HC, int WW) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long word = gid >> 5;
+    const int bit = (int)(gid & 31);
+    bool nz = false;
+    if (word < nwords) {
+        const int ww = (int)(word % WW);
+        const long long t = word / WW;
+        const int hc = (int)(t % HC);
+        const long long bc = t / HC;
+        const int w0 = ww * 256 + bit * 8;
+        if (w0 < W) {
+            const float* base = x + (bc * H + hc * 4) * (long long)W + w0;
+            const int rows = min(4, H - hc * 4);
+            if ((W & 3) == 0) {
+                const bool two = w0 + 4 < W;
+                for (int r = 0; r < rows; ++r) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(base + (long long)r * W);
+                    nz = nz || a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f;
+                    if (two) {
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(base + (long long)r * W + 4);
+                        nz = nz || c[0] != 0.f || c[1] != 0.f || c[2] != 0.f || c[3] != 0.f;
+                    }
+                }
+            } else {
+                const int cols = min(8, W - w0);
+                for (int r = 0; r < rows; ++r)
+                    for (int c = 0; c < cols; ++c) nz = nz || base[(long long)r * W + c] != 0.f;
+            }
+        }
+    }
+    const unsigned long long m = __ballot(nz);
+    if (bit == 0 && word < nwords) mask[word] = (unsigned)(m >> (32 * ((threadIdx.x & 63) >> 5)));
+}
+
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wfrag,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                   float* __restrict__ y, float* __restrict__ stats, int B, int C, int H, int W,
+                                                   float* __restrict__ y, float* __restrict__ stats,
+                                                   const unsigned* __restrict__ nzmask, int B, int C, int H, int W,
                                                    int Ho, int Wo, int tiles_x, int tiles_y, int K, int Kp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;                                        // [C][PH][PW]
@@ -43,11 +84,39 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     const int y0 = ty * TY, x0 = tx * TX;
     const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
 
-    for (int idx = tid; idx < C * PH; idx += 256) rowflag[idx] = 0;
-    __syncthreads();
+    // ---- strip flags: does (channel c, patch row) hold a non-zero?  With the caller's non-zero map they come from one
+    // word per strip BEFORE anything is loaded (and an all-zero tile skips the patch altogether); without it they are
+    // found by probing the loaded values ----
+    const int HC = (H + 3) >> 2, WW = (W + 255) >> 8;
+    int tile_any = 1;
+    if (nzmask) {
+        int mine = 0;
+        const int wa = max(wi0 - 1, 0), wb = min(wi0 - 2 + PW, W - 1);
+        for (int rc = tid; rc < C * PH; rc += 256) {
+            const int row = rc % PH, c = rc / PH;
+            const int hi = hi0 + row;
+            unsigned any = 0;
+            if ((unsigned)hi < (unsigned)H) {
+                for (int word = wa >> 8; word <= (wb >> 8); ++word) {
+                    const int lo = max(wa, word << 8), hi_c = min(wb, (word << 8) + 255);
+                    const int b0 = (lo >> 3) & 31, b1 = (hi_c >> 3) & 31;
+                    const unsigned bits = (b1 == 31 ? 0xffffffffu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+                    any |= nzmask[(((long long)b * C + c) * HC + (hi >> 2)) * WW + word] & bits;
+                }
+            }
+            rowflag[rc] = any != 0u;
+            mine |= any != 0u;
+        }
+        tile_any = __syncthreads_or(mine);
+    } else {
+        for (int idx = tid; idx < C * PH; idx += 256) rowflag[idx] = 0;
+        __syncthreads();
+    }
     // patch column p holds input column wi0 - 1 + p: the patch origin is shifted one column left so that every row is
     // 18 ALIGNED float4 loads (wi0 - 1 = 2*x0 - 4 is a multiple of 4) instead of 69 scalar ones
-    if ((W & 3) == 0) {
+    if (!tile_any) {
+        // nothing but zeros under this tile: the contraction below runs over an empty group list
+    } else if ((W & 3) == 0) {
         const int nvec = C * PH * (PW / 4);
         for (int idx = tid; idx < nvec; idx += 256) {
             const int q = idx % (PW / 4);
@@ -55,10 +124,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             const int row = rc % PH, c = rc / PH;
             const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
+            if ((!nzmask || rowflag[rc]) && (unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
                 v = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
             *reinterpret_cast<f32x4*>(patch + rc * PW + 4 * q) = v;
-            if (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f) rowflag[rc] = 1;      // (NaN counts as non-zero)
+            if (!nzmask && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f)) rowflag[rc] = 1;      // (NaN counts as non-zero)
         }
     } else {
         const int npatch = C * PH * PW;
@@ -68,9 +137,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             const int row = rc % PH, c = rc / PH;
             const int hi = hi0 + row, wi = wi0 - 1 + col;
             float v = 0.f;
-            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
+            if ((!nzmask || rowflag[rc]) && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
             patch[idx] = v;
-            if (v != 0.f) rowflag[rc] = 1;
+            if (!nzmask && v != 0.f) rowflag[rc] = 1;
         }
     }
     for (int k = tid; k < Kp; k += 256) {
@@ -211,8 +280,23 @@ extern "C" int straps_stem_stat_blocks(int batch, int h, int w) {
     return batch * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX);
 }
 
+extern "C" size_t straps_stem_nzmask_words(int batch, int cin, int h, int w) {
+    if (batch <= 0 || cin <= 0 || h <= 0 || w <= 0) return 0;
+    return (size_t)batch * cin * ((h + 3) / 4) * ((w + 255) / 256);
+}
+
+extern "C" int straps_stem_nzmask(const float* x, uint32_t* mask, int batch, int cin, int h, int w, void* stream) {
+    STRAPS_REQUIRE(x && mask && batch > 0 && cin > 0 && h > 0 && w > 0, "straps_stem_nzmask: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nwords = (long long)straps_stem_nzmask_words(batch, cin, h, w);
+    STRAPS_REQUIRE((nwords * 32 + 255) / 256 < (1LL << 31), "straps_stem_nzmask: input too large for one launch");
+    hipLaunchKernelGGL(stem_nzmask_kernel, dim3((unsigned)((nwords * 32 + 255) / 256)), dim3(256), 0, st, x, mask, nwords, h, w, (h + 3) / 4, (w + 255) / 256);
+    STRAPS_CHECK_LAUNCH("stem_nzmask_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_stem_fwd(const float* x, const float* w_frag, const float* scale, const float* shift, int relu, float* y,
-                               float* stats_partial, int batch, int cin, int h, int w, void* stream) {
+                               float* stats_partial, const uint32_t* nzmask, int batch, int cin, int h, int w, void* stream) {
     STRAPS_REQUIRE(x && w_frag && y, "straps_stem_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0 && cin > 0 && h >= 7 && w >= 7, "straps_stem_fwd: bad shape B=%d C=%d H=%d W=%d", batch, cin, h, w);
     STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_stem_fwd: scale and shift must be given together");
@@ -230,7 +314,7 @@ extern "C" int straps_stem_fwd(const float* x, const float* w_frag, const float*
     const long long nblk = (long long)batch * tiles_x * tiles_y;
     STRAPS_REQUIRE(nblk < (1LL << 31), "straps_stem_fwd: grid too large");
     hipLaunchKernelGGL(stem_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, x, w_frag, scale, shift, relu, y,
-                       stats_partial, batch, cin, h, w, Ho, Wo, tiles_x, tiles_y, K, Kp);
+                       stats_partial, nzmask, batch, cin, h, w, Ho, Wo, tiles_x, tiles_y, K, Kp);
     STRAPS_CHECK_LAUNCH("stem_kernel");
     return STRAPS_OK;
 }

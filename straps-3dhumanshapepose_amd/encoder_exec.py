@@ -92,15 +92,20 @@ def encoder_forward(net, x, tape=None):
     if tape is not None:
         rec = dict(kind='stem', conv=net.conv1, bn=net.bn1, x=x, geom=(B, C, H, W, Ho, Wo), relu=True, residual=None)
         tape["stem"] = rec
+    # non-zero map of the input (the proxy representation is ~98 % exact zeros): the stem kernels skip those cells
+    nzmask = torch.empty(L.straps_stem_nzmask_words(B, C, H, W), device=x.device, dtype=torch.int32)
+    hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nzmask), B, C, H, W, hipabi.stream_ptr()), 'straps_stem_nzmask')
+    if rec is not None:
+        rec['nzmask'] = nzmask
     if not net.training:
         ss = net._folded_bn(net.bn1)
         hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), 1, hipabi.ptr(y),
-                                       None, B, C, H, W, hipabi.stream_ptr()), 'straps_stem_fwd')
+                                       None, hipabi.ptr(nzmask), B, C, H, W, hipabi.stream_ptr()), 'straps_stem_fwd')
     else:
         nblk = L.straps_stem_stat_blocks(B, H, W)
         part = ctx.empty(nblk, 64, 2)
-        hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, C, H, W,
-                                       hipabi.stream_ptr()), 'straps_stem_fwd')
+        hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), hipabi.ptr(nzmask),
+                                       B, C, H, W, hipabi.stream_ptr()), 'straps_stem_fwd')
         y = _bn_train_finish(ctx, net.bn1, y, part, nblk, B * Ho * Wo, None, True, rec)
     # ---- maxpool 3x3/s2/p1 (:149) ----
     H, W = Ho, Wo

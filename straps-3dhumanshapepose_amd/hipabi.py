@@ -67,7 +67,9 @@ SIGNATURES = {
     'straps_pack_stem_weight': (_I, [_P, _P, _I, _P]),
     'straps_bn_fold': (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     'straps_stem_stat_blocks': (_I, [_I, _I, _I]),
-    'straps_stem_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_stem_nzmask_words': (_Z, [_I, _I, _I, _I]),
+    'straps_stem_nzmask': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'straps_stem_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I, _I]),
     'straps_conv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_maxpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -87,7 +89,7 @@ SIGNATURES = {
     'straps_conv_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
     'straps_conv_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_stem_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I]),
-    'straps_stem_wgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'straps_stem_wgrad': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'straps_bn_bwd_blocks': (_I, [_L, _I]),
     'straps_bn_bwd_workspace_bytes': (_Z, [_L, _I]),
     'straps_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),

@@ -78,8 +78,39 @@ def test_stem_wgrad(dev, B, C, H, W):
     xd, dyd = x.float().to(dev), nhwc(dy.float(), dev)
     ws = torch.empty(L.straps_stem_wgrad_workspace_bytes(B, C, H, W) // 4, device=dev)
     dw = torch.empty(64, C, 7, 7, device=dev)
-    hipabi.check(L.straps_stem_wgrad(hipabi.ptr(xd), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws), B, C, H, W, 0, None), 'stem wgrad')
+    hipabi.check(L.straps_stem_wgrad(hipabi.ptr(xd), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws), None, B, C, H, W, 0, None), 'stem wgrad')
     assert _relerr(dw, w.grad) < 2e-5
+
+
+def test_stem_wgrad_zero_skipping_is_exact(dev):
+    """proxy-like input (mostly exact zeros): probing, mask-driven and skip-defeated runs agree (the first two bit for bit)."""
+    L = hipabi.lib()
+    B, C, H, W = 3, 18, 96, 128
+    x = torch.zeros(B, C, H, W)
+    blob = torch.from_numpy(det_uniform((B, C, 16, 16), 40, 0.1, 1.0))
+    for b in range(B):
+        for c in range(C):
+            if (b + c) % 5 == 4:
+                continue                                   # some channels stay entirely zero
+            y0, x0 = (7 * c + 13 * b) % (H - 16), (11 * c + 5 * b) % (W - 16)
+            x[b, c, y0:y0 + 16, x0:x0 + 16] = blob[b, c]
+    x[:, 0, 20:80, 40:90] = 1.0                            # silhouette-like channel
+    w = torch.zeros(64, C, 7, 7, dtype=torch.float64, requires_grad=True)
+    yref = F.conv2d(x.double(), w, None, 2, 3)
+    dy = torch.from_numpy(det_uniform(tuple(yref.shape), 41, -1, 1))
+    yref.backward(dy.double())
+    xd, dyd = x.to(dev), nhwc(dy, dev)
+    ws = torch.empty(L.straps_stem_wgrad_workspace_bytes(B, C, H, W) // 4, device=dev)
+    mask = torch.empty(L.straps_stem_nzmask_words(B, C, H, W), device=dev, dtype=torch.int32)
+    hipabi.check(L.straps_stem_nzmask(hipabi.ptr(xd), hipabi.ptr(mask), B, C, H, W, None), 'nzmask')
+    outs = []
+    for inp, m in ((xd, None), (xd, mask), (torch.where(xd == 0, torch.full_like(xd, 1e-30), xd), None)):
+        dw = torch.empty(64, C, 7, 7, device=dev)
+        hipabi.check(L.straps_stem_wgrad(hipabi.ptr(inp), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws), hipabi.ptr(m), B, C, H, W, 0, None), 'stem wgrad')
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - outs[2]).abs().max()) < 1e-20          # nothing skipped vs skipped: only the 1e-30 fill differs
+    assert _relerr(outs[0], w.grad) < 2e-5
 
 
 @pytest.mark.parametrize('C,relu', [(64, True), (512, True), (2048, False), (128, False)])

@@ -193,7 +193,7 @@ def test_stem_vs_cpu(dev, B, C, H, W):
     hipabi.check(L.straps_pack_stem_weight(hipabi.ptr(wd), hipabi.ptr(wf), C, None), 'pack stem')
     y = torch.empty(B, Ho, Wo, 64, device=dev)
     part = torch.empty(L.straps_stem_stat_blocks(B, H, W), 64, 2, device=dev)
-    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, C, H, W, None), 'stem')
+    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), None, B, C, H, W, None), 'stem')
     _close(y.permute(0, 3, 1, 2), ref, 2e-5, 2e-5, 'stem raw')
     s = part.double().sum(0).cpu()
     np.testing.assert_allclose(s[:, 0].numpy(), ref.sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
@@ -201,10 +201,49 @@ def test_stem_vs_cpu(dev, B, C, H, W):
     sc = torch.from_numpy(det_uniform((64,), 3, 0.5, 1.5))
     sh = torch.from_numpy(det_uniform((64,), 4, -0.5, 0.5))
     scd, shd = sc.to(dev), sh.to(dev)          # keep the device copies alive across the launch
-    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), hipabi.ptr(scd), hipabi.ptr(shd), 1, hipabi.ptr(y), None,
+    hipabi.check(L.straps_stem_fwd(hipabi.ptr(xd), hipabi.ptr(wf), hipabi.ptr(scd), hipabi.ptr(shd), 1, hipabi.ptr(y), None, None,
                                    B, C, H, W, None), 'stem fused')
     want = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
     _close(y.permute(0, 3, 1, 2), want, 3e-5, 3e-5, 'stem fused')
+
+
+def test_stem_zero_skipping_is_exact(dev):
+    """proxy-like input (mostly exact zeros): probing, mask-driven and skip-defeated runs agree (the first two bit for bit)."""
+    L = hipabi.lib()
+    B, C, H, W = 3, 18, 96, 128
+    x = torch.zeros(B, C, H, W)
+    blob = torch.from_numpy(det_uniform((B, C, 16, 16), 30, 0.1, 1.0))
+    for b in range(B):
+        for c in range(C):
+            if (b + c) % 5 == 4:
+                continue
+            y0, x0 = (7 * c + 13 * b) % (H - 16), (11 * c + 5 * b) % (W - 16)
+            x[b, c, y0:y0 + 16, x0:x0 + 16] = blob[b, c]
+    x[:, 0, 20:80, 40:90] = 1.0
+    w = torch.from_numpy(det_uniform((64, C, 7, 7), 31, -1, 1)) * (2.0 / (C * 49)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    Ho, Wo = ref.shape[2:]
+    xd, wd = x.to(dev), w.to(dev)
+    wf = torch.empty(L.straps_stem_weight_floats(C), device=dev)
+    hipabi.check(L.straps_pack_stem_weight(hipabi.ptr(wd), hipabi.ptr(wf), C, None), 'pack stem')
+    mask = torch.empty(L.straps_stem_nzmask_words(B, C, H, W), device=dev, dtype=torch.int32)
+    hipabi.check(L.straps_stem_nzmask(hipabi.ptr(xd), hipabi.ptr(mask), B, C, H, W, None), 'nzmask')
+    cells = (x.reshape(B, C, H // 4, 4, W // 8, 8) != 0).any(5).any(3)                      # [B,C,H/4,W/8]
+    bits = (mask.cpu().view(B, C, H // 4, 1).to(torch.int64) & 0xffffffff)
+    got = torch.stack([(bits[..., 0] >> k) & 1 for k in range(W // 8)], dim=-1).bool()
+    assert torch.equal(got, cells)
+    outs, parts = [], []
+    for inp, m in ((xd, None), (xd, mask), (torch.where(xd == 0, torch.full_like(xd, 1e-30), xd), None)):
+        y = torch.empty(B, Ho, Wo, 64, device=dev)
+        part = torch.empty(L.straps_stem_stat_blocks(B, H, W), 64, 2, device=dev)
+        hipabi.check(L.straps_stem_fwd(hipabi.ptr(inp), hipabi.ptr(wf), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), hipabi.ptr(m),
+                                       B, C, H, W, None), 'stem')
+        outs.append(y)
+        parts.append(part)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(parts[0], parts[1])
+    assert float((outs[0] - outs[2]).abs().max()) < 1e-20
+    _close(outs[0].permute(0, 3, 1, 2), ref, 2e-5, 2e-5, 'stem sparse')
+    assert float((outs[0] == 0).float().mean()) > 0.05            # there really are untouched output regions
 
 
 def test_pool_gap_bn_helpers(dev):
