@@ -265,6 +265,12 @@ def main():
                                     'frac': round(byt / secs / 1e9 / HBM_PEAK_GBS, 4)}
         others = {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'avg_launch_us': round(v[2] / v[0] * 1e6, 2),
                       'ms_per_step': round(v[2] / args.steps * 1e3, 3)} for k, v in agg.items()}
+        for k in others:
+            if k.startswith('stem'):
+                # the stem kernels skip the all-zero strips of the proxy input (exact): their rate is the DENSE-EQUIVALENT one,
+                # i.e. the dense conv's flops over the measured time -- not a fraction of the MFMA peak
+                others[k]['tflops_dense_equivalent'] = others[k].pop('tflops')
+                others[k]['zero_skipping'] = True
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, mp, smpl_model)
@@ -272,7 +278,7 @@ def main():
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
                'config': {'workload': workload, 'bodies_per_gpu_per_step': B, 'global_batch': B * world,
-                          'input': 'theta(24x3x3), beta(10)' if args.workload == 'smpl' else '18x256x256 fp32 NCHW proxy (silhouette + 17 heatmaps)',
+                          'input': 'theta(24x3x3), beta(10)' if args.workload == 'smpl' else '18x256x256 fp32 NCHW proxy built on the device by the step itself (rendered part silhouette + 17 joint heat-maps, ~98 % exact zeros as in the reference pipeline)',
                           'parallelism': par},
                'roofline': roof, 'kernels': others, 'cpu_baseline': cpu}
         if args.workload == 'train':
