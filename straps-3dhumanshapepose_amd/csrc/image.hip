@@ -12,17 +12,27 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void crop_bbox_kernel(const float* __restrict__ seg, const float* __restrict__ u, float orig_scale,
+__global__ __launch_bounds__(1024) void crop_bbox_kernel(const float* __restrict__ seg, const float* __restrict__ u, float orig_scale,
                                                         float ds_lo, float ds_hi, float dc_lo, float dc_hi, int use_jitter,
                                                         int* __restrict__ box, int wh) {
-    __shared__ int red[4][4];
+    __shared__ int red[16][4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* s = seg + (long long)b * wh * wh;
     int rmin = 1 << 30, rmax = -1, cmin = 1 << 30, cmax = -1;
-    for (int i = tid; i < wh * wh; i += 256) {
-        if (s[i] != 0.f) {
+    if ((wh & 3) == 0) {                                  // 16 waves x float4: the 256 KB image is one short sweep
+        for (int i = tid * 4; i < wh * wh; i += 4096) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s + i);
             const int r = i / wh, c = i - r * wh;
-            rmin = min(rmin, r); rmax = max(rmax, r); cmin = min(cmin, c); cmax = max(cmax, c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] != 0.f) { rmin = min(rmin, r); rmax = max(rmax, r); cmin = min(cmin, c + e); cmax = max(cmax, c + e); }
+        }
+    } else {
+        for (int i = tid; i < wh * wh; i += 1024) {
+            if (s[i] != 0.f) {
+                const int r = i / wh, c = i - r * wh;
+                rmin = min(rmin, r); rmax = max(rmax, r); cmin = min(cmin, c); cmax = max(cmax, c);
+            }
         }
     }
 #pragma unroll
@@ -33,7 +43,7 @@ __global__ __launch_bounds__(256) void crop_bbox_kernel(const float* __restrict_
     if (lane == 0) { red[wave][0] = rmin; red[wave][1] = rmax; red[wave][2] = cmin; red[wave][3] = cmax; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < 16; ++w) {
             rmin = min(rmin, red[w][0]); rmax = max(rmax, red[w][1]); cmin = min(cmin, red[w][2]); cmax = max(cmax, red[w][3]);
         }
         int* o = box + b * 6;
@@ -103,7 +113,7 @@ extern "C" int straps_crop_resize(const float* seg, const float* joints2d, const
                    "straps_crop_resize: bad arguments");
     STRAPS_REQUIRE(wh < 32768, "straps_crop_resize: image side must fit int16 like the reference's box arithmetic");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(crop_bbox_kernel, dim3(batch), dim3(256), 0, st, seg, uniforms, orig_scale_factor, delta_scale_lo, delta_scale_hi,
+    hipLaunchKernelGGL(crop_bbox_kernel, dim3(batch), dim3(1024), 0, st, seg, uniforms, orig_scale_factor, delta_scale_lo, delta_scale_hi,
                        delta_centre_lo, delta_centre_hi, uniforms != nullptr, boxes, wh);
     STRAPS_CHECK_LAUNCH("crop_bbox_kernel");
     long long g = ((long long)batch * out_wh * out_wh + 255) / 256;

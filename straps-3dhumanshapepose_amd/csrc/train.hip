@@ -13,37 +13,54 @@ __constant__ int c_h36m14[14] = {73 + 6, 73 + 5, 73 + 4, 73 + 1, 73 + 2, 73 + 3,
 // =====================================================================================================
 // input construction: binary silhouette + Gaussian joint heat-maps (utils/label_conversions.py:48-55,90-127)
 // =====================================================================================================
+// one (body, channel) plane per blockIdx.y, 4 consecutive pixels of a row per thread (32-bit index math, float4
+// stores: the kernel is a 302 MB write at B = 64 and should cost no more than that)
+__device__ __forceinline__ float heat_value(int x, int y, int jx, int jy, int WH) {
+    constexpr int size = 8;
+    const float step = 16.0f / 15.0f;
+    if (!(jx > -size && jy > -size && jx < WH - 1 + size && jy < WH - 1 + size)) return 0.f;
+    const int hx0 = max(0, jx - size), hx1 = min(WH - 1, jx + size);
+    const int hy0 = max(0, jy - size), hy1 = min(WH - 1, jy + size);
+    if (!(x >= hx0 && x < hx1 && y >= hy0 && y < hy1)) return 0.f;
+    const int gx = x - hx0 + max(0, size - jx), gy = y - hy0 + max(0, size - jy);
+    // torch.linspace(-8, 8, 16): start + i*step in the first half, end - (15-i)*step in the second
+    const float lx = gx < 8 ? -8.f + step * gx : 8.f - step * (15 - gx);
+    const float ly = gy < 8 ? -8.f + step * gy : 8.f - step * (15 - gy);
+    const float d = sqrtf(lx * lx + ly * ly);
+    return expf(-(d * d / 32.f));
+}
+
 __global__ __launch_bounds__(256) void build_proxy_kernel(const float* __restrict__ seg, const float* __restrict__ j2d,
                                                           float* __restrict__ out, int B, int NJ, int WH) {
-    const long long n = (long long)B * (NJ + 1) * WH * WH;
-    const int size = 8;
-    const float step = 16.0f / 15.0f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % WH);
-        long long t = i / WH;
-        const int y = (int)(t % WH); t /= WH;
-        const int ch = (int)(t % (NJ + 1));
-        const int b = (int)(t / (NJ + 1));
-        float v = 0.f;
-        if (ch == 0) {
-            v = seg[((long long)b * WH + y) * WH + x] != 0.f ? 1.f : 0.f;
-        } else {
-            const int jx = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 0];     // truncation toward zero == .int()
-            const int jy = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 1];
-            if (jx > -size && jy > -size && jx < WH - 1 + size && jy < WH - 1 + size) {
-                const int hx0 = max(0, jx - size), hx1 = min(WH - 1, jx + size);
-                const int hy0 = max(0, jy - size), hy1 = min(WH - 1, jy + size);
-                if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1) {
-                    const int gx = x - hx0 + max(0, size - jx), gy = y - hy0 + max(0, size - jy);
-                    // torch.linspace(-8, 8, 16): start + i*step in the first half, end - (15-i)*step in the second
-                    const float lx = gx < 8 ? -8.f + step * gx : 8.f - step * (15 - gx);
-                    const float ly = gy < 8 ? -8.f + step * gy : 8.f - step * (15 - gy);
-                    const float d = sqrtf(lx * lx + ly * ly);
-                    v = expf(-(d * d / 32.f));
+    const int plane = blockIdx.y;                       // b * (NJ + 1) + ch
+    const int b = plane / (NJ + 1), ch = plane - b * (NJ + 1);
+    const int npix = WH * WH;
+    float* o = out + (long long)plane * npix;
+    int jx = 0, jy = 0;
+    if (ch > 0) {
+        jx = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 0];     // truncation toward zero == .int()
+        jy = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 1];
+    }
+    const float* s = seg + (long long)b * npix;
+    const bool vec = (WH & 3) == 0;
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < npix; p += gridDim.x * 1024) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = p + e;
+            v[e] = 0.f;
+            if (q < npix) {
+                if (ch == 0) v[e] = s[q] != 0.f ? 1.f : 0.f;
+                else {
+                    const int y = q / WH, x = q - y * WH;
+                    v[e] = heat_value(x, y, jx, jy, WH);
                 }
             }
         }
-        out[i] = v;
+        if (vec) *reinterpret_cast<f32x4*>(o + p) = f32x4{v[0], v[1], v[2], v[3]};
+        else
+            for (int e = 0; e < 4; ++e)
+                if (p + e < npix) o[p + e] = v[e];
     }
 }
 
@@ -224,8 +241,9 @@ inline unsigned capped_grid(long long n, int cap = 4096) {
 extern "C" int straps_build_proxy_input(const float* seg, const float* joints2d, float* out_nchw, int batch, int nj, int wh,
                                         void* stream) {
     STRAPS_REQUIRE(seg && joints2d && out_nchw && batch > 0 && nj > 0 && wh > 16, "straps_build_proxy_input: bad arguments");
-    const long long n = (long long)batch * (nj + 1) * wh * wh;
-    hipLaunchKernelGGL(build_proxy_kernel, dim3(capped_grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, seg, joints2d, out_nchw, batch, nj, wh);
+    STRAPS_REQUIRE((long long)batch * (nj + 1) <= 65535 && wh <= 16384, "straps_build_proxy_input: batch*(nj+1) must be <= 65535 per call");
+    const int gx = (wh * wh / 4 + 255) / 256;
+    hipLaunchKernelGGL(build_proxy_kernel, dim3(gx < 64 ? gx : 64, batch * (nj + 1)), dim3(256), 0, (hipStream_t)stream, seg, joints2d, out_nchw, batch, nj, wh);
     STRAPS_CHECK_LAUNCH("build_proxy_kernel");
     return STRAPS_OK;
 }

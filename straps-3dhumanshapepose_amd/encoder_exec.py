@@ -22,6 +22,7 @@ class _Ctx:
         self.device = device
         self.training = training
         self.tape = tape
+        self.defer_nbt = False        # True: the caller bumps every BatchNorm's num_batches_tracked itself (one fused add)
 
     def empty(self, *shape):
         return torch.empty(*shape, device=self.device, dtype=torch.float32)
@@ -37,7 +38,7 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec):
                                             mom, hipabi.ptr(bn.running_mean if track else None),
                                             hipabi.ptr(bn.running_var if track else None), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]),
                                             hipabi.ptr(ss[2]), hipabi.ptr(ss[3]), hipabi.stream_ptr()), 'straps_bn_stats_finalize')
-    if track:
+    if track and not ctx.defer_nbt:
         bn.num_batches_tracked.add_(1)
     y = torch.empty_like(raw)
     hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
@@ -83,6 +84,7 @@ def encoder_forward(net, x, tape=None):
     x = x.contiguous()
     B, C, H, W = x.shape
     ctx = _Ctx(x.device, net.training, tape)
+    ctx.defer_nbt = getattr(net, '_nbt_flat', None) is not None
     L = ctx.L
     # ---- stem: conv7x7/s2 + BN + ReLU (models/resnet.py:145-148) ----
     Ho, Wo = _conv_out(H, 7, 2, 3), _conv_out(W, 7, 2, 3)

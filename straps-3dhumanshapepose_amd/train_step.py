@@ -94,6 +94,13 @@ class TrainStep:
             renderer = NMRRenderer(batch_size, self.cam_K.cpu(), torch.eye(3), config.REGRESSOR_IMG_WH, rend_parts_seg=True,
                                    faces=smpl.faces, face_parts=smpl.face_parts).to(d)
         self.renderer = renderer
+        # the BatchNorm step counters become views of one int64 buffer: one add per step instead of one tiny launch per layer
+        bns = [m for m in regressor.image_encoder.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats
+               and m.num_batches_tracked is not None]
+        self.nbt_flat = torch.stack([m.num_batches_tracked.detach().to(d) for m in bns]) if bns else None
+        for k, m in enumerate(bns):
+            m.num_batches_tracked = self.nbt_flat[k]
+        regressor.image_encoder._nbt_flat = self.nbt_flat
         # stand-in for data/synthetic_training_dataset.py: a resident pool of (pose axis-angle [72]) samples
         if pose_pool is None:
             g = torch.Generator().manual_seed(seed)
@@ -151,6 +158,8 @@ class TrainStep:
         self.flat_g.zero_()
         enc_tape, ief_tape = {}, []
         reg.image_encoder.prepack(with_dgrad=True)          # every conv's forward + data-gradient weight layout, one launch
+        if self.nbt_flat is not None:
+            self.nbt_flat.add_(1)                           # num_batches_tracked of every BatchNorm (encoder_exec defers to this)
         feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape)
         est = reg.ief_module.forward_estimate(feat, ief_tape)                      # [B,160]
         pose6d = est[:, 3:147]
