@@ -53,6 +53,10 @@ __device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by,
 __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
                                                           unsigned long long* __restrict__ zbuf, long long n, int nverts,
                                                           int nfaces, int wh, float near, float far) {
+    // pixel-centre coordinates (2k + 1 - wh) / wh once per workgroup instead of two IEEE divisions per sample
+    extern __shared__ float sample[];
+    for (int k = threadIdx.x; k < wh; k += 256) sample[k] = (float)(2 * k + 1 - wh) / (float)wh;
+    __syncthreads();
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long i = gid >> 4;                  // (body, face)
     const int sub = (int)(gid & 15);               // lane within the face's 16-lane group
@@ -86,8 +90,8 @@ __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restric
     while (xi > xb) { xi -= bw; ++yi; }
     for (; yi <= yb;) {
         {
-            const float yp = (float)(2 * yi + 1 - wh) / fw;
-            const float xp = (float)(2 * xi + 1 - wh) / fw;
+            const float yp = sample[yi];
+            const float xp = sample[xi];
             const float e0 = edge_fn(x1, y1, x2, y2, xp, yp);     // weight of vertex 0
             const float e1 = edge_fn(x2, y2, x0, y0, xp, yp);
             const float e2 = edge_fn(x0, y0, x1, y1, xp, yp);
@@ -149,7 +153,7 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     hipLaunchKernelGGL(raster_project_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam_K, cam_R, cam_t, ndc, nv, nverts,
                        cam_per_body, (float)wh);
     STRAPS_CHECK_LAUNCH("raster_project_kernel");
-    hipLaunchKernelGGL(raster_face_kernel, dim3((unsigned)((nf * 16 + 255) / 256)), dim3(256), 0, st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far);
+    hipLaunchKernelGGL(raster_face_kernel, dim3((unsigned)((nf * 16 + 255) / 256)), dim3(256), (size_t)wh * sizeof(float), st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far);
     STRAPS_CHECK_LAUNCH("raster_face_kernel");
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, zbuf, face_parts, parts, depth, np, wh, far);
     STRAPS_CHECK_LAUNCH("raster_resolve_kernel");
