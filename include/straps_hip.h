@@ -197,6 +197,12 @@ typedef struct {
     const int32_t* jrt_ptr;    /* [216 + 1] */
     const int32_t* jrt_code;
     const float* jrt_w;
+    /* skinning weights regrouped for the joint-transform gradient: the non-zero weights of round rd (= 4 tiles of 32
+     * vertices) on joint j live in [dj_ptr[rd*24 + j], dj_ptr[rd*24 + j + 1]), ascending vertex;
+     * dj_code = (tile_in_round << 5) | vertex_in_tile.                                                           */
+    const int32_t* dj_ptr;     /* [54*24 + 1] */
+    const int32_t* dj_code;
+    const float* dj_w;
 } straps_smpl_model_t;
 
 /* bytes of caller-owned scratch for `batch` bodies (depends on the model's virtual-tile count)  */

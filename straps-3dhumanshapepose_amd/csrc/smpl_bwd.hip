@@ -4,8 +4,10 @@
 //   smpl_verts_bwd_kernel : same tiling as the forward (32 bodies x vertex chunk per workgroup, one 32-vertex tile
 //       per wave per round).  Per tile: (1) recompute v_posed with the K=218 MFMA contraction, (2) gather the vertex
 //       gradient (dverts + sparse J-regressor / picked-vertex contributions of djoints) through an LDS-staged tile,
-//       (3) per-vertex skinning backward on the VALU: g_vposed = T_R^T g, dA_j += w_j * g (x) [v_posed;1] (LDS float
-//       adds), (4) second MFMA contraction dF[b][k] += sum_{v,c} D[k][v][c] * g_vposed[b][v][c] with the transposed
+//       (3) per-vertex skinning backward on the VALU: g_vposed = T_R^T g; v_posed is staged next to g and, after a
+//       barrier, dA_j += w_j * g (x) [v_posed;1] is accumulated BY JOINT OWNER: lane (body, h) of wave w owns joints
+//       w + 4*(2i + h), i = 0..2, walks the round's (tile, vertex, weight) entries of those joints in a fixed order and
+//       keeps the 3 x 12 sums in registers -- no atomics, bit-reproducible, (4) second MFMA contraction dF[b][k] += sum_{v,c} D[k][v][c] * g_vposed[b][v][c] with the transposed
 //       blend fragments; per-chunk partials of dF and dA are written out.
 //   smpl_pose_bwd_kernel  : lane = (body, joint): sums the chunk partials, back-propagates through rest-pose removal
 //       and the kinematic chain (children -> parents by depth with wave shuffles), the joint regression and the pose
@@ -15,7 +17,7 @@
 namespace {
 
 constexpr int KP = STRAPS_SMPL_KP, KG = KP / 8, NT = STRAPS_SMPL_TILES, NV = STRAPS_SMPL_V, NROUNDS = NT / 4;
-constexpr int BT = 32, FS = 228, AS = 292, SS = 97, DS = 289;
+constexpr int BT = 32, AS = 292, SS = 193;        // SS: stage row = 32 vertices x (g[3], v_posed[3]) + 1
 constexpr int NJS = STRAPS_SMPL_NPICK + STRAPS_SMPL_NEXTRA;   // 66 joint-gradient sources (joints 24..89)
 
 __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_model_t m, const float* __restrict__ F,
@@ -23,10 +25,8 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
                                                                 const float* __restrict__ djoints, float* __restrict__ dFp,
                                                                 float* __restrict__ dAp, long long B, int rounds_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Fs = smem;                      // [32][FS]
-    float* As_ = Fs + BT * FS;             // [32][AS]
-    float* dAs = As_ + BT * AS;            // [32][DS]  accumulated with LDS float adds
-    float* stage = dAs + BT * DS;          // [4][32][SS]
+    float* As_ = smem;                     // [32][AS]
+    float* stage = As_ + BT * AS;          // [4][32][SS]   (the F rows are read straight from global / L1: 16 B per lane per step)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, bl = lane & 31;
@@ -34,19 +34,12 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
     const long long b0 = (long long)blockIdx.y * BT;
     const int nb = (int)((B - b0) < BT ? (B - b0) : BT);
 
-    for (int i = tid; i < BT * (KP / 4); i += 256) {
-        const int b = i / (KP / 4), q = i % (KP / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b < nb) v = *reinterpret_cast<const f32x4*>(F + (b0 + b) * KP + q * 4);
-        *reinterpret_cast<f32x4*>(Fs + b * FS + q * 4) = v;
-    }
     for (int i = tid; i < BT * 72; i += 256) {
         const int b = i / 72, q = i % 72;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b < nb) v = *reinterpret_cast<const f32x4*>(Amat + (b0 + b) * 288 + q * 4);
         *reinterpret_cast<f32x4*>(As_ + b * AS + q * 4) = v;
     }
-    for (int i = tid; i < BT * DS; i += 256) dAs[i] = 0.f;
     __syncthreads();
 
     const int round0 = chunk * rounds_per_chunk;
@@ -57,6 +50,11 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
     const int KW = m.skin_k;
     const bool vbody = bl < nb;
 
+    float dacc[3][12];                     // dA of this lane's three joints
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) dacc[i][e] = 0.f;
     f32x16 accF[7];
 #pragma unroll
     for (int f = 0; f < 7; ++f)
@@ -73,13 +71,17 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
             const f32x4* px = blend + ((long long)(tile * 3 + 0) * KG) * 64 + lane;
             const f32x4* py = px + KG * 64;
             const f32x4* pz = py + KG * 64;
-            const float* frow = Fs + bl * FS + 4 * h;
+            const float* frow = F + (b0 + (vbody ? bl : 0)) * KP + 4 * h;
             f32x4 cx0 = px[0], cy0 = py[0], cz0 = pz[0];
+            f32x4 fn = *reinterpret_cast<const f32x4*>(frow);
 #pragma unroll 2
             for (int g = 0; g < KG; ++g) {
                 f32x4 nx0 = cx0, ny0 = cy0, nz0 = cz0;
-                if (g + 1 < KG) { nx0 = px[(g + 1) * 64]; ny0 = py[(g + 1) * 64]; nz0 = pz[(g + 1) * 64]; }
-                const f32x4 f0 = *reinterpret_cast<const f32x4*>(frow + 8 * g);
+                const f32x4 f0 = vbody ? fn : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g + 1 < KG) {
+                    nx0 = px[(g + 1) * 64]; ny0 = py[(g + 1) * 64]; nz0 = pz[(g + 1) * 64];
+                    fn = *reinterpret_cast<const f32x4*>(frow + 8 * (g + 1));
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     ax = mfma32(cx0[e], f0[e], ax);
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
                 const int b = i / 96, c = i - b * 96;
                 float v = 0.f;
                 if (dverts && b < nb && c < ncol) v = dverts[(b0 + b) * (long long)(NV * 3) + tile * 96 + c];
-                mystage[b * SS + c] = v;
+                mystage[b * SS + (c / 3) * 6 + (c % 3)] = v;
             }
         }
         __syncthreads();
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
             for (int e = e0; e < e1; ++e) {
                 const int code = m.jrt_code[e];
                 const float w = m.jrt_w[e];
-                float* sv = mystage + bl * SS + (code >> 8) * 3;
+                float* sv = mystage + bl * SS + (code >> 8) * 6;
                 const float* g = dj + (code & 255) * 3;
                 sv[0] = fmaf(w, g[0], sv[0]); sv[1] = fmaf(w, g[1], sv[1]); sv[2] = fmaf(w, g[2], sv[2]);
             }
@@ -115,14 +117,13 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
         // ---- (3) skinning backward per (body, vertex) ----
         {
             const float* Ab = As_ + bl * AS;
-            float* dAb = dAs + bl * DS;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int vrow = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int v = tile * 32 + vrow;
-                const float* sv = mystage + bl * SS + vrow * 3;
+                float* sv = mystage + bl * SS + vrow * 6;
                 const float gx = sv[0], gy = sv[1], gz = sv[2];
-                const float x = ax[r], y = ay[r], z = az[r];
+                sv[3] = ax[r]; sv[4] = ay[r]; sv[5] = az[r];              // v_posed, for the joint owners below
                 float t00 = 0.f, t01 = 0.f, t02 = 0.f, t10 = 0.f, t11 = 0.f, t12 = 0.f, t20 = 0.f, t21 = 0.f, t22 = 0.f;
                 for (int k = 0; k < KW; ++k) {
                     const float w = m.skin_w[v * KW + k];
@@ -133,18 +134,28 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
                     t00 += w * a0[0]; t01 += w * a0[1]; t02 += w * a0[2];
                     t10 += w * a1[0]; t11 += w * a1[1]; t12 += w * a1[2];
                     t20 += w * a2[0]; t21 += w * a2[1]; t22 += w * a2[2];
-                    if (w != 0.f) {
-                        const float wx = w * gx, wy = w * gy, wz = w * gz;
-                        float* d = dAb + jo;
-                        atomicAdd(d + 0, wx * x); atomicAdd(d + 1, wx * y); atomicAdd(d + 2, wx * z); atomicAdd(d + 3, wx);
-                        atomicAdd(d + 4, wy * x); atomicAdd(d + 5, wy * y); atomicAdd(d + 6, wy * z); atomicAdd(d + 7, wy);
-                        atomicAdd(d + 8, wz * x); atomicAdd(d + 9, wz * y); atomicAdd(d + 10, wz * z); atomicAdd(d + 11, wz);
-                    }
                 }
                 // g_vposed = T_R^T g
                 ax[r] = t00 * gx + t10 * gy + t20 * gz;
                 ay[r] = t01 * gx + t11 * gy + t21 * gz;
                 az[r] = t02 * gx + t12 * gy + t22 * gz;
+            }
+        }
+        __syncthreads();   // all four tiles of the round are staged (g and v_posed)
+        // ---- (3b) dA_j += w * g (x) [v_posed; 1], by joint owner, entries in table order ----
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 4 * (2 * i + h);
+            const int e0 = m.dj_ptr[rd * 24 + j], e1 = m.dj_ptr[rd * 24 + j + 1];
+            for (int e = e0; e < e1; ++e) {
+                const int code = m.dj_code[e];                            // tile_in_round << 5 | vertex row
+                const float w = m.dj_w[e];
+                const float* sv = stage + ((code >> 5) * BT + bl) * SS + (code & 31) * 6;
+                const float wx = w * sv[0], wy = w * sv[1], wz = w * sv[2];
+                const float x = sv[3], y = sv[4], z = sv[5];
+                dacc[i][0] = fmaf(wx, x, dacc[i][0]); dacc[i][1] = fmaf(wx, y, dacc[i][1]); dacc[i][2] = fmaf(wx, z, dacc[i][2]); dacc[i][3] += wx;
+                dacc[i][4] = fmaf(wy, x, dacc[i][4]); dacc[i][5] = fmaf(wy, y, dacc[i][5]); dacc[i][6] = fmaf(wy, z, dacc[i][6]); dacc[i][7] += wy;
+                dacc[i][8] = fmaf(wz, x, dacc[i][8]); dacc[i][9] = fmaf(wz, y, dacc[i][9]); dacc[i][10] = fmaf(wz, z, dacc[i][10]); dacc[i][11] += wz;
             }
         }
         // ---- (4) dF^T[k][b] += sum_v D[k][v][c] * g_vposed[v][b][c] ----
@@ -172,7 +183,8 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
     // each wave holds dF sums over ITS tiles: fixed-order tree reduction over the 4 waves through the (now free)
     // F/A staging area: (0 += 2, 1 += 3) then (0 += 1)
     {
-        float* red = smem;                                   // 2 x 7168 floats fit in Fs + As_ (16640 floats)
+        __syncthreads();
+        float* red = smem;                                   // 2 x 7168 floats fit in As_ + stage (34048 floats)
         if (wave >= 2) {
 #pragma unroll
             for (int f = 0; f < 7; ++f)
@@ -208,9 +220,14 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
 #pragma unroll
             for (int q = 0; q < 16; ++q) o[f * 32 + mfma_row(q, lane)] = accF[f][q];
     }
-    for (int i = tid; i < BT * 288; i += 256) {
-        const int b = i / 288, r = i - b * 288;
-        if (b < nb) dAp[((long long)chunk * B + b0 + b) * 288 + r] = dAs[b * DS + r];
+    if (vbody) {
+        float* o = dAp + ((long long)chunk * B + b0 + bl) * 288;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 4 * (2 * i + h);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) o[j * 12 + e] = dacc[i][e];
+        }
     }
 }
 
@@ -397,7 +414,8 @@ extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* be
                                const float* djoints, float* dbetas, float* drotmats, void* workspace, long long batch, int chunks,
                                void* stream) {
     STRAPS_REQUIRE(model && betas && rotmats && dbetas && drotmats && workspace, "straps_smpl_bwd: null pointer");
-    STRAPS_REQUIRE(model->blend_frag_t && model->children && model->jrt_ptr, "straps_smpl_bwd: model lacks the backward tables");
+    STRAPS_REQUIRE(model->blend_frag_t && model->children && model->jrt_ptr && model->dj_ptr && model->dj_code && model->dj_w,
+                   "straps_smpl_bwd: model lacks the backward tables");
     STRAPS_REQUIRE(batch > 0, "straps_smpl_bwd: batch must be positive");
     hipStream_t st = (hipStream_t)stream;
     const int rpc = resolve_rpc(batch, chunks);
@@ -408,7 +426,7 @@ extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* be
     float* dAp = dFp + (long long)nch * batch * KP;
     int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, nullptr, batch, st);
     if (rc != STRAPS_OK) return rc;
-    const size_t lds = (size_t)(BT * FS + BT * AS + BT * DS + 4 * BT * SS) * sizeof(float);
+    const size_t lds = (size_t)(BT * AS + 4 * BT * SS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)smpl_verts_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -117,7 +117,17 @@ def pack_smpl_model(model):
     jrt_ptr = np.zeros(TILES + 1, np.int32)
     np.add.at(jrt_ptr, vs // 32 + 1, 1)
     jrt_ptr = np.cumsum(jrt_ptr).astype(np.int32)
+    # skinning weights by (round of 4 tiles, joint) for the joint-transform gradient (fixed summation order)
+    dv, dk = np.nonzero(sw[:VPAD])
+    dj, dw = sj[:VPAD][dv, dk], sw[:VPAD][dv, dk]
+    o3 = np.lexsort((dv, dj, dv // 128))
+    dv, dj, dw = dv[o3], dj[o3], dw[o3]
+    dj_ptr = np.zeros(54 * 24 + 1, np.int32)
+    np.add.at(dj_ptr, (dv // 128) * 24 + dj + 1, 1)
+    dj_ptr = np.cumsum(dj_ptr).astype(np.int32)
+    dj_code = ((((dv % 128) // 32) << 5) | (dv % 32)).astype(np.int32)
     return {
+        'dj_ptr': dj_ptr, 'dj_code': dj_code, 'dj_w': dw.astype(np.float32),
         'blend_frag_t': frag_t.reshape(-1), 'children': children,
         'jrt_ptr': jrt_ptr, 'jrt_code': (((vs % 32) << 8) | src).astype(np.int32), 'jrt_w': ws,
         'blend_frag': frag.reshape(-1),
@@ -170,7 +180,7 @@ class SMPL(nn.Module):
         if self._struct_key != key:
             s = hipabi.SmplModelStruct()
             for f in ('blend_frag', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
-                      'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w'):
+                      'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w', 'dj_ptr', 'dj_code', 'dj_w'):
                 setattr(s, f, getattr(self, '_k_' + f).data_ptr())
             s.max_depth, s.skin_k, s.n_tiles = self.max_depth, self.skin_k, self.n_tiles
             self._struct, self._struct_key = s, key
