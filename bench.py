@@ -132,6 +132,7 @@ def main():
     ap.add_argument('--layers', type=int, default=18)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
     ap.add_argument('--no-overlap', action='store_true', help='keep weight-gradient kernels on the main stream (profiling: per-kernel times become additive)')
     args = ap.parse_args()
 
@@ -161,6 +162,7 @@ def main():
         from straps_amd.train_step import TrainStep
         torch.manual_seed(1234)                                  # identical replicated weights on every rank
         reg = straps_amd.SingleInputRegressor(18, args.layers, 3, mean_params=mp).to(dev).train()
+        reg.image_encoder.dense_stem = args.dense_stem
         crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(
             ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
             init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}).to(dev)
@@ -173,6 +175,7 @@ def main():
     elif args.workload == 'fwd':
         torch.manual_seed(1234)
         reg = straps_amd.SingleInputRegressor(18, args.layers, 3, mean_params=mp).to(dev).eval()
+        reg.image_encoder.dense_stem = args.dense_stem
         x = synthetic_proxy_batch(B, dev, 1234 + rank)           # each rank owns its own shard of bodies
 
         def step():
@@ -286,6 +289,8 @@ def main():
             out['launch_mode'] = 'hipGraph replay of data-gen + forward + loss + backward (all-reduce and Adam eager)' if graph_mode else 'eager'
         else:
             out['launch_mode'] = 'hipGraph replay of the whole forward' if graph_mode else 'eager'
+        if args.workload != 'smpl':
+            out['stem_zero_skipping'] = not args.dense_stem
         if eager_ms is not None:
             out['eager_ms_per_step'] = round(eager_ms, 4)
             if roof is not None:

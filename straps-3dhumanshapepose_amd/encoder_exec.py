@@ -96,7 +96,10 @@ def encoder_forward(net, x, tape=None):
         tape["stem"] = rec
     # non-zero map of the input (the proxy representation is ~98 % exact zeros): the stem kernels skip those cells
     nzmask = torch.empty(L.straps_stem_nzmask_words(B, C, H, W), device=x.device, dtype=torch.int32)
-    hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nzmask), B, C, H, W, hipabi.stream_ptr()), 'straps_stem_nzmask')
+    if getattr(net, 'dense_stem', False):
+        nzmask.fill_(-1)          # A/B switch (bench.py --dense-stem): every cell marked non-zero = the plain dense convolution
+    else:
+        hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nzmask), B, C, H, W, hipabi.stream_ptr()), 'straps_stem_nzmask')
     if rec is not None:
         rec['nzmask'] = nzmask
     if not net.training:
