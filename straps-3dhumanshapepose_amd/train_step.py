@@ -57,7 +57,7 @@ def allreduce_gradients(flat_g, world_size, group=None):
 class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
                  mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=True,
-                 renderer=None):
+                 renderer=None, track_metrics=False):
         """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
         launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches."""
         p0 = next(regressor.parameters())
@@ -94,6 +94,14 @@ class TrainStep:
             renderer = NMRRenderer(batch_size, self.cam_K.cpu(), torch.eye(3), config.REGRESSOR_IMG_WH, rend_parts_seg=True,
                                    faces=smpl.faces, face_parts=smpl.face_parts).to(d)
         self.renderer = renderer
+        # optional per-batch metric sums of the reference's tracker (train loop :236, metrics/train_loss_and_metrics_tracker.py
+        # :127-213), accumulated on the device inside the step (no host sync); `metrics_summary()` normalises them
+        self.metrics = None
+        if track_metrics:
+            from .metrics import BatchMetrics
+            self.metrics = BatchMetrics(self.dev)
+        self._coco = torch.tensor(config.ALL_JOINTS_TO_COCO_MAP, device=d)
+        self._h36m14 = torch.tensor([config.ALL_JOINTS_TO_H36M_MAP[k] for k in config.H36M_TO_J14], device=d)
         # the BatchNorm step counters become views of one int64 buffer: one add per step instead of one tiny launch per layer
         bns = [m for m in regressor.image_encoder.modules() if isinstance(m, torch.nn.BatchNorm2d) and m.track_running_stats
                and m.num_batches_tracked is not None]
@@ -198,7 +206,22 @@ class TrainStep:
             if p.requires_grad:
                 self.gviews[p].copy_(dlv[k])
         self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed)
+        if self.metrics is not None:
+            from .cam_utils import orthographic_project_torch
+            pred = {'verts': verts, 'joints3D': joints.index_select(1, self._h36m14), 'shape_params': pred_shape,
+                    'pose_params_rot_matrices': R,
+                    'joints2D': orthographic_project_torch(joints.index_select(1, self._coco), est[:, :3])}
+            tgt = {'verts': batch['verts'], 'joints3D': batch['joints3d'], 'shape_params': batch['shape'],
+                   'pose_params_rot_matrices': batch['rot'], 'joints2D': batch['joints2d']}
+            self.metrics.update(pred, tgt, pred_reposed_vertices=reposed, target_reposed_vertices=batch['reposed'])
         return loss
+
+    def metrics_summary(self):
+        """per-sample means of the tracked metrics over the steps taken so far (tracker's update_per_epoch normalisers)."""
+        if self.metrics is None:
+            raise RuntimeError('TrainStep was built with track_metrics=False')
+        self.metrics.n = self.steps * self.B          # a replayed hipGraph does not run the Python-side counter
+        return self.metrics.summary()
 
     def optimise(self):
         gscale = allreduce_gradients(self.flat_g, self.world, self.group)

@@ -85,3 +85,33 @@ def test_training_reduces_loss_and_updates_running_stats():
     with torch.no_grad():
         cam, pose, shape = reg(ts.make_batch()['input'])
     assert torch.isfinite(cam).all() and torch.isfinite(pose).all()
+
+
+def test_tracked_metrics_match_oracle_on_the_step_outputs():
+    """f3 wired into the step: the on-device metric sums equal the oracle's per-sample numpy/SVD evaluation of the same
+    predictions (utils/eval_utils.py semantics), also when the step is replayed from a hipGraph."""
+    B = 8
+    dev, reg, smpl, crit = _setup(B, seed=3)
+    ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], track_metrics=True, use_graph=False)
+    with torch.no_grad():
+        batch = ts.make_batch()
+        ts.forward_backward(batch)
+    ts.steps = 1
+    got = ts.metrics_summary()
+    verts, joints, reposed = ts.last['verts'].cpu(), ts.last['joints'].cpu(), ts.last['reposed'].cpu()
+    j14 = [straps_amd.config.ALL_JOINTS_TO_H36M_MAP[k] for k in straps_amd.config.H36M_TO_J14]
+    pv = O.point_metrics(verts.numpy(), batch['verts'].cpu().numpy()).sum(0) / (B * 6890)
+    pj = O.point_metrics(joints[:, j14].numpy(), batch['joints3d'].cpu().numpy()).sum(0) / (B * 14)
+    pt = O.point_metrics(reposed.numpy(), batch['reposed'].cpu().numpy()).sum(0) / (B * 6890)
+    want = {'pves': pv[0], 'pves_sc': pv[1], 'pves_pa': pv[2], 'pve-ts': pt[0], 'pve-ts_sc': pt[1], 'mpjpes': pj[0], 'mpjpes_sc': pj[1],
+            'mpjpes_pa': pj[2]}
+    for k, v in want.items():
+        assert got[k] == pytest.approx(float(v), rel=2e-4), k
+    assert got['shape_mses'] > 0 and got['pose_mses'] > 0 and got['joints2D_l2es'] > 0
+    # graph replay accumulates too
+    dev, reg, smpl, crit = _setup(B, seed=3)
+    tg = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], track_metrics=True, use_graph=True)
+    for _ in range(5):
+        tg.step()
+    s5 = tg.metrics_summary()
+    assert tg.graph is not None and all(np.isfinite(list(s5.values()))) and s5['pves'] > 0
