@@ -171,7 +171,10 @@ def main():
         workload = 'configs[2]: full synthetic OTF training step (augmentation + proxy construction + forward + multi-task loss ' \
                    '+ backward + Adam), %s, 18x256x256 proxy' % net
         dominant = 'conv_igemm_kernel'
-        par = 'data parallel: bodies sharded over %d rank(s), replicated weights, one RCCL all-reduce of the flat fp32 gradient per step' % world
+        par = 'data parallel: bodies sharded over %d rank(s), replicated weights, one RCCL sum all-reduce of the flat fp32 gradient per step' % world
+        if ts.comm_overlap:
+            par += ' in two buckets (layer3.. = %.0f %% of the bytes starts while backward runs through layer2/layer1/stem)' % (
+                100.0 * (1.0 - ts.exchange.split_off / ts.flat_g.numel()))
     elif args.workload == 'fwd':
         torch.manual_seed(1234)
         reg = straps_amd.SingleInputRegressor(18, args.layers, 3, mean_params=mp).to(dev).eval()

@@ -104,9 +104,11 @@ def _conv_dgrad(L, net, rec, draw, addend):
     return dx
 
 
-def encoder_backward(net, tape, dfeat, views=None, side_stream=None):
+def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer3=None):
     """tape: dict filled by encoder_forward(net, x, tape) in training mode.  Returns {param: grad}.
-    side_stream: optional second torch stream for the weight-gradient kernels (joined before returning)."""
+    side_stream: optional second torch stream for the weight-gradient kernels (joined before returning).
+    after_layer3: optional callback run once the gradients of layer4 and layer3 (78 % / 94 % of resnet18 / 50's parameters)
+    are final on the current stream -- the training step starts their all-reduce there (and switches hipGraphs)."""
     L = hipabi.lib()
     grads = GradSink(views)
     side = _SideStream(side_stream)
@@ -133,6 +135,9 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None):
                 draw, _ = _bn_bwd(L, rec, dt, True, False, grads)
                 side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads), draw)
             dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip)   # + skip gradient fused in the epilogue
+        if li == 3 and after_layer3 is not None:
+            side.join()
+            after_layer3()
     rec = tape['maxpool']
     B, H, W, Cc, Hp, Wp = rec['geom']
     dstem = _empty_like(rec['x'])

@@ -54,10 +54,37 @@ def allreduce_gradients(flat_g, world_size, group=None):
     return 1.0 / world_size
 
 
+class GradientExchange:
+    """The step's gradient exchange: a sum all-reduce of the flat fp32 gradient buffer (RCCL over xGMI on GPUs, gloo in the
+    CPU tests), in two buckets so that it overlaps the backward pass.  `start_tail()` is called as soon as the tail of
+    the buffer (layer3, layer4, IEF, loss weights: the bulk of the bytes, and the FIRST gradients backward finishes) is
+    final and launches its all-reduce asynchronously; `finish()` waits for it, reduces the head (stem, layer1, layer2)
+    and returns the 1/world_size the Adam kernel folds in.  split_off = 0 degenerates to one bucket."""
+
+    def __init__(self, flat_g, split_off, world_size, group=None):
+        self.flat_g, self.split_off, self.world, self.group = flat_g, int(split_off), world_size, group
+        self._work = None
+
+    def start_tail(self):
+        if self.world > 1 and self._work is None:
+            import torch.distributed as dist
+            self._work = dist.all_reduce(self.flat_g[self.split_off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            self.start_tail()                      # (no-op when the caller already started it)
+            self._work.wait()
+            self._work = None
+            if self.split_off > 0:
+                dist.all_reduce(self.flat_g[:self.split_off], op=dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / self.world
+
+
 class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
                  mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=True,
-                 renderer=None, track_metrics=False):
+                 renderer=None, track_metrics=False, comm_overlap=None):
         """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
         launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches."""
         p0 = next(regressor.parameters())
@@ -71,13 +98,26 @@ class TrainStep:
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.steps = 0
         self.n_reg = sum(p.numel() for p in regressor.parameters())
+        # gradient exchange in two buckets: everything from layer3 on is reduced while backward still runs through layer2,
+        # layer1 and the stem (comm_overlap: default on when there is someone to talk to; STRAPS_NO_COMM_OVERLAP=1 turns it off)
+        if comm_overlap is None:
+            import os
+            comm_overlap = world_size > 1 and os.environ.get('STRAPS_NO_COMM_OVERLAP', '0') != '1'
+        self.comm_overlap = bool(comm_overlap)
+        split_off, off = 0, 0
+        for n_, p_ in regressor.named_parameters():
+            if n_.startswith('image_encoder.layer3.'):
+                split_off = off
+                break
+            off += p_.numel()
+        self.exchange = GradientExchange(self.flat_g, split_off if self.comm_overlap else 0, world_size, group)
         self.logvar_params = [getattr(criterion, n + '_log_var') for n in TASKS]
         # random draws come from torch's default device generator (graph-capture safe), seeded per rank
         with torch.cuda.device(self.dev):
             torch.cuda.manual_seed(seed + rank)
         self.gen = None
         self.step_t = torch.zeros(1, dtype=torch.int32, device=self.dev)     # Adam step count, lives on the device
-        self.use_graph, self.graph, self._warm, self._g_loss = use_graph, None, 0, None
+        self.use_graph, self.graph, self.graph_tail, self._warm, self._g_loss = use_graph, None, None, 0, None
         self.side_stream = torch.cuda.Stream(device=self.dev) if overlap_wgrad else None
         d = self.dev
         self.mean_shape = torch.zeros(10, device=d) if mean_shape is None else torch.as_tensor(mean_shape, dtype=torch.float32, device=d)
@@ -159,7 +199,7 @@ class TrainStep:
         return dict(input=x, verts=tgt_verts, joints2d=tgt_j2d, joints3d=tgt_j3d, shape=tgt_shape, rot=tgt_rot, reposed=tgt_reposed)
 
     # ------------------------------------------------------------------ forward + loss + backward
-    def forward_backward(self, batch):
+    def forward_backward(self, batch, after_layer3=None):
         L, st, d, B = hipabi.lib(), hipabi.stream_ptr(), self.dev, self.B
         reg, smpl = self.reg, self.smpl
         assert reg.training, 'TrainStep needs the regressor in .train() mode'
@@ -201,10 +241,10 @@ class TrainStep:
                      'straps_rot6d_bwd')
         # regressor backward, gradients land in the flat buffer
         dfeat, _ = ief_backward(reg.ief_module, feat, ief_tape, dest, self.gviews)
-        encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews, self.side_stream)
-        for k, p in enumerate(self.logvar_params):
+        for k, p in enumerate(self.logvar_params):            # (they sit at the very end of the flat buffer: part of the tail bucket)
             if p.requires_grad:
                 self.gviews[p].copy_(dlv[k])
+        encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews, self.side_stream, after_layer3)
         self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed)
         if self.metrics is not None:
             from .cam_utils import orthographic_project_torch
@@ -224,7 +264,7 @@ class TrainStep:
         return self.metrics.summary()
 
     def optimise(self):
-        gscale = allreduce_gradients(self.flat_g, self.world, self.group)
+        gscale = self.exchange.finish()
         self.steps += 1
         self.step_t.add_(1)
         hipabi.check(hipabi.lib().straps_adam_step(hipabi.ptr(self.flat_p), hipabi.ptr(self.flat_g), hipabi.ptr(self.exp_avg),
@@ -237,31 +277,65 @@ class TrainStep:
     def step(self):
         """one full training step; returns the 12-float loss record (device tensor, no sync)."""
         with torch.no_grad():
+            start_tail = self.exchange.start_tail if self.comm_overlap else None
             if not self.use_graph or self._warm < 2:
                 self._warm += 1
                 batch = self.make_batch()
-                loss = self.forward_backward(batch)
+                loss = self.forward_backward(batch, start_tail)
                 self.optimise()
                 return loss
             if self.graph is None:
-                # capture with empty weight caches so the repacking kernels are part of the graph.  thread_local error
-                # mode: other threads (e.g. the RCCL watchdog) may touch the HIP runtime while this thread captures.
-                torch.cuda.synchronize()
-                try:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                        batch = self.make_batch()
-                        self._g_loss = self.forward_backward(batch)
-                    self.graph = g
-                except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, never to another path
-                    import warnings
-                    warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager launches' % (e,))
-                    self.use_graph = False
-                    torch.cuda.synchronize()
+                self._capture()
+                if not self.use_graph:
                     return self.step()
             self.graph.replay()
+            if self.graph_tail is not None:
+                self.exchange.start_tail()       # layer3.. gradients are final: their all-reduce runs under the rest of backward
+                self.graph_tail.replay()
             self.optimise()
             return self._g_loss
+
+    def _capture(self):
+        """capture data generation + forward + loss + backward in one hipGraph -- or, with comm_overlap, in two (split
+        where the tail bucket's gradients are final) that share a memory pool.  Captured with empty weight caches so the
+        repacking kernels are part of the graph; thread_local error mode: other threads (e.g. the RCCL watchdog) may
+        touch the HIP runtime while this thread captures.  Any failure falls back to eager launches of the same kernels."""
+        torch.cuda.synchronize()
+        self.graph_tail = None
+        try:
+            if not self.comm_overlap:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    batch = self.make_batch()
+                    self._g_loss = self.forward_backward(batch)
+                self.graph = g
+                return
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream(device=self.dev)
+            s.wait_stream(torch.cuda.current_stream())
+            state = {'second': False}
+
+            def switch():
+                g1.capture_end()
+                g2.capture_begin(pool=g1.pool(), capture_error_mode='thread_local')
+                state['second'] = True
+
+            with torch.cuda.stream(s):
+                g1.capture_begin(capture_error_mode='thread_local')
+                try:
+                    batch = self.make_batch()
+                    self._g_loss = self.forward_backward(batch, switch)
+                finally:
+                    (g2 if state['second'] else g1).capture_end()
+            torch.cuda.current_stream().wait_stream(s)
+            if not state['second']:
+                raise RuntimeError('the backward pass never reached the split point')
+            self.graph, self.graph_tail = g1, g2
+        except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, never to another path
+            import warnings
+            warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager launches' % (e,))
+            self.use_graph, self.graph, self.graph_tail = False, None, None
+            torch.cuda.synchronize()
 
     def state_dict(self):
         """optimiser state in torch.optim.Adam's schema (checkpoint key 'optimiser_state_dict')."""

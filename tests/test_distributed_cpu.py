@@ -17,7 +17,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import straps_amd
-    from straps_amd.train_step import allreduce_gradients, flatten_parameters
+    from straps_amd.train_step import GradientExchange, allreduce_gradients, flatten_parameters
     import straps_oracle as O
     torch.manual_seed(1234)                                     # replicated initial weights
     reg = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=straps_amd.synthetic_mean_params(0))
@@ -34,6 +34,17 @@ def _worker(rank, world, port, q):
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     assert torch.allclose(flat_g, sum(gathered), rtol=0, atol=1e-6)
+    # the two-bucket exchange the GPU step uses (tail started asynchronously mid-backward, head at the end) gives the same sums
+    names = [n for n, _ in reg.named_parameters()]
+    split = sum(p.numel() for n, p in zip(names, params) if not n.startswith(('image_encoder.layer3', 'image_encoder.layer4', 'ief_module')))
+    assert 0 < split < flat_g.numel()
+    for off in (split, 0):
+        flat_g.copy_(local)
+        ex = GradientExchange(flat_g, off, world)
+        ex.start_tail()
+        flat_g[:max(off, 1)].mul_(1.0)                          # (the rest of backward keeps writing the head meanwhile)
+        assert ex.finish() == 1.0 / world
+        assert torch.allclose(flat_g, sum(gathered), rtol=0, atol=1e-6)
     m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
     O.adam_step([flat_p], [flat_g * scale], [m], [v], 1)
     digest = torch.stack([flat_p.double().sum(), flat_p.double().abs().sum(), reg.image_encoder.conv1.weight.double().sum()])

@@ -16,12 +16,13 @@ W = {'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'jo
 LOSSES = ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D']
 
 
-def _train(use_graph, steps, overlap=True):
+def _train(use_graph, steps, overlap=True, comm_overlap=False):
     torch.manual_seed(7)
     reg = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP).to(DEV).train()
     smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=64).to(DEV)
     crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(LOSSES, init_loss_weights=W, reduction='mean').to(DEV)
-    ts = TrainStep(reg, smpl, crit, 64, lr=1e-4, seed=99, mean_shape=MP['shape'], use_graph=use_graph, overlap_wgrad=overlap)
+    ts = TrainStep(reg, smpl, crit, 64, lr=1e-4, seed=99, mean_shape=MP['shape'], use_graph=use_graph, overlap_wgrad=overlap,
+                   comm_overlap=comm_overlap)
     losses = [ts.step().clone() for _ in range(steps)]
     torch.cuda.synchronize()
     return torch.stack(losses).cpu(), ts.flat_p.clone().cpu(), reg.image_encoder.bn1.running_var.clone().cpu(), ts
@@ -38,6 +39,14 @@ def test_train_step_b64_deterministic_and_graph_equals_eager():
     assert torch.equal(l_graph, l_again) and torch.equal(p_graph, p_again)
     assert torch.equal(l_graph, l_eager) and torch.equal(p_graph, p_eager) and torch.equal(rv_graph, rv_eager)
     assert int(ts.reg.image_encoder.layer4[1].bn2.num_batches_tracked) == 5
+    # the multi-GPU capture (two hipGraphs split where the layer3.. gradients are final, the all-reduce of that bucket starts
+    # in between) runs the same kernels: identical results on one GPU, where the exchange itself is a no-op
+    l_split, p_split, rv_split, ts2 = _train(True, 5, comm_overlap=True)
+    assert ts2.graph is not None and ts2.graph_tail is not None, 'split capture fell back'
+    assert ts2.exchange.split_off > 0
+    assert torch.equal(l_graph, l_split) and torch.equal(p_graph, p_split) and torch.equal(rv_graph, rv_split)
+    l_se, p_se, _, _ = _train(False, 5, comm_overlap=True)
+    assert torch.equal(l_graph, l_se) and torch.equal(p_graph, p_se)
 
 
 def test_smpl_bench_size_slices_are_batch_independent():
