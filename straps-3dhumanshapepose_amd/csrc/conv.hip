@@ -29,18 +29,29 @@ struct ConvP {
     float* y;
     float* stats;
     int H, W, Cin, Cout, relu;      // source tensor [B][H][W][Cin]
-    int Mh, Mw;                     // logical output grid enumerated by M = B*Mh*Mw
     int stride;                     // source pixel of logical (ho,wo) before the tap offset: (ho*stride, wo*stride)
-    int OH, OW, omul, oah, oaw;     // physical output pixel = (b, ho*omul + oah, wo*omul + oaw) in [B][OH][OW][Cout]
-    int M, MT, NT;
-    int ntaps, wtaps;               // taps used / taps stored per output channel in w
-    int tap_w[9], tap_dh[9], tap_dw[9];
+    int OH, OW, omul;               // physical output pixel = (b, ho*omul + oah, wo*omul + oaw) in [B][OH][OW][Cout]
+    int NT, wtaps;                  // N tiles; taps stored per output channel in w
+    // Up to four independent sub-problems per launch (blockIdx.y): the output-parity classes of a stride-2 data gradient
+    // are GEMMs over a quarter of the pixels each with their own tap subset -- launched together they fill the chip
+    // instead of queueing as four small grids.  A forward conv / stride-1 gradient is the single class 0.
+    struct Class {
+        int Mh, Mw;                 // logical output grid enumerated by M = B*Mh*Mw
+        int M, MT;
+        int oah, oaw;
+        int ntaps;                  // taps used
+        int tap_w[9], tap_dh[9], tap_dw[9];
+    } cls[4];
+    int ncls;
 };
 
 constexpr int LS = 36;   // LDS row stride in floats (32 data + 4 pad)
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+    const ConvP::Class& c = p.cls[blockIdx.y];
+    const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, coah = c.oah, coaw = c.oaw, cntaps = c.ntaps;
+    if ((int)blockIdx.x >= cMT * p.NT) return;                 // a smaller class of the same launch
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 32, NI = WTN / 32;
     constexpr int AP = BM / 32, BP = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -49,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(blockIdx.x, cMT * p.NT);
     const int nt = bid % p.NT, mt = bid / p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
     const int lr = tid >> 3, lc = tid & 7;
@@ -57,14 +68,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     // per-thread im2col row descriptors (AP rows of the A tile)
     int a_hi0[AP], a_wi0[AP];
     long long a_base[AP];
-    const int MhMw = p.Mh * p.Mw;
+    const int MhMw = cMh * cMw;
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
         const int m = m0 + lr + 32 * q;
-        if (m < p.M) {
+        if (m < cM) {
             const int b = m / MhMw;
             const int rem = m - b * MhMw;
-            const int ho = rem / p.Mw, wo = rem - ho * p.Mw;
+            const int ho = rem / cMw, wo = rem - ho * cMw;
             a_hi0[q] = ho * p.stride;
             a_wi0[q] = wo * p.stride;
             a_base[q] = (long long)b * p.H * p.W * p.Cin + lc * 4;
@@ -79,13 +90,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     for (int q = 0; q < BP; ++q) wrow[q] = p.w + (long long)(n0 + lr + 32 * q) * p.wtaps * p.Cin + lc * 4;
 
     const int cchunks = p.Cin >> 5;
-    const int nchunks = p.ntaps * cchunks;
+    const int nchunks = cntaps * cchunks;
 
     f32x4 ra[AP], rb[BP];
     auto load_tile = [&](int q) {
         const int tap = q / cchunks;
         const int c0 = (q - tap * cchunks) << 5;
-        const int dh = p.tap_dh[tap], dw = p.tap_dw[tap], tw = p.tap_w[tap];
+        const int dh = c.tap_dh[tap], dw = c.tap_dw[tap], tw = c.tap_w[tap];
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
 
     // ---------------- epilogue ----------------
-    const bool remap = p.omul != 1 || p.oah != 0 || p.oaw != 0 || p.OH != p.Mh || p.OW != p.Mw;
+    const bool remap = p.omul != 1 || coah != 0 || coaw != 0 || p.OH != cMh || p.OW != cMw;
     float s1[NI], s2[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WTM + i * 32 + mfma_row(r, lane);
-                if (m < p.M) {
+                if (m < cM) {
                     float v = acc[i][j][r];
                     t1 += v;
                     t2 = fmaf(v, v, t2);
@@ -164,8 +175,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
                     if (remap) {
                         const int b = m / MhMw;
                         const int rem = m - b * MhMw;
-                        const int ho = rem / p.Mw, wo = rem - ho * p.Mw;
-                        pix = ((long long)b * p.OH + ho * p.omul + p.oah) * p.OW + wo * p.omul + p.oaw;
+                        const int ho = rem / cMw, wo = rem - ho * cMw;
+                        pix = ((long long)b * p.OH + ho * p.omul + coah) * p.OW + wo * p.omul + coaw;
                     }
                     const long long o = pix * p.Cout + n;
                     if (p.scale) v = fmaf(v, sc, sh);
@@ -217,8 +228,12 @@ inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn
 template <int BM, int BN>
 int launch(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
-    p.MT = (p.M + BM - 1) / BM;
     p.NT = p.Cout / BN;
+    int maxblk = 0;
+    for (int i = 0; i < p.ncls; ++i) {
+        p.cls[i].MT = (p.cls[i].M + BM - 1) / BM;
+        if (p.cls[i].MT * p.NT > maxblk) maxblk = p.cls[i].MT * p.NT;
+    }
     const size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -226,14 +241,20 @@ int launch(const ConvP& p0, hipStream_t st) {
         if (e != hipSuccess) { straps_set_error("conv_igemm_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3(p.MT * p.NT), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3(maxblk, p.ncls), dim3(256), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_kernel");
     return STRAPS_OK;
 }
 
+// all classes of one launch share the tile choice (made for their total size)
 int dispatch(const ConvP& p, int tile_cfg, hipStream_t st) {
-    int bm, bn;
-    pick_tile(tile_cfg, p.M, p.Cout, p.ntaps * p.Cin, bm, bn);
+    int bm, bn, kdim = 0;
+    long long M = 0;
+    for (int i = 0; i < p.ncls; ++i) {
+        M += p.cls[i].M;
+        if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
+    }
+    pick_tile(tile_cfg, M, p.Cout, kdim, bm, bn);
     if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
     if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
     return launch<64, 64>(p, st);
@@ -259,15 +280,17 @@ extern "C" int straps_conv_fwd(const float* x, const float* w, const float* scal
     ConvP p;
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
-    p.Mh = (h + 2 * pad - kh) / stride + 1;
-    p.Mw = (wdt + 2 * pad - kw) / stride + 1;
-    p.OH = p.Mh; p.OW = p.Mw; p.omul = 1; p.oah = 0; p.oaw = 0;
-    p.ntaps = p.wtaps = kh * kw;
+    ConvP::Class& c = p.cls[0];
+    p.ncls = 1;
+    c.Mh = (h + 2 * pad - kh) / stride + 1;
+    c.Mw = (wdt + 2 * pad - kw) / stride + 1;
+    p.OH = c.Mh; p.OW = c.Mw; p.omul = 1; c.oah = 0; c.oaw = 0;
+    c.ntaps = p.wtaps = kh * kw;
     for (int r = 0; r < kh; ++r)
-        for (int s = 0; s < kw; ++s) { p.tap_w[r * kw + s] = r * kw + s; p.tap_dh[r * kw + s] = r - pad; p.tap_dw[r * kw + s] = s - pad; }
-    const long long M = (long long)batch * p.Mh * p.Mw;
+        for (int s = 0; s < kw; ++s) { c.tap_w[r * kw + s] = r * kw + s; c.tap_dh[r * kw + s] = r - pad; c.tap_dw[r * kw + s] = s - pad; }
+    const long long M = (long long)batch * c.Mh * c.Mw;
     STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_fwd: problem too large");
-    p.M = (int)M;
+    c.M = (int)M;
     return dispatch(p, tile_cfg, (hipStream_t)stream);
 }
 
@@ -289,34 +312,36 @@ extern "C" int straps_conv_dgrad(const float* dy, const float* w_crsk, const flo
     p.x = dy; p.w = w_crsk; p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
+    p.omul = stride;
+    p.ncls = 0;
     for (int ph = 0; ph < stride; ++ph) {
         for (int pw = 0; pw < stride; ++pw) {
-            p.Mh = (h - ph + stride - 1) / stride;
-            p.Mw = (wdt - pw + stride - 1) / stride;
-            if (p.Mh <= 0 || p.Mw <= 0) continue;
-            p.omul = stride; p.oah = ph; p.oaw = pw;
-            p.ntaps = 0;
+            ConvP::Class& c = p.cls[p.ncls];
+            c.Mh = (h - ph + stride - 1) / stride;
+            c.Mw = (wdt - pw + stride - 1) / stride;
+            if (c.Mh <= 0 || c.Mw <= 0) continue;
+            c.oah = ph; c.oaw = pw;
+            c.ntaps = 0;
             for (int r = 0; r < kh; ++r) {
                 const int nh = ph - padh + r;                 // source row numerator of logical row 0
                 if (((nh % stride) + stride) % stride) continue;
                 for (int s = 0; s < kw; ++s) {
                     const int nw = pw - padw + s;
                     if (((nw % stride) + stride) % stride) continue;
-                    p.tap_w[p.ntaps] = r * kw + s;
-                    p.tap_dh[p.ntaps] = (nh - (((nh % stride) + stride) % stride)) / stride;   // exact: nh divisible
-                    p.tap_dw[p.ntaps] = (nw - (((nw % stride) + stride) % stride)) / stride;
+                    c.tap_w[c.ntaps] = r * kw + s;
+                    c.tap_dh[c.ntaps] = (nh - (((nh % stride) + stride) % stride)) / stride;   // exact: nh divisible
+                    c.tap_dw[c.ntaps] = (nw - (((nw % stride) + stride) % stride)) / stride;
                     // floor division for negative numerators
-                    if (nh < 0) p.tap_dh[p.ntaps] = -((-nh) / stride);
-                    if (nw < 0) p.tap_dw[p.ntaps] = -((-nw) / stride);
-                    ++p.ntaps;
+                    if (nh < 0) c.tap_dh[c.ntaps] = -((-nh) / stride);
+                    if (nw < 0) c.tap_dw[c.ntaps] = -((-nw) / stride);
+                    ++c.ntaps;
                 }
             }
-            const long long M = (long long)batch * p.Mh * p.Mw;
+            const long long M = (long long)batch * c.Mh * c.Mw;
             STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_dgrad: problem too large");
-            p.M = (int)M;
-            const int rc = dispatch(p, tile_cfg, st);
-            if (rc != STRAPS_OK) return rc;
+            c.M = (int)M;
+            ++p.ncls;
         }
     }
-    return STRAPS_OK;
+    return p.ncls ? dispatch(p, tile_cfg, st) : STRAPS_OK;
 }
