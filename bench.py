@@ -140,13 +140,21 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the hot path has no CPU fallback)'
+    # (validation hooks, unset in normal use: STRAPS_FORCE_DEVICE puts every rank on one GPU and STRAPS_DIST_BACKEND=gloo lets
+    #  the N > 1 control flow -- split hipGraph capture, two-bucket exchange -- be exercised on a single-GPU box)
+    if os.environ.get('STRAPS_FORCE_DEVICE') is not None:
+        local_rank = int(os.environ['STRAPS_FORCE_DEVICE'])
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)          # nccl == RCCL on ROCm
+        backend = os.environ.get('STRAPS_DIST_BACKEND', 'nccl')  # nccl == RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     hipabi.load()
 
