@@ -169,9 +169,6 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_kernel(straps_smpl_model_t
     const float* Ab = As_ + bl * AS;
     const float* frow = Fs + bl * FS + 4 * h;
 
-#ifdef SMPL_STAGGER
-    if (wave >= 4) { for (int i = 0; i < SMPL_STAGGER; ++i) __builtin_amdgcn_s_sleep(127); }
-#endif
     for (int rd = round0; rd < round1; ++rd) {
         const int tile = rd * NW + wave;
         // skinning weights / joint offsets of this tile's 32 vertices -> LDS now, so their L2 latency hides under the
