@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const int lr = tid >> 3, lc = tid & 7;
 
     // per-thread im2col row descriptors (AP rows of the A tile)
+    // (32-bit element offsets: 64-bit integer multiplies in the per-chunk address math cost the kernel ~8 % -- the VALU
+    //  work of the loads competes with the MFMA issue; the launcher checks that the tensors stay below 2^31 elements)
     int a_hi0[AP], a_wi0[AP];
-    long long a_base[AP];
+    int a_base[AP];
     const int MhMw = cMh * cMw;
 #pragma unroll
     for (int q = 0; q < AP; ++q) {
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
             const int ho = rem / cMw, wo = rem - ho * cMw;
             a_hi0[q] = ho * p.stride;
             a_wi0[q] = wo * p.stride;
-            a_base[q] = (long long)b * p.H * p.W * p.Cin + lc * 4;
+            a_base[q] = ((b * p.H + a_hi0[q]) * p.W + a_wi0[q]) * p.Cin + lc * 4;   // element offset of the tap-(0,0) source pixel
         } else {
             a_hi0[q] = -(1 << 28);
             a_wi0[q] = 0;
@@ -97,16 +99,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         const int tap = q / cchunks;
         const int c0 = (q - tap * cchunks) << 5;
         const int dh = c.tap_dh[tap], dw = c.tap_dw[tap], tw = c.tap_w[tap];
+        const int toff = (dh * p.W + dw) * p.Cin + c0;            // wave-uniform: the per-lane part is one add
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + a_base[i] + ((long long)hi * p.W + wi) * p.Cin + c0);
+            if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (a_base[i] + toff));
             ra[i] = v;
         }
+        const int woff = tw * p.Cin + c0;                       // wave-uniform
 #pragma unroll
-        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (long long)tw * p.Cin + c0);
+        for (int i = 0; i < BP; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + woff);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -293,7 +297,8 @@ extern "C" int straps_conv_fwd(const float* x, const float* w, const float* scal
     for (int r = 0; r < kh; ++r)
         for (int s = 0; s < kw; ++s) { c.tap_w[r * kw + s] = r * kw + s; c.tap_dh[r * kw + s] = r - pad; c.tap_dw[r * kw + s] = s - pad; }
     const long long M = (long long)batch * c.Mh * c.Mw;
-    STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_fwd: problem too large");
+    STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 31) && M * cout < (1LL << 31),
+                   "straps_conv_fwd: tensors must stay below 2^31 elements (32-bit offsets)");
     c.M = (int)M;
     return dispatch(p, tile_cfg, (hipStream_t)stream);
 }
@@ -342,7 +347,8 @@ extern "C" int straps_conv_dgrad(const float* dy, const float* w_crsk, const flo
                 }
             }
             const long long M = (long long)batch * c.Mh * c.Mw;
-            STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_dgrad: problem too large");
+            STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * ho * wo * cout < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 31),
+                           "straps_conv_dgrad: tensors must stay below 2^31 elements (32-bit offsets)");
             c.M = (int)M;
             ++p.ncls;
         }
