@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 
     const int lr = tid >> 4, lc = tid & 15;   // 16 rows x 16 float4 per pass, 2 passes
     const int HoWo = p.Ho * p.Wo;
+    const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
     f32x4 rd[2], rx[2];
     auto load_tile = [&](int st) {
 #pragma unroll
@@ -52,12 +53,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
             f32x4 vd = {0.f, 0.f, 0.f, 0.f}, vx = vd;
             if (m < mend) {
                 vd = *reinterpret_cast<const f32x4*>(p.dy + (long long)m * p.Cout + co0 + lc * 4);
-                const int b = m / HoWo;
-                const int rem = m - b * HoWo;
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
-                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    vx = *reinterpret_cast<const f32x4*>(p.x + (((long long)b * p.H + hi) * p.W + wi) * p.Cin + ci0 + lc * 4);
+                if (pointwise) {                               // 1x1 / stride 1: the source pixel IS the output pixel (no index math)
+                    vx = *reinterpret_cast<const f32x4*>(p.x + (long long)m * p.Cin + ci0 + lc * 4);
+                } else {
+                    const int b = m / HoWo;
+                    const int rem = m - b * HoWo;
+                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        vx = *reinterpret_cast<const f32x4*>(p.x + (((long long)b * p.H + hi) * p.W + wi) * p.Cin + ci0 + lc * 4);
+                }
             }
             rd[q] = vd;
             rx[q] = vx;
