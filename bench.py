@@ -248,6 +248,7 @@ def main():
         if args.workload == 'train':
             ts.use_graph = False
             ts.side_stream = None          # one stream: kernels run back to back, so each event pair times ONE kernel alone
+            ts.pipeline = False            # (and no next-batch generation running beside the timed kernels)
         step()
         torch.cuda.synchronize()
         timer.on = True
@@ -297,7 +298,8 @@ def main():
                'roofline': roof, 'kernels': others, 'cpu_baseline': cpu}
         if args.workload == 'train':
             out['final_loss'] = round(float(ts.last['loss'][0]), 5)
-            out['launch_mode'] = 'hipGraph replay of data-gen + forward + loss + backward (all-reduce and Adam eager)' if graph_mode else 'eager'
+            out['launch_mode'] = ('hipGraph replay of data-gen (next batch, second stream) + forward + loss + backward (all-reduce and Adam eager)'
+                                  if graph_mode else 'eager')
         else:
             out['launch_mode'] = 'hipGraph replay of the whole forward' if graph_mode else 'eager'
         if args.workload != 'smpl':

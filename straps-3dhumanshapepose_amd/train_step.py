@@ -84,7 +84,7 @@ class GradientExchange:
 class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
                  mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=True,
-                 renderer=None, track_metrics=False, comm_overlap=None):
+                 renderer=None, track_metrics=False, comm_overlap=None, pipeline_data=True):
         """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
         launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches."""
         p0 = next(regressor.parameters())
@@ -157,9 +157,22 @@ class TrainStep:
             pose_pool[:, 1] = (torch.rand(4096, generator=g) * 2 - 1) * np.pi * 0.5       # global orientation about y
         self.pose_pool = pose_pool.to(d)
         self.last = {}
+        # data pipeline: the batch of step t+1 (two SMPL forwards, rasteriser, crop, augmentation, proxy construction: ~0.8 ms of
+        # small latency-bound kernels) is generated on a second stream WHILE step t runs its MFMA-bound forward / backward, into
+        # the other of two resident buffer sets.  The random draws happen in the same order as without the pipeline, so the
+        # results are bit-identical.
+        self.pipeline = bool(pipeline_data)
+        self.data_stream = torch.cuda.Stream(device=d) if self.pipeline else None
+        B_ = batch_size
+        self._bufs = [dict(input=torch.empty(B_, 18, 256, 256, device=d), verts=torch.empty(B_, 6890, 3, device=d),
+                           joints2d=torch.empty(B_, 17, 2, device=d), joints3d=torch.empty(B_, 14, 3, device=d),
+                           shape=torch.empty(B_, 10, device=d), rot=torch.empty(B_, 24, 3, 3, device=d),
+                           reposed=torch.empty(B_, 6890, 3, device=d)) for _ in range(2)] if self.pipeline else None
+        self._cur, self._primed = 0, False
 
     # ------------------------------------------------------------------ data generation (no grad)
-    def make_batch(self):
+    def make_batch(self, out=None):
+        """one synthetic batch; out: optional dict of resident buffers to fill instead of fresh tensors (the data pipeline)."""
         L, st, d, B = hipabi.lib(), hipabi.stream_ptr(), self.dev, self.B
         from .rigid_transform_utils import batch_rodrigues
         idx = torch.randint(0, self.pose_pool.shape[0], (B,), device=d, generator=self.gen)
@@ -194,9 +207,15 @@ class TrainStep:
                      'straps_augment_seg')
         j2d_in = tgt_j2d + (torch.rand(B, 17, 2, device=d, generator=self.gen) * 16.0 - 8.0)
         # G4 + G5
-        x = torch.empty(B, 18, 256, 256, device=d)
+        x = torch.empty(B, 18, 256, 256, device=d) if out is None else out['input']
         hipabi.check(L.straps_build_proxy_input(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), B, 17, 256, st), 'straps_build_proxy_input')
-        return dict(input=x, verts=tgt_verts, joints2d=tgt_j2d, joints3d=tgt_j3d, shape=tgt_shape, rot=tgt_rot, reposed=tgt_reposed)
+        batch = dict(input=x, verts=tgt_verts, joints2d=tgt_j2d, joints3d=tgt_j3d, shape=tgt_shape, rot=tgt_rot, reposed=tgt_reposed)
+        if out is None:
+            return batch
+        for k, v in batch.items():
+            if k != 'input':
+                out[k].copy_(v)
+        return out
 
     # ------------------------------------------------------------------ forward + loss + backward
     def forward_backward(self, batch, after_layer3=None):
@@ -274,63 +293,112 @@ class TrainStep:
         self.reg.image_encoder._cache.clear()
         self.reg.ief_module._cache = {}
 
+    def _run(self, after_layer3):
+        """forward + backward of the current batch on the current stream; with the data pipeline the next batch is generated
+        meanwhile on the data stream (joined before `after_layer3` -- where a split capture ends its first graph -- and at the
+        end).  Used for eager launches and, unchanged, under hipGraph capture."""
+        if not self.pipeline:
+            return self.forward_backward(self.make_batch(), after_layer3)
+        if not self._primed:                                   # very first step: there is no batch in flight yet
+            self.make_batch(out=self._bufs[self._cur])
+            self._primed = True
+        cur, nxt = self._bufs[self._cur], self._bufs[1 - self._cur]
+        main, side = torch.cuda.current_stream(), self.data_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.make_batch(out=nxt)
+        state = {'joined': False}
+
+        def join():
+            if not state['joined']:
+                main.wait_stream(side)
+                state['joined'] = True
+
+        def hook():
+            join()
+            after_layer3()
+
+        loss = self.forward_backward(cur, hook if after_layer3 is not None else None)
+        join()
+        return loss
+
     def step(self):
         """one full training step; returns the 12-float loss record (device tensor, no sync)."""
         with torch.no_grad():
             start_tail = self.exchange.start_tail if self.comm_overlap else None
             if not self.use_graph or self._warm < 2:
                 self._warm += 1
-                batch = self.make_batch()
-                loss = self.forward_backward(batch, start_tail)
+                loss = self._run(start_tail)
+                self._cur ^= 1
                 self.optimise()
                 return loss
             if self.graph is None:
                 self._capture()
                 if not self.use_graph:
                     return self.step()
-            self.graph.replay()
-            if self.graph_tail is not None:
+            g1, g2, loss = self.graph[self._cur if self.pipeline else 0]
+            g1.replay()
+            if g2 is not None:
                 self.exchange.start_tail()       # layer3.. gradients are final: their all-reduce runs under the rest of backward
-                self.graph_tail.replay()
+                g2.replay()
+            self._cur ^= 1
             self.optimise()
-            return self._g_loss
+            return loss
+
+    def _capture_one(self):
+        """one step as a hipGraph (or two, split where the tail bucket's gradients are final, sharing a memory pool)."""
+        if not self.comm_overlap:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._pool, capture_error_mode='thread_local'):
+                loss = self._run(None)
+            if self._pool is None:
+                self._pool = g.pool()
+            return g, None, loss
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream())
+        state = {'second': False}
+
+        def switch():
+            g1.capture_end()
+            if self._pool is None:
+                self._pool = g1.pool()
+            g2.capture_begin(pool=self._pool, capture_error_mode='thread_local')
+            state['second'] = True
+
+        with torch.cuda.stream(s):
+            if self._pool is None:
+                g1.capture_begin(capture_error_mode='thread_local')
+            else:
+                g1.capture_begin(pool=self._pool, capture_error_mode='thread_local')
+            try:
+                loss = self._run(switch)
+            finally:
+                (g2 if state['second'] else g1).capture_end()
+        torch.cuda.current_stream().wait_stream(s)
+        if not state['second']:
+            raise RuntimeError('the backward pass never reached the split point')
+        return g1, g2, loss
 
     def _capture(self):
-        """capture data generation + forward + loss + backward in one hipGraph -- or, with comm_overlap, in two (split
-        where the tail bucket's gradients are final) that share a memory pool.  Captured with empty weight caches so the
-        repacking kernels are part of the graph; thread_local error mode: other threads (e.g. the RCCL watchdog) may
-        touch the HIP runtime while this thread captures.  Any failure falls back to eager launches of the same kernels."""
+        """capture data generation + forward + loss + backward as hipGraphs: one per buffer parity of the data pipeline, each
+        split in two with comm_overlap.  Captured with empty weight caches so the repacking kernels are part of the graph;
+        thread_local error mode: other threads (e.g. the RCCL watchdog) may touch the HIP runtime while this thread captures.
+        Nothing executes during capture.  Any failure falls back to eager launches of the same kernels."""
         torch.cuda.synchronize()
-        self.graph_tail = None
+        self._pool = None
         try:
-            if not self.comm_overlap:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    batch = self.make_batch()
-                    self._g_loss = self.forward_backward(batch)
-                self.graph = g
-                return
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream(device=self.dev)
-            s.wait_stream(torch.cuda.current_stream())
-            state = {'second': False}
-
-            def switch():
-                g1.capture_end()
-                g2.capture_begin(pool=g1.pool(), capture_error_mode='thread_local')
-                state['second'] = True
-
-            with torch.cuda.stream(s):
-                g1.capture_begin(capture_error_mode='thread_local')
-                try:
-                    batch = self.make_batch()
-                    self._g_loss = self.forward_backward(batch, switch)
-                finally:
-                    (g2 if state['second'] else g1).capture_end()
-            torch.cuda.current_stream().wait_stream(s)
-            if not state['second']:
-                raise RuntimeError('the backward pass never reached the split point')
-            self.graph, self.graph_tail = g1, g2
+            graphs = {}
+            start = self._cur
+            for par in ((start, 1 - start) if self.pipeline else (0,)):
+                self._cur = par
+                # every captured step must re-pack the weights itself: drop what the previous capture left in the caches
+                self.reg.image_encoder._cache.clear()
+                self.reg.ief_module._cache = {}
+                graphs[par] = self._capture_one()
+            self._cur = start
+            self.graph = graphs
+            self.graph_tail = next(iter(graphs.values()))[1]
         except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, never to another path
             import warnings
             warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager launches' % (e,))

@@ -16,13 +16,13 @@ W = {'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'jo
 LOSSES = ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D']
 
 
-def _train(use_graph, steps, overlap=True, comm_overlap=False):
+def _train(use_graph, steps, overlap=True, comm_overlap=False, pipeline=True):
     torch.manual_seed(7)
     reg = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP).to(DEV).train()
     smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=64).to(DEV)
     crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(LOSSES, init_loss_weights=W, reduction='mean').to(DEV)
     ts = TrainStep(reg, smpl, crit, 64, lr=1e-4, seed=99, mean_shape=MP['shape'], use_graph=use_graph, overlap_wgrad=overlap,
-                   comm_overlap=comm_overlap)
+                   comm_overlap=comm_overlap, pipeline_data=pipeline)
     losses = [ts.step().clone() for _ in range(steps)]
     torch.cuda.synchronize()
     return torch.stack(losses).cpu(), ts.flat_p.clone().cpu(), reg.image_encoder.bn1.running_var.clone().cpu(), ts
@@ -47,6 +47,11 @@ def test_train_step_b64_deterministic_and_graph_equals_eager():
     assert torch.equal(l_graph, l_split) and torch.equal(p_graph, p_split) and torch.equal(rv_graph, rv_split)
     l_se, p_se, _, _ = _train(False, 5, comm_overlap=True)
     assert torch.equal(l_graph, l_se) and torch.equal(p_graph, p_se)
+    # the data pipeline (next batch generated on a second stream during the step) does not change a bit either
+    l_np, p_np, _, _ = _train(False, 5, overlap=False, pipeline=False)
+    assert torch.equal(l_graph, l_np) and torch.equal(p_graph, p_np)
+    l_npg, p_npg, _, _ = _train(True, 5, pipeline=False)
+    assert torch.equal(l_graph, l_npg) and torch.equal(p_graph, p_npg)
 
 
 def test_smpl_bench_size_slices_are_batch_independent():
