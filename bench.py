@@ -133,7 +133,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
-    ap.add_argument('--no-overlap', action='store_true', help='keep weight-gradient kernels on the main stream (profiling: per-kernel times become additive)')
+    ap.add_argument('--no-overlap', action='store_true', help='(default now) weight-gradient kernels stay on the main stream')
+    ap.add_argument('--overlap-wgrad', action='store_true', help='A/B: run the weight-gradient kernels on a side stream (0.1 ms slower since the data pipeline)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -174,7 +175,7 @@ def main():
         crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(
             ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
             init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}).to(dev)
-        ts = TrainStep(reg, smpl, crit, B, lr=1e-4, rank=rank, world_size=world, seed=1234, mean_shape=mp['shape'], use_graph=not args.no_graph, overlap_wgrad=not args.no_overlap)
+        ts = TrainStep(reg, smpl, crit, B, lr=1e-4, rank=rank, world_size=world, seed=1234, mean_shape=mp['shape'], use_graph=not args.no_graph, overlap_wgrad=args.overlap_wgrad and not args.no_overlap)
         step = ts.step
         workload = 'configs[2]: full synthetic OTF training step (augmentation + proxy construction + forward + multi-task loss ' \
                    '+ backward + Adam), %s, 18x256x256 proxy' % net
