@@ -33,6 +33,31 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32-input MFMA p
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel`, from the committed PMC passes (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py --json from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload;
+    reads carry the gfx950 x2 correction of MI355X_MICROARCH.md).  Counters cannot be collected from inside this
+    process, so the figure is the recorded one; {} -> 'traffic' stays null when no pass exists for this configuration."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    tag = '%s_r%d_b%d' % (args.workload, args.layers, args.batch or (65536 if args.workload == 'smpl' else 64))
+    try:
+        rec = json.load(open(path)).get(tag)
+    except (OSError, ValueError):
+        return {}
+    if not rec:
+        return {}
+    n = byt = 0.0
+    for name, k in rec['kernels'].items():
+        if name.replace('void ', '').startswith(kernel):
+            n += k['launches']
+            byt += k['launches'] * (k['hbm_read_bytes'] + k['hbm_write_bytes'])
+    if not n:
+        return {}
+    return {'traffic': round(byt / n), 'traffic_unit': 'HBM bytes per launch (read x2-corrected + write), launch-weighted mean',
+            'traffic_source': rec['source']}
+
+
 def synthetic_proxy_batch(B, device, seed):
     """seeded silhouette (union of ellipses, ~25 % foreground) + 17 Gaussian joint heatmaps
     (16x16 truncated, sigma 4) -- the 18-channel input of run_train.py:35, NCHW fp32."""
@@ -59,23 +84,24 @@ class KernelTimer:
         self.recs = []
         self.on = False
 
-    def wrap(self, name, flops, fn):
+    def wrap(self, name, flops, fn, nbytes=0.0):
         if not self.on:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = fn()
         e.record()
-        self.recs.append((name, flops, s, e))
+        self.recs.append((name, flops, s, e, nbytes))
         return out
 
     def summary(self):
         agg = {}
-        for name, flops, s, e in self.recs:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, flops, s, e, nbytes in self.recs:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += s.elapsed_time(e) * 1e-3
+            a[3] += nbytes
         return agg
 
 
@@ -91,15 +117,19 @@ def instrument(timer):
     def conv_flops(B, H, W, Cin, Cout, kh, kw, stride, pad):
         return 2.0 * B * _out(H, kh, stride, pad) * _out(W, kw, stride, pad) * Cout * Cin * kh * kw
 
+    def conv_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad):
+        # algorithmic HBM bytes of one convolution launch: input + packed weights + output, each touched once (fp32)
+        return 4.0 * (B * H * W * Cin + Cout * Cin * kh * kw + B * _out(H, kh, stride, pad) * _out(W, kw, stride, pad) * Cout)
+
     class Proxy:
         def __getattr__(self, k):
             return getattr(L, k)
 
         def straps_conv_fwd(self, *a):
-            return timer.wrap('conv_igemm_kernel', conv_flops(*a[8:17]), lambda: L.straps_conv_fwd(*a))
+            return timer.wrap('conv_igemm_kernel', conv_flops(*a[8:17]), lambda: L.straps_conv_fwd(*a), conv_bytes(*a[8:17]))
 
         def straps_conv_dgrad(self, *a):
-            return timer.wrap('conv_igemm_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_dgrad(*a))
+            return timer.wrap('conv_igemm_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_dgrad(*a), conv_bytes(*a[4:13]))
 
         def straps_conv_wgrad(self, *a):
             return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a))
@@ -270,11 +300,14 @@ def main():
         agg = timer.summary()
         roof = None
         if dominant in agg:
-            n, flops, secs = agg[dominant]
+            n, flops, secs, abytes = agg[dominant]
             ach = flops / secs / 1e12
             roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
                     'flops_per_launch': round(flops / n)}
+            if abytes:
+                roof['algorithmic_bytes_per_launch'] = round(abytes / n)
+            roof.update(pmc_traffic(args, dominant))
             if args.workload == 'smpl':
                 byt = n * B * (6890 * 12 + 90 * 12 + 24 * 36 + 40)
                 roof['hbm_side'] = {'achieved': round(byt / secs / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -5,9 +5,9 @@
 //   GEMM view:  M = output pixels,  N = output channels,  K = taps x Cin  (tap-major, channel-minor).
 //   A operand = im2col rows gathered on the fly (each 32-channel K chunk of one tap is 128 contiguous bytes of one
 //   source pixel -> 8 lanes x float4), B operand = weights repacked [n][tap][cin].
-//   Both are staged global -> registers -> LDS (issue-early / write-late, double-buffered LDS, one barrier per K
-//   chunk) and read back as ds_read_b128 fragments: row stride 36 floats (= 4 * odd) makes both the b128 writes and
-//   the b128 fragment reads bank-conflict free.  K is permuted inside each group of 8 (lane half h takes
+//   Both are copied global -> LDS by the LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass),
+//   double-buffered with one barrier per K chunk, and read back as ds_read_b128 fragments; an XOR swizzle of the
+//   16-byte K groups keeps the unpadded 128-byte rows bank-conflict free.  K is permuted inside each group of 8 (lane half h takes
 //   k = 8g+4h..+3) so one b128 read feeds four MFMAs; A and B use the same permutation.
 //   The taps are a small table (weight tap index, source-row offset, source-col offset), which lets ONE kernel run
 //     * the forward conv (all R*S taps, source pixel = out*stride + tap - pad), and
@@ -47,7 +47,15 @@ struct ConvP {
 
 constexpr int LS = 36;   // LDS row stride in floats (32 data + 4 pad)
 
-template <int BM, int BN>
+__device__ __attribute__((aligned(16))) float k_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // source of the padding pixels (LDS-DMA path)
+
+// NS = 2 (default): operands copied global -> LDS directly (global_load_lds_dwordx4, two stages of unpadded 128-byte rows): no
+//   staging registers, no ds_write pass, 32 KiB of LDS per 64x64 workgroup (5 resident per CU).  +3..10 % over NS = 0 on every
+//   resnet layer shape, bit-identical results (tools/sweep_igemm_staging.py).  The DMA writes lane-linear (wave base + lane*16 B), so the bank-conflict-free layout is an XOR swizzle applied on BOTH sides: lane
+//   (row r, slot c) fetches the 16-byte K group c ^ (r & 7), and the fragment read of K group g at row r goes to slot g ^ (r & 7).
+//   Padding pixels copy from a 16-byte zero constant.
+// NS = 0 (tile_cfg bit 4, kept for the A/B): operands staged global -> registers -> LDS (rows padded to 36 floats, two buffers).
+template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const ConvP::Class& c = p.cls[blockIdx.y];
     const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, coah = c.oah, coaw = c.oaw, cntaps = c.ntaps;
@@ -55,15 +63,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 32, NI = WTN / 32;
     constexpr int AP = BM / 32, BP = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [2][BM][LS]
-    float* Bs = smem + 2 * BM * LS;   // [2][BN][LS]
+    constexpr int RS_ = NS ? 32 : LS;            // LDS row stride
+    constexpr int NBUF = NS ? NS : 2;
+    float* As = smem;                    // [NBUF][BM][RS_]
+    float* Bs = smem + NBUF * BM * RS_;  // [NBUF][BN][RS_]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = xcd_remap(blockIdx.x, cMT * p.NT);
     const int nt = bid % p.NT, mt = bid / p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int lr = tid >> 3, lc = tid & 7;
+    const int lr = tid >> 3;
+    const int lc = NS ? ((tid & 7) ^ (lr & 7)) : (tid & 7);     // 16-byte K group this thread fetches
 
     // per-thread im2col row descriptors (AP rows of the A tile)
     // (32-bit element offsets: 64-bit integer multiplies in the per-chunk address math cost the kernel ~8 % -- the VALU
@@ -119,6 +130,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lr + 32 * i) * LS + lc * 4) = rb[i];
     };
 
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_tile = [&](int q, int stage) {
+        const int tap = q / cchunks;
+        const int c0 = (q - tap * cchunks) << 5;
+        const int dh = c.tap_dh[tap], dw = c.tap_dw[tap], tw = c.tap_w[tap];
+        const int toff = (dh * p.W + dw) * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float* src = ok ? p.x + (a_base[i] + toff) : k_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(As + (stage * BM + 32 * i + 8 * wave_u) * 32), 16, 0, 0);
+        }
+        const int woff = tw * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + woff),
+                                             (__attribute__((address_space(3))) void*)(Bs + (stage * BN + 32 * i + 8 * wave_u) * 32), 16, 0, 0);
+    };
+
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -127,6 +159,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (NS >= 2) {
+        // two stages: chunk q lives in stage q & 1.  (Deeper rings that keep copies in flight across the barrier measured
+        // slower -- 48 / 64 KiB of LDS leave 3 / 2 workgroups per CU instead of 5: tools/README.md.)
+        if (nchunks > 0) dma_tile(0, 0);
+        int fo[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ (lane & 7)) << 2);
+        for (int q = 0; q < nchunks; ++q) {
+            const int stage = q & 1;
+            // my copies of chunk q have landed, then everybody's have -- and every wave is done reading the other stage.
+            // (raw s_barrier: __syncthreads() would be the same wait here, but the explicit count documents the protocol)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (q + 1 < nchunks) dma_tile(q + 1, stage ^ 1);
+            const float* Ab = As + (stage * BM + wm * WTM) * 32;
+            const float* Bb = Bs + (stage * BN + wn * WTN) * 32;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f32x4 a[MI], b[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * 32 + fo[kk]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * 32 + fo[kk]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    } else {
     if (nchunks > 0) {
         load_tile(0);
         store_tile(0);
@@ -159,6 +226,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         __builtin_amdgcn_s_setprio(0);
         if (q + 1 < nchunks) store_tile(buf ^ 1);
         __syncthreads();
+    }
     }
 
     // ---------------- epilogue ----------------
@@ -225,6 +293,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // prologue / epilogue, otherwise 64x64 whose 4+ resident workgroups per CU hide each other's barrier / LDS-refill
 // bubbles (128x64 never wins).
 inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
+    cfg &= 15;               // bit 4 selects the register-staged operand path (A/B tools only)
     if (cfg == 1) { bm = 128; bn = 128; }
     else if (cfg == 2) { bm = 128; bn = 64; }
     else if (cfg == 3) { bm = 64; bn = 64; }
@@ -233,7 +302,7 @@ inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn
     if (cout % bn != 0) bn = 64;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NS>
 int launch(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     p.NT = p.Cout / BN;
@@ -242,14 +311,14 @@ int launch(const ConvP& p0, hipStream_t st) {
         p.cls[i].MT = (p.cls[i].M + BM - 1) / BM;
         if (p.cls[i].MT * p.NT > maxblk) maxblk = p.cls[i].MT * p.NT;
     }
-    const size_t lds = (size_t)2 * (BM + BN) * LS * sizeof(float);
+    const size_t lds = NS ? (size_t)NS * (BM + BN) * 32 * sizeof(float) : (size_t)2 * (BM + BN) * LS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("conv_igemm_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), dim3(maxblk, p.ncls), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NS>), dim3(maxblk, p.ncls), dim3(256), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_kernel");
     return STRAPS_OK;
 }
@@ -263,9 +332,14 @@ int dispatch(const ConvP& p, int tile_cfg, hipStream_t st) {
         if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
     }
     pick_tile(tile_cfg, M, p.Cout, kdim, bm, bn);
-    if (bm == 128 && bn == 128) return launch<128, 128>(p, st);
-    if (bm == 128 && bn == 64) return launch<128, 64>(p, st);
-    return launch<64, 64>(p, st);
+    if (tile_cfg & 16) {
+        if (bm == 128 && bn == 128) return launch<128, 128, 0>(p, st);
+        if (bm == 128 && bn == 64) return launch<128, 64, 0>(p, st);
+        return launch<64, 64, 0>(p, st);
+    }
+    if (bm == 128 && bn == 128) return launch<128, 128, 2>(p, st);
+    if (bm == 128 && bn == 64) return launch<128, 64, 2>(p, st);
+    return launch<64, 64, 2>(p, st);
 }
 
 }  // namespace

@@ -20,6 +20,7 @@ for C in "MfmaUtil" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-overlap > $O/pmc$i.log 2>&1
 done
-python $R/tools/pmc_summary.py $(find $O/pmc1 $O/pmc2 $O/pmc3 -name '*counter_collection.csv') > $O/r01_train_b64_pmc_summary.txt 2>&1
+cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
+python $R/tools/pmc_summary.py --json $O/pmc_traffic.json train_r18_b64 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh' $(find $O/pmc1 $O/pmc2 $O/pmc3 -name '*counter_collection.csv') > $O/r01_train_b64_pmc_summary.txt 2>&1
 rm -rf $O/prof_*/ $O/pmc*/
 ls -la $O
