@@ -122,14 +122,21 @@ struct Wgrad3P {
     int chunks_per_row, chunk_rows_per_img, nchunks, chunks_per_split, it;
 };
 
-constexpr int W3L = 68;   // floats per staged pixel (64 channels + 4 pad)
+constexpr int W3PX = 32 + 112;   // pixels per LDS stage: dy tile + input patch rounded up to whole 16-pixel copy rounds
 
+__device__ __attribute__((aligned(16))) float k_zero16b[4] = {0.f, 0.f, 0.f, 0.f};   // source of the out-of-image halo pixels
+
+// Staging: both operands go global -> LDS through the LDS-DMA (global_load_lds_dwordx4; one wave-instruction = 4 pixels x 256 B,
+// rows unpadded: the fragment reads are ds_read_b32 over 32 consecutive channels, conflict-free as they are), two stages, one
+// barrier per chunk.  Operands: the four pixels a lane half handles per 8-pixel group sit side by side in one row, so their
+// nine-tap windows overlap: 3 x 6 patch values + 4 dy values feed 36 MFMAs (instead of 36 + 4), and the next group's 22 values
+// are read while the current 36 MFMAs issue.
 __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int pw = p.cw + 2;
     const int npatch = (p.rpc + 2) * pw;                 // <= 102 pixels
-    const int buf_floats = (32 + npatch) * W3L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave >> 1, wn = wave & 1;
     const int itile = blockIdx.x % p.it, ctile = blockIdx.x / p.it;
     const int co0 = ctile * 64, ci0 = itile * 64;
@@ -137,40 +144,41 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
     const int cend = min(cbeg + p.chunks_per_split, p.nchunks);
     const int lp = tid >> 4, lc = tid & 15;              // staging: pixel slot, float4 column
 
-    f32x4 rd[2], rx[7];
-    auto load_chunk = [&](int c) {
-        const int b = c / (p.chunk_rows_per_img * p.chunks_per_row);
-        const int rem = c - b * p.chunk_rows_per_img * p.chunks_per_row;
+    // chunk-independent part of the copy addresses: dy pixel (row, col) inside the chunk, patch pixel (row, col) inside the patch
+    int d_off[2], x_pr[7], x_pc[7];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int px = lp + 16 * q;
+        d_off[q] = ((px >> p.cw_log2) * p.W + (px & (p.cw - 1))) * p.Cout + co0 + lc * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int pp = lp + 16 * q;
+        x_pr[q] = pp / pw - 1;
+        x_pc[q] = pp - (x_pr[q] + 1) * pw - 1;
+    }
+    auto dma_chunk = [&](int c, int stage) {
+        const int per_img = p.chunk_rows_per_img * p.chunks_per_row;
+        const int b = c / per_img;
+        const int rem = c - b * per_img;
         const int cr = rem / p.chunks_per_row, cc = rem - cr * p.chunks_per_row;
         const int ho0 = cr * p.rpc, wo0 = cc * p.cw;
+        float* D = smem + stage * (W3PX * 64);
+        float* X = D + 32 * 64;
+        const float* dsrc = p.dy + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cout;
+        const float* xsrc = p.x + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cin + ci0 + lc * 4;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int px = lp + 16 * q;
-            const int ho = ho0 + (px >> p.cw_log2), wo = wo0 + (px & (p.cw - 1));
-            rd[q] = *reinterpret_cast<const f32x4*>(p.dy + (((long long)b * p.H + ho) * p.W + wo) * p.Cout + co0 + lc * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const int pp = lp + 16 * q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pp < npatch) {
-                const int pr = pp / pw, pc = pp - pr * pw;
-                const int hi = ho0 - 1 + pr, wi = wo0 - 1 + pc;
-                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(p.x + (((long long)b * p.H + hi) * p.W + wi) * p.Cin + ci0 + lc * 4);
-            }
-            rx[q] = v;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-        float* D = smem + buf * buf_floats;
-        float* X = D + 32 * W3L;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(D + (lp + 16 * q) * W3L + lc * 4) = rd[q];
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + d_off[q]),
+                                             (__attribute__((address_space(3))) void*)(D + (4 * wave_u + 16 * q) * 64), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            const int pp = lp + 16 * q;
-            if (pp < npatch) *reinterpret_cast<f32x4*>(X + pp * W3L + lc * 4) = rx[q];
+            if (q * 16 >= npatch) break;                 // wave-uniform
+            const int hi = ho0 + x_pr[q], wi = wo0 + x_pc[q];
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;     // (slots past the patch read anything)
+            const float* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin : k_zero16b;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(X + (4 * wave_u + 16 * q) * 64), 16, 0, 0);
         }
     };
     f32x16 acc[9];
@@ -178,32 +186,50 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-    if (cbeg < cend) {
-        load_chunk(cbeg);
-        store_chunk(0);
-    }
-    __syncthreads();
+    if (cbeg < cend) dma_chunk(cbeg, 0);
     const int i = lane & 31, h = lane >> 5;
-    for (int c = cbeg; c < cend; ++c) {
-        const int buf = (c - cbeg) & 1;
-        if (c + 1 < cend) load_chunk(c + 1);
-        const float* D = smem + buf * buf_floats + wm * 32 + i;
-        const float* X = smem + buf * buf_floats + 32 * W3L + wn * 32 + i;
-#pragma unroll 2
-        for (int kk = 0; kk < 4; ++kk) {
+    // LDS float offsets of the lane's four 4-pixel groups (group kk = pixels kk*8 + h*4 .. +3 of the chunk)
+    int g_d[4], g_x[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int px = kk * 8 + h * 4 + e;
-                const float a = D[px * W3L];
-                const float* xb = X + ((px >> p.cw_log2) * pw + (px & (p.cw - 1))) * W3L;
+    for (int kk = 0; kk < 4; ++kk) {
+        const int px = kk * 8 + h * 4;
+        g_d[kk] = px * 64 + wm * 32 + i;
+        g_x[kk] = 32 * 64 + ((px >> p.cw_log2) * pw + (px & (p.cw - 1))) * 64 + wn * 32 + i;
+    }
+    const int pw64 = pw * 64;
+    for (int c = cbeg; c < cend; ++c) {
+        const int stage = (c - cbeg) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies of chunk c have landed ...
+        __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
+        asm volatile("" ::: "memory");
+        if (c + 1 < cend) dma_chunk(c + 1, stage ^ 1);
+        const float* S = smem + stage * (W3PX * 64);
+        float a[2][4], w[2][18];
+        auto read_group = [&](int kk, float* av, float* wv) {
+            const float* D = S + g_d[kk];
+            const float* X = S + g_x[kk];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = D[e * 64];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cidx = 0; cidx < 6; ++cidx) wv[r * 6 + cidx] = X[r * pw64 + cidx * 64];
+        };
+        read_group(0, a[0], w[0]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) read_group(kk + 1, a[(kk + 1) & 1], w[(kk + 1) & 1]);
+            const float* av = a[kk & 1];
+            const float* wv = w[kk & 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) acc[r * 3 + s] = mfma32(a, xb[(r * pw + s) * W3L], acc[r * 3 + s]);
-            }
+                    for (int s2 = 0; s2 < 3; ++s2) acc[r * 3 + s2] = mfma32(av[e], wv[r * 6 + e + s2], acc[r * 3 + s2]);
         }
-        if (c + 1 < cend) store_chunk(buf ^ 1);
-        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
     }
     float* o = p.part + (long long)blockIdx.y * p.Cout * 9 * p.Cin;
 #pragma unroll
@@ -890,7 +916,7 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
         int splits3;
         if (wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) {
             p3.x = x; p3.dy = dy; p3.part = (float*)workspace;
-            const size_t lds = (size_t)2 * (32 + (p3.rpc + 2) * (p3.cw + 2)) * W3L * sizeof(float);
+            const size_t lds = (size_t)2 * W3PX * 64 * sizeof(float);
             static bool attr_set = false;
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
