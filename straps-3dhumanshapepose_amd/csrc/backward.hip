@@ -888,7 +888,10 @@ static bool wgrad3_plan(int batch, int h, int w, int cin, int cout, int kh, int 
     p->nchunks = batch * p->chunk_rows_per_img * p->chunks_per_row;
     p->it = cin / 64;
     const int tiles = (cout / 64) * (cin / 64);
-    int s = (512 + tiles - 1) / tiles;
+#ifndef W3_TARGET
+#define W3_TARGET 512
+#endif
+    int s = (W3_TARGET + tiles - 1) / tiles;
     const int max_s = (p->nchunks + 3) / 4;                     // at least 4 chunks (576 MFMAs per wave) per workgroup
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;

@@ -176,15 +176,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
             // my copies of chunk q have landed, then everybody's have -- and every wave is done reading the other stage.
             // (raw s_barrier: __syncthreads() would be the same wait here, but the explicit count documents the protocol)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef ABL_NOBAR
             __builtin_amdgcn_s_barrier();
-#endif
             asm volatile("" ::: "memory");
-#ifdef ABL_NODMA
-            if (q + 1 < nchunks && q < 1) dma_tile(q + 1, stage ^ 1);
-#else
             if (q + 1 < nchunks) dma_tile(q + 1, stage ^ 1);
-#endif
             const float* Ab = As + (stage * BM + wm * WTM) * 32;
             const float* Bb = Bs + (stage * BN + wn * WTN) * 32;
             __builtin_amdgcn_s_setprio(1);
@@ -301,8 +295,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
 // tile choice from the per-layer sweep (tools/sweep_conv.py, B=64): 128x128 where it still yields >= 2 workgroups
 // per CU (one barrier per 64 MFMAs per wave) AND the reduction is long enough (K >= 1024) to amortise its heavier
-// prologue / epilogue, otherwise 64x64 whose 4+ resident workgroups per CU hide each other's barrier / LDS-refill
-// bubbles (128x64 never wins).
+// prologue / epilogue, otherwise 64x64 whose 5 resident workgroups per CU hide each other's barrier / LDS-refill
+// bubbles.  (128x64 measures +3 % on layer1 / layer3 shapes in isolation, tools/sweep_igemm_staging.py, but the whole
+// training step got 1.5 % slower with it: not used.)
 inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
     cfg &= 15;               // bit 4 selects the register-staged operand path (A/B tools only)
     if (cfg == 1) { bm = 128; bn = 128; }

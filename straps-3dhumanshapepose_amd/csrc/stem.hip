@@ -117,17 +117,32 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     if (!tile_any) {
         // nothing but zeros under this tile: the contraction below runs over an empty group list
     } else if ((W & 3) == 0) {
+        // eight loads in flight per thread before the first LDS store (the flagged strips come from HBM: one exposed
+        // round trip per batch of eight instead of one per float4)
         const int nvec = C * PH * (PW / 4);
-        for (int idx = tid; idx < nvec; idx += 256) {
-            const int q = idx % (PW / 4);
-            const int rc = idx / (PW / 4);
-            const int row = rc % PH, c = rc / PH;
-            const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((!nzmask || rowflag[rc]) && (unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
-                v = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
-            *reinterpret_cast<f32x4*>(patch + rc * PW + 4 * q) = v;
-            if (!nzmask && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f)) rowflag[rc] = 1;      // (NaN counts as non-zero)
+        for (int base = 0; base < nvec; base += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < nvec) {
+                    const int q = idx % (PW / 4);
+                    const int rc = idx / (PW / 4);
+                    const int row = rc % PH, c = rc / PH;
+                    const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;
+                    if ((!nzmask || rowflag[rc]) && (unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
+                        v[u] = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < nvec) {
+                    *reinterpret_cast<f32x4*>(patch + 4 * idx) = v[u];        // (PW = 18 float4: rc * PW + 4 * q == 4 * idx)
+                    if (!nzmask && (v[u][0] != 0.f || v[u][1] != 0.f || v[u][2] != 0.f || v[u][3] != 0.f)) rowflag[idx / (PW / 4)] = 1;   // (NaN counts as non-zero)
+                }
+            }
         }
     } else {
         const int npatch = C * PH * PW;
@@ -142,70 +157,73 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             if (!nzmask && v != 0.f) rowflag[rc] = 1;
         }
     }
-    for (int k = tid; k < Kp; k += 256) {
-        int o = 0;
-        if (k < K) {
-            const int c = k / 49, rs = k - c * 49;
-            const int r = rs / 7, s = rs - r * 7;
-            o = (c * PH + r) * PW + s + 1;      // +1: the patch origin sits one column left of the receptive field
-        }
-        koff[k] = o;
-    }
-    __syncthreads();
-
     const int i = lane & 31, h = lane >> 5;
     const float* pbase = patch + (2 * wave) * PW + 2 * i;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wfrag) + lane;
-    const int G = Kp >> 3;
-    // ---- this wave's active K groups: group g is needed iff one of its 8 taps reads a flagged strip of rows 2*wave + r ----
-    int* gl = glist + wave * G;
-    int ng = 0;
-    for (int gb = 0; gb < G; gb += 64) {
-        const int g = gb + lane;
-        bool act = false;
-        if (g < G) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 8 * g + e;
-                if (k < K) act = act || rowflag[koff[k] / PW + 2 * wave] != 0;
+    if (tile_any) {      // (block-uniform) an all-zero tile goes straight to the epilogue: no tap table, no group list, acc = 0
+        for (int k = tid; k < Kp; k += 256) {
+            int o = 0;
+            if (k < K) {
+                const int c = k / 49, rs = k - c * 49;
+                const int r = rs / 7, s = rs - r * 7;
+                o = (c * PH + r) * PW + s + 1;      // +1: the patch origin sits one column left of the receptive field
             }
+            koff[k] = o;
         }
-        const unsigned long long m = __ballot(act);
-        if (act) gl[ng + __popcll(m & ((1ULL << lane) - 1ULL))] = g;
-        ng += (int)__popcll(m);
-    }
-    // (the list is written and read by this wave only; LDS operations of one wave retire in order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // software pipeline over the active groups: the offset table is read two groups ahead and the (dependent) patch
-    // gather one group ahead, so no MFMA of a group waits on an LDS round trip issued in that group
-    if (ng > 0) {
-        int gcur = gl[0];
-        int gnext = gl[ng > 1 ? 1 : 0];
-        f32x4 b0 = wp[gcur * 128], b1 = wp[gcur * 128 + 64];
-        int4 ko_n = *reinterpret_cast<const int4*>(koff + 8 * gcur + 4 * h);
-        float a0 = pbase[ko_n.x], a1 = pbase[ko_n.y], a2 = pbase[ko_n.z], a3 = pbase[ko_n.w];
-        ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
-        for (int j = 0; j < ng; ++j) {
-            f32x4 nb0 = b0, nb1 = b1;
-            float n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-            if (j + 1 < ng) {
-                nb0 = wp[gnext * 128]; nb1 = wp[gnext * 128 + 64];
-                n0 = pbase[ko_n.x]; n1 = pbase[ko_n.y]; n2 = pbase[ko_n.z]; n3 = pbase[ko_n.w];
+        __syncthreads();
+
+        const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wfrag) + lane;
+        const int G = Kp >> 3;
+        // ---- this wave's active K groups: group g is needed iff one of its 8 taps reads a flagged strip of rows 2*wave + r ----
+        int* gl = glist + wave * G;
+        int ng = 0;
+        for (int gb = 0; gb < G; gb += 64) {
+            const int g = gb + lane;
+            bool act = false;
+            if (g < G) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 8 * g + e;
+                    if (k < K) act = act || rowflag[koff[k] / PW + 2 * wave] != 0;
+                }
             }
-            if (j + 2 < ng) {
-                gnext = gl[j + 2];
-                ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
+            const unsigned long long m = __ballot(act);
+            if (act) gl[ng + __popcll(m & ((1ULL << lane) - 1ULL))] = g;
+            ng += (int)__popcll(m);
+        }
+        // (the list is written and read by this wave only; LDS operations of one wave retire in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // software pipeline over the active groups: the offset table is read two groups ahead and the (dependent) patch
+        // gather one group ahead, so no MFMA of a group waits on an LDS round trip issued in that group.  (Fetching the weight
+        // fragments two groups ahead instead of one changes nothing: 338 us either way on the proxy batch.)
+        if (ng > 0) {
+            int gcur = gl[0];
+            int gnext = gl[ng > 1 ? 1 : 0];
+            f32x4 b0 = wp[gcur * 128], b1 = wp[gcur * 128 + 64];
+            int4 ko_n = *reinterpret_cast<const int4*>(koff + 8 * gcur + 4 * h);
+            float a0 = pbase[ko_n.x], a1 = pbase[ko_n.y], a2 = pbase[ko_n.z], a3 = pbase[ko_n.w];
+            ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
+            for (int j = 0; j < ng; ++j) {
+                f32x4 nb0 = b0, nb1 = b1;
+                float n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+                if (j + 1 < ng) {
+                    nb0 = wp[gnext * 128]; nb1 = wp[gnext * 128 + 64];
+                    n0 = pbase[ko_n.x]; n1 = pbase[ko_n.y]; n2 = pbase[ko_n.z]; n3 = pbase[ko_n.w];
+                }
+                if (j + 2 < ng) {
+                    gnext = gl[j + 2];
+                    ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
+                }
+                acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
+                acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
+                acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
+                acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
+                b0 = nb0; b1 = nb1; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
             }
-            acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
-            acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
-            acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
-            acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
-            b0 = nb0; b1 = nb1; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
         }
     }
 
