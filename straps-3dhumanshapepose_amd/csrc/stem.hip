@@ -10,8 +10,8 @@
 //   * A fragments (pixels) are gathered from the patch with stride-2 ds_read_b32, B fragments
 //     (weights, prepacked in fragment order by straps_pack_stem_weight) stream from L2 as
 //     coalesced float4,
-//   * ZERO SKIPPING: the proxy representation is a binary silhouette + 17 joint heat-maps whose Gaussians
-//     underflow to exactly 0 about 55 px from the joint, so most (channel, patch row) strips are all zero.
+//   * ZERO SKIPPING: the proxy representation is a binary silhouette + 17 joint heat-maps that are non-zero only inside a
+//     16x16 window around their joint (utils/label_conversions.py:58-87), so most (channel, patch row) strips are all zero.
 //     The patch load flags the non-zero strips; each wave (one output row) compacts the 8-tap K groups that
 //     touch a flagged strip of ITS 7 input rows into an LDS list and contracts only those.  A skipped group
 //     would have added 0*w = 0 to every accumulator, so the result is the dense one bit for bit (finite weights);
@@ -65,16 +65,22 @@ __global__ __launch_bounds__(256) void stem_nzmask_kernel(const float* __restric
     if (bit == 0 && word < nwords) mask[word] = (unsigned)(m >> (32 * ((threadIdx.x & 63) >> 5)));
 }
 
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wfrag,
+constexpr int NSLOT = 4;   // input channels resident in LDS per pass (slot 0 of the patch is the all-zero channel)
+
+__global__ __launch_bounds__(256, 5) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wfrag,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int relu,
                                                    float* __restrict__ y, float* __restrict__ stats,
                                                    const unsigned* __restrict__ nzmask, int B, int C, int H, int W,
                                                    int Ho, int Wo, int tiles_x, int tiles_y, int K, int Kp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* patch = smem;                                        // [C][PH][PW]
-    int* koff = reinterpret_cast<int*>(smem + C * PH * PW);     // [Kp]
-    int* rowflag = koff + Kp;                                   // [C*PH]  strip (channel, patch row) holds a non-zero
-    int* glist = rowflag + C * PH;                              // [4 waves][Kp/8] active K groups of each wave
+    float* patch = smem;                                                    // [1 + NSLOT][PH][PW]
+    int* koff = reinterpret_cast<int*>(smem + (1 + NSLOT) * PH * PW);       // [Kp]   patch offset of tap k in the current pass
+    int* krow = koff + Kp;                                                  // [Kp]   strip (c * PH + r) of tap k, -1 for the K padding
+    int* rowflag = krow + Kp;                                               // [C*PH] strip (channel, patch row) holds a non-zero
+    int* rank = rowflag + C * PH;                                           // [C]    position of channel c among the tile's active ones / -1
+    int* chan = rank + C;                                                   // [C]    the active channels, ascending
+    int* glist = chan + C;                                                  // [4 waves][Kp/8] active K groups of each wave
+    __shared__ int n_active_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -84,9 +90,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     const int y0 = ty * TY, x0 = tx * TX;
     const int hi0 = 2 * y0 - 3, wi0 = 2 * x0 - 3;
 
-    // ---- strip flags: does (channel c, patch row) hold a non-zero?  With the caller's non-zero map they come from one
-    // word per strip BEFORE anything is loaded (and an all-zero tile skips the patch altogether); without it they are
-    // found by probing the loaded values ----
+    // ---- strip flags: does (channel c, patch row) hold a non-zero?  One word of the caller's non-zero map per strip, BEFORE
+    // anything is loaded; without a map every strip counts as non-zero (the plain dense convolution) ----
     const int HC = (H + 3) >> 2, WW = (W + 255) >> 8;
     int tile_any = 1;
     if (nzmask) {
@@ -109,121 +114,156 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
         }
         tile_any = __syncthreads_or(mine);
     } else {
-        for (int idx = tid; idx < C * PH; idx += 256) rowflag[idx] = 0;
+        for (int idx = tid; idx < C * PH; idx += 256) rowflag[idx] = 1;
         __syncthreads();
     }
-    // patch column p holds input column wi0 - 1 + p: the patch origin is shifted one column left so that every row is
-    // 18 ALIGNED float4 loads (wi0 - 1 = 2*x0 - 4 is a multiple of 4) instead of 69 scalar ones
-    if (!tile_any) {
-        // nothing but zeros under this tile: the contraction below runs over an empty group list
-    } else if ((W & 3) == 0) {
-        // eight loads in flight per thread before the first LDS store (the flagged strips come from HBM: one exposed
-        // round trip per batch of eight instead of one per float4)
-        const int nvec = C * PH * (PW / 4);
-        for (int base = 0; base < nvec; base += 8 * 256) {
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + tid;
-                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (idx < nvec) {
-                    const int q = idx % (PW / 4);
-                    const int rc = idx / (PW / 4);
-                    const int row = rc % PH, c = rc / PH;
-                    const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;
-                    if ((!nzmask || rowflag[rc]) && (unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
-                        v[u] = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + tid;
-                if (idx < nvec) {
-                    *reinterpret_cast<f32x4*>(patch + 4 * idx) = v[u];        // (PW = 18 float4: rc * PW + 4 * q == 4 * idx)
-                    if (!nzmask && (v[u][0] != 0.f || v[u][1] != 0.f || v[u][2] != 0.f || v[u][3] != 0.f)) rowflag[idx / (PW / 4)] = 1;   // (NaN counts as non-zero)
-                }
-            }
-        }
-    } else {
-        const int npatch = C * PH * PW;
-        for (int idx = tid; idx < npatch; idx += 256) {
-            const int col = idx % PW;
-            const int rc = idx / PW;
-            const int row = rc % PH, c = rc / PH;
-            const int hi = hi0 + row, wi = wi0 - 1 + col;
-            float v = 0.f;
-            if ((!nzmask || rowflag[rc]) && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
-            patch[idx] = v;
-            if (!nzmask && v != 0.f) rowflag[rc] = 1;
-        }
-    }
+
     const int i = lane & 31, h = lane >> 5;
     const float* pbase = patch + (2 * wave) * PW + 2 * i;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (tile_any) {      // (block-uniform) an all-zero tile goes straight to the epilogue: no tap table, no group list, acc = 0
+    if (tile_any) {      // (block-uniform) an all-zero tile goes straight to the epilogue with acc = 0
+        // ---- the tile's active channels (ascending), the pass-independent tap -> strip table, the zero slot ----
         for (int k = tid; k < Kp; k += 256) {
-            int o = 0;
+            int v = -1;
             if (k < K) {
                 const int c = k / 49, rs = k - c * 49;
-                const int r = rs / 7, s = rs - r * 7;
-                o = (c * PH + r) * PW + s + 1;      // +1: the patch origin sits one column left of the receptive field
+                v = c * PH + rs / 7;
             }
-            koff[k] = o;
+            krow[k] = v;
+        }
+        for (int idx = tid; idx < PH * PW; idx += 256) patch[idx] = 0.f;
+        if (wave == 0) {
+            int n = 0;
+            for (int cb = 0; cb < C; cb += 64) {
+                const int c = cb + lane;
+                bool act = false;
+                if (c < C)
+                    for (int row = 0; row < PH; ++row) act = act || rowflag[c * PH + row] != 0;
+                const unsigned long long m = __ballot(act);
+                const int pos = n + (int)__popcll(m & ((1ULL << lane) - 1ULL));
+                if (c < C) rank[c] = act ? pos : -1;
+                if (act) chan[pos] = c;
+                n += (int)__popcll(m);
+            }
+            if (lane == 0) n_active_s = n;
         }
         __syncthreads();
-
+        const int n_active = n_active_s;
         const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wfrag) + lane;
         const int G = Kp >> 3;
-        // ---- this wave's active K groups: group g is needed iff one of its 8 taps reads a flagged strip of rows 2*wave + r ----
         int* gl = glist + wave * G;
-        int ng = 0;
-        for (int gb = 0; gb < G; gb += 64) {
-            const int g = gb + lane;
-            bool act = false;
-            if (g < G) {
+        // ---- passes over the active channels: only NSLOT halo patches are resident in LDS (29 KB per workgroup instead of 67:
+        // five workgroups per CU hide each other's load / table / list latencies); taps of every other channel point into the
+        // zero slot.  Consecutive passes OVERLAP by one channel, so that a K group straddling two active channels always finds
+        // both resident in exactly one pass; every group is contracted once, in ascending order over the whole tile, with all
+        // of its non-zero taps -- the accumulators see exactly the sequence of a single dense sweep (bit-identical) ----
+        for (int c0 = 0;; c0 += NSLOT - 1) {
+            const int nch = min(NSLOT, n_active - c0);
+            // patch column p holds input column wi0 - 1 + p: the patch origin is shifted one column left so that every row is
+            // 18 ALIGNED float4 loads (wi0 - 1 = 2*x0 - 4 is a multiple of 4) instead of 69 scalar ones
+            if ((W & 3) == 0) {
+                const int nvec = nch * PH * (PW / 4);                 // <= 936: all loads of a thread in flight before the first LDS store
+                f32x4 v[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = 8 * g + e;
-                    if (k < K) act = act || rowflag[koff[k] / PW + 2 * wave] != 0;
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = u * 256 + tid;
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (idx < nvec) {
+                        const int q = idx % (PW / 4);
+                        const int rc = idx / (PW / 4);
+                        const int row = rc % PH, c = chan[c0 + rc / PH];
+                        const int hi = hi0 + row, wi = wi0 - 1 + 4 * q;
+                        if (rowflag[c * PH + row] && (unsigned)hi < (unsigned)H && wi >= 0 && wi < W)
+                            v[u] = *reinterpret_cast<const f32x4*>(x + (((long long)b * C + c) * H + hi) * W + wi);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = u * 256 + tid;
+                    if (idx < nvec) *reinterpret_cast<f32x4*>(patch + PH * PW + 4 * idx) = v[u];     // (PW = 18 float4: slot/row/q linear in idx)
+                }
+            } else {
+                const int npatch = nch * PH * PW;
+                for (int idx = tid; idx < npatch; idx += 256) {
+                    const int col = idx % PW;
+                    const int rc = idx / PW;
+                    const int row = rc % PH, c = chan[c0 + rc / PH];
+                    const int hi = hi0 + row, wi = wi0 - 1 + col;
+                    float v = 0.f;
+                    if (rowflag[c * PH + row] && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[(((long long)b * C + c) * H + hi) * W + wi];
+                    patch[PH * PW + idx] = v;
                 }
             }
-            const unsigned long long m = __ballot(act);
-            if (act) gl[ng + __popcll(m & ((1ULL << lane) - 1ULL))] = g;
-            ng += (int)__popcll(m);
-        }
-        // (the list is written and read by this wave only; LDS operations of one wave retire in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // software pipeline over the active groups: the offset table is read two groups ahead and the (dependent) patch
-        // gather one group ahead, so no MFMA of a group waits on an LDS round trip issued in that group.  (Fetching the weight
-        // fragments two groups ahead instead of one changes nothing: 338 us either way on the proxy batch.)
-        if (ng > 0) {
-            int gcur = gl[0];
-            int gnext = gl[ng > 1 ? 1 : 0];
-            f32x4 b0 = wp[gcur * 128], b1 = wp[gcur * 128 + 64];
-            int4 ko_n = *reinterpret_cast<const int4*>(koff + 8 * gcur + 4 * h);
-            float a0 = pbase[ko_n.x], a1 = pbase[ko_n.y], a2 = pbase[ko_n.z], a3 = pbase[ko_n.w];
-            ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
-            for (int j = 0; j < ng; ++j) {
-                f32x4 nb0 = b0, nb1 = b1;
-                float n0 = a0, n1 = a1, n2 = a2, n3 = a3;
-                if (j + 1 < ng) {
-                    nb0 = wp[gnext * 128]; nb1 = wp[gnext * 128 + 64];
-                    n0 = pbase[ko_n.x]; n1 = pbase[ko_n.y]; n2 = pbase[ko_n.z]; n3 = pbase[ko_n.w];
+            for (int k = tid; k < Kp; k += 256) {
+                int o = 0;
+                if (k < K) {
+                    const int c = k / 49, rs = k - c * 49;
+                    const int r = rs / 7, s = rs - r * 7;
+                    const int rk = rank[c] - c0;
+                    const int slot = (rk >= 0 && rk < nch) ? rk + 1 : 0;
+                    o = (slot * PH + r) * PW + s + 1;      // +1: the patch origin sits one column left of the receptive field
                 }
-                if (j + 2 < ng) {
-                    gnext = gl[j + 2];
-                    ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
-                }
-                acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
-                acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
-                acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
-                acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
-                b0 = nb0; b1 = nb1; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+                koff[k] = o;
             }
+            __syncthreads();
+            // ---- this wave's K groups of this pass.  A group is needed iff one of its 8 taps reads a flagged strip of rows
+            // 2*wave + r; it belongs to THIS pass iff the channels of those taps (one, or two neighbours) are all resident --
+            // except that a group of the first resident channel alone was already done as the previous pass's last channel ----
+            int ng = 0;
+            for (int gb = 0; gb < G; gb += 64) {
+                const int g = gb + lane;
+                int lo = 1 << 30, hi = -1;
+                if (g < G) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int rc = krow[8 * g + e];
+                        if (rc >= 0 && rowflag[rc + 2 * wave] != 0) {
+                            const int rk = rank[rc / PH];
+                            lo = min(lo, rk);
+                            hi = max(hi, rk);
+                        }
+                    }
+                }
+                const bool act = hi >= 0 && lo >= c0 && hi < c0 + nch && !(c0 > 0 && hi == c0);
+                const unsigned long long m = __ballot(act);
+                if (act) gl[ng + __popcll(m & ((1ULL << lane) - 1ULL))] = g;
+                ng += (int)__popcll(m);
+            }
+            // (the list is written and read by this wave only; LDS operations of one wave retire in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // software pipeline over the active groups: the offset table is read two groups ahead and the (dependent) patch
+            // gather one group ahead, so no MFMA of a group waits on an LDS round trip issued in that group
+            if (ng > 0) {
+                int gcur = gl[0];
+                int gnext = gl[ng > 1 ? 1 : 0];
+                f32x4 b0 = wp[gcur * 128], b1 = wp[gcur * 128 + 64];
+                int4 ko_n = *reinterpret_cast<const int4*>(koff + 8 * gcur + 4 * h);
+                float a0 = pbase[ko_n.x], a1 = pbase[ko_n.y], a2 = pbase[ko_n.z], a3 = pbase[ko_n.w];
+                ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
+                for (int j = 0; j < ng; ++j) {
+                    f32x4 nb0 = b0, nb1 = b1;
+                    float n0 = a0, n1 = a1, n2 = a2, n3 = a3;
+                    if (j + 1 < ng) {
+                        nb0 = wp[gnext * 128]; nb1 = wp[gnext * 128 + 64];
+                        n0 = pbase[ko_n.x]; n1 = pbase[ko_n.y]; n2 = pbase[ko_n.z]; n3 = pbase[ko_n.w];
+                    }
+                    if (j + 2 < ng) {
+                        gnext = gl[j + 2];
+                        ko_n = *reinterpret_cast<const int4*>(koff + 8 * gnext + 4 * h);
+                    }
+                    acc0 = mfma32(a0, b0[0], acc0); acc1 = mfma32(a0, b1[0], acc1);
+                    acc0 = mfma32(a1, b0[1], acc0); acc1 = mfma32(a1, b1[1], acc1);
+                    acc0 = mfma32(a2, b0[2], acc0); acc1 = mfma32(a2, b1[2], acc1);
+                    acc0 = mfma32(a3, b0[3], acc0); acc1 = mfma32(a3, b1[3], acc1);
+                    b0 = nb0; b1 = nb1; a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+                }
+            }
+            if (c0 + nch >= n_active) break;
+            __syncthreads();      // the next pass overwrites the patch and the tap table
         }
     }
 
@@ -319,7 +359,7 @@ extern "C" int straps_stem_fwd(const float* x, const float* w_frag, const float*
     STRAPS_REQUIRE(batch > 0 && cin > 0 && h >= 7 && w >= 7, "straps_stem_fwd: bad shape B=%d C=%d H=%d W=%d", batch, cin, h, w);
     STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_stem_fwd: scale and shift must be given together");
     const int K = cin * 49, Kp = (K + 7) / 8 * 8;
-    const size_t lds = (size_t)cin * PH * PW * sizeof(float) + ((size_t)Kp + (size_t)cin * PH + 4 * (size_t)(Kp >> 3)) * sizeof(int);
+    const size_t lds = (size_t)(1 + NSLOT) * PH * PW * sizeof(float) + (2 * (size_t)Kp + (size_t)cin * PH + 2 * (size_t)cin + 4 * (size_t)(Kp >> 3)) * sizeof(int);
     STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_fwd: %d input channels need %zu B of LDS (max 160 KiB)", cin, lds);
     const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
     const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;

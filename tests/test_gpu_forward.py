@@ -181,6 +181,41 @@ def test_conv_igemm_vs_cpu(dev, B, Cin, Cout, H, k, stride, cfg):
     _close(y2, want, 3e-5, 3e-5, 'fused epilogue')
 
 
+@pytest.mark.parametrize('B,Cin,Cout,H,k,stride,tile', [
+    (3, 64, 64, 13, 3, 1, 3), (2, 128, 128, 16, 3, 1, 1), (2, 64, 128, 18, 3, 2, 2), (2, 96, 64, 9, 1, 1, 3), (1, 256, 256, 8, 3, 1, 0)])
+def test_conv_lds_dma_equals_register_staging(dev, B, Cin, Cout, H, k, stride, tile):
+    """The default operand path (global -> LDS by the LDS-DMA, XOR-swizzled rows, zero constant for the padding pixels) against
+    the register-staged path of the same kernel (tile_cfg bit 4): same MFMA order, so the outputs must agree bit for bit --
+    ragged M (partial last tile), halo pixels, fused epilogue, statistics partials, and the four-class stride-2 data gradient."""
+    L = hipabi.lib()
+    pad = 1 if k == 3 else 0
+    x = torch.from_numpy(det_uniform((B, Cin, H, H), 11, -1, 1))
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 12, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
+    ya, pa = _run_conv(dev, x, w, stride, pad, cfg=tile, stats=True)
+    yb, pb = _run_conv(dev, x, w, stride, pad, cfg=tile | 16, stats=True)
+    assert torch.equal(ya, yb) and torch.equal(pa, pb)
+    sc = torch.from_numpy(det_uniform((Cout,), 13, 0.5, 1.5))
+    sh = torch.from_numpy(det_uniform((Cout,), 14, -0.5, 0.5))
+    res = torch.from_numpy(det_uniform(tuple(ya.shape), 15, -1, 1))
+    ya, _ = _run_conv(dev, x, w, stride, pad, sc, sh, res, True, tile)
+    yb, _ = _run_conv(dev, x, w, stride, pad, sc, sh, res, True, tile | 16)
+    assert torch.equal(ya, yb)
+    if Cin % 64 == 0 and not (tile == 1 and Cin % 128):
+        Ho = (H + 2 * pad - k) // stride + 1
+        dy = torch.from_numpy(det_uniform((B, Ho, Ho, Cout), 16, -1, 1)).to(dev)
+        wd = w.contiguous().to(dev)
+        wpk = torch.empty_like(wd)
+        hipabi.check(L.straps_pack_conv_weight_dgrad(hipabi.ptr(wd), hipabi.ptr(wpk), Cout, Cin, k, k, None), 'pack dgrad')
+        outs = []
+        for cfg in (tile, tile | 16):
+            dx = torch.full((B, H, H, Cin), float('nan'), device=dev)
+            hipabi.check(L.straps_conv_dgrad(hipabi.ptr(dy), hipabi.ptr(wpk), None, hipabi.ptr(dx), B, H, H, Cin, Cout, k, k, stride, pad,
+                                             cfg, None), 'dgrad')
+            outs.append(dx)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+
+
 @pytest.mark.parametrize('B,C,H,W', [(2, 18, 256, 256), (1, 1, 64, 96), (3, 18, 40, 72)])
 def test_stem_vs_cpu(dev, B, C, H, W):
     L = hipabi.lib()

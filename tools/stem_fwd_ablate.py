@@ -16,7 +16,7 @@ B, C, H, W = x.shape
 net = reg.image_encoder
 wfrag = net._packed_weight(net.conv1, stem=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-paths = sorted(glob.glob(os.path.join(ROOT, 'build_dbg', 'lib_*.so')))
+paths = sorted(glob.glob(os.path.join(ROOT, 'build_dbg', 'lib_*.so'))) or [hipabi.LIB_PATH]
 wa = torch.randn(8192, 8192, device=dev)
 for _ in range(40): wa @ wa
 torch.cuda.synchronize()
@@ -27,7 +27,7 @@ for path in paths + paths[:1]:
     y = torch.empty(B, 128, 128, 64, device=dev)
     part = torch.empty(L.straps_stem_stat_blocks(B, H, W), 64, 2, device=dev)
     row = os.path.basename(path) + ':'
-    for tag, mask in (('sparse', nz), ('dense', torch.full_like(nz, -1))):
+    for tag, mask in (('sparse', nz), ('dense', torch.full_like(nz, -1)), ('empty', torch.zeros_like(nz))):
         fn = lambda: L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), hipabi.ptr(mask), B, C, H, W, None)
         assert fn() == 0, L.straps_last_error()
         torch.cuda.synchronize()
