@@ -140,11 +140,25 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
             after_layer3()
     rec = tape['maxpool']
     B, H, W, Cc, Hp, Wp = rec['geom']
-    dstem = _empty_like(rec['x'])
-    hipabi.check(L.straps_maxpool_bwd(hipabi.ptr(dy), hipabi.ptr(rec['idx']), hipabi.ptr(dstem), B, H, W, Cc, hipabi.stream_ptr()),
-                 'straps_maxpool_bwd')
-    rec = tape['stem']
-    draw, _ = _bn_bwd(L, rec, dstem, True, False, grads)
+    if rec['kind'] == 'maxpool_fused':
+        # max-pool backward + BatchNorm/ReLU backward in one: the un-pooled gradient is gathered, never written
+        idx = rec['idx']
+        rec = tape['stem']
+        bn, raw, ss = rec['bn'], rec['raw'], rec['stats']
+        ws = torch.empty(L.straps_bn_bwd_workspace_bytes(B * H * W, Cc) // 4, device=raw.device, dtype=torch.float32)
+        dgamma, dbeta = grads.buf(bn.weight), grads.buf(bn.bias)
+        draw = _empty_like(raw)
+        hipabi.check(L.straps_bn_bwd_pooled(hipabi.ptr(dy), hipabi.ptr(idx), hipabi.ptr(raw), hipabi.ptr(ss[2]), hipabi.ptr(ss[3]),
+                                            hipabi.ptr(bn.weight), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(dgamma), hipabi.ptr(dbeta),
+                                            hipabi.ptr(draw), hipabi.ptr(ws), B, H, W, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd_pooled')
+        grads[bn.weight] = dgamma
+        grads[bn.bias] = dbeta
+    else:
+        dstem = _empty_like(rec['x'])
+        hipabi.check(L.straps_maxpool_bwd(hipabi.ptr(dy), hipabi.ptr(rec['idx']), hipabi.ptr(dstem), B, H, W, Cc, hipabi.stream_ptr()),
+                     'straps_maxpool_bwd')
+        rec = tape['stem']
+        draw, _ = _bn_bwd(L, rec, dstem, True, False, grads)
     B, Cin, H, W, Ho, Wo = rec['geom']
     ws = torch.empty(L.straps_stem_wgrad_workspace_bytes(B, Cin, H, W) // 4, device=draw.device, dtype=torch.float32)
     dw = grads.buf(net.conv1.weight)

@@ -514,11 +514,47 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
 // (few rows, many channels) still fills the chip, and every wave load is 4 full 256-byte row segments.
 // ReLU mask: (yact > 0), or -- when the activation is exactly relu(raw*msc + msh), no residual -- recomputed from raw
 // with the forward's own fmaf (bit-identical to reading yact, one tensor read less).
+//
+// POOL variants (the stem's BatchNorm, whose output only feeds the 3x3/s2 max-pool): the incoming gradient is never materialised --
+// each element gathers it from the <= 4 pooling windows that cover it, in the order straps_maxpool_bwd uses (bit-identical).
+struct PoolSrc {
+    const float* dyp;       // [B][Ho][Wo][C] gradient of the pooled tensor
+    const uint8_t* idx;     // [B][Ho][Wo][C] arg-max tap of every window
+    int H, W, Ho, Wo;
+};
+
+__device__ __forceinline__ f32x4 pool_grad(const PoolSrc& ps, long long row, int c4, int C) {
+    const int wi = (int)(row % ps.W);
+    const long long t = row / ps.W;
+    const int hi = (int)(t % ps.H);
+    const long long b = t / ps.H;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;        // windows (ho,wo) with 2*ho-1 <= hi <= 2*ho+1
+    const int wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        if (ho >= ps.Ho) continue;
+        const int r = hi - (2 * ho - 1);
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            if (wo >= ps.Wo) continue;
+            const int want = r * 3 + wi - (2 * wo - 1);
+            const long long o = ((b * ps.Ho + ho) * ps.Wo + wo) * C + c4 * 4;
+            const uchar4 k = *reinterpret_cast<const uchar4*>(ps.idx + o);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(ps.dyp + o);
+            if (k.x == want) g[0] += d[0];
+            if (k.y == want) g[1] += d[1];
+            if (k.z == want) g[2] += d[2];
+            if (k.w == want) g[3] += d[3];
+        }
+    }
+    return g;
+}
+
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ msc,
                                                             const float* __restrict__ msh, float* __restrict__ part, long long rows,
-                                                            int C, int rows_per_block) {
+                                                            int C, int rows_per_block, PoolSrc ps) {
     __shared__ float red[256][8];
     constexpr int TR = 16;
     const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
@@ -539,7 +575,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long o = (r + (long long)u * TR) * C + c4 * 4;
-                g[u] = *reinterpret_cast<const f32x4*>(dy + o);
+                if constexpr (POOL) g[u] = pool_grad(ps, r + (long long)u * TR, c4, C);
+                else g[u] = *reinterpret_cast<const f32x4*>(dy + o);
                 xr[u] = *reinterpret_cast<const f32x4*>(raw + o);
                 if (yact) ya[u] = *reinterpret_cast<const f32x4*>(yact + o);
             }
@@ -558,7 +595,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         }
         for (; r < r1; r += TR) {
             const long long o = r * C + c4 * 4;
-            f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+            f32x4 g;
+            if constexpr (POOL) g = pool_grad(ps, r, c4, C);
+            else g = *reinterpret_cast<const f32x4*>(dy + o);
             const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + o);
             if (yact) {
                 const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + o);
@@ -606,15 +645,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // pass 2: draw = k1 * (dz - m1 - xhat*m2);  optionally also writes dz (the gradient the skip connection receives)
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                            const float* __restrict__ raw, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            const float* __restrict__ msc, const float* __restrict__ msh,
-                                                           float* __restrict__ draw, float* dz_out, long long n4, int C) {
+                                                           float* __restrict__ draw, float* dz_out, long long n4, int C, PoolSrc ps) {
     const int C4 = C >> 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
         const int c4 = (int)(idx % C4);
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+        f32x4 g;
+        if constexpr (POOL) g = pool_grad(ps, idx / C4, c4, C);
+        else g = *reinterpret_cast<const f32x4*>(dy + idx * 4);
         const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + idx * 4);
         if (yact) {
             const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + idx * 4);
@@ -666,6 +708,47 @@ __global__ __launch_bounds__(256) void maxpool_idx_kernel(const float* __restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (first || v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; am[e] = r * 3 + s; }
+                first = false;
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = m;
+        *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4((unsigned char)am[0], (unsigned char)am[1], (unsigned char)am[2], (unsigned char)am[3]);
+    }
+}
+
+// training-mode stem tail: max-pool 3x3/s2/p1 of y = relu(raw*scale + shift) straight from raw -- y itself is never written (the
+// backward re-derives the ReLU mask from raw and gathers the pooled gradient, straps_bn_bwd_pooled).  Same fmaf / fmaxf / compare
+// sequence as straps_bn_apply followed by straps_maxpool_fwd_idx: bit-identical outputs and arg-max taps.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                                              int B, int H, int W, int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const long long n = (long long)B * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int am[4] = {0, 0, 0, 0};
+        bool first = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(raw + (((long long)b * H + hi) * W + wi) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+                    if (first || v[e] > m[e] || v[e] != v[e]) { m[e] = v[e]; am[e] = r * 3 + s; }
+                }
                 first = false;
             }
         }
@@ -1023,13 +1106,48 @@ extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* ra
     const int rpb = (int)((rows + nblk - 1) / nblk);
     float* part = (float*)workspace;                 // [nblk][c][2]
     float* coef = part + (size_t)nblk * c * 2;       // [3][c]
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coef, mask_scale, mask_shift, draw, dz_out, n4, c);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coef, mask_scale, mask_shift, draw, dz_out, n4, c, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, const float* raw, const float* save_mean, const float* save_invstd,
+                                    const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta,
+                                    float* draw, void* workspace, int batch, int h, int w, int c, int accumulate, void* stream) {
+    STRAPS_REQUIRE(dy_pool && idx && raw && save_mean && save_invstd && gamma && mask_scale && mask_shift && dgamma && dbeta && draw && workspace,
+                   "straps_bn_bwd_pooled: null pointer");
+    STRAPS_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd_pooled: bad shape %dx%dx%dx%d", batch, h, w, c);
+    const int C4 = c >> 2;
+    STRAPS_REQUIRE(C4 <= 256 ? (256 % C4 == 0) : (C4 % 256 == 0), "straps_bn_bwd_pooled: channel count %d not supported", c);
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)batch * h * w;
+    const int nblk = straps_bn_bwd_blocks(rows, c);
+    const int rpb = (int)((rows + nblk - 1) / nblk);
+    float* part = (float*)workspace;                 // [nblk][c][2]  (straps_bn_bwd_workspace_bytes(rows, c))
+    float* coef = part + (size_t)nblk * c * 2;       // [3][c]
+    const PoolSrc ps{dy_pool, idx, h, w, (h - 1) / 2 + 1, (w - 1) / 2 + 1};
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, ps);
+    STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel<pool>");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
+    STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    const long long n4 = rows * C4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(capped_grid(n4)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coef, mask_scale, mask_shift, draw, nullptr, n4, c, ps);
+    STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel<pool>");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_relu_maxpool_fwd(const float* raw, const float* scale, const float* shift, float* y_pool, uint8_t* idx, int batch, int h,
+                                          int w, int c, void* stream) {
+    STRAPS_REQUIRE(raw && scale && shift && y_pool && idx && batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0, "straps_bn_relu_maxpool_fwd: bad arguments");
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const long long n = (long long)batch * Ho * Wo * (c >> 2);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, y_pool, idx, batch, h, w, c, Ho, Wo);
+    STRAPS_CHECK_LAUNCH("bn_relu_maxpool_kernel");
     return STRAPS_OK;
 }
 

@@ -28,7 +28,7 @@ class _Ctx:
         return torch.empty(*shape, device=self.device, dtype=torch.float32)
 
 
-def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec):
+def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=True):
     C = bn.weight.shape[0]
     L = ctx.L
     ss = ctx.empty(4, C)          # scale, shift, save_mean, save_invstd
@@ -40,6 +40,10 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec):
                                             hipabi.ptr(ss[2]), hipabi.ptr(ss[3]), hipabi.stream_ptr()), 'straps_bn_stats_finalize')
     if track and not ctx.defer_nbt:
         bn.num_batches_tracked.add_(1)
+    if not apply:                 # the caller fuses the normalisation into its consumer (stem: straps_bn_relu_maxpool_fwd)
+        if rec is not None:
+            rec.update(raw=raw, stats=ss, out=None)
+        return ss
     y = torch.empty_like(raw)
     hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
                                    hipabi.ptr(y), rows, C, hipabi.stream_ptr()), 'straps_bn_apply')
@@ -111,6 +115,18 @@ def encoder_forward(net, x, tape=None):
         part = ctx.empty(nblk, 64, 2)
         hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), hipabi.ptr(nzmask),
                                        B, C, H, W, hipabi.stream_ptr()), 'straps_stem_fwd')
+        if tape is not None and not getattr(net, 'unfused_stem_tail', False):      # (attribute: A/B switch for tests / tools)
+            # bn1 + relu + maxpool in one pass over the raw conv output: the 268 MB (B=64) activation is never written, the
+            # backward gathers the pooled gradient instead of materialising it (straps_bn_bwd_pooled)
+            ss = _bn_train_finish(ctx, net.bn1, y, part, nblk, B * Ho * Wo, None, True, rec, apply=False)
+            H, W = Ho, Wo
+            Hp, Wp = _conv_out(H, 3, 2, 1), _conv_out(W, 3, 2, 1)
+            p = ctx.empty(B, Hp, Wp, 64)
+            idx = torch.empty(B, Hp, Wp, 64, device=x.device, dtype=torch.uint8)
+            hipabi.check(L.straps_bn_relu_maxpool_fwd(hipabi.ptr(y), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(p), hipabi.ptr(idx),
+                                                      B, H, W, 64, hipabi.stream_ptr()), 'straps_bn_relu_maxpool_fwd')
+            tape['maxpool'] = dict(kind='maxpool_fused', out=p, idx=idx, geom=(B, H, W, 64, Hp, Wp))
+            return _residual_stages(ctx, net, p, B, Hp, Wp, tape)
         y = _bn_train_finish(ctx, net.bn1, y, part, nblk, B * Ho * Wo, None, True, rec)
     # ---- maxpool 3x3/s2/p1 (:149) ----
     H, W = Ho, Wo
@@ -123,7 +139,11 @@ def encoder_forward(net, x, tape=None):
         tape['maxpool'] = dict(kind='maxpool', x=y, out=p, idx=idx, geom=(B, H, W, 64, Hp, Wp))
     else:
         hipabi.check(L.straps_maxpool_fwd(hipabi.ptr(y), hipabi.ptr(p), B, H, W, 64, hipabi.stream_ptr()), 'straps_maxpool_fwd')
-    y, H, W = p, Hp, Wp
+    return _residual_stages(ctx, net, p, B, Hp, Wp, tape)
+
+
+def _residual_stages(ctx, net, y, B, H, W, tape):
+    L = ctx.L
     # ---- residual stages (:150-156) ----
     for li in range(1, 5):
         for unit in getattr(net, 'layer%d' % li):

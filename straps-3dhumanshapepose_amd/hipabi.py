@@ -94,6 +94,8 @@ SIGNATURES = {
     'straps_bn_bwd_blocks': (_I, [_L, _I]),
     'straps_bn_bwd_workspace_bytes': (_Z, [_L, _I]),
     'straps_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'straps_bn_relu_maxpool_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_bn_bwd_pooled': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'straps_maxpool_fwd_idx': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),

@@ -255,6 +255,32 @@ def test_regressor_param_grads_vs_reference_golden(dev, layers):
     print('r%d worst grad-norm rel err %.2e, worst cosine %.6f' % (layers, worst, worst_cos))
 
 
+def test_fused_stem_tail_equals_unfused(dev):
+    """bn1 + relu + maxpool fused (straps_bn_relu_maxpool_fwd / straps_bn_bwd_pooled: the stem activation and its gradient are
+    never materialised) against the unfused calls (straps_bn_apply, straps_maxpool_fwd_idx, straps_maxpool_bwd, straps_bn_bwd):
+    same arithmetic in the same order, so features and every parameter gradient agree bit for bit; also an odd-sized input
+    (pool windows clipped at the border)."""
+    for shape in ((3, 18, 256, 256), (2, 18, 120, 88)):
+        outs = []
+        for unfused in (False, True):
+            reg, _ = _load_det(straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP), 18, dev)
+            reg.train()
+            reg.image_encoder.unfused_stem_tail = unfused
+            x = torch.from_numpy(det_uniform(shape, 77, 0.0, 1.0)).to(dev)
+            x[:, 1:, ::3] = 0.0
+            coef = torch.from_numpy(det_uniform((shape[0], 157), 78)).to(dev)
+            cam, pose, shp = reg(x)
+            (torch.cat([cam, pose, shp], 1) * coef).sum().backward()
+            outs.append((torch.cat([cam, pose, shp], 1).detach().clone(), {n: p.grad.clone() for n, p in reg.named_parameters()},
+                         {n: b.clone() for n, b in reg.named_buffers()}))
+        (ya, ga, ba), (yb, gb, bb) = outs
+        assert torch.equal(ya, yb)
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), n
+        for n in ba:
+            assert torch.equal(ba[n], bb[n]), n
+
+
 def test_smpl_backward_vs_oracle_autograd(dev):
     model = straps_amd.synthetic_smpl_model(0)
     for B in (3, 37):
