@@ -112,6 +112,13 @@ class TrainStep:
             off += p_.numel()
         self.exchange = GradientExchange(self.flat_g, split_off if self.comm_overlap else 0, world_size, group)
         self.logvar_params = [getattr(criterion, n + '_log_var') for n in TASKS]
+        # the five loss log-variances are neighbours at the end of the flat buffer: the loss kernel writes their gradients in place
+        self._lv_flat = None
+        if all(p.requires_grad and p in self.gviews for p in self.logvar_params):
+            ptrs = [self.gviews[p].data_ptr() for p in self.logvar_params]
+            if all(ptrs[i + 1] - ptrs[i] == 4 for i in range(len(ptrs) - 1)):
+                off = (ptrs[0] - self.flat_g.data_ptr()) // 4
+                self._lv_flat = self.flat_g[off:off + len(ptrs)]
         # random draws come from torch's default device generator (graph-capture safe), seeded per rank
         with torch.cuda.device(self.dev):
             torch.cuda.manual_seed(seed + rank)
@@ -122,6 +129,7 @@ class TrainStep:
         d = self.dev
         self.mean_shape = torch.zeros(10, device=d) if mean_shape is None else torch.as_tensor(mean_shape, dtype=torch.float32, device=d)
         self.mean_cam_t = torch.tensor(mean_cam_t, device=d).expand(batch_size, 3).contiguous()
+        self._eye = torch.eye(3, device=d).expand(batch_size, 24, 3, 3).contiguous()        # rest pose of the 'reposed' SMPL passes
         K = np.array([[config.FOCAL_LENGTH, 0., config.REGRESSOR_IMG_WH / 2.0], [0., config.FOCAL_LENGTH, config.REGRESSOR_IMG_WH / 2.0],
                       [0., 0., 1.]], dtype=np.float32)
         self.cam_K = torch.from_numpy(K).to(d)
@@ -186,7 +194,7 @@ class TrainStep:
         cam_t[:, 2] += torch.rand(B, device=d, generator=self.gen) * 10.0 - 5.0
         # SMPL #1 / #2
         tgt_verts, tgt_joints = self.smpl.forward_arrays(tgt_shape, tgt_rot)
-        eye = torch.eye(3, device=d).expand(B, 24, 3, 3).contiguous()
+        eye = self._eye
         tgt_reposed, _ = self.smpl.forward_arrays(tgt_shape, eye, want_joints=False)
         # H36M-LSP 3D joints + P2: perspective projection of the COCO joints (utils/cam_utils.py:40-71, cam_R = I)
         tgt_j3d, tgt_j2d = torch.empty(B, 14, 3, device=d), torch.empty(B, 17, 2, device=d)
@@ -234,14 +242,14 @@ class TrainStep:
         hipabi.check(L.straps_rot6d_fwd(hipabi.ptr(pose6d), EST_LD, 24, hipabi.ptr(R), B, st), 'straps_rot6d_fwd')
         pred_shape = est[:, 147:157].contiguous()
         verts, joints = smpl.forward_arrays(pred_shape, R)                         # SMPL #3
-        eye = torch.eye(3, device=d).expand(B, 24, 3, 3).contiguous()
+        eye = self._eye
         reposed, _ = smpl.forward_arrays(pred_shape, eye, want_joints=False)       # SMPL #4 (metrics only, train loop :206)
         # heads + loss + gradients
         lv = self.crit.log_var_vector()
         loss = torch.empty(12, device=d)
         dverts, djoints = torch.empty_like(verts), torch.empty_like(joints)
         dest, drot = torch.empty(B, EST_LD, device=d), torch.empty(B, 24, 3, 3, device=d)
-        dlv = torch.empty(5, device=d)
+        dlv = self._lv_flat if self._lv_flat is not None else torch.empty(5, device=d)
         ws = torch.empty(L.straps_loss_workspace_bytes(B) // 4, device=d)
         hipabi.check(L.straps_loss_fwd_bwd(hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(est), EST_LD, hipabi.ptr(R), hipabi.ptr(batch['verts']),
                                            hipabi.ptr(batch['joints2d']), hipabi.ptr(batch['joints3d']), hipabi.ptr(batch['shape']),
@@ -260,9 +268,10 @@ class TrainStep:
                      'straps_rot6d_bwd')
         # regressor backward, gradients land in the flat buffer
         dfeat, _ = ief_backward(reg.ief_module, feat, ief_tape, dest, self.gviews)
-        for k, p in enumerate(self.logvar_params):            # (they sit at the very end of the flat buffer: part of the tail bucket)
-            if p.requires_grad:
-                self.gviews[p].copy_(dlv[k])
+        if self._lv_flat is None:
+            for k, p in enumerate(self.logvar_params):        # (they sit at the very end of the flat buffer: part of the tail bucket)
+                if p.requires_grad:
+                    self.gviews[p].copy_(dlv[k])
         encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews, self.side_stream, after_layer3)
         self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed)
         if self.metrics is not None:
