@@ -24,12 +24,23 @@ struct WgradP {
     int M, rows_per_split, ct, it;   // ct = Cout/64 tiles, it = Cin/64 tiles
 };
 
-constexpr int WL = 68;   // LDS row stride (floats) of the [32 pixels][64 channels] staging tiles
+__device__ __attribute__((aligned(16))) float k_zero16w[4] = {0.f, 0.f, 0.f, 0.f};   // source of padding / out-of-range pixels
 
+// One workgroup = one filter tap x a BCO(co) x BCI(ci) block x one split of the B*Ho*Wo pixels, 32 pixels per step.  Both operand
+// tiles ([32 px][BCO | BCI channels], unpadded rows) go global -> LDS through the LDS-DMA (one wave-instruction = 1 KiB = 4 or 2
+// pixels), two stages, one barrier per step; the fragment reads are ds_read_b32 over 32 consecutive channels (conflict-free without
+// padding).  The pixel coordinates of a thread's copy slots advance incrementally (no division in the loop).
+// The operands of this contraction stream from HBM (every pixel row is read once per tile of the OTHER channel dimension), so the
+// tile sets the roofline: 64x64 = 16 flop/B (~80 TFLOP/s at 5 TB/s), 128x128 = 32 flop/B.
+template <int BCO, int BCI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
-    __shared__ __attribute__((aligned(16))) float Ds[2][32][WL];
-    __shared__ __attribute__((aligned(16))) float Xs[2][32][WL];
+    constexpr int STG = 32 * (BCO + BCI);                         // floats per stage: [32 px][BCO] then [32 px][BCI]
+    constexpr int LPD = BCO / 4, PWD = 64 / LPD, RDD = 8 / PWD;   // dy: lanes per pixel, pixels per wave-copy, copy rounds per wave
+    constexpr int LPX = BCI / 4, PWX = 64 / LPX, RDX = 8 / PWX;
+    constexpr int MI = BCO / 64, NI = BCI / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][STG]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave >> 1, wn = wave & 1;
     int t = blockIdx.x;
     const int itile = t % p.it; t /= p.it;
@@ -37,75 +48,106 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     const int tap = t;
     const int r = tap / p.S, s = tap - r * p.S;
     const int split = blockIdx.y;
-    const int co0 = ctile * 64, ci0 = itile * 64;
+    const int co0 = ctile * BCO, ci0 = itile * BCI;
     const int mbeg = split * p.rows_per_split;
     const int mend = min(mbeg + p.rows_per_split, p.M);
     const int nsteps = (mend - mbeg + 31) >> 5;
-
-    const int lr = tid >> 4, lc = tid & 15;   // 16 rows x 16 float4 per pass, 2 passes
-    const int HoWo = p.Ho * p.Wo;
     const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
-    f32x4 rd[2], rx[2];
-    auto load_tile = [&](int st) {
+
+    // copy slots at step 0: round q of this wave copies pixels (q*4 + wave) * PW .. of the tile
+    int md[RDD];                                                  // dy rows need only the linear pixel index
+    int mx[RDX], wo_[RDX], ho_[RDX], b_[RDX];
+    const int cd = (lane % LPD) * 4, cx = (lane % LPX) * 4;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int m = mbeg + st * 32 + lr + 16 * q;
-            f32x4 vd = {0.f, 0.f, 0.f, 0.f}, vx = vd;
-            if (m < mend) {
-                vd = *reinterpret_cast<const f32x4*>(p.dy + (long long)m * p.Cout + co0 + lc * 4);
-                if (pointwise) {                               // 1x1 / stride 1: the source pixel IS the output pixel (no index math)
-                    vx = *reinterpret_cast<const f32x4*>(p.x + (long long)m * p.Cin + ci0 + lc * 4);
-                } else {
-                    const int b = m / HoWo;
-                    const int rem = m - b * HoWo;
-                    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
-                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                        vx = *reinterpret_cast<const f32x4*>(p.x + (((long long)b * p.H + hi) * p.W + wi) * p.Cin + ci0 + lc * 4);
-                }
-            }
-            rd[q] = vd;
-            rx[q] = vx;
-        }
-    };
-    auto store_tile = [&](int buf) {
+    for (int q = 0; q < RDD; ++q) md[q] = mbeg + (q * 4 + wave) * PWD + lane / LPD;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<f32x4*>(&Ds[buf][lr + 16 * q][lc * 4]) = rd[q];
-            *reinterpret_cast<f32x4*>(&Xs[buf][lr + 16 * q][lc * 4]) = rx[q];
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    if (nsteps > 0) {
-        load_tile(0);
-        store_tile(0);
+    for (int q = 0; q < RDX; ++q) {
+        const int m = mbeg + (q * 4 + wave) * PWX + lane / LPX;
+        mx[q] = m;
+        const int HoWo = p.Ho * p.Wo;
+        b_[q] = m / HoWo;
+        const int rem = m - b_[q] * HoWo;
+        ho_[q] = rem / p.Wo;
+        wo_[q] = rem - ho_[q] * p.Wo;
     }
-    __syncthreads();
+    const int adv_h = 32 / p.Wo, adv_w = 32 - adv_h * p.Wo;      // a step moves every slot 32 pixels on
+    auto dma_step = [&](int stage) {
+        float* D = smem + stage * STG;
+        float* X = D + 32 * BCO;
+#pragma unroll
+        for (int q = 0; q < RDD; ++q) {
+            const float* src = md[q] < mend ? p.dy + (long long)md[q] * p.Cout + co0 + cd : k_zero16w;
+            md[q] += 32;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(D + (q * 4 + wave_u) * PWD * BCO), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < RDX; ++q) {
+            const bool in = mx[q] < mend;
+            const float* src = k_zero16w;
+            if (pointwise) {
+                if (in) src = p.x + (long long)mx[q] * p.Cin + ci0 + cx;
+            } else {
+                const int hi = ho_[q] * p.stride - p.pad + r, wi = wo_[q] * p.stride - p.pad + s;
+                if (in && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    src = p.x + (((long long)b_[q] * p.H + hi) * p.W + wi) * p.Cin + ci0 + cx;
+                wo_[q] += adv_w; ho_[q] += adv_h;
+                if (wo_[q] >= p.Wo) { wo_[q] -= p.Wo; ++ho_[q]; }
+                if (ho_[q] >= p.Ho) { const int k = ho_[q] / p.Ho; ho_[q] -= k * p.Ho; b_[q] += k; }
+            }
+            mx[q] += 32;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(X + (q * 4 + wave_u) * PWX * BCI), 16, 0, 0);
+        }
+    };
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NI; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][c][q] = 0.f;
+    if (nsteps > 0) dma_step(0);
     const int i = lane & 31, h = lane >> 5;
+    const int fa = h * 4 * BCO + wm * (BCO / 2) + i, fb = 32 * BCO + h * 4 * BCI + wn * (BCI / 2) + i;
     for (int st = 0; st < nsteps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nsteps) load_tile(st + 1);
+        const int stage = st & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies of step st have landed ...
+        __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
+        asm volatile("" ::: "memory");
+        if (st + 1 < nsteps) dma_step(stage ^ 1);
+        const float* S = smem + stage * STG;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int k = kk * 8 + h * 4 + e;
-                acc = mfma32(Ds[buf][k][wm * 32 + i], Xs[buf][k][wn * 32 + i], acc);
+                const int k = kk * 8 + e;
+                float av[MI], bv[NI];
+#pragma unroll
+                for (int a = 0; a < MI; ++a) av[a] = S[fa + k * BCO + a * 32];
+#pragma unroll
+                for (int c = 0; c < NI; ++c) bv[c] = S[fb + k * BCI + c * 32];
+#pragma unroll
+                for (int a = 0; a < MI; ++a)
+#pragma unroll
+                    for (int c = 0; c < NI; ++c) acc[a][c] = mfma32(av[a], bv[c], acc[a][c]);
             }
         }
-        if (st + 1 < nsteps) store_tile(buf ^ 1);
-        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
     }
     // C layout: lane -> ci (col), reg -> co (row).  partial[split][co][tap][ci]
     const long long RS = (long long)p.R * p.S;
     float* o = p.part + (long long)split * p.Cout * RS * p.Cin;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int co = co0 + wm * 32 + mfma_row(q, lane);
-        o[((long long)co * RS + tap) * p.Cin + ci0 + wn * 32 + i] = acc[q];
-    }
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NI; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = co0 + wm * (BCO / 2) + a * 32 + mfma_row(q, lane);
+                o[((long long)co * RS + tap) * p.Cin + ci0 + wn * (BCI / 2) + c * 32 + i] = acc[a][c][q];
+            }
 }
 
 // ---- 3x3 / stride 1 / pad 1 weight gradient with an LDS-staged input halo patch ----------------------------------
@@ -123,8 +165,6 @@ struct Wgrad3P {
 };
 
 constexpr int W3PX = 32 + 112;   // pixels per LDS stage: dy tile + input patch rounded up to whole 16-pixel copy rounds
-
-__device__ __attribute__((aligned(16))) float k_zero16b[4] = {0.f, 0.f, 0.f, 0.f};   // source of the out-of-image halo pixels
 
 // Staging: both operands go global -> LDS through the LDS-DMA (global_load_lds_dwordx4; one wave-instruction = 4 pixels x 256 B,
 // rows unpadded: the fragment reads are ds_read_b32 over 32 consecutive channels, conflict-free as they are), two stages, one
@@ -176,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
             if (q * 16 >= npatch) break;                 // wave-uniform
             const int hi = ho0 + x_pr[q], wi = wo0 + x_pc[q];
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;     // (slots past the patch read anything)
-            const float* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin : k_zero16b;
+            const float* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin : k_zero16w;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(X + (4 * wave_u + 16 * q) * 64), 16, 0, 0);
         }
@@ -947,8 +987,17 @@ inline unsigned capped_grid(long long n) {
     return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
 }
 
-inline int wgrad_splits(long long M, int tiles) {
-    int s = (1536 + tiles - 1) / tiles;
+// 128x128 tiles (32 flop per operand byte instead of 16) for the big 1x1 layers (resnet50): +10 % there; the 3x3 / strided layers
+// and small pixel counts do better with 64x64 (more workgroups per tap: tools/sweep_wgrad_splits.py)
+inline bool wgrad_big_tile(long long M, int cin, int cout, int taps) {
+#ifdef WGRAD_NO_BIG
+    return false;
+#endif
+    return cin % 128 == 0 && cout % 128 == 0 && taps == 1 && M >= 8192;
+}
+
+inline int wgrad_splits(long long M, int tiles, bool big = false) {
+    int s = ((big ? 512 : 1536) + tiles - 1) / tiles;
     const long long max_s = (M + 127) / 128;      // at least 4 K-steps of 32 pixels per split
     if (s > max_s) s = (int)max_s;
     return s < 1 ? 1 : s;
@@ -989,8 +1038,10 @@ extern "C" size_t straps_conv_wgrad_workspace_bytes(int batch, int h, int w, int
     if (wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) return (size_t)splits3 * cout * 9 * cin * sizeof(float);
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     const long long M = (long long)batch * ho * wo;
-    const int tiles = kh * kw * (cout / 64) * (cin / 64);
-    return (size_t)wgrad_splits(M, tiles) * cout * kh * kw * cin * sizeof(float);
+    const bool big = wgrad_big_tile(M, cin, cout, kh * kw);
+    const int tile = big ? 128 : 64;
+    const int tiles = kh * kw * (cout / tile) * (cin / tile);
+    return (size_t)wgrad_splits(M, tiles, big) * cout * kh * kw * cin * sizeof(float);
 }
 
 extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw, void* workspace, int batch, int h, int w, int cin,
@@ -1026,12 +1077,24 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
     const long long M = (long long)batch * p.Ho * p.Wo;
     STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_wgrad: problem too large");
     p.M = (int)M;
-    p.ct = cout / 64; p.it = cin / 64;
+    const bool big = wgrad_big_tile(M, cin, cout, kh * kw);
+    const int tile = big ? 128 : 64;
+    p.ct = cout / tile; p.it = cin / tile;
     const int tiles = kh * kw * p.ct * p.it;
-    const int splits = wgrad_splits(M, tiles);
+    const int splits = wgrad_splits(M, tiles, big);
     p.rows_per_split = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
+    if (big) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) { straps_set_error("conv_wgrad_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3(tiles, splits), dim3(256), 64 * 1024, st, p);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3(tiles, splits), dim3(256), 32 * 1024, st, p);
+    }
     STRAPS_CHECK_LAUNCH("conv_wgrad_kernel");
     const long long n = (long long)cout * kh * kw * cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, st, p.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);

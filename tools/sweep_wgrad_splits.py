@@ -4,11 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import straps_amd
 from straps_amd import hipabi
 dev = torch.device('cuda:0')
-B = 32
+B = int(os.environ.get("SWEEP_B", "32"))
 SHAPES = [('l1 64>256', 64, 64, 256, 1, 1), ('l2 256>128', 64, 256, 128, 1, 1), ('l2 128>512', 32, 128, 512, 1, 1), ('l3 512>256', 32, 512, 256, 1, 1),
-          ('l3 256>1024', 16, 256, 1024, 1, 1), ('l4 1024>512', 16, 1024, 512, 1, 1), ('l4 512>2048', 8, 512, 2048, 1, 1), ('l3 3x3 s2', 32, 256, 256, 3, 2)]
+          ('l3 256>1024', 16, 256, 1024, 1, 1), ('l4 1024>512', 16, 1024, 512, 1, 1), ('l4 512>2048', 8, 512, 2048, 1, 1), ('l3 3x3 s2', 32, 256, 256, 3, 2),
+          ('r18 l2.0 s2', 64, 64, 128, 3, 2), ('r18 l3.0 s2', 32, 128, 256, 3, 2), ('r18 l4.0 s2', 16, 256, 512, 3, 2), ('r18 l3.0 ds', 32, 128, 256, 1, 2)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for path in sorted(glob.glob(os.path.join(ROOT, 'build_dbg', 'lib_sp*.so'))):
+paths = sorted(glob.glob(os.path.join(ROOT, 'build_dbg', 'lib_sp*.so')))
+for path in paths + paths[:1]:
     L = hipabi.load(path)
     row = os.path.basename(path) + ':'
     for name, H, Cin, Cout, k, stride in SHAPES:
@@ -21,8 +23,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, 'build_dbg', 'lib_sp*.so'))):
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10): run()
+        for _ in range(20): run()
         e1.record(); torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / 10 * 1e-3
+        t = e0.elapsed_time(e1) / 20 * 1e-3
         row += ' %s %.0fus(%.0fTF)' % (name, t * 1e6, 2.0 * B * Ho * Ho * Cout * Cin * k * k / t / 1e12)
     print(row, flush=True)
