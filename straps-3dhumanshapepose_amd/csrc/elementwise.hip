@@ -30,32 +30,61 @@ __global__ __launch_bounds__(256) void pack_crsk_flip_kernel(const float* __rest
     dst[i] = src[(((long long)o * C + c) * R + (R - 1 - r)) * S + (S - 1 - s)];
 }
 
-// both packings of every layer in one launch: thread i finds its layer by binary search over the element prefix sums
-__global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_desc_t* __restrict__ descs, int n, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].first <= i) lo = mid; else hi = mid - 1;
-    }
-    const straps_pack_desc_t d = descs[lo];
-    const long long j = i - d.first;
-    {   // j as KRSC index
-        const int c = (int)(j % d.c);
-        long long t = j / d.c;
-        const int s = (int)(t % d.s); t /= d.s;
-        const int r = (int)(t % d.r);
-        const int o = (int)(t / d.r);
-        d.dst_krsc[j] = d.src[(((long long)o * d.c + c) * d.r + r) * d.s + s];
-    }
-    if (d.dst_crsk) {   // j as flipped CRSK index
-        const int o = (int)(j % d.o);
-        long long t = j / d.o;
-        const int s = (int)(t % d.s); t /= d.s;
-        const int r = (int)(t % d.r);
-        const int c = (int)(t / d.r);
-        d.dst_crsk[j] = d.src[(((long long)o * d.c + c) * d.r + (d.r - 1 - r)) * d.s + (d.s - 1 - s)];
+// both packings of every layer in one launch.  Work unit = (layer, 32 output channels, 32 input channels, <= 9 taps): the source block
+// (32 runs of 32*RS contiguous floats) is read coalesced into an LDS tile, then written once as KRSC (128-byte runs over ci) and once
+// as flipped CRSK (128-byte runs over co) -- both sides of the transposes coalesced.  Blocks stride over the units; the layer of a
+// unit is found by walking the (few dozen) descriptors, wave-uniformly.
+constexpr int PK_T = 32, PK_RS = 9, PK_LD = PK_T * PK_RS + 1;
+__global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_desc_t* __restrict__ descs, int n) {
+    __shared__ float tile[PK_T * PK_LD];
+    const int tid = threadIdx.x;
+    int d = 0;
+    long long base = 0;                                    // first unit of descriptor d
+    for (long long u = blockIdx.x;; u += gridDim.x) {
+        long long units = 0;
+        int ot = 0, ct = 0, rt = 0;
+        for (; d < n; ++d) {
+            ot = (descs[d].o + PK_T - 1) / PK_T;
+            ct = (descs[d].c + PK_T - 1) / PK_T;
+            rt = (descs[d].r * descs[d].s + PK_RS - 1) / PK_RS;
+            units = (long long)ot * ct * rt;
+            if (u < base + units) break;
+            base += units;
+        }
+        if (d >= n) return;
+        const straps_pack_desc_t D = descs[d];
+        const int RS = D.r * D.s;
+        int v = (int)(u - base);
+        const int ri = v % rt; v /= rt;
+        const int ci = v % ct;
+        const int oi = v / ct;
+        const int o0 = oi * PK_T, c0 = ci * PK_T, rs0 = ri * PK_RS;
+        const int no = min(PK_T, D.o - o0), nc = min(PK_T, D.c - c0), nr = min(PK_RS, RS - rs0);
+        // load: for each o a run of nc*RS floats (contiguous when the layer has <= 9 taps)
+        const int run = nc * nr;
+        for (int idx = tid; idx < no * run; idx += 256) {
+            const int o = idx / run, k = idx - o * run;
+            const int c = k / nr, j = k - c * nr;
+            tile[o * PK_LD + c * PK_RS + j] = D.src[((long long)(o0 + o) * D.c + c0 + c) * RS + rs0 + j];
+        }
+        __syncthreads();
+        // KRSC: dst[o][rs][c]
+        for (int idx = tid; idx < no * nr * PK_T; idx += 256) {
+            const int c = idx & (PK_T - 1);
+            const int k = idx >> 5;
+            const int j = k % nr, o = k / nr;
+            if (c < nc) D.dst_krsc[((long long)(o0 + o) * RS + rs0 + j) * D.c + c0 + c] = tile[o * PK_LD + c * PK_RS + j];
+        }
+        // flipped CRSK: dst[c][R-1-r][S-1-s][o] -- flipping (r, s) jointly is reversing the tap index rs
+        if (D.dst_crsk) {
+            for (int idx = tid; idx < nc * nr * PK_T; idx += 256) {
+                const int o = idx & (PK_T - 1);
+                const int k = idx >> 5;
+                const int j = k % nr, c = k / nr;
+                if (o < no) D.dst_crsk[((long long)(c0 + c) * RS + (RS - 1 - (rs0 + j))) * D.o + o0 + o] = tile[o * PK_LD + c * PK_RS + j];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -176,7 +205,9 @@ extern "C" int straps_pack_conv_weight_dgrad(const float* w_oihw, float* w_crsk,
 
 extern "C" int straps_pack_conv_weights_batched(const straps_pack_desc_t* descs, int n, long long total, void* stream) {
     STRAPS_REQUIRE(descs && n > 0 && total > 0, "straps_pack_conv_weights_batched: bad arguments");
-    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, descs, n, total);
+    long long blocks = (total + PK_T * PK_T * PK_RS - 1) / (PK_T * PK_T * PK_RS);       // ~ one unit per block for 3x3 layers, grid-stride beyond
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs, n);
     STRAPS_CHECK_LAUNCH("pack_batched_kernel");
     return STRAPS_OK;
 }

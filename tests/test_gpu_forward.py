@@ -281,6 +281,42 @@ def test_stem_zero_skipping_is_exact(dev):
     assert float((outs[0] == 0).float().mean()) > 0.05            # there really are untouched output regions
 
 
+def test_batched_weight_pack_equals_single_packs(dev):
+    """straps_pack_conv_weights_batched (LDS-tiled transposes, all layers in one launch) against straps_pack_conv_weight and
+    straps_pack_conv_weight_dgrad layer by layer: 1x1 / 3x3 / 5x5 taps, channel counts that are not multiples of the 32x32 tile,
+    a layer without the data-gradient layout."""
+    import numpy as np
+    L = hipabi.lib()
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (96, 40, 3, 3), (33, 70, 5, 5), (256, 128, 3, 3), (8, 8, 1, 1)]
+    ws = [torch.from_numpy(det_uniform(sh, 40 + i, -1, 1)).to(dev) for i, sh in enumerate(shapes)]
+    total = sum(w.numel() for w in ws)
+    krsc = torch.full((total,), float('nan'), device=dev)
+    crsk = torch.full((total,), float('nan'), device=dev)
+    descs = (hipabi.PackDesc * len(ws))()
+    off = 0
+    for i, (d, w) in enumerate(zip(descs, ws)):
+        d.src, d.dst_krsc = w.data_ptr(), krsc.data_ptr() + 4 * off
+        d.dst_crsk = None if i == 2 else crsk.data_ptr() + 4 * off
+        d.o, d.c, d.r, d.s, d.first = w.shape[0], w.shape[1], w.shape[2], w.shape[3], off
+        off += w.numel()
+    table = torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()).to(dev)
+    hipabi.check(L.straps_pack_conv_weights_batched(hipabi.ptr(table), len(ws), total, None), 'batched pack')
+    off = 0
+    for i, w in enumerate(ws):
+        O, C, R, S = w.shape
+        a, b = torch.empty_like(w), torch.empty_like(w)
+        hipabi.check(L.straps_pack_conv_weight(hipabi.ptr(w), hipabi.ptr(a), O, C, R, S, None), 'pack')
+        hipabi.check(L.straps_pack_conv_weight_dgrad(hipabi.ptr(w), hipabi.ptr(b), O, C, R, S, None), 'pack dgrad')
+        n = w.numel()
+        assert torch.equal(krsc[off:off + n], a.reshape(-1)), shapes[i]
+        assert torch.equal(a.reshape(O, R, S, C), w.permute(0, 2, 3, 1))
+        if i == 2:
+            assert bool(torch.isnan(crsk[off:off + n]).all())
+        else:
+            assert torch.equal(crsk[off:off + n], b.reshape(-1)), shapes[i]
+        off += n
+
+
 def test_pool_gap_bn_helpers(dev):
     L = hipabi.lib()
     x = torch.from_numpy(det_uniform((3, 64, 17, 22), 8, -1, 1))
