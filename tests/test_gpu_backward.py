@@ -67,6 +67,30 @@ def test_conv_dgrad_wgrad(dev, B, Cin, Cout, H, k, stride):
     assert _relerr(dw, 2 * w.grad) < 2e-5
 
 
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride', [
+    (2, 128, 256, 64, 64, 1, 1),      # 128x128-tile per-tap kernel (big 1x1 layer)
+    (8, 128, 128, 64, 64, 1, 2),      # the same through a strided 1x1 (down-sample branch)
+    (3, 64, 64, 20, 12, 3, 2),        # non-square, 3x3/s2: incremental pixel coordinates with Wo = 6
+    (2, 64, 64, 10, 24, 3, 1),        # non-square, W not a power of two: per-tap kernel for a 3x3/s1 layer
+    (2, 64, 128, 12, 32, 3, 1),       # non-square through the halo-patch kernel (cw = 32, one row per chunk)
+    (1, 64, 64, 4, 4, 3, 1),          # 16 pixels in all: a single partial step
+    (5, 64, 64, 7, 9, 1, 1)])         # ragged pixel count (315) through the pointwise path
+def test_conv_wgrad_shapes(dev, B, Cin, Cout, H, W, k, stride):
+    """weight gradient on shapes outside the resnet geometry (all three kernels) vs autograd fp64."""
+    L = hipabi.lib()
+    pad = 1 if k == 3 else 0
+    x = torch.from_numpy(det_uniform((B, Cin, H, W), 21, -1, 1)).double()
+    w = (torch.from_numpy(det_uniform((Cout, Cin, k, k), 22, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5).double().requires_grad_()
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = torch.from_numpy(det_uniform(tuple(y.shape), 23, -1, 1)).double()
+    y.backward(dy)
+    xd, dyd = nhwc(x.float(), dev), nhwc(dy.float(), dev)
+    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=dev)
+    dw = torch.full((Cout, Cin, k, k), float('nan'), device=dev)
+    hipabi.check(L.straps_conv_wgrad(hipabi.ptr(xd), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride, pad, 0, None), 'wgrad')
+    assert _relerr(dw, w.grad) < 2e-5
+
+
 @pytest.mark.parametrize('B,C,H,W', [(2, 18, 64, 64), (1, 1, 40, 72), (3, 18, 33, 50)])
 def test_stem_wgrad(dev, B, C, H, W):
     L = hipabi.lib()
