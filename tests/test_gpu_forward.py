@@ -181,6 +181,28 @@ def test_conv_igemm_vs_cpu(dev, B, Cin, Cout, H, k, stride, cfg):
     _close(y2, want, 3e-5, 3e-5, 'fused epilogue')
 
 
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride', [(2, 64, 64, 10, 24, 3, 1), (3, 96, 128, 7, 13, 3, 2), (2, 64, 64, 5, 40, 1, 1), (1, 32, 64, 3, 3, 3, 1)])
+def test_conv_igemm_non_square(dev, B, Cin, Cout, H, W, k, stride):
+    """implicit GEMM forward + data gradient on non-square maps, channel counts of 32 / 96, a 3x3 map smaller than one tile."""
+    L = hipabi.lib()
+    pad = 1 if k == 3 else 0
+    x = torch.from_numpy(det_uniform((B, Cin, H, W), 51, -1, 1)).double().requires_grad_()
+    w = (torch.from_numpy(det_uniform((Cout, Cin, k, k), 52, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5).double().requires_grad_()
+    ref = F.conv2d(x, w, None, stride, pad)
+    y, _ = _run_conv(dev, x.detach().float(), w.detach().float(), stride, pad, stats=True)
+    _close(y, ref.detach(), 2e-5, 2e-5, 'raw conv')
+    if Cin % 64 == 0:
+        dy = torch.from_numpy(det_uniform(tuple(ref.shape), 53, -1, 1)).double()
+        ref.backward(dy)
+        wd = w.detach().float().to(dev)
+        wpk = torch.empty_like(wd)
+        hipabi.check(L.straps_pack_conv_weight_dgrad(hipabi.ptr(wd), hipabi.ptr(wpk), Cout, Cin, k, k, None), 'pack dgrad')
+        dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+        dx = torch.full((B, H, W, Cin), float('nan'), device=dev)
+        hipabi.check(L.straps_conv_dgrad(hipabi.ptr(dyd), hipabi.ptr(wpk), None, hipabi.ptr(dx), B, H, W, Cin, Cout, k, k, stride, pad, 0, None), 'dgrad')
+        _close(dx.permute(0, 3, 1, 2).cpu(), x.grad, 2e-5, 2e-5, 'dgrad')
+
+
 @pytest.mark.parametrize('B,Cin,Cout,H,k,stride,tile', [
     (3, 64, 64, 13, 3, 1, 3), (2, 128, 128, 16, 3, 1, 1), (2, 64, 128, 18, 3, 2, 2), (2, 96, 64, 9, 1, 1, 3), (1, 256, 256, 8, 3, 1, 0)])
 def test_conv_lds_dma_equals_register_staging(dev, B, Cin, Cout, H, k, stride, tile):
