@@ -79,8 +79,10 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
     return out, Ho, Wo
 
 
-def encoder_forward(net, x, tape=None):
-    """net: resnet.ResNet; x: float32 [B,C,H,W] NCHW on the GPU.  Returns features [B, 512|2048]."""
+def encoder_forward(net, x, tape=None, nzmask=None):
+    """net: resnet.ResNet; x: float32 [B,C,H,W] NCHW on the GPU.  Returns features [B, 512|2048].
+    nzmask: optional non-zero map of x already computed by straps_stem_nzmask (the training step's data pipeline makes it next to
+    the input, off the critical path)."""
     hipabi.require_gpu_tensor(x, 'encoder input', torch.float32)
     if x.dim() != 4 or x.shape[1] != net.in_channels:
         raise RuntimeError('encoder expects [B,%d,H,W], got %s' % (net.in_channels, tuple(x.shape)))
@@ -99,10 +101,15 @@ def encoder_forward(net, x, tape=None):
         rec = dict(kind='stem', conv=net.conv1, bn=net.bn1, x=x, geom=(B, C, H, W, Ho, Wo), relu=True, residual=None)
         tape["stem"] = rec
     # non-zero map of the input (the proxy representation is ~98 % exact zeros): the stem kernels skip those cells
-    nzmask = torch.empty(L.straps_stem_nzmask_words(B, C, H, W), device=x.device, dtype=torch.int32)
+    nwords = L.straps_stem_nzmask_words(B, C, H, W)
     if getattr(net, 'dense_stem', False):
+        nzmask = torch.empty(nwords, device=x.device, dtype=torch.int32)
         nzmask.fill_(-1)          # A/B switch (bench.py --dense-stem): every cell marked non-zero = the plain dense convolution
+    elif nzmask is not None:
+        if nzmask.dtype != torch.int32 or nzmask.numel() != nwords or nzmask.device != x.device or not nzmask.is_contiguous():
+            raise RuntimeError('encoder_forward: nzmask must be a contiguous int32 tensor of %d words on %s' % (nwords, x.device))
     else:
+        nzmask = torch.empty(nwords, device=x.device, dtype=torch.int32)
         hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nzmask), B, C, H, W, hipabi.stream_ptr()), 'straps_stem_nzmask')
     if rec is not None:
         rec['nzmask'] = nzmask

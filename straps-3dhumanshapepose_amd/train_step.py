@@ -175,7 +175,9 @@ class TrainStep:
         self._bufs = [dict(input=torch.empty(B_, 18, 256, 256, device=d), verts=torch.empty(B_, 6890, 3, device=d),
                            joints2d=torch.empty(B_, 17, 2, device=d), joints3d=torch.empty(B_, 14, 3, device=d),
                            shape=torch.empty(B_, 10, device=d), rot=torch.empty(B_, 24, 3, 3, device=d),
-                           reposed=torch.empty(B_, 6890, 3, device=d)) for _ in range(2)] if self.pipeline else None
+                           reposed=torch.empty(B_, 6890, 3, device=d),
+                           nzmask=torch.empty(hipabi.lib().straps_stem_nzmask_words(B_, 18, 256, 256), device=d, dtype=torch.int32))
+                      for _ in range(2)] if self.pipeline else None
         self._cur, self._primed = 0, False
 
     # ------------------------------------------------------------------ data generation (no grad)
@@ -217,11 +219,14 @@ class TrainStep:
         # G4 + G5
         x = torch.empty(B, 18, 256, 256, device=d) if out is None else out['input']
         hipabi.check(L.straps_build_proxy_input(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), B, 17, 256, st), 'straps_build_proxy_input')
-        batch = dict(input=x, verts=tgt_verts, joints2d=tgt_j2d, joints3d=tgt_j3d, shape=tgt_shape, rot=tgt_rot, reposed=tgt_reposed)
+        # non-zero map of the input for the stem's zero skipping: made here, next to the input, off the step's critical path
+        nz = torch.empty(L.straps_stem_nzmask_words(B, 18, 256, 256), device=d, dtype=torch.int32) if out is None else out['nzmask']
+        hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nz), B, 18, 256, 256, st), 'straps_stem_nzmask')
+        batch = dict(input=x, verts=tgt_verts, joints2d=tgt_j2d, joints3d=tgt_j3d, shape=tgt_shape, rot=tgt_rot, reposed=tgt_reposed, nzmask=nz)
         if out is None:
             return batch
         for k, v in batch.items():
-            if k != 'input':
+            if k not in ('input', 'nzmask'):
                 out[k].copy_(v)
         return out
 
@@ -235,7 +240,7 @@ class TrainStep:
         reg.image_encoder.prepack(with_dgrad=True)          # every conv's forward + data-gradient weight layout, one launch
         if self.nbt_flat is not None:
             self.nbt_flat.add_(1)                           # num_batches_tracked of every BatchNorm (encoder_exec defers to this)
-        feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape)
+        feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape, nzmask=batch.get('nzmask'))
         est = reg.ief_module.forward_estimate(feat, ief_tape)                      # [B,160]
         pose6d = est[:, 3:147]
         R = torch.empty(B, 24, 3, 3, device=d)
