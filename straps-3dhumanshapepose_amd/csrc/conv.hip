@@ -136,24 +136,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     };
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto dma_tile = [&](int q, int stage) {
-        const int tap = q / cchunks;
-        const int c0 = (q - tap * cchunks) << 5;
-        const int dh = c.tap_dh[tap], dw = c.tap_dw[tap], tw = c.tap_w[tap];
-        const int toff = (dh * p.W + dw) * p.Cin + c0;
+    // LDS-DMA copies of the NEXT chunk.  Chunks run tap-major: inside a tap the source pointers just move 32 channels on, so the
+    // tap table, the halo test and the 64-bit address arithmetic are done once per tap, not once per chunk.
+    const float* a_src[AP];
+    int a_inc[AP];                 // 32 floats per chunk, 0 for a padding pixel (its source stays the zero constant)
+    const float* b_src[BP];
+    int n_tap = 0, n_cc = 0;
+    // the tap table lives in three VGPRs (lane t = tap t) and is read with v_readlane: no scalar memory round trip in the loop
+    const int tl = lane < 9 ? lane : 0;
+    const int v_dh = c.tap_dh[tl], v_dw = c.tap_dw[tl], v_tw = c.tap_w[tl];
+    const float* zsrc = k_zero16;
+    asm volatile("" : "+s"(zsrc));          // (keep the constant's address in SGPRs instead of re-deriving it per tap)
+    auto setup_tap = [&](int tap) {
+        const int dh = __builtin_amdgcn_readlane(v_dh, tap), dw = __builtin_amdgcn_readlane(v_dw, tap), tw = __builtin_amdgcn_readlane(v_tw, tap);
+        const int toff = (dh * p.W + dw) * p.Cin;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const float* src = ok ? p.x + (a_base[i] + toff) : k_zero16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(As + (stage * BM + 32 * i + 8 * wave_u) * 32), 16, 0, 0);
+            a_src[i] = ok ? p.x + (a_base[i] + toff) : zsrc;
+            a_inc[i] = ok ? 32 : 0;
         }
-        const int woff = tw * p.Cin + c0;
 #pragma unroll
-        for (int i = 0; i < BP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + woff),
+        for (int i = 0; i < BP; ++i) b_src[i] = wrow[i] + tw * p.Cin;
+    };
+    auto dma_next = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_src[i],
+                                             (__attribute__((address_space(3))) void*)(As + (stage * BM + 32 * i + 8 * wave_u) * 32), 16, 0, 0);
+            a_src[i] += a_inc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_src[i],
                                              (__attribute__((address_space(3))) void*)(Bs + (stage * BN + 32 * i + 8 * wave_u) * 32), 16, 0, 0);
+            b_src[i] += 32;
+        }
+        if (++n_cc == cchunks) {
+            n_cc = 0;
+            if (++n_tap < cntaps) setup_tap(n_tap);
+        }
     };
 
     f32x16 acc[MI][NI];
@@ -167,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     if constexpr (NS >= 2) {
         // two stages: chunk q lives in stage q & 1.  (Deeper rings that keep copies in flight across the barrier measured
         // slower -- 48 / 64 KiB of LDS leave 3 / 2 workgroups per CU instead of 5: tools/README.md.)
-        if (nchunks > 0) dma_tile(0, 0);
+        if (nchunks > 0) { setup_tap(0); dma_next(0); }
         int fo[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ swz(lane & 31)) << 2);
@@ -178,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (q + 1 < nchunks) dma_tile(q + 1, stage ^ 1);
+            if (q + 1 < nchunks) dma_next(stage ^ 1);
             const float* Ab = As + (stage * BM + wm * WTM) * 32;
             const float* Bb = Bs + (stage * BN + wn * WTN) * 32;
             __builtin_amdgcn_s_setprio(1);
@@ -293,17 +316,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
 }
 
-// tile choice from the per-layer sweep (tools/sweep_conv.py, B=64): 128x128 where it still yields >= 2 workgroups
-// per CU (one barrier per 64 MFMAs per wave) AND the reduction is long enough (K >= 1024) to amortise its heavier
-// prologue / epilogue, otherwise 64x64 whose 5 resident workgroups per CU hide each other's barrier / LDS-refill
-// bubbles.  (128x64 measures +3 % on layer1 / layer3 shapes in isolation, tools/sweep_igemm_staging.py, but the whole
-// training step got 1.5 % slower with it: not used.)
+// tile choice from the per-layer sweeps (tools/sweep_conv.py, tools/sweep_igemm_staging.py, B=64): the larger the tile the fewer
+// operand bytes per flop go through L2 -> LDS, but a size only pays while it still yields >= 2 workgroups per CU and the
+// reduction is long enough (K >= 1024) to amortise its heavier prologue / epilogue: 128x128 first (layer2: 121 vs 112 TFLOP/s),
+// then 128x64 (layer3: 122 vs 113), otherwise 64x64 whose 5 resident workgroups per CU hide each other's barrier / refill
+// bubbles (layer1's short K, layer4's 4096 pixels).
 inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
     cfg &= 15;               // bit 4 selects the register-staged operand path (A/B tools only)
+    const long long mt128 = (M + 127) / 128;
     if (cfg == 1) { bm = 128; bn = 128; }
     else if (cfg == 2) { bm = 128; bn = 64; }
     else if (cfg == 3) { bm = 64; bn = 64; }
-    else if (cout % 128 == 0 && kdim >= 1024 && ((M + 127) / 128) * (cout / 128) >= 512) { bm = 128; bn = 128; }
+    else if (cout % 128 == 0 && kdim >= 1024 && mt128 * (cout / 128) >= 512) { bm = 128; bn = 128; }
+    else if (kdim >= 1024 && mt128 * (cout / 64) >= 512) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
     if (cout % bn != 0) bn = 64;
 }
