@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     const int mend = min(mbeg + p.rows_per_split, p.M);
     const int nsteps = (mend - mbeg + 31) >> 5;
     const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+    const float* zsrc = k_zero16w;
+    asm volatile("" : "+s"(zsrc));          // the constant's address stays in SGPRs (else: a GOT load + wait per copy, inside the loop)
 
     // copy slots at step 0: round q of this wave copies pixels (q*4 + wave) * PW .. of the tile
     int md[RDD];                                                  // dy rows need only the linear pixel index
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         float* X = D + 32 * BCO;
 #pragma unroll
         for (int q = 0; q < RDD; ++q) {
-            const float* src = md[q] < mend ? p.dy + (long long)md[q] * p.Cout + co0 + cd : k_zero16w;
+            const float* src = md[q] < mend ? p.dy + (long long)md[q] * p.Cout + co0 + cd : zsrc;
             md[q] += 32;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(D + (q * 4 + wave_u) * PWD * BCO), 16, 0, 0);
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int q = 0; q < RDX; ++q) {
             const bool in = mx[q] < mend;
-            const float* src = k_zero16w;
+            const float* src = zsrc;
             if (pointwise) {
                 if (in) src = p.x + (long long)mx[q] * p.Cin + ci0 + cx;
             } else {
@@ -183,6 +185,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
     const int cbeg = blockIdx.y * p.chunks_per_split;
     const int cend = min(cbeg + p.chunks_per_split, p.nchunks);
     const int lp = tid >> 4, lc = tid & 15;              // staging: pixel slot, float4 column
+    const float* zsrc = k_zero16w;
+    asm volatile("" : "+s"(zsrc));          // the constant's address stays in SGPRs (else: a GOT load + wait per copy, inside the loop)
 
     // chunk-independent part of the copy addresses: dy pixel (row, col) inside the chunk, patch pixel (row, col) inside the patch
     int d_off[2], x_pr[7], x_pc[7];
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
             if (q * 16 >= npatch) break;                 // wave-uniform
             const int hi = ho0 + x_pr[q], wi = wo0 + x_pc[q];
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;     // (slots past the patch read anything)
-            const float* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin : k_zero16w;
+            const float* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin : zsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(X + (4 * wave_u + 16 * q) * 64), 16, 0, 0);
         }
