@@ -173,12 +173,17 @@ constexpr int W3PX = 32 + 112;   // pixels per LDS stage: dy tile + input patch 
 // barrier per chunk.  Operands: the four pixels a lane half handles per 8-pixel group sit side by side in one row, so their
 // nine-tap windows overlap: 3 x 6 patch values + 4 dy values feed 36 MFMAs (instead of 36 + 4), and the next group's 22 values
 // are read while the current 36 MFMAs issue.
-__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// NG = 2: two 4-wave groups per workgroup take alternate chunks of the split into their own LDS stages and add their accumulators
+// through LDS at the end -- one partial per CU instead of two: half the partial-sum traffic (write here, read in the reduce pass).
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_kernel(Wgrad3P p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int pw = p.cw + 2;
     const int npatch = (p.rpc + 2) * pw;                 // <= 102 pixels
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;              // position inside the 4-wave group
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int grp = NG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    float* smem = smem_all + grp * (2 * W3PX * 64);
     const int wm = wave >> 1, wn = wave & 1;
     const int itile = blockIdx.x % p.it, ctile = blockIdx.x / p.it;
     const int co0 = ctile * 64, ci0 = itile * 64;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-    if (cbeg < cend) dma_chunk(cbeg, 0);
+    if (cbeg + grp < cend) dma_chunk(cbeg + grp, 0);
     const int i = lane & 31, h = lane >> 5;
     // LDS float offsets of the lane's four 4-pixel groups (group kk = pixels kk*8 + h*4 .. +3 of the chunk)
     int g_d[4], g_x[4];
@@ -241,12 +246,15 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
         g_x[kk] = 32 * 64 + ((px >> p.cw_log2) * pw + (px & (p.cw - 1))) * 64 + wn * 32 + i;
     }
     const int pw64 = pw * 64;
-    for (int c = cbeg; c < cend; ++c) {
-        const int stage = (c - cbeg) & 1;
+    const int nj = (cend - cbeg + NG - 1) / NG;               // both groups run the same number of rounds (the barrier is shared)
+    for (int j = 0; j < nj; ++j) {
+        const int c = cbeg + grp + NG * j;
+        const int stage = j & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies of chunk c have landed ...
         __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
         asm volatile("" ::: "memory");
-        if (c + 1 < cend) dma_chunk(c + 1, stage ^ 1);
+        if (c + NG < cend) dma_chunk(c + NG, stage ^ 1);
+        if (NG > 1 && c >= cend) continue;                    // (odd chunk count: the second group idles in the last round)
         const float* S = smem + stage * (W3PX * 64);
         float a[2][4], w[2][18];
         auto read_group = [&](int kk, float* av, float* wv) {
@@ -274,6 +282,28 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(Wgrad3P p) {
                     for (int s2 = 0; s2 < 3; ++s2) acc[r * 3 + s2] = mfma32(av[e], wv[r * 6 + e + s2], acc[r * 3 + s2]);
         }
         __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (NG > 1) {
+        // group 1 -> LDS -> group 0, three taps per round (48 KB), fixed order: acc(group 0) + acc(group 1)
+        float* R = smem_all + ((wave * 3) * 16) * 64 + lane;
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) {
+            __syncthreads();                                  // the stages (round 0) / the previous round's values are no longer needed
+            if (grp == 1) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) R[(t * 16 + q) * 64] = acc[rd * 3 + t][q];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[rd * 3 + t][q] += R[(t * 16 + q) * 64];
+            }
+        }
+        if (grp != 0) return;
     }
     float* o = p.part + (long long)blockIdx.y * p.Cout * 9 * p.Cin;
 #pragma unroll
@@ -1025,7 +1055,7 @@ static bool wgrad3_plan(int batch, int h, int w, int cin, int cout, int kh, int 
     p->it = cin / 64;
     const int tiles = (cout / 64) * (cin / 64);
 #ifndef W3_TARGET
-#define W3_TARGET 512
+#define W3_TARGET 256          // one 8-wave workgroup per CU (two 4-wave groups that share one partial)
 #endif
     int s = (W3_TARGET + tiles - 1) / tiles;
     const int max_s = (p->nchunks + 3) / 4;                     // at least 4 chunks (576 MFMAs per wave) per workgroup
@@ -1057,15 +1087,16 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
         int splits3;
         if (wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) {
             p3.x = x; p3.dy = dy; p3.part = (float*)workspace;
-            const size_t lds = (size_t)2 * W3PX * 64 * sizeof(float);
+            constexpr int NG3 = 2;
+            const size_t lds = (size_t)NG3 * 2 * W3PX * 64 * sizeof(float);
             static bool attr_set = false;
             if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<NG3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
                 attr_set = true;
             }
             hipStream_t st3 = (hipStream_t)stream;
-            hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((cout / 64) * (cin / 64), splits3), dim3(256), lds, st3, p3);
+            hipLaunchKernelGGL(conv_wgrad3x3_kernel<NG3>, dim3((cout / 64) * (cin / 64), splits3), dim3(256 * NG3), lds, st3, p3);
             STRAPS_CHECK_LAUNCH("conv_wgrad3x3_kernel");
             const long long n3 = (long long)cout * 9 * cin;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n3 / 256)), dim3(256), 0, st3, p3.part, dw_oihw, splits3, cout, cin, 9, accumulate);
