@@ -259,39 +259,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
     // ---------------- epilogue ----------------
     const bool remap = p.omul != 1 || coah != 0 || coaw != 0 || p.OH != cMh || p.OW != cMw;
-    float s1[NI], s2[NI];
+    float s1[NI], s2[NI], sc[NI], sh[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
-        float t1 = 0.f, t2 = 0.f;
+        sc[j] = p.scale ? p.scale[n] : 1.f;
+        sh[j] = p.shift ? p.shift[n] : 0.f;
+        s1[j] = 0.f;
+        s2[j] = 0.f;
+    }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < MI; ++i) {
+        // the lane's 16 rows are m = mb + (r & 3) + 8 * (r >> 2): the physical pixel of a remapped output (a parity class of a
+        // stride-2 data gradient) is found by division once and then walked row by row
+        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+        int b_ = 0, ho_ = 0, wo_ = 0;
+        if (remap) {
+            b_ = mb / MhMw;
+            const int rem = mb - b_ * MhMw;
+            ho_ = rem / cMw;
+            wo_ = rem - ho_ * cMw;
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + i * 32 + mfma_row(r, lane);
-                if (m < cM) {
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            long long pix = m;
+            if (remap) {
+                pix = ((long long)b_ * p.OH + ho_ * p.omul + coah) * p.OW + wo_ * p.omul + coaw;
+                wo_ += (r & 3) == 3 ? 5 : 1;
+                while (wo_ >= cMw) {
+                    wo_ -= cMw;
+                    if (++ho_ == cMh) { ho_ = 0; ++b_; }
+                }
+            }
+            if (m < cM) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
                     float v = acc[i][j][r];
-                    t1 += v;
-                    t2 = fmaf(v, v, t2);
-                    long long pix = m;
-                    if (remap) {
-                        const int b = m / MhMw;
-                        const int rem = m - b * MhMw;
-                        const int ho = rem / cMw, wo = rem - ho * cMw;
-                        pix = ((long long)b * p.OH + ho * p.omul + coah) * p.OW + wo * p.omul + coaw;
-                    }
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
                     const long long o = pix * p.Cout + n;
-                    if (p.scale) v = fmaf(v, sc, sh);
+                    if (p.scale) v = fmaf(v, sc[j], sh[j]);
                     if (p.res) v += p.res[o];
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.y[o] = v;
                 }
             }
         }
-        s1[j] = t1;
-        s2[j] = t2;
     }
     if (p.stats) {
         // lanes l and l+32 hold the same channel; the two M-waves are combined through LDS
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
 // tile choice from the per-layer sweeps (tools/sweep_conv.py, tools/sweep_igemm_staging.py, B=64): the larger the tile the fewer
 // operand bytes per flop go through L2 -> LDS, but a size only pays while it still yields >= 2 workgroups per CU and the
-// reduction is long enough (K >= 1024) to amortise its heavier prologue / epilogue: 128x128 first (layer2: 121 vs 112 TFLOP/s),
+// reduction is long enough (K >= 512 / 1024) to amortise its heavier prologue / epilogue: 128x128 first (layer2: 124 vs 111 TFLOP/s),
 // then 128x64 (layer3: 122 vs 113), otherwise 64x64 whose 5 resident workgroups per CU hide each other's barrier / refill
 // bubbles (layer1's short K, layer4's 4096 pixels).
 inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
@@ -327,7 +342,7 @@ inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn
     if (cfg == 1) { bm = 128; bn = 128; }
     else if (cfg == 2) { bm = 128; bn = 64; }
     else if (cfg == 3) { bm = 64; bn = 64; }
-    else if (cout % 128 == 0 && kdim >= 1024 && mt128 * (cout / 128) >= 512) { bm = 128; bn = 128; }
+    else if (cout % 128 == 0 && kdim >= 512 && mt128 * (cout / 128) >= 512) { bm = 128; bn = 128; }
     else if (kdim >= 1024 && mt128 * (cout / 64) >= 512) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
     if (cout % bn != 0) bn = 64;
