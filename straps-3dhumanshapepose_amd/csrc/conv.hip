@@ -17,6 +17,7 @@
 //   raw output + per-channel (sum, sumsq) partials in training mode.
 //   Block ids are remapped so that consecutive tiles (same A rows / neighbouring halos) share an XCD's L2.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -268,46 +269,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         s1[j] = 0.f;
         s2[j] = 0.f;
     }
+    // (32-bit element offsets, see the launcher's size check; an M tile that lies inside the problem skips the per-row test)
+    const bool full = m0 + BM <= cM;
+    auto rows = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        // the lane's 16 rows are m = mb + (r & 3) + 8 * (r >> 2): the physical pixel of a remapped output (a parity class of a
-        // stride-2 data gradient) is found by division once and then walked row by row
-        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
-        int b_ = 0, ho_ = 0, wo_ = 0;
-        if (remap) {
-            b_ = mb / MhMw;
-            const int rem = mb - b_ * MhMw;
-            ho_ = rem / cMw;
-            wo_ = rem - ho_ * cMw;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mb + (r & 3) + 8 * (r >> 2);
-            long long pix = m;
+        for (int i = 0; i < MI; ++i) {
+            // the lane's 16 rows are m = mb + (r & 3) + 8 * (r >> 2): the physical pixel of a remapped output (a parity class of
+            // a stride-2 data gradient) is found by division once and then walked row by row
+            const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+            int b_ = 0, ho_ = 0, wo_ = 0;
             if (remap) {
-                pix = ((long long)b_ * p.OH + ho_ * p.omul + coah) * p.OW + wo_ * p.omul + coaw;
-                wo_ += (r & 3) == 3 ? 5 : 1;
-                while (wo_ >= cMw) {
-                    wo_ -= cMw;
-                    if (++ho_ == cMh) { ho_ = 0; ++b_; }
-                }
+                b_ = mb / MhMw;
+                const int rem = mb - b_ * MhMw;
+                ho_ = rem / cMw;
+                wo_ = rem - ho_ * cMw;
             }
-            if (m < cM) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-                    float v = acc[i][j][r];
-                    s1[j] += v;
-                    s2[j] = fmaf(v, v, s2[j]);
-                    const long long o = pix * p.Cout + n;
-                    if (p.scale) v = fmaf(v, sc[j], sh[j]);
-                    if (p.res) v += p.res[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.y[o] = v;
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                int pix = m;
+                if (remap) {
+                    pix = (b_ * p.OH + ho_ * p.omul + coah) * p.OW + wo_ * p.omul + coaw;
+                    wo_ += (r & 3) == 3 ? 5 : 1;
+                    while (wo_ >= cMw) {
+                        wo_ -= cMw;
+                        if (++ho_ == cMh) { ho_ = 0; ++b_; }
+                    }
+                }
+                if (FULL || m < cM) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int o = pix * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
+                        float v = acc[i][j][r];
+                        s1[j] += v;
+                        s2[j] = fmaf(v, v, s2[j]);
+                        if (p.scale) v = fmaf(v, sc[j], sh[j]);
+                        if (p.res) v += p.res[o];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        p.y[o] = v;
+                    }
                 }
             }
         }
-    }
+    };
+    if (full) rows(std::true_type{}); else rows(std::false_type{});
     if (p.stats) {
         // lanes l and l+32 hold the same channel; the two M-waves are combined through LDS
         __syncthreads();   // all fragment reads of the last chunk are done: LDS is free
