@@ -19,6 +19,7 @@
 //   * epilogue writes NHWC (lane = channel) with BN scale/shift + ReLU fused (eval) or raw output
 //     plus per-channel (sum, sumsq) partials (training).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -269,27 +270,34 @@ __global__ __launch_bounds__(256, 5) void stem_kernel(const float* __restrict__ 
 
     const int yo = y0 + wave;
     float s1[2], s2[2];
+    // (a tile inside the image skips the per-element range test; the row base is one 64-bit address, the rest 32-bit offsets)
+    const bool full = x0 + TX <= Wo && y0 + TY <= Ho;
+    float* yrow = y + (((long long)b * Ho + min(yo, Ho - 1)) * Wo + x0) * 64 + i;
+    auto rows = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = nt * 32 + i;
-        const float sc = scale ? scale[n] : 1.f;
-        const float sh = shift ? shift[n] : 0.f;
-        float t1 = 0.f, t2 = 0.f;
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = nt * 32 + i;
+            const float sc = scale ? scale[n] : 1.f;
+            const float sh = shift ? shift[n] : 0.f;
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int xo = x0 + mfma_row(r, lane);
-            if (xo < Wo && yo < Ho) {
-                float v = nt == 0 ? acc0[r] : acc1[r];
-                t1 += v;
-                t2 = fmaf(v, v, t2);
-                if (scale) v = fmaf(v, sc, sh);
-                if (relu) v = fmaxf(v, 0.f);
-                y[(((long long)b * Ho + yo) * Wo + xo) * 64 + n] = v;
+            for (int r = 0; r < 16; ++r) {
+                const int xr = mfma_row(r, lane);
+                if (FULL || (x0 + xr < Wo && yo < Ho)) {
+                    float v = nt == 0 ? acc0[r] : acc1[r];
+                    t1 += v;
+                    t2 = fmaf(v, v, t2);
+                    if (scale) v = fmaf(v, sc, sh);
+                    if (relu) v = fmaxf(v, 0.f);
+                    yrow[xr * 64 + nt * 32] = v;
+                }
             }
+            s1[nt] = t1;
+            s2[nt] = t2;
         }
-        s1[nt] = t1;
-        s2[nt] = t2;
-    }
+    };
+    if (full) rows(std::true_type{}); else rows(std::false_type{});
     if (stats) {
         __syncthreads();
         float* red = smem;   // [4 waves][64][2]
