@@ -879,14 +879,15 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
 // small strided GEMM on the fp32 MFMA:  C[m][n] = (mask? ...)(sum_k A(m,k) * B(k,n)) (+ C)
 // =====================================================================================================
 // A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn].  One 32x32 tile per wave, 4 tiles (along n) per block.
-__global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restrict__ a, long long sam, long long sak,
+constexpr int GW = 8;      // waves per workgroup (K groups dealt round-robin)
+__global__ __launch_bounds__(64 * GW) void gemm_strided_kernel(const float* __restrict__ a, long long sam, long long sak,
                                                            const float* __restrict__ b, long long sbk, long long sbn, float* c,
                                                            int ldc, const float* __restrict__ mask, int ldmask, int M, int N, int K,
                                                            int accumulate) {
-    // one 32x32 output tile per workgroup; the K groups of 8 are dealt round-robin to the 4 waves (these GEMMs are
-    // tiny and latency-bound: 4x shorter dependent load chains, two groups of loads in flight per wave), partial
+    // one 32x32 output tile per workgroup; the K groups of 8 are dealt round-robin to the 8 waves (these GEMMs are
+    // tiny and latency-bound: 8x shorter dependent load chains, two groups of loads in flight per wave), partial
     // tiles combined through LDS in a fixed order.
-    __shared__ float red[4][32][33];
+    __shared__ float red[GW][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -897,13 +898,13 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     const int G = (K + 7) >> 3;
-    for (int g = wave; g < G; g += 8) {
+    for (int g = wave; g < G; g += 2 * GW) {
         float av[8], bv[8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int k = (g + 4 * u) * 8 + 4 * h + e;
+                const int k = (g + GW * u) * 8 + 4 * h + e;
                 const bool ok = k < K;
                 av[u * 4 + e] = ok ? ap[(long long)k * sak] : 0.f;
                 bv[u * 4 + e] = ok ? bp[(long long)k * sbk] : 0.f;
@@ -916,12 +917,13 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
     for (int q = 0; q < 16; ++q) red[wave][mfma_row(q, lane)][i] = acc[q];
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = threadIdx.x + 256 * q;
+    for (int q = 0; q < 1024 / (64 * GW); ++q) {
+        const int idx = threadIdx.x + 64 * GW * q;
         const int row = idx >> 5, col = idx & 31;
         const int m = m0 + row, n = n0 + col;
         if (m < M && n < N) {
-            float v = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+            float v = ((red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col])) +
+                      ((red[4][row][col] + red[5][row][col]) + (red[6][row][col] + red[7][row][col]));
             if (mask) v = mask[(long long)m * ldmask + n] > 0.f ? v : 0.f;
             float* o = c + (long long)m * ldc + n;
             *o = accumulate ? *o + v : v;
@@ -1283,7 +1285,7 @@ extern "C" int straps_gemm_strided(const float* a, long long sam, long long sak,
                                    int ldc, const float* mask, int ldmask, int m, int n, int k, int accumulate, void* stream) {
     STRAPS_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0, "straps_gemm_strided: bad arguments");
     dim3 grid((n + 31) / 32, (m + 31) / 32);
-    hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, sam, sak, b, sbk, sbn, c, ldc, mask, ldmask, m, n, k, accumulate);
+    hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(64 * GW), 0, (hipStream_t)stream, a, sam, sak, b, sbk, sbn, c, ldc, mask, ldmask, m, n, k, accumulate);
     STRAPS_CHECK_LAUNCH("gemm_strided_kernel");
     return STRAPS_OK;
 }

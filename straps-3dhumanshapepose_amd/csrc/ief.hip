@@ -11,10 +11,12 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
+constexpr int LW = 8;      // waves per workgroup: the K groups of one 32x32 output tile are dealt round-robin to them (these GEMMs are
+                           // tiny and latency-bound: 8 short dependent load chains instead of 4 longer ones)
+__global__ __launch_bounds__(64 * LW) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
                                                      const float* __restrict__ bias, const float* addend, float* out, int ldo,
                                                      int M, int N, int K, int relu) {
-    __shared__ float red[4][32][33];
+    __shared__ float red[LW][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int i = lane & 31, h = lane >> 5;
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int G = K >> 3;
 #pragma unroll 4
-    for (int g = wave; g < G; g += 4) {
+    for (int g = wave; g < G; g += LW) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 8 * g);
         const f32x4 b = *reinterpret_cast<const f32x4*>(wp + 8 * g);
 #pragma unroll
@@ -36,12 +38,13 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     for (int r = 0; r < 16; ++r) red[wave][mfma_row(r, lane)][i] = acc[r];
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
+    for (int q = 0; q < 1024 / (64 * LW); ++q) {
+        const int idx = tid + 64 * LW * q;
         const int row = idx >> 5, col = idx & 31;
         const int m = m0 + row, n = n0 + col;
         if (m < M && n < N) {
-            float v = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+            float v = ((red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col])) +
+                      ((red[4][row][col] + red[5][row][col]) + (red[6][row][col] + red[7][row][col]));
             if (bias) v += bias[n];
             if (addend) v += addend[(long long)m * ldo + n];
             if (relu) v = fmaxf(v, 0.f);
@@ -76,7 +79,7 @@ extern "C" int straps_linear_fwd(const float* x, int ldx, const float* w, int ld
                    "straps_linear_fwd: need kdim%%8==0, ldx%%4==0, ldw%%4==0 (kdim=%d ldx=%d ldw=%d)", kdim, ldx, ldw);
     STRAPS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "straps_linear_fwd: x and w must be 16-byte aligned");
     dim3 grid((n + 31) / 32, (m + 31) / 32);
-    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, addend, out, ldo, m, n, kdim, relu);
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LW), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, addend, out, ldo, m, n, kdim, relu);
     STRAPS_CHECK_LAUNCH("linear_kernel");
     return STRAPS_OK;
 }
