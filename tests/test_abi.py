@@ -46,3 +46,18 @@ def test_version_and_error_channel(lib):
     ms.n_tiles = 224
     assert lib.straps_smpl_workspace_bytes(C.byref(ms), 64) == 64 * (224 + 288 + 8 * 96) * 4
     assert lib.straps_abi_version() == 2
+
+
+def test_tile_choice_of_the_implicit_gemm(lib):
+    """straps_conv_stat_blocks = ceil(M / BM) exposes the tile rule (host arithmetic only): 128x128 for layer2, 128x64 for
+    layer3, 64x64 for layer1's short K and layer4's 4096 pixels (resnet18, B=64), and the explicit tile_cfg overrides."""
+    B = 64
+    assert lib.straps_conv_stat_blocks(B, 64, 64, 64, 576, 0) == B * 64 * 64 // 64          # layer1: 64x64 tiles
+    assert lib.straps_conv_stat_blocks(B, 32, 32, 128, 1152, 0) == B * 32 * 32 // 128       # layer2: 128x128
+    assert lib.straps_conv_stat_blocks(B, 16, 16, 256, 2304, 0) == B * 16 * 16 // 128       # layer3: 128x64
+    assert lib.straps_conv_stat_blocks(B, 8, 8, 512, 4608, 0) == B * 8 * 8 // 64            # layer4: 64x64
+    assert lib.straps_conv_stat_blocks(B, 16, 16, 256, 128, 0) == B * 16 * 16 // 64         # 1x1 down-sample: short K
+    for cfg, bm in ((1, 128), (2, 128), (3, 64), (3 | 16, 64)):
+        assert lib.straps_conv_stat_blocks(2, 10, 10, 128, 1152, cfg) == -(-200 // bm)
+    # BatchNorm-backward reduction grid and the workspace that goes with it
+    assert lib.straps_bn_bwd_workspace_bytes(4096, 64) == (lib.straps_bn_bwd_blocks(4096, 64) * 64 * 2 + 3 * 64) * 4

@@ -144,3 +144,37 @@ def test_checkpoint_roundtrip_reference_schema(tmp_path):
     with pytest.raises(KeyError):
         torch.save({'epoch': 1}, path)
         cu.load_checkpoint(path)
+
+
+def test_pmc_summary_and_bench_traffic_reader(tmp_path):
+    """tools/pmc_summary.py --json turns rocprofv3 counter CSVs into per-kernel HBM bytes per launch (FETCH_SIZE in KiB with the
+    gfx950 x2 correction, WRITE_SIZE in KiB) and bench.pmc_traffic() reports the launch-weighted mean for the dominant kernel."""
+    import importlib.util, json, subprocess, sys, types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = ['Kernel_Name,Counter_Name,Counter_Value,Dispatch_Id,Start_Timestamp,End_Timestamp']
+    for i, (fetch, write, name) in enumerate([(1000, 500, 'void (anonymous namespace)::conv_igemm_kernel<64, 64, 2>((anonymous namespace)::ConvP)'),
+                                              (3000, 1500, 'void (anonymous namespace)::conv_igemm_kernel<64, 64, 2>((anonymous namespace)::ConvP)'),
+                                              (8000, 4000, 'void (anonymous namespace)::conv_igemm_kernel<128, 128, 2>((anonymous namespace)::ConvP)'),
+                                              (100, 100, '(anonymous namespace)::bn_apply_kernel(float const*)')]):
+        rows.append('"%s",FETCH_SIZE,%d,%d,1000,3000' % (name, fetch, i))
+        rows.append('"%s",WRITE_SIZE,%d,%d,1000,3000' % (name, write, i))
+    csv_path = tmp_path / 'counter_collection.csv'
+    csv_path.write_text('\n'.join(rows) + '\n')
+    out = tmp_path / 'pmc_traffic.json'
+    subprocess.run([sys.executable, os.path.join(root, 'tools', 'pmc_summary.py'), '--json', str(out), 'train_r18_b64', 'unit test', str(csv_path)],
+                   check=True, capture_output=True)
+    doc = json.load(open(out))['train_r18_b64']
+    k = doc['kernels']['void conv_igemm_kernel<64, 64, 2>']
+    assert k['launches'] == 2 and k['hbm_read_bytes'] == 2 * 1024 * 2000 and k['hbm_write_bytes'] == 1024 * 1000
+    # the reader: launch-weighted mean over both tile variants of the dominant kernel
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = os.path.join(root, 'profiles', 'pmc_traffic.json')
+    committed = json.load(open(prof))
+    assert 'train_r18_b64' in committed and any(n.replace('void ', '').startswith('conv_igemm_kernel') for n in committed['train_r18_b64']['kernels'])
+    got = bench.pmc_traffic(types.SimpleNamespace(workload='train', layers=18, batch=0), 'conv_igemm_kernel')
+    ks = [v for n, v in committed['train_r18_b64']['kernels'].items() if n.replace('void ', '').startswith('conv_igemm_kernel')]
+    want = sum(v['launches'] * (v['hbm_read_bytes'] + v['hbm_write_bytes']) for v in ks) / sum(v['launches'] for v in ks)
+    assert got['traffic'] == round(want)
+    assert bench.pmc_traffic(types.SimpleNamespace(workload='train', layers=101, batch=0), 'conv_igemm_kernel') == {}
