@@ -285,27 +285,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
                 ho_ = rem / cMw;
                 wo_ = rem - ho_ * cMw;
             }
+            int pixr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                int pix = m;
+                pixr[r] = mb + (r & 3) + 8 * (r >> 2);
                 if (remap) {
-                    pix = (b_ * p.OH + ho_ * p.omul + coah) * p.OW + wo_ * p.omul + coaw;
+                    pixr[r] = (b_ * p.OH + ho_ * p.omul + coah) * p.OW + wo_ * p.omul + coaw;
                     wo_ += (r & 3) == 3 ? 5 : 1;
                     while (wo_ >= cMw) {
                         wo_ -= cMw;
                         if (++ho_ == cMh) { ho_ = 0; ++b_; }
                     }
                 }
+            }
+            // the residual / skip-gradient values of all 16 rows are fetched before the first store: p.res may alias p.y (in
+            // place), so the compiler would otherwise serialise load -> store -> load through 16 memory round trips
+            float rv[16][NI];
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        rv[r][j] = (FULL || m < cM) ? p.res[pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31)] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (FULL || m < cM) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        const int o = pix * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
+                        const int o = pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
                         float v = acc[i][j][r];
                         s1[j] += v;
                         s2[j] = fmaf(v, v, s2[j]);
                         if (p.scale) v = fmaf(v, sc[j], sh[j]);
-                        if (p.res) v += p.res[o];
+                        if (p.res) v += rv[r][j];
                         if (p.relu) v = fmaxf(v, 0.f);
                         p.y[o] = v;
                     }
@@ -479,5 +495,13 @@ extern "C" int straps_conv_dgrad(const float* dy, const float* w_crsk, const flo
             ++p.ncls;
         }
     }
+    // heaviest class first (blockIdx.y = 0 is dispatched first): the 4-tap class of a 3x3/s2 gradient runs four times as long per
+    // workgroup as the 1-tap one -- started last it would be the launch's tail
+    for (int a = 1; a < p.ncls; ++a)
+        for (int b = a; b > 0 && (long long)p.cls[b].ntaps * p.cls[b].M > (long long)p.cls[b - 1].ntaps * p.cls[b - 1].M; --b) {
+            const ConvP::Class t = p.cls[b];
+            p.cls[b] = p.cls[b - 1];
+            p.cls[b - 1] = t;
+        }
     return p.ncls ? dispatch(p, tile_cfg, st) : STRAPS_OK;
 }

@@ -32,6 +32,9 @@ for name, H, Cin, Cout, k, stride in SHAPES:
         fns = [('f', lambda: L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wp), None, None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, H, H, Cin, Cout, k, k, stride, pad, cfg, None), lambda: (y, part))]
         if not (t == 1 and Cin % 128):
             fns.append(('d', lambda: L.straps_conv_dgrad(hipabi.ptr(dy), hipabi.ptr(wd), None, hipabi.ptr(dx), B, H, H, Cin, Cout, k, k, stride, pad, cfg, None), lambda: (dx,)))
+            if os.environ.get('SWEEP_ADDEND'):
+                add = torch.randn_like(x)
+                fns.append(('da', lambda: L.straps_conv_dgrad(hipabi.ptr(dy), hipabi.ptr(wd), hipabi.ptr(add), hipabi.ptr(dx), B, H, H, Cin, Cout, k, k, stride, pad, cfg, None), lambda: (dx,)))
         for tag, fn, outs in fns:
             assert fn() == 0, L.straps_last_error()
             torch.cuda.synchronize()
