@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STRAPS_ABI_VERSION 2
+#define STRAPS_ABI_VERSION 3
 
 #define STRAPS_OK 0
 #define STRAPS_EINVAL 1       /* bad argument (shape, alignment, null pointer) */
@@ -328,6 +328,50 @@ int straps_mse_bwd(const float* pred, const float* tgt, const uint8_t* row_mask,
  * 1 occlusion draw, 2 box-centre draws), remove_prob[6] device array.                              */
 int straps_augment_seg(const float* seg, const float* uniforms, const float* remove_prob,
                        float occlude_prob, int box_dim, float* out, int batch, int wh, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Random draws + the augmentations that consume them (train loop :121-129,146-151,173-175).  The reference mixes
+ * torch's device generator and numpy's host generator; here ONE counter-based generator (Philox4x32-10, 10 rounds,
+ * key = seed, counter = {index/4, step, sub-stream}) fills draw buffers on the device.  `step_dev` (optional device
+ * int64) overrides step_host so a replayed hipGraph advances the sequence with straps_counter_add.
+ * Range / scale parameters of the augmentations are doubles -- the reference's Python scalars: (h - l) is formed in double
+ * and rounded once to the fp32 scalar its tensor expression uses, so results are bit-identical given the draws.
+ * kind 0: uniform [0,1) = (x >> 8) * 2^-24;  kind 1: standard normal (Box-Muller on consecutive pairs).
+ * ------------------------------------------------------------------------------------------ */
+int straps_philox_fill(unsigned long long seed, const long long* step_dev, long long step_host,
+                       unsigned substream, float* out, long long n, int kind, void* stream);
+/* counters[i] += delta for i < n (device int64: the generator's step, Adam's step, the BatchNorm num_batches_tracked row) */
+int straps_counter_add(long long* counters, int n, long long delta, void* stream);
+/* dst[i] = src[index[i]], i < n (device index array): the step keeps the five loss log-variances in the kernel's task
+ * order while the parameters sit in the criterion's registration order (losses/multi_task_loss.py:46-55).            */
+int straps_gather_f32(const float* src, const int* index, float* dst, int n, void* stream);
+/* hipMemsetAsync(ptr, 0, bytes) on `stream` (the step zeroes its flat gradient buffer with it) */
+int straps_memset_zero(void* ptr, size_t bytes, void* stream);
+/* augment_smpl (augmentation/smpl_augmentation.py:27-61) + the dataset gather in front of it:
+ * body b takes pose_rows[b] ([n_rows][72] axis-angle, global orientation first), or with u_index [B] in [0,1) the
+ * row floor(u * n_rows) of a resident pose pool (stand-in for data/synthetic_training_dataset.py);
+ * out_rotmats [B][24][3][3] = batch_rodrigues of it (joint 0 = glob_rotmats, 1..23 = pose_rotmats);
+ * out_shape [B][10]: shape_mode 0 = orig_shape, 1 = shape_draws * std_vector + mean_shape (normal_sample_shape :18-25,
+ * shape_draws ~ N(0,1)), 2 = (range_hi - range_lo) * shape_draws + range_lo + mean_shape (uniform_sample_shape :6-15,
+ * shape_draws ~ U[0,1)).  out_pose (optional [B][72]) receives the gathered axis-angle rows.                   */
+int straps_augment_smpl(const float* pose_rows, long long n_rows, const float* u_index,
+                        const float* orig_shape, const float* mean_shape, const float* shape_draws,
+                        int shape_mode, const float* std_vector, double range_lo, double range_hi,
+                        float* out_shape, float* out_rotmats, float* out_pose, long long batch,
+                        void* stream);
+/* augment_cam_t (augmentation/cam_augmentation.py:4-14): out[:, :2] = mean[:, :2] + normals_xy [B][2] * xy_std,
+ * out[:, 2] = mean[:, 2] + (z_hi - z_lo) * uniform_z [B] + z_lo.                                               */
+int straps_augment_cam_t(const float* mean_cam_t, const float* normals_xy, const float* uniform_z,
+                         double xy_std, double z_lo, double z_hi, float* out_cam_t, long long batch,
+                         void* stream);
+/* random_joints2D_deviation (augmentation/proxy_rep_augmentation.py:25-49) on [B][17][2] COCO joints:
+ * out = joints + (hi - lo) * u + lo, the hip joints 11 and 12 with their own range; uniforms [B][17][2].        */
+int straps_deviate_joints2d(const float* joints2d, const float* uniforms, double lo, double hi,
+                            double hip_lo, double hip_hi, float* out, long long batch, void* stream);
+/* random_verts2D_deviation (augmentation/proxy_rep_augmentation.py:5-22) as a materialised copy: out [n][3] = verts with
+ * x,y += (hi - lo) * u + lo, uniforms [n][2].  (The training step does not call this: straps_rasterize_parts applies the
+ * same noise inside its projection kernel.)                                                                     */
+int straps_deviate_verts2d(const float* verts, const float* uniforms, double lo, double hi, float* out,
+                           long long nverts_total, void* stream);
 /* target-side heads of the train step (train loop :138-143): joints3d [B,14,3] = H36M-LSP subset of
  * joints [B,90,3]; joints2d [B,17,2] = perspective projection of the COCO subset with identity
  * rotation, translation cam_t [B,3] and intrinsics fx,fy,cx,cy (utils/cam_utils.py:40-71).         */
@@ -343,15 +387,20 @@ size_t straps_rasterize_workspace_bytes(long long batch, int nverts, int wh);
 int straps_rasterize_parts(const float* verts, const int32_t* faces, const uint8_t* face_parts,
                            const float* cam_K, const float* cam_R, const float* cam_t, float* parts,
                            float* depth, void* workspace, long long batch, int nverts, int nfaces, int wh,
-                           int cam_per_body, float near, float far, void* stream);
+                           int cam_per_body, float near, float far, const float* vert_noise_u, double noise_lo,
+                           double noise_hi, void* stream);
+/* (vert_noise_u: NULL, or uniforms [B][nverts][2] in [0,1): the rendered copy of the mesh gets x,y += (hi-lo)*u + lo --
+ *  random_verts2D_deviation, augmentation/proxy_rep_augmentation.py:5-22, train loop :146-151 -- inside the projection
+ *  kernel; the caller's vertices, i.e. the loss targets, are not touched.)                                        */
 /* On-device bounding-box crop + nearest-neighbour resize (utils/image_utils.py:44-105,
  * train loop :161-170): per sample, box of the non-zero pixels of seg [B,wh,wh] -> centre / max(h,w) * scale
  * (scale = orig_scale_factor + U(delta_scale), centre += U(delta_centre); uniforms [B][3] in [0,1), NULL = no
  * jitter) -> int16-truncated corners -> crop -> resize to out_wh with cv2.INTER_NEAREST index rule; joints are
- * shifted by the top-left corner and scaled by out_wh / crop size.  boxes [B][6] receives {r0,c0,r1,c1,shift_r,shift_c}. */
+ * shifted by the top-left corner and scaled by out_wh / crop size.  boxes [B][6] receives {r0,c0,r1,c1,shift_r,shift_c}.
+ * The scale / range parameters are doubles: the box arithmetic is the reference's float64 arithmetic on the given draws.  */
 int straps_crop_resize(const float* seg, const float* joints2d, const float* uniforms,
-                       float orig_scale_factor, float delta_scale_lo, float delta_scale_hi,
-                       float delta_centre_lo, float delta_centre_hi, float* out_seg,
+                       double orig_scale_factor, double delta_scale_lo, double delta_scale_hi,
+                       double delta_centre_lo, double delta_centre_hi, float* out_seg,
                        float* out_joints2d, int* boxes, int batch, int wh, int out_wh, int nj,
                        void* stream);
 /* On-device evaluation metrics (metrics/train_loss_and_metrics_tracker.py:127-197 +
@@ -363,10 +412,10 @@ int straps_point_metrics(const float* pred, const float* target, float* out3, lo
 /* torch.optim.Adam defaults (run_train.py:200-201) over one flat fp32 buffer:
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);
  * grad_scale multiplies g first (1/world_size after a sum all-reduce).  step_dev (optional device
- * int) overrides `step` so that a captured hipGraph can advance the step count on the device.       */
+ * int64) overrides `step` so that the step count can live on the device (straps_counter_add).       */
 int straps_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      long long n, int step, float lr, float beta1, float beta2, float eps,
-                     float grad_scale, const int* step_dev, void* stream);
+                     float grad_scale, const long long* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

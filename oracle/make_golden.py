@@ -243,6 +243,25 @@ def main():
     nseg, nj = augment_proxy_representation(segs, j2, params)
     small['aug_seg_class_counts'] = np.stack([(nseg == c).sum(dim=(1, 2)).numpy() for c in range(7)], 1)
     small['aug_j2d'] = nj.numpy()
+    small['aug_seg_rowsum'] = nseg.sum(dim=2).numpy().astype(np.float64)          # [6,256] + [6,256]: pins every removed part
+    small['aug_seg_colsum'] = nseg.sum(dim=1).numpy().astype(np.float64)          # and the occlusion box position
+    from augmentation.proxy_rep_augmentation import random_verts2D_deviation
+    torch.manual_seed(9)
+    small['aug_verts'] = random_verts2D_deviation(torch.from_numpy(det_uniform((2, 40, 3), 60, -1.0, 1.0)),
+                                                  delta_verts2d_dev_range=[-0.01, 0.01]).numpy()
+    # augmentation/smpl_augmentation.py imports smplx.lbs.batch_rodrigues at module level; smplx is absent, so a stub module
+    # lets the two shape-sampling helpers (pure torch) be imported -- augment_smpl's Rodrigues half stays unpinned
+    if 'smplx' not in sys.modules:
+        smplx_stub, lbs_stub = types.ModuleType('smplx'), types.ModuleType('smplx.lbs')
+        lbs_stub.batch_rodrigues = None
+        smplx_stub.lbs = lbs_stub
+        sys.modules['smplx'], sys.modules['smplx.lbs'] = smplx_stub, lbs_stub
+    from augmentation.smpl_augmentation import normal_sample_shape, uniform_sample_shape
+    mean_shape_t = torch.from_numpy(mp['shape'])
+    torch.manual_seed(10)
+    small['aug_shape_normal'] = normal_sample_shape(5, mean_shape_t, torch.full((10,), 1.5)).numpy()
+    torch.manual_seed(10)
+    small['aug_shape_uniform'] = uniform_sample_shape(5, mean_shape_t, [-3., 3.]).numpy()
 
     # ================= G-metrics: PVE / PVE-SC / PVE-PA, MPJPE / -SC / -PA per-sample sums ==
     from utils.eval_utils import procrustes_analysis_batch, scale_and_translation_transform_batch
@@ -266,6 +285,43 @@ def main():
     crops0, cjs0 = batch_crop_seg_to_bounding_box(cseg, cj, orig_scale_factor=1.2)
     small['crop0_shapes'] = np.array([c.shape for c in crops0], np.int64)
     small['crop0_joints'] = np.stack(cjs0).astype(np.float64)
+
+    # ================= G-predict: config 1 plumbing on a committed STAND-IN proxy =============
+    # The reference has no precomputed proxy (detectron2 builds it at run time, predict/predict_3D.py:108-126).  The stand-in
+    # is a rendered silhouette of the synthetic SMPL-shaped model + its projected COCO joints (all made by this repo's oracle,
+    # nothing from the reference); what IS the reference's is everything computed FROM it below: the numpy heat-maps of
+    # utils/label_conversions.py:58-87, create_proxy_representation's layout (predict_3D.py:67-76) and the regressor outputs.
+    import straps_oracle as O
+    from straps_amd.synthetic_smpl import synthetic_smpl_model
+    from utils.label_conversions import convert_2Djoints_to_gaussian_heatmaps
+    smodel = synthetic_smpl_model(0)
+    aa = det_uniform((1, 24, 3), 401, -0.25, 0.25)
+    aa[0, 0] = [0.0, 0.3, 0.0]
+    with torch.no_grad():
+        sv, sj = O.smpl_forward(smodel, torch.from_numpy(det_uniform((1, 10), 402, -1.0, 1.0)),
+                                rotmats=O.batch_rodrigues(torch.from_numpy(aa).view(-1, 3)).view(1, 24, 3, 3))
+    cam_t1 = np.array([[0.0, 0.2, 42.0]], np.float32)
+    Kmat = get_intrinsics_matrix(256, 256, 5000.0).astype(np.float32)
+    seg1 = O.rasterize_parts(sv.numpy(), smodel['faces'], smodel['face_parts'], Kmat, np.eye(3, dtype=np.float32), cam_t1)
+    sil = (seg1[0] != 0).astype(np.uint8)
+    j2 = O.perspective_project(sj[:, O.ALL_JOINTS_TO_COCO_MAP], torch.eye(3)[None], torch.from_numpy(cam_t1), torch.from_numpy(Kmat)[None])[0].numpy()
+    j2[3] = [250.4, 3.7]                                  # border cases of the heat-map paste (:71-83): near a corner,
+    j2[4] = [-5.2, 120.0]                                 # partly outside,
+    j2[16] = [300.0, 300.0]                               # and skipped entirely (:67)
+    jconf = np.concatenate([j2, np.ones((17, 1), np.float32)], axis=1).astype(np.float32)     # predict_joints2D returns [17,3]
+    heat = convert_2Djoints_to_gaussian_heatmaps(jconf[:, :2].astype(np.int16), 256)            # [256,256,17]
+    proxy = np.transpose(np.concatenate([sil.astype(np.float32)[:, :, None], heat], axis=-1), [2, 0, 1])
+    pred = {'sil_bits': np.packbits(sil), 'joints2D': jconf, 'heat_idx': np.flatnonzero(heat).astype(np.int32),
+            'heat_val': heat.reshape(-1)[np.flatnonzero(heat)].astype(np.float32), 'proxy_sum': np.float64(proxy.astype(np.float64).sum())}
+    for layers in (18, 50):
+        man_ = json.load(open(os.path.join(OUT, 'state_dict_keys_r%d.json' % layers)))['keys']
+        mm = SingleInputRegressor(18, layers, 3)
+        mm.load_state_dict({k: torch.from_numpy(v) for k, v in det_state_dict(man_).items()})
+        mm.eval()
+        with torch.no_grad():
+            pc, pp, ps = mm(torch.from_numpy(proxy[None]).float())
+        pred['out_r%d' % layers] = torch.cat([pc, pp, ps], dim=1).numpy()
+    np.savez_compressed(os.path.join(OUT, 'predict_golden.npz'), **pred)
 
     # ================= G-opt: one Adam step over all 71 tensors =============================
     man = json.load(open(os.path.join(OUT, 'state_dict_keys_r18.json')))['keys']

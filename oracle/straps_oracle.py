@@ -8,7 +8,7 @@ function cites the reference file:line it follows (paths relative to /root/refer
 
 Pinning status
   * encoder / IEF / regressor / rot6d / projections / visibility / heatmaps / loss / cam+proxy
-    augmentation: PINNED -- tests/test_oracle_golden.py checks every function below against golden
+    augmentation (draws supplied: fed with the reference's generator streams they reproduce its outputs): PINNED -- tests/test_oracle_golden.py checks every function below against golden
     vectors produced by importing the reference itself (oracle/make_golden.py, run in the authoring
     container, fixtures in tests/golden/).
   * SMPL forward (smpl_forward, batch_rodrigues): PARITY UNPINNED against the third-party `smplx`
@@ -340,6 +340,136 @@ def predict_forward(x, sd, init_estimate, smpl_model, layers=18, iterations=3):
 
 
 # --------------------------------------------------------------------------------------------
+# random draws of the synthetic training step + the augmentations that consume them
+# (augmentation/smpl_augmentation.py, cam_augmentation.py, proxy_rep_augmentation.py; train loop :121-175)
+# --------------------------------------------------------------------------------------------
+# The reference draws from torch's device generator and numpy's host generator; the product draws from ONE counter-based
+# generator (Philox4x32-10, Salmon et al. SC'11 -- the published algorithm, restated here in numpy) so that every draw of
+# any step can be regenerated on the CPU.  The augmentation functions below take the draws as arguments: fed with the
+# reference's own generator streams they reproduce the reference (tests/test_oracle_golden.py), fed with the Philox
+# buffers they are what the HIP kernels must equal.
+_PHILOX_M0, _PHILOX_M1, _PHILOX_W0, _PHILOX_W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(counter, key):
+    """counter [n,4] uint32, key (k0, k1) -> [n,4] uint32 (10 rounds)."""
+    c = [np.asarray(counter[:, i], np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(_PHILOX_M0) * c[0]
+        p1 = np.uint64(_PHILOX_M1) * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0 = (k0 + np.uint64(_PHILOX_W0)) & mask
+        k1 = (k1 + np.uint64(_PHILOX_W1)) & mask
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def philox_bits(seed, step, substream, n):
+    """the n uint32 words straps_philox_fill consumes: word i = lane i%4 of Philox(counter = {i//4 lo, i//4 hi, step lo,
+    substream + step hi * 0x10000}, key = {seed lo, seed hi})."""
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    ctr = np.stack([q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full_like(q, np.uint64(step & 0xFFFFFFFF)),
+                    np.full_like(q, np.uint64((substream + ((step >> 32) & 0xFFFFFFFF) * 0x10000) & 0xFFFFFFFF))], axis=1)
+    return philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(-1)[:((n + 3) // 4) * 4]
+
+
+def philox_uniform(seed, step, substream, n):
+    """uniform [0,1) fp32 with 24 random bits: (x >> 8) * 2^-24 (kind 0 of straps_philox_fill)."""
+    return ((philox_bits(seed, step, substream, n) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))[:n]
+
+
+def philox_normal(seed, step, substream, n):
+    """standard normal fp32, Box-Muller on consecutive word pairs (kind 1 of straps_philox_fill)."""
+    b = philox_bits(seed, step, substream, n).reshape(-1, 2)
+    u1 = ((b[:, 0] >> np.uint32(8)) + np.uint32(1)).astype(np.float32) * np.float32(2.0 ** -24)
+    th = np.float32(6.283185307179586) * ((b[:, 1] >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24))
+    r = np.sqrt(np.float32(-2.0) * np.log(u1))
+    return np.stack([r * np.cos(th), r * np.sin(th)], axis=1).astype(np.float32).reshape(-1)[:n]
+
+
+def sample_shape(mean_shape, draws, distribution='normal', std_vector=None, delta_betas_range=(-3.0, 3.0)):
+    """normal_sample_shape / uniform_sample_shape (augmentation/smpl_augmentation.py:6-25) with the draws supplied
+    (torch fp32 ops in the reference's order)."""
+    draws, mean_shape = torch.as_tensor(draws, dtype=torch.float32), torch.as_tensor(mean_shape, dtype=torch.float32)
+    if distribution == 'normal':
+        return draws * torch.as_tensor(std_vector, dtype=torch.float32) + mean_shape
+    l, h = delta_betas_range
+    return ((h - l) * draws + l) + mean_shape
+
+
+def augment_smpl(orig_shape, pose, global_orients, mean_shape, smpl_augment_params, shape_draws=None):
+    """augmentation/smpl_augmentation.py:27-61 with the shape draws supplied."""
+    p = smpl_augment_params
+    if p['augment_shape']:
+        new_shape = sample_shape(mean_shape, shape_draws, p['delta_betas_distribution'], p['delta_betas_std_vector'], p['delta_betas_range'])
+    else:
+        new_shape = orig_shape
+    pose_rotmats = batch_rodrigues(pose.contiguous().view(-1, 3)).view(-1, 23, 3, 3)
+    glob_rotmats = batch_rodrigues(global_orients.contiguous().view(-1, 3)).unsqueeze(1)
+    return new_shape, pose_rotmats, glob_rotmats
+
+
+def augment_cam_t(mean_cam_t, normals_xy, uniform_z, xy_std=0.05, delta_z_range=(-5, 5)):
+    """augmentation/cam_augmentation.py:4-14 with the draws supplied."""
+    mean_cam_t = torch.as_tensor(mean_cam_t, dtype=torch.float32)
+    new_cam_t = mean_cam_t.clone()
+    new_cam_t[:, :2] = mean_cam_t[:, :2] + torch.as_tensor(normals_xy, dtype=torch.float32).view(-1, 2) * xy_std
+    l, h = delta_z_range
+    new_cam_t[:, 2] = mean_cam_t[:, 2] + ((h - l) * torch.as_tensor(uniform_z, dtype=torch.float32).view(-1) + l)
+    return new_cam_t
+
+
+def random_verts2D_deviation(vertices, uniforms, delta_verts2d_dev_range=(-0.01, 0.01)):
+    """augmentation/proxy_rep_augmentation.py:5-22 with the draws [B,N,2] supplied."""
+    vertices = torch.as_tensor(vertices, dtype=torch.float32)
+    noisy = vertices.clone()
+    l, h = delta_verts2d_dev_range
+    noisy[:, :, :2] = noisy[:, :, :2] + ((h - l) * torch.as_tensor(uniforms, dtype=torch.float32).view(vertices.shape[0], -1, 2) + l)
+    return noisy
+
+
+def random_joints2D_deviation(joints2D, uniforms, delta_j2d_dev_range=(-5, 5), delta_j2d_hip_dev_range=(-15, 15)):
+    """augmentation/proxy_rep_augmentation.py:25-49 with the draws supplied as ONE [B,17,2] array (entry (b,j) is joint j's
+    draw; the reference draws the 15 other joints and the 2 hips in two calls)."""
+    joints2D = torch.as_tensor(joints2D, dtype=torch.float32).clone()
+    u = torch.as_tensor(uniforms, dtype=torch.float32).view(-1, 17, 2)
+    hip, other = [11, 12], [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16]
+    l, h = delta_j2d_dev_range
+    joints2D[:, other, :] = joints2D[:, other, :] + ((h - l) * u[:, other] + l)
+    l, h = delta_j2d_hip_dev_range
+    joints2D[:, hip, :] = joints2D[:, hip, :] + ((h - l) * u[:, hip] + l)
+    return joints2D
+
+
+def augment_seg(seg, uniforms, remove_classes=(1, 2, 3, 4, 5, 6), remove_probs=(0.1, 0.1, 0.1, 0.1, 0.05, 0.05), occlude_probability=0.5,
+                occlude_box_dim=48):
+    """random_remove_bodyparts + random_occlude (augmentation/proxy_rep_augmentation.py:52-101) with the draws supplied:
+    uniforms [B,9] = 6 removal draws (one per entry of remove_classes), the occlusion draw, the two box-centre draws.
+    Removal compares in the dtype of the supplied draws (float32 draws against float32(prob): what the kernel does; float64
+    draws against the float64 prob: what the reference does); the box follows the reference's float64 arithmetic."""
+    seg = np.array(seg, copy=True)
+    u = np.asarray(uniforms)
+    B, wh = seg.shape[0], seg.shape[-1]
+    for i, (c, pr) in enumerate(zip(remove_classes, remove_probs)):
+        rm = u[:, i] < u.dtype.type(pr)
+        blk = seg[rm]
+        blk[blk == c] = 0
+        seg[rm] = blk
+    centre = wh / 2
+    x_h, x_l = centre - 0.3 * wh / 2, centre + 0.3 * wh / 2
+    x = (x_h - x_l) * u[:, 7].astype(np.float64) + x_l
+    y = (x_h - x_l) * u[:, 8].astype(np.float64) + x_l
+    bx1, bx2 = (x - occlude_box_dim / 2).astype(np.int16), (x + occlude_box_dim / 2).astype(np.int16)
+    by1, by2 = (y - occlude_box_dim / 2).astype(np.int16), (y + occlude_box_dim / 2).astype(np.int16)
+    for i in range(B):
+        if u[i, 6] < u.dtype.type(occlude_probability):
+            seg[i, bx1[i]:bx2[i], by1[i]:by2[i]] = 0
+    return seg
+
+
+# --------------------------------------------------------------------------------------------
 # bounding-box crop + nearest resize  (utils/image_utils.py:44-105)
 # --------------------------------------------------------------------------------------------
 def crop_boxes(seg, joints2d, uniforms=None, orig_scale_factor=1.2, delta_scale_range=(-0.2, 0.2), delta_centre_range=(-5, 5)):
@@ -372,8 +502,8 @@ def crop_boxes(seg, joints2d, uniforms=None, orig_scale_factor=1.2, delta_scale_
 
 def crop_resize(seg, joints2d, uniforms=None, out_wh=REGRESSOR_IMG_WH, **kw):
     """crop (above) then batch_resize (utils/image_utils.py:85-105).  cv2 is not installed here: INTER_NEAREST is
-    restated from its documented index rule src = floor(dst * src_size / dst_size) (clamped) -- this half is NOT pinned
-    by a reference import."""
+    restated as OpenCV's resizeNN computes it (src = min(floor(dst * ifx), size - 1), ifx = 1 / ((double)dst_size /
+    src_size)) -- this half is NOT pinned by a reference import."""
     boxes, cj = crop_boxes(seg, joints2d, uniforms, **kw)
     B = seg.shape[0]
     out = np.zeros((B, out_wh, out_wh), seg.dtype)
@@ -382,8 +512,9 @@ def crop_resize(seg, joints2d, uniforms=None, out_wh=REGRESSOR_IMG_WH, **kw):
         r0, c0, r1, c1 = boxes[i]
         crop = seg[i, r0:r1, c0:c1]
         ch, cw = crop.shape
-        ys = np.minimum(np.floor(np.arange(out_wh) * (ch / out_wh)).astype(np.int64), ch - 1)
-        xs = np.minimum(np.floor(np.arange(out_wh) * (cw / out_wh)).astype(np.int64), cw - 1)
+        # OpenCV resizeNN: ifx = 1. / inv_scale_x, inv_scale_x = (double)dsize.width / ssize.width; sx = min(cvFloor(x * ifx), w - 1)
+        ys = np.minimum(np.floor(np.arange(out_wh) * (1.0 / (out_wh / float(ch)))).astype(np.int64), ch - 1)
+        xs = np.minimum(np.floor(np.arange(out_wh) * (1.0 / (out_wh / float(cw)))).astype(np.int64), cw - 1)
         out[i] = crop[ys][:, xs]
         oj[i] = cj[i] * np.array([out_wh / float(cw), out_wh / float(ch)])
     return out, oj, boxes

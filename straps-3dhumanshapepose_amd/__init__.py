@@ -14,4 +14,4 @@ from .smpl import SMPL, ModelOutput, pack_smpl_model  # noqa: F401
 from .rigid_transform_utils import rot6d_to_rotmat, batch_rodrigues  # noqa: F401
 from .multi_task_loss import HomoscedasticUncertaintyWeightedMultiTaskLoss  # noqa: F401
 from .nmr_renderer import NMRRenderer  # noqa: F401
-from . import cam_utils, label_conversions, augmentation, metrics, checkpoint_utils, image_utils  # noqa: F401
+from . import cam_utils, label_conversions, augmentation, metrics, checkpoint_utils, image_utils, device_rng  # noqa: F401

@@ -6,14 +6,17 @@
 //                        arithmetic of batch_crop_seg_to_bounding_box (:56-78): centre/height/width, scale and centre
 //                        jitter from the supplied uniforms, int16 truncation of the corners, clamp of negatives to 0,
 //                        numpy slice clamping at the far edge.  Emits box[b] = {r0, c0, r1, c1} (crop = seg[r0:r1, c0:c1]).
-//   crop_resize_kernel : out[y][x] = crop[floor(y*ch/out)][floor(x*cw/out)]  (cv2.INTER_NEAREST: source index =
-//                        floor(dst * src/dst), clamped) and joints' = (joints - [c0_orig, r0_orig]) * [out/cw, out/ch].
+//   crop_resize_kernel : out[y][x] = crop[sy][sx], sx = min(floor(x * ifx), cw - 1), ifx = 1 / ((double)out / cw)  (cv2.INTER_NEAREST
+//                        as OpenCV's resizeNN computes it) and joints' = (joints - [c0_orig, r0_orig]) * [out/cw, out/ch].
 #include "common.h"
+
+// the box arithmetic is the reference's double arithmetic, unfused, so that the int16 truncations agree with numpy's
+#pragma clang fp contract(off)
 
 namespace {
 
-__global__ __launch_bounds__(1024) void crop_bbox_kernel(const float* __restrict__ seg, const float* __restrict__ u, float orig_scale,
-                                                        float ds_lo, float ds_hi, float dc_lo, float dc_hi, int use_jitter,
+__global__ __launch_bounds__(1024) void crop_bbox_kernel(const float* __restrict__ seg, const float* __restrict__ u, double orig_scale,
+                                                        double ds_lo, double ds_hi, double dc_lo, double dc_hi, int use_jitter,
                                                         int* __restrict__ box, int wh) {
     __shared__ int red[16][4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,9 +59,9 @@ __global__ __launch_bounds__(1024) void crop_bbox_kernel(const float* __restrict
         const double height = rmax - rmin, width = cmax - cmin;
         double scale = orig_scale;
         if (use_jitter) {
-            scale += (double)(ds_hi - ds_lo) * u[b * 3 + 0] + ds_lo;
-            cr += (double)(dc_hi - dc_lo) * u[b * 3 + 1] + dc_lo;
-            cc += (double)(dc_hi - dc_lo) * u[b * 3 + 2] + dc_lo;
+            scale += (ds_hi - ds_lo) * (double)u[b * 3 + 0] + ds_lo;
+            cr += (dc_hi - dc_lo) * (double)u[b * 3 + 1] + dc_lo;
+            cc += (dc_hi - dc_lo) * (double)u[b * 3 + 2] + dc_lo;
         }
         const double side = (height > width ? height : width) * scale;
         int r0 = (int)(short)(cr - side / 2.0), c0 = (int)(short)(cc - side / 2.0);      // .astype(np.int16): truncation
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restric
         const int ch = bx[2] - bx[0], cw = bx[3] - bx[1];
         float v = 0.f;
         if (ch > 0 && cw > 0) {
-            int sy = (int)floor((double)y * ch / owh), sx = (int)floor((double)x * cw / owh);
+            // OpenCV resizeNN: ifx = 1 / inv_scale_x with inv_scale_x = (double)dst / src; sx = min(cvFloor(x * ifx), src - 1)
+            const double ify = 1.0 / ((double)owh / (double)ch), ifx = 1.0 / ((double)owh / (double)cw);
+            int sy = (int)floor((double)y * ify), sx = (int)floor((double)x * ifx);
             sy = sy < ch - 1 ? sy : ch - 1;
             sx = sx < cw - 1 ? sx : cw - 1;
             v = seg[((long long)b * wh + bx[0] + sy) * wh + bx[1] + sx];
@@ -106,8 +111,8 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int straps_crop_resize(const float* seg, const float* joints2d, const float* uniforms, float orig_scale_factor,
-                                  float delta_scale_lo, float delta_scale_hi, float delta_centre_lo, float delta_centre_hi,
+extern "C" int straps_crop_resize(const float* seg, const float* joints2d, const float* uniforms, double orig_scale_factor,
+                                  double delta_scale_lo, double delta_scale_hi, double delta_centre_lo, double delta_centre_hi,
                                   float* out_seg, float* out_joints2d, int* boxes, int batch, int wh, int out_wh, int nj, void* stream) {
     STRAPS_REQUIRE(seg && joints2d && out_seg && out_joints2d && boxes && batch > 0 && wh > 0 && out_wh > 0 && nj > 0,
                    "straps_crop_resize: bad arguments");

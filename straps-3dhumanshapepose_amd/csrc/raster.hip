@@ -4,7 +4,9 @@
 //
 // HBM-bound integer/byte work, no MFMA.  Three launches per call:
 //   1. project kernel  : one thread per (body, vertex): camera transform + pin-hole projection to NDC, exactly
-//                        neural_renderer's `projection` camera mode.
+//                        neural_renderer's `projection` camera mode.  The training loop's vertex noise
+//                        (random_verts2D_deviation, train loop :146-151) is added here from a buffer of uniforms, so the
+//                        noisy copy of the mesh is never materialised.
 //   2. face kernel     : 16 lanes per (body, face) share the pixel-centre samples inside the face's bounding box (SMPL
 //                        faces cover a few pixels, so that is 1-2 trips; a stretched face no longer serialises a wave),
 //                        two-sided inside test, perspective-correct depth, 64-bit atomicMin of (depth bits << 32 | face id)
@@ -24,14 +26,20 @@ namespace {
 __global__ __launch_bounds__(256) void raster_project_kernel(const float* __restrict__ verts, const float* __restrict__ K,
                                                              const float* __restrict__ R, const float* __restrict__ t,
                                                              float* __restrict__ ndc, long long n, int nverts, int cam_per_body,
-                                                             float orig) {
+                                                             float orig, const float* __restrict__ noise_u, float noise_lo,
+                                                             float noise_scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const long long b = i / nverts;
     const float* Kb = K + (cam_per_body ? b * 9 : 0);
     const float* Rb = R + (cam_per_body ? b * 9 : 0);
     const float* tb = t + b * 3;
-    const float x = verts[i * 3 + 0], y = verts[i * 3 + 1], z = verts[i * 3 + 2];
+    float x = verts[i * 3 + 0], y = verts[i * 3 + 1];
+    const float z = verts[i * 3 + 2];
+    if (noise_u) {   // random_verts2D_deviation (augmentation/proxy_rep_augmentation.py:5-22): x,y += (h - l) * rand + l, rendering copy only
+        x = x + (noise_scale * noise_u[i * 2 + 0] + noise_lo);
+        y = y + (noise_scale * noise_u[i * 2 + 1] + noise_lo);
+    }
     const float xc = ((Rb[0] * x + Rb[1] * y) + Rb[2] * z) + tb[0];
     const float yc = ((Rb[3] * x + Rb[4] * y) + Rb[5] * z) + tb[1];
     const float zc = ((Rb[6] * x + Rb[7] * y) + Rb[8] * z) + tb[2];
@@ -137,7 +145,7 @@ extern "C" size_t straps_rasterize_workspace_bytes(long long batch, int nverts, 
 extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, const uint8_t* face_parts, const float* cam_K,
                                       const float* cam_R, const float* cam_t, float* parts, float* depth, void* workspace,
                                       long long batch, int nverts, int nfaces, int wh, int cam_per_body, float near, float far,
-                                      void* stream) {
+                                      const float* vert_noise_u, double noise_lo, double noise_hi, void* stream) {
     STRAPS_REQUIRE(verts && faces && face_parts && cam_K && cam_R && cam_t && workspace, "straps_rasterize_parts: null pointer");
     STRAPS_REQUIRE(parts || depth, "straps_rasterize_parts: neither parts nor depth requested");
     STRAPS_REQUIRE(batch > 0 && nverts > 0 && nfaces > 0 && wh > 0 && wh <= 4096, "straps_rasterize_parts: bad sizes (batch %lld, %d verts, %d faces, wh %d)",
@@ -151,7 +159,7 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     const long long nv = batch * nverts, nf = batch * nfaces, np = batch * (long long)wh * wh;
     STRAPS_REQUIRE((nv + 255) / 256 < (1LL << 31) && (nf * 16 + 255) / 256 < (1LL << 31) && (np + 255) / 256 < (1LL << 31), "straps_rasterize_parts: batch too large for one launch");
     hipLaunchKernelGGL(raster_project_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam_K, cam_R, cam_t, ndc, nv, nverts,
-                       cam_per_body, (float)wh);
+                       cam_per_body, (float)wh, vert_noise_u, (float)noise_lo, (float)(noise_hi - noise_lo));
     STRAPS_CHECK_LAUNCH("raster_project_kernel");
     hipLaunchKernelGGL(raster_face_kernel, dim3((unsigned)((nf * 16 + 255) / 256)), dim3(256), (size_t)wh * sizeof(float), st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far);
     STRAPS_CHECK_LAUNCH("raster_face_kernel");

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void loss_grad_heads_kernel(const float* __rest
 // =====================================================================================================
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float b1, float b2, float eps, float step_size,
-                                                   float inv_sqrt_bc2, float gscale, float lr, const int* __restrict__ step_dev) {
+                                                   float inv_sqrt_bc2, float gscale, float lr, const long long* __restrict__ step_dev) {
     if (step_dev) {   // step counter lives on the device (hipGraph replay): bias corrections computed here, in double
         const double t = (double)step_dev[0];
         step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
@@ -284,7 +284,7 @@ extern "C" int straps_loss_fwd_bwd(const float* pred_verts, const float* pred_jo
 }
 
 extern "C" int straps_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
-                                float beta1, float beta2, float eps, float grad_scale, const int* step_dev, void* stream) {
+                                float beta1, float beta2, float eps, float grad_scale, const long long* step_dev, void* stream) {
     STRAPS_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && (step >= 1 || step_dev), "straps_adam_step: bad arguments");
     if (step < 1) step = 1;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -296,7 +296,7 @@ extern "C" int straps_adam_step(float* params, const float* grads, float* exp_av
 }
 
 // =====================================================================================================
-// generic (row-masked) MSE used by the drop-in criterion module, and the fused proxy augmentation
+// generic (row-masked) MSE used by the drop-in criterion module
 // =====================================================================================================
 namespace {
 
@@ -338,31 +338,6 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
     const float c = coef[0];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
         g[i] = (mask && !mask[i / cols]) ? 0.f : c * (p[i] - (t[i] * ts + tb));
-}
-
-// seg augmentation (augmentation/proxy_rep_augmentation.py:52-101) folded into the input build: u[b][0..5] < prob[c] removes part
-// class c+1, u[b][6] < occlude_prob zeroes a box centred at (u[b][7], u[b][8]) mapped to [0.35*wh, 0.65*wh].
-__global__ __launch_bounds__(256) void augment_seg_kernel(const float* __restrict__ seg, const float* __restrict__ u,
-                                                          const float* __restrict__ prob, float occl_prob, int box, float* __restrict__ out,
-                                                          int B, int WH) {
-    const long long n = (long long)B * WH * WH;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % WH);
-        const int y = (int)((i / WH) % WH);
-        const int b = (int)(i / ((long long)WH * WH));
-        const float* ub = u + b * 9;
-        float v = seg[i];
-        const int cls = (int)v;
-        if (cls >= 1 && cls <= 6 && ub[cls - 1] < prob[cls - 1]) v = 0.f;
-        if (ub[6] < occl_prob) {
-            // reference: x = (x_h - x_l) * rand + x_l with x_h = c - 0.3*wh/2, x_l = c + 0.3*wh/2; first image axis is rows
-            const float c = WH * 0.5f, lo = c + 0.15f * WH, hi = c - 0.15f * WH;
-            const float cx = (hi - lo) * ub[7] + lo, cy = (hi - lo) * ub[8] + lo;
-            const int r1 = (int)(cx - box * 0.5f), r2 = (int)(cx + box * 0.5f), c1 = (int)(cy - box * 0.5f), c2 = (int)(cy + box * 0.5f);
-            if (y >= r1 && y < r2 && x >= c1 && x < c2) v = 0.f;
-        }
-        out[i] = v;
-    }
 }
 
 }  // namespace
@@ -416,15 +391,5 @@ extern "C" int straps_project_targets(const float* joints, const float* cam_t, f
     hipLaunchKernelGGL(project_targets_kernel, dim3((unsigned)((batch * 31 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, joints, cam_t, fx,
                        fy, cx, cy, joints2d, joints3d, batch);
     STRAPS_CHECK_LAUNCH("project_targets_kernel");
-    return STRAPS_OK;
-}
-
-extern "C" int straps_augment_seg(const float* seg, const float* uniforms, const float* remove_prob, float occlude_prob, int box_dim,
-                                  float* out, int batch, int wh, void* stream) {
-    STRAPS_REQUIRE(seg && uniforms && remove_prob && out && batch > 0 && wh > 0, "straps_augment_seg: bad arguments");
-    const long long n = (long long)batch * wh * wh;
-    hipLaunchKernelGGL(augment_seg_kernel, dim3(capped_grid(n, 8192)), dim3(256), 0, (hipStream_t)stream, seg, uniforms, remove_prob,
-                       occlude_prob, box_dim, out, batch, wh);
-    STRAPS_CHECK_LAUNCH("augment_seg_kernel");
     return STRAPS_OK;
 }

@@ -1,0 +1,69 @@
+"""Counter-based random draws on the device (csrc/augment.hip: Philox4x32-10 behind `straps_philox_fill`).
+
+The reference draws its augmentation noise from two generators -- torch's device generator (shape, camera, joint and
+vertex noise) and numpy's host generator (body-part removal, occlusion boxes, crop jitter), train loop :121-175.  Here one
+generator lives on the GPU: a draw is a pure function of (seed, step, sub-stream, index), the step counter is a device
+int64 that `advance()` bumps with a kernel, so a captured hipGraph replays with fresh numbers and the CPU oracle can
+regenerate every draw of any step (oracle/straps_oracle.py::philox_uniform / philox_normal)."""
+import torch
+
+from . import hipabi
+
+UNIFORM, NORMAL = 0, 1
+
+
+class DeviceDraws:
+    def __init__(self, seed, device):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('DeviceDraws needs a GPU device (the STRAPS hot path has no CPU fallback)')
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    def fill(self, out, kind, substream):
+        """fill the contiguous fp32 tensor `out` with uniform [0,1) (kind 0) or standard-normal (kind 1) draws."""
+        hipabi.require_gpu_tensor(out, 'draw buffer', torch.float32)
+        if not out.is_contiguous():
+            raise RuntimeError('DeviceDraws.fill: the draw buffer must be contiguous')
+        hipabi.check(hipabi.lib().straps_philox_fill(self.seed, hipabi.ptr(self.counter), 0, int(substream), hipabi.ptr(out), out.numel(),
+                                                     int(kind), hipabi.stream_ptr()), 'straps_philox_fill')
+        return out
+
+    def uniform(self, *shape, substream=0):
+        return self.fill(torch.empty(*shape, device=self.device, dtype=torch.float32), UNIFORM, substream)
+
+    def normal(self, *shape, substream=1):
+        return self.fill(torch.empty(*shape, device=self.device, dtype=torch.float32), NORMAL, substream)
+
+    def advance(self, delta=1):
+        hipabi.check(hipabi.lib().straps_counter_add(hipabi.ptr(self.counter), 1, int(delta), hipabi.stream_ptr()), 'straps_counter_add')
+
+    def step(self):
+        """host copy of the step counter (synchronises; for tests / checkpoints)."""
+        return int(self.counter.item())
+
+    def set_step(self, step):
+        self.counter.fill_(int(step))
+
+
+_default = {}
+
+
+def default_draws(device):
+    """module-level generator of the function-style augmentation entry points (one per device, seed 0 until `manual_seed`)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _default:
+        _default[key] = DeviceDraws(0, device)
+    return _default[key]
+
+
+def manual_seed(seed, device=None):
+    """reseed the module-level generator(s) used by augmentation.augment_* when no `draws=` is passed."""
+    if device is None:
+        _default.clear()
+        device = torch.device('cuda', torch.cuda.current_device())
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    _default[key] = DeviceDraws(seed, device)
+    return _default[key]

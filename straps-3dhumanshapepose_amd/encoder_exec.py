@@ -90,6 +90,8 @@ def encoder_forward(net, x, tape=None, nzmask=None):
     x = x.contiguous()
     B, C, H, W = x.shape
     ctx = _Ctx(x.device, net.training, tape)
+    if net.training:
+        net._bn_epoch = getattr(net, '_bn_epoch', 0) + 1      # running statistics are about to change: folded-BN cache entries expire
     ctx.defer_nbt = getattr(net, '_nbt_flat', None) is not None
     L = ctx.L
     # ---- stem: conv7x7/s2 + BN + ReLU (models/resnet.py:145-148) ----

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
-SOURCES = ['abi.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'stem.hip', 'smpl.hip',
+SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'stem.hip', 'smpl.hip',
            'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip', 'raster.hip']
 
 _lib = None
@@ -30,7 +30,24 @@ def build(force=False, verbose=False):
     if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    # one object per source (csrc/build/*.o, compiled in parallel, rebuilt only when the source or a header is newer), then one link
+    objdir = os.path.join(CSRC, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, 'common.h'), HEADER]
+    jobs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + '.o')
+        if force or not os.path.isfile(o) or any(os.path.getmtime(o) < os.path.getmtime(d) for d in [s] + hdrs):
+            cmd = [hipcc] + flags + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + '.o') for s in srcs]
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -53,7 +70,7 @@ class PackDesc(C.Structure):
                 ('r', C.c_int32), ('s', C.c_int32), ('first', C.c_longlong)]
 
 
-_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+_P, _I, _L, _F, _Z, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
@@ -111,10 +128,18 @@ SIGNATURES = {
     'straps_mse_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
     'straps_augment_seg': (_I, [_P, _P, _P, _F, _I, _P, _I, _I, _P]),
     'straps_rasterize_workspace_bytes': (_Z, [_L, _I, _I]),
-    'straps_rasterize_parts': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P]),
+    'straps_rasterize_parts': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _D, _D, _P]),
+    'straps_philox_fill': (_I, [C.c_ulonglong, _P, _L, C.c_uint, _P, _L, _I, _P]),
+    'straps_counter_add': (_I, [_P, _I, _L, _P]),
+    'straps_gather_f32': (_I, [_P, _P, _P, _I, _P]),
+    'straps_memset_zero': (_I, [_P, _Z, _P]),
+    'straps_augment_smpl': (_I, [_P, _L, _P, _P, _P, _P, _I, _P, _D, _D, _P, _P, _P, _L, _P]),
+    'straps_augment_cam_t': (_I, [_P, _P, _P, _D, _D, _D, _P, _L, _P]),
+    'straps_deviate_verts2d': (_I, [_P, _P, _D, _D, _P, _L, _P]),
+    'straps_deviate_joints2d': (_I, [_P, _P, _D, _D, _D, _D, _P, _L, _P]),
     'straps_project_targets': (_I, [_P, _P, _F, _F, _F, _F, _P, _P, _L, _P]),
     'straps_point_metrics': (_I, [_P, _P, _P, _L, _I, _P]),
-    'straps_crop_resize': (_I, [_P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_crop_resize': (_I, [_P, _P, _P, _D, _D, _D, _D, _D, _P, _P, _P, _I, _I, _I, _I, _P]),
 }
 
 
@@ -149,8 +174,40 @@ def check(rc, what):
 
 
 def stream_ptr():
+    """the current HIP stream of the CURRENT device: every launch goes there.  `require_gpu_tensor` refuses tensors that
+    live on another device, and the module entry points run under `on_tensor_device`, so pointers and stream always belong
+    to the same GPU."""
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _first_cuda_tensor(values):
+    import torch
+    for v in values:
+        if isinstance(v, torch.Tensor):
+            if v.is_cuda:
+                return v
+        elif isinstance(v, dict):
+            t = _first_cuda_tensor(v.values())
+            if t is not None:
+                return t
+    return None
+
+
+def on_tensor_device(fn):
+    """decorator for module entry points: run under torch.cuda.device(<device of the first GPU tensor argument>), so a
+    module living on cuda:N launches on cuda:N's stream whatever the caller's current device is."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        import torch
+        t = _first_cuda_tensor(list(a) + list(k.values()))
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(*a, **k)
+        with torch.cuda.device(t.device):
+            return fn(*a, **k)
+    return wrapper
 
 
 def ptr(t):
@@ -165,4 +222,8 @@ def require_gpu_tensor(t, name, dtype=None):
                            '(no CPU fallback)' % name)
     if dtype is not None and t.dtype != dtype:
         raise RuntimeError('%s must have dtype %s (got %s)' % (name, dtype, t.dtype))
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError('%s lives on %s but the current device is cuda:%d: kernels are launched on the current device\'s '
+                           'stream -- call torch.cuda.set_device(%d) or wrap the call in `with torch.cuda.device(...)`'
+                           % (name, t.device, torch.cuda.current_device(), t.device.index))
     return t

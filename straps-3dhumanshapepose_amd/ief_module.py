@@ -103,6 +103,7 @@ class IEFModule(nn.Module):
                 tape.append(dict(est_in=est_in, h1=h1, h2=h2))
         return est
 
+    @hipabi.on_tensor_device
     def forward(self, img_features):
         if torch.is_grad_enabled() and (img_features.requires_grad or self.fc1.weight.requires_grad):
             from .autograd_ops import ief_autograd

@@ -56,6 +56,7 @@ class HomoscedasticUncertaintyWeightedMultiTaskLoss(nn.Module):
         """the five log-variances in kernel order (verts, joints2D, joints3D, shape_params, pose_params)."""
         return torch.stack([getattr(self, n + '_log_var') for n in TASKS]).detach().contiguous()
 
+    @hipabi.on_tensor_device
     def forward(self, labels, outputs):
         total_loss = 0.
         loss_dict = {}

@@ -61,8 +61,11 @@ class NMRRenderer(nn.Module):
         self.batch_size, self.img_wh, self.rend_parts_seg = batch_size, int(img_wh), True
         self.near, self.far = float(near), float(far)
 
-    def render_arrays(self, vertices, cam_ts, want_depth=False):
-        """raw entry: vertices [B,N,3], cam_ts [B,3] (fp32 GPU) -> float part map [B,wh,wh] (+ depth)."""
+    @hipabi.on_tensor_device
+    def render_arrays(self, vertices, cam_ts, want_depth=False, vert_noise_u=None, noise_range=(-0.01, 0.01), out=None):
+        """raw entry: vertices [B,N,3], cam_ts [B,3] (fp32 GPU) -> float part map [B,wh,wh] (+ depth).
+        vert_noise_u: optional uniforms [B,N,2] in [0,1): the rendered copy of the mesh gets x,y += (h-l)*u + l
+        (random_verts2D_deviation, proxy_rep_augmentation.py:5-22) inside the projection kernel."""
         hipabi.require_gpu_tensor(vertices, 'vertices', torch.float32)
         hipabi.require_gpu_tensor(cam_ts, 'cam_ts', torch.float32)
         hipabi.require_gpu_tensor(self.faces, 'NMRRenderer buffers (call .to(device))')
@@ -78,12 +81,17 @@ class NMRRenderer(nn.Module):
         vertices, cam_ts = vertices.contiguous(), cam_ts.contiguous()
         L = hipabi.lib()
         wh = self.img_wh
-        parts = torch.empty(B, wh, wh, device=vertices.device, dtype=torch.float32)
+        parts = torch.empty(B, wh, wh, device=vertices.device, dtype=torch.float32) if out is None else out
+        if vert_noise_u is not None:
+            hipabi.require_gpu_tensor(vert_noise_u, 'vert_noise_u', torch.float32)
+            if vert_noise_u.numel() != B * N * 2 or not vert_noise_u.is_contiguous():
+                raise RuntimeError('NMRRenderer: vert_noise_u must be contiguous [B,N,2] uniforms')
         depth = torch.empty(B, wh, wh, device=vertices.device, dtype=torch.float32) if want_depth else None
         ws = torch.empty(L.straps_rasterize_workspace_bytes(B, N, wh) // 4, device=vertices.device, dtype=torch.float32)
         hipabi.check(L.straps_rasterize_parts(hipabi.ptr(vertices), hipabi.ptr(self.faces), hipabi.ptr(self.face_parts), hipabi.ptr(self.cam_K),
                                               hipabi.ptr(self.cam_R), hipabi.ptr(cam_ts), hipabi.ptr(parts), hipabi.ptr(depth), hipabi.ptr(ws),
                                               B, N, self.faces.shape[0], wh, 1 if per_body else 0, self.near, self.far,
+                                              hipabi.ptr(vert_noise_u), float(noise_range[0]), float(noise_range[1]),
                                               hipabi.stream_ptr()), 'straps_rasterize_parts')
         return (parts, depth) if want_depth else parts
 

@@ -3,6 +3,7 @@ arguments, attribute names `image_encoder` / `ief_module`, 132/330 state-dict ke
 import torch
 import torch.nn as nn
 
+from . import hipabi
 from .ief_module import IEFModule
 from .resnet import resnet18, resnet50
 
@@ -21,6 +22,7 @@ class SingleInputRegressor(nn.Module):
             self.image_encoder = resnet50(in_channels=resnet_in_channels, pretrained=False)
             self.ief_module = IEFModule([1024, 1024], 2048, num_output_params, iterations=ief_iters, mean_params=mean_params)
 
+    @hipabi.on_tensor_device
     def forward(self, input):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .autograd_ops import regressor_autograd

@@ -78,10 +78,11 @@ class ResNet(nn.Module):
                 if isinstance(m, ResidualUnit):
                     nn.init.constant_((m.bn3 if m.kind == 'bottleneck' else m.bn2).weight, 0)
         self._cache = {}
+        self._bn_epoch = 0          # bumped by every training-mode forward (running statistics change behind torch's back)
 
     # ---- packed-weight / folded-BN caches, refreshed when a parameter's version changes ----
-    def _cached(self, key, tensors, make):
-        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+    def _cached(self, key, tensors, make, extra=()):
+        sig = tuple((t.data_ptr(), t._version) for t in tensors) + tuple(extra)
         hit = self._cache.get(key)
         if hit is None or hit[0] != sig:
             hit = (sig, make())
@@ -152,8 +153,11 @@ class ResNet(nn.Module):
                                                      hipabi.ptr(bn.running_var), bn.eps, hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), C,
                                                      hipabi.stream_ptr()), 'straps_bn_fold')
             return ss
-        return self._cached(('bn', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make)
+        # running_mean / running_var are updated by straps_bn_stats_finalize through raw pointers (no _version bump): the
+        # training-forward counter is part of the signature, so eval() after train-mode forwards never sees stale folds
+        return self._cached(('bn', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make, extra=(self._bn_epoch,))
 
+    @hipabi.on_tensor_device
     def forward(self, x):
         from .encoder_exec import encoder_forward
         return encoder_forward(self, x)

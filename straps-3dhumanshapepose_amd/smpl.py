@@ -186,8 +186,10 @@ class SMPL(nn.Module):
             self._struct, self._struct_key = s, key
         return self._struct
 
-    def forward_arrays(self, betas, rotmats, want_joints=True, chunks=0):
-        """raw entry: betas [B,10], rotmats [B,24,3,3] (contiguous fp32 GPU) -> (verts, joints|None)."""
+    @hipabi.on_tensor_device
+    def forward_arrays(self, betas, rotmats, want_joints=True, chunks=0, out_verts=None, out_joints=None):
+        """raw entry: betas [B,10], rotmats [B,24,3,3] (contiguous fp32 GPU) -> (verts, joints|None).
+        out_verts / out_joints: optional resident output buffers ([B,6890,3] / [B,90,3], contiguous fp32)."""
         hipabi.require_gpu_tensor(betas, 'betas', torch.float32)
         hipabi.require_gpu_tensor(rotmats, 'rotmats', torch.float32)
         hipabi.require_gpu_tensor(self._k_blend_frag, 'SMPL model buffers (call .to(device))')
@@ -197,14 +199,20 @@ class SMPL(nn.Module):
                                % (tuple(betas.shape), tuple(rotmats.shape)))
         betas, rotmats = betas.contiguous(), rotmats.contiguous()
         L = hipabi.lib()
-        verts = torch.empty(B, V, 3, device=betas.device, dtype=torch.float32)
-        joints = torch.empty(B, 90, 3, device=betas.device, dtype=torch.float32) if want_joints else None
+        verts = torch.empty(B, V, 3, device=betas.device, dtype=torch.float32) if out_verts is None else out_verts
+        joints = None
+        if want_joints:
+            joints = torch.empty(B, 90, 3, device=betas.device, dtype=torch.float32) if out_joints is None else out_joints
+        for t, shp, nm in ((verts, (B, V, 3), 'out_verts'), (joints, (B, 90, 3), 'out_joints')):
+            if t is not None and (tuple(t.shape) != shp or not t.is_contiguous() or t.dtype != torch.float32 or t.device != betas.device):
+                raise RuntimeError('SMPL: %s must be a contiguous fp32 %s tensor on %s' % (nm, shp, betas.device))
         ws = torch.empty(L.straps_smpl_workspace_bytes(C.byref(self._model_struct()), B) // 4, device=betas.device, dtype=torch.float32)
         hipabi.check(L.straps_smpl_fwd(C.byref(self._model_struct()), hipabi.ptr(betas), hipabi.ptr(rotmats),
                                        hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(ws), B, chunks,
                                        hipabi.stream_ptr()), 'straps_smpl_fwd')
         return verts, joints
 
+    @hipabi.on_tensor_device
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True, **kwargs):
         # kwargs swallows get_skin etc. exactly like the reference (models/smpl_official.py:28)
         from .rigid_transform_utils import batch_rodrigues

@@ -11,8 +11,8 @@
   exchange   (world > 1) one sum all-reduce of that buffer over RCCL/xGMI
   update     Adam over the flat parameter buffer (66|165 regressor tensors + 5 log-variances)
 
-Random draws use torch's device generator (seeded per rank); they are inputs of the step, not part
-of its arithmetic.
+Random draws come from the device-resident Philox generator of `device_rng` (seed + rank, step counter on the device):
+no torch operator runs inside the step -- torch provides memory, streams, hipGraph capture and `torch.distributed`.
 """
 import ctypes as C
 
@@ -25,7 +25,16 @@ from .encoder_exec import encoder_forward
 from .ief_module import EST_LD
 from .multi_task_loss import TASKS
 
-REMOVE_PROBS = (0.1, 0.1, 0.1, 0.1, 0.05, 0.05)        # run_train.py:167-168
+# augmentation parameter dictionaries of run_train.py:133-190 (the defaults of TrainStep)
+SMPL_AUGMENT_PARAMS = {'augment_shape': True, 'delta_betas_distribution': 'normal', 'delta_betas_std_vector': [1.5] * 10,
+                       'delta_betas_range': [-3., 3.]}
+CAM_AUGMENT_PARAMS = {'xy_std': 0.05, 'delta_z_range': [-5, 5]}
+BBOX_AUGMENT_PARAMS = {'crop_input': True, 'mean_scale_factor': 1.2, 'delta_scale_range': [-0.2, 0.2], 'delta_centre_range': [-5, 5]}
+PROXY_REP_AUGMENT_PARAMS = {'remove_appendages': True, 'deviate_joints2D': True, 'deviate_verts2D': True, 'occlude_seg': True,
+                            'remove_appendages_classes': [1, 2, 3, 4, 5, 6],
+                            'remove_appendages_probabilities': [0.1, 0.1, 0.1, 0.1, 0.05, 0.05],
+                            'delta_j2d_dev_range': [-8, 8], 'delta_j2d_hip_dev_range': [-8, 8], 'delta_verts2d_dev_range': [-0.01, 0.01],
+                            'occlude_probability': 0.5, 'occlude_box_dim': 48}
 H36M14 = [73 + i for i in config.H36M_TO_J14]
 
 
@@ -84,12 +93,24 @@ class GradientExchange:
 class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
                  mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=False,
-                 renderer=None, track_metrics=False, comm_overlap=None, pipeline_data=True):
+                 renderer=None, track_metrics=False, comm_overlap=None, pipeline_data=True, smpl_augment_params=None,
+                 cam_augment_params=None, bbox_augment_params=None, proxy_rep_augment_params=None):
         """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
-        launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches."""
+        launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches.
+        *_augment_params: the dictionaries of run_train.py:133-190 (defaults = the values that script sets)."""
         p0 = next(regressor.parameters())
-        hipabi.require_gpu_tensor(p0, 'regressor parameters (call .to(device) first)')
+        if not (isinstance(p0, torch.Tensor) and p0.is_cuda):
+            raise RuntimeError('TrainStep: regressor parameters must be GPU tensors (call .to(device) first): the STRAPS hot path runs only '
+                               'through the HIP library (no CPU fallback)')
         self.dev = p0.device
+        with torch.cuda.device(self.dev):
+            self._init(regressor, smpl, criterion, batch_size, lr, rank, world_size, seed, group, mean_shape, mean_cam_t, pose_pool, use_graph,
+                       overlap_wgrad, renderer, track_metrics, comm_overlap, pipeline_data, smpl_augment_params, cam_augment_params,
+                       bbox_augment_params, proxy_rep_augment_params)
+
+    def _init(self, regressor, smpl, criterion, batch_size, lr, rank, world_size, seed, group, mean_shape, mean_cam_t, pose_pool, use_graph,
+              overlap_wgrad, renderer, track_metrics, comm_overlap, pipeline_data, smpl_augment_params, cam_augment_params, bbox_augment_params,
+              proxy_rep_augment_params):
         self.reg, self.smpl, self.crit = regressor, smpl, criterion
         self.B, self.lr, self.rank, self.world, self.group = batch_size, lr, rank, world_size, group
         self.params = list(regressor.parameters()) + list(criterion.parameters())          # run_train.py:200 order
@@ -112,18 +133,28 @@ class TrainStep:
             off += p_.numel()
         self.exchange = GradientExchange(self.flat_g, split_off if self.comm_overlap else 0, world_size, group)
         self.logvar_params = [getattr(criterion, n + '_log_var') for n in TASKS]
-        # the five loss log-variances are neighbours at the end of the flat buffer: the loss kernel writes their gradients in place
-        self._lv_flat = None
+        # the five loss log-variances are the last five floats of the flat buffers, in the criterion's registration order; the
+        # loss kernel wants its own task order: two 5-element gathers (values in, gradients out) instead of torch stack / copies
+        self._lv_index = None
         if all(p.requires_grad and p in self.gviews for p in self.logvar_params):
-            ptrs = [self.gviews[p].data_ptr() for p in self.logvar_params]
-            if all(ptrs[i + 1] - ptrs[i] == 4 for i in range(len(ptrs) - 1)):
-                off = (ptrs[0] - self.flat_g.data_ptr()) // 4
-                self._lv_flat = self.flat_g[off:off + len(ptrs)]
-        # random draws come from torch's default device generator (graph-capture safe), seeded per rank
-        with torch.cuda.device(self.dev):
-            torch.cuda.manual_seed(seed + rank)
-        self.gen = None
-        self.step_t = torch.zeros(1, dtype=torch.int32, device=self.dev)     # Adam step count, lives on the device
+            offs = [(self.gviews[p].data_ptr() - self.flat_g.data_ptr()) // 4 for p in self.logvar_params]
+            base = min(offs)
+            if sorted(o - base for o in offs) == list(range(5)):
+                rel = [o - base for o in offs]                                     # kernel slot k reads flat slot rel[k]
+                inv = [rel.index(i) for i in range(5)]                             # flat slot i receives kernel slot inv[i]
+                self._lv_index = torch.tensor(rel, dtype=torch.int32, device=self.dev)
+                self._lv_index_inv = torch.tensor(inv, dtype=torch.int32, device=self.dev)
+                self._lv_params_flat = self.flat_p[base:base + 5]
+                self._lv_grads_flat = self.flat_g[base:base + 5]
+        # random draws: device-resident Philox generator, seeded per rank; its step counter lives on the device (graph replay)
+        from .device_rng import DeviceDraws
+        self.draws = DeviceDraws(seed + rank, self.dev)
+        self.smpl_augment_params = dict(SMPL_AUGMENT_PARAMS if smpl_augment_params is None else smpl_augment_params)
+        self.cam_augment_params = dict(CAM_AUGMENT_PARAMS if cam_augment_params is None else cam_augment_params)
+        self.bbox_augment_params = dict(BBOX_AUGMENT_PARAMS if bbox_augment_params is None else bbox_augment_params)
+        self.proxy_rep_augment_params = dict(PROXY_REP_AUGMENT_PARAMS if proxy_rep_augment_params is None else proxy_rep_augment_params)
+        assert self.smpl_augment_params['delta_betas_distribution'] in ['uniform', 'normal']
+        self.step_t = torch.zeros(1, dtype=torch.int64, device=self.dev)     # Adam step count, lives on the device
         self.use_graph, self.graph, self.graph_tail, self._warm, self._g_loss = use_graph, None, None, 0, None
         self.side_stream = torch.cuda.Stream(device=self.dev) if overlap_wgrad else None
         d = self.dev
@@ -133,7 +164,12 @@ class TrainStep:
         K = np.array([[config.FOCAL_LENGTH, 0., config.REGRESSOR_IMG_WH / 2.0], [0., config.FOCAL_LENGTH, config.REGRESSOR_IMG_WH / 2.0],
                       [0., 0., 1.]], dtype=np.float32)
         self.cam_K = torch.from_numpy(K).to(d)
-        self.remove_prob = torch.tensor(REMOVE_PROBS, device=d)
+        from .augmentation import remove_probabilities
+        self.remove_prob = remove_probabilities(self.proxy_rep_augment_params, d)
+        std = self.smpl_augment_params.get('delta_betas_std_vector')
+        self._std_vector = None if std is None else torch.as_tensor(std, dtype=torch.float32, device=d).expand(10).contiguous()
+        # dataset shape rows (used only with augment_shape = False): the pose-pool stand-in carries the mean shape
+        self.pool_shape = self.mean_shape[None].expand(batch_size, 10).contiguous()
         # part-segmentation renderer of the target meshes (run_train.py:119-124: NMRRenderer(batch, cam_K, cam_R = I, 256, parts))
         if renderer is None:
             if smpl.faces is None or smpl.face_parts is None:
@@ -171,63 +207,107 @@ class TrainStep:
         # results are bit-identical.
         self.pipeline = bool(pipeline_data)
         self.data_stream = torch.cuda.Stream(device=d) if self.pipeline else None
-        B_ = batch_size
-        self._bufs = [dict(input=torch.empty(B_, 18, 256, 256, device=d), verts=torch.empty(B_, 6890, 3, device=d),
-                           joints2d=torch.empty(B_, 17, 2, device=d), joints3d=torch.empty(B_, 14, 3, device=d),
-                           shape=torch.empty(B_, 10, device=d), rot=torch.empty(B_, 24, 3, 3, device=d),
-                           reposed=torch.empty(B_, 6890, 3, device=d),
-                           nzmask=torch.empty(hipabi.lib().straps_stem_nzmask_words(B_, 18, 256, 256), device=d, dtype=torch.int32))
-                      for _ in range(2)] if self.pipeline else None
+        self._bufs = [self._new_buffers() for _ in range(2)] if self.pipeline else None
         self._cur, self._primed = 0, False
+        self._last_by_parity = {}
 
     # ------------------------------------------------------------------ data generation (no grad)
-    def make_batch(self, out=None):
-        """one synthetic batch; out: optional dict of resident buffers to fill instead of fresh tensors (the data pipeline)."""
+    def _new_buffers(self):
+        d, B = self.dev, self.B
+        return dict(input=torch.empty(B, 18, 256, 256, device=d), verts=torch.empty(B, 6890, 3, device=d),
+                    joints2d=torch.empty(B, 17, 2, device=d), joints3d=torch.empty(B, 14, 3, device=d),
+                    shape=torch.empty(B, 10, device=d), rot=torch.empty(B, 24, 3, 3, device=d),
+                    reposed=torch.empty(B, 6890, 3, device=d), cam_t=torch.empty(B, 3, device=d),
+                    nzmask=torch.empty(hipabi.lib().straps_stem_nzmask_words(B, 18, 256, 256), device=d, dtype=torch.int32))
+
+    def draw_layout(self):
+        """where each consumer's draws sit in the step's two Philox buffers (element offsets; sub-stream 0 = uniforms,
+        sub-stream 1 = normals).  The oracle regenerates the same buffers from (seed + rank, step)."""
+        B = self.B
+        u, off = {}, 0
+        for name, n in (('pose_index', B), ('cam_z', B), ('crop', 3 * B), ('seg', 9 * B), ('joints2d', 34 * B), ('shape_uniform', 10 * B),
+                        ('verts2d', 2 * 6890 * B)):
+            u[name] = (off, n)
+            off += (n + 3) // 4 * 4                      # keep every segment 16-byte aligned
+        n_shape = (10 * B + 3) // 4 * 4
+        return {'uniform': u, 'n_uniform': off, 'normal': {'shape': (0, 10 * B), 'cam_xy': (n_shape, 2 * B)}, 'n_normal': n_shape + 2 * B}
+
+    def make_batch(self, out=None, keep=None):
+        """one synthetic batch (train loop :112-182), every stage a C-ABI call: draws -> G1/G2 -> SMPL x2 -> P2 -> part
+        rasteriser (with the vertex noise) -> crop/resize -> G3 -> G4+G5 -> non-zero map.  out: optional dict of resident
+        buffers to fill (the data pipeline); keep: optional dict that receives the intermediate tensors (tests)."""
         L, st, d, B = hipabi.lib(), hipabi.stream_ptr(), self.dev, self.B
-        from .rigid_transform_utils import batch_rodrigues
-        idx = torch.randint(0, self.pose_pool.shape[0], (B,), device=d, generator=self.gen)
-        pose = self.pose_pool[idx]
-        # G1: shape ~ mean + N(0, 1.5^2) (run_train.py:133-137), axis-angle -> rotation matrices
-        tgt_shape = self.mean_shape[None] + torch.randn(B, 10, device=d, generator=self.gen) * 1.5
-        tgt_rot = batch_rodrigues(pose.reshape(-1, 3)).view(B, 24, 3, 3)
-        # G2: camera translation (augmentation/cam_augmentation.py:4-14)
-        cam_t = self.mean_cam_t.clone()
-        cam_t[:, :2] += torch.randn(B, 2, device=d, generator=self.gen) * 0.05
-        cam_t[:, 2] += torch.rand(B, device=d, generator=self.gen) * 10.0 - 5.0
+        out = self._new_buffers() if out is None else out
+        lay = self.draw_layout()
+        U = self.draws.fill(torch.empty(lay['n_uniform'], device=d), 0, 0)
+        N = self.draws.fill(torch.empty(lay['n_normal'], device=d), 1, 1)
+        self.draws.advance()
+
+        def useg(name):
+            o, n = lay['uniform'][name]
+            return U[o:o + n]
+
+        def nseg(name):
+            o, n = lay['normal'][name]
+            return N[o:o + n]
+        sp, cp, bp, pp = self.smpl_augment_params, self.cam_augment_params, self.bbox_augment_params, self.proxy_rep_augment_params
+        # G1: dataset row (stand-in pose pool) + shape resampling + axis-angle -> rotation matrices (smpl_augmentation.py:27-61)
+        mode = 0
+        if sp['augment_shape']:
+            mode = 1 if sp['delta_betas_distribution'] == 'normal' else 2
+        sdraws = nseg('shape') if mode == 1 else useg('shape_uniform')
+        rng = sp['delta_betas_range'] if mode == 2 else (0.0, 0.0)
+        tgt_shape, tgt_rot = out['shape'], out['rot']
+        hipabi.check(L.straps_augment_smpl(hipabi.ptr(self.pose_pool), self.pose_pool.shape[0], hipabi.ptr(useg('pose_index')),
+                                           hipabi.ptr(self.pool_shape), hipabi.ptr(self.mean_shape), hipabi.ptr(sdraws), mode, hipabi.ptr(self._std_vector),
+                                           float(rng[0]), float(rng[1]), hipabi.ptr(tgt_shape), hipabi.ptr(tgt_rot), None, B, st),
+                     'straps_augment_smpl')
+        # G2: camera translation (cam_augmentation.py:4-14)
+        cam_t = out['cam_t']
+        hipabi.check(L.straps_augment_cam_t(hipabi.ptr(self.mean_cam_t), hipabi.ptr(nseg('cam_xy')), hipabi.ptr(useg('cam_z')), float(cp['xy_std']),
+                                            float(cp['delta_z_range'][0]), float(cp['delta_z_range'][1]), hipabi.ptr(cam_t), B, st),
+                     'straps_augment_cam_t')
         # SMPL #1 / #2
-        tgt_verts, tgt_joints = self.smpl.forward_arrays(tgt_shape, tgt_rot)
-        eye = self._eye
-        tgt_reposed, _ = self.smpl.forward_arrays(tgt_shape, eye, want_joints=False)
+        tgt_verts, tgt_joints = self.smpl.forward_arrays(tgt_shape, tgt_rot, out_verts=out['verts'])
+        self.smpl.forward_arrays(tgt_shape, self._eye, want_joints=False, out_verts=out['reposed'])
         # H36M-LSP 3D joints + P2: perspective projection of the COCO joints (utils/cam_utils.py:40-71, cam_R = I)
-        tgt_j3d, tgt_j2d = torch.empty(B, 14, 3, device=d), torch.empty(B, 17, 2, device=d)
+        j2d_full = torch.empty(B, 17, 2, device=d)
         wh = float(config.REGRESSOR_IMG_WH)
         hipabi.check(L.straps_project_targets(hipabi.ptr(tgt_joints), hipabi.ptr(cam_t), config.FOCAL_LENGTH, config.FOCAL_LENGTH, wh / 2, wh / 2,
-                                              hipabi.ptr(tgt_j2d), hipabi.ptr(tgt_j3d), B, st), 'straps_project_targets')
-        # part segmentation of the target mesh (train loop :155, renderers/nmr_renderer.py), then G3 (+ joints deviation
-        # U[-8,8], proxy_rep_augmentation.py:25-49)
-        seg = self.renderer.render_arrays(tgt_verts, cam_t)
-        # bounding-box crop with scale / centre jitter + nearest resize back to 256 (train loop :161-170, run_train.py:140-148),
-        # on the device; the 2-D joint targets follow the crop like in the reference
-        from .image_utils import batch_crop_and_resize
-        seg, tgt_j2d, _ = batch_crop_and_resize(seg, tgt_j2d, 256, 1.2, (-0.2, 0.2), (-5.0, 5.0),
-                                                uniforms=torch.rand(B, 3, device=d, generator=self.gen))
-        u = torch.rand(B, 9, device=d, generator=self.gen)
-        seg_aug = torch.empty_like(seg)
-        hipabi.check(L.straps_augment_seg(hipabi.ptr(seg), hipabi.ptr(u), hipabi.ptr(self.remove_prob), 0.5, 48, hipabi.ptr(seg_aug), B, 256, st),
-                     'straps_augment_seg')
-        j2d_in = tgt_j2d + (torch.rand(B, 17, 2, device=d, generator=self.gen) * 16.0 - 8.0)
+                                              hipabi.ptr(j2d_full), hipabi.ptr(out['joints3d']), B, st), 'straps_project_targets')
+        # part segmentation of the (noisy copy of the) target mesh: random_verts2D_deviation folded into the rasteriser's
+        # projection kernel (train loop :146-155, proxy_rep_augmentation.py:5-22); the loss keeps the clean vertices
+        noise = useg('verts2d') if pp['deviate_verts2D'] else None
+        seg = self.renderer.render_arrays(tgt_verts, cam_t, vert_noise_u=noise, noise_range=pp['delta_verts2d_dev_range'])
+        # bounding-box crop with scale / centre jitter + nearest resize back to 256 (train loop :161-170), on the device; the 2-D
+        # joint targets follow the crop like in the reference
+        if bp['crop_input']:
+            from .image_utils import batch_crop_and_resize
+            seg_c, tgt_j2d, boxes = batch_crop_and_resize(seg, j2d_full, config.REGRESSOR_IMG_WH, bp['mean_scale_factor'], bp['delta_scale_range'],
+                                                          bp['delta_centre_range'], uniforms=useg('crop'), jout=out['joints2d'])
+        else:
+            seg_c, boxes = seg, None
+            tgt_j2d = out['joints2d']
+            hipabi.check(L.straps_masked_copy(hipabi.ptr(j2d_full), 34, None, 0, hipabi.ptr(tgt_j2d), 34, B, 34, 0, st), 'joints2d copy')
+        # G3: body-part removal + occlusion box (:52-101) and joint jitter (:25-49)
+        seg_aug = torch.empty_like(seg_c)
+        hipabi.check(L.straps_augment_seg(hipabi.ptr(seg_c), hipabi.ptr(useg('seg')), hipabi.ptr(self.remove_prob),
+                                          float(pp['occlude_probability']) if pp['occlude_seg'] else 0.0, int(pp['occlude_box_dim']),
+                                          hipabi.ptr(seg_aug), B, 256, st), 'straps_augment_seg')
+        j2d_in = tgt_j2d
+        if pp['deviate_joints2D']:
+            j2d_in = torch.empty(B, 17, 2, device=d)
+            r, hr = pp['delta_j2d_dev_range'], pp['delta_j2d_hip_dev_range']
+            hipabi.check(L.straps_deviate_joints2d(hipabi.ptr(tgt_j2d), hipabi.ptr(useg('joints2d')), float(r[0]), float(r[1]), float(hr[0]),
+                                                   float(hr[1]), hipabi.ptr(j2d_in), B, st), 'straps_deviate_joints2d')
         # G4 + G5
-        x = torch.empty(B, 18, 256, 256, device=d) if out is None else out['input']
+        x = out['input']
         hipabi.check(L.straps_build_proxy_input(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), B, 17, 256, st), 'straps_build_proxy_input')
         # non-zero map of the input for the stem's zero skipping: made here, next to the input, off the step's critical path
-        nz = torch.empty(L.straps_stem_nzmask_words(B, 18, 256, 256), device=d, dtype=torch.int32) if out is None else out['nzmask']
-        hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nz), B, 18, 256, 256, st), 'straps_stem_nzmask')
-        batch = dict(input=x, verts=tgt_verts, joints2d=tgt_j2d, joints3d=tgt_j3d, shape=tgt_shape, rot=tgt_rot, reposed=tgt_reposed, nzmask=nz)
-        if out is None:
-            return batch
-        for k, v in batch.items():
-            if k not in ('input', 'nzmask'):
-                out[k].copy_(v)
+        hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(out['nzmask']), B, 18, 256, 256, st), 'straps_stem_nzmask')
+        if keep is not None:
+            keep.update(uniforms=U, normals=N, joints=tgt_joints, joints2d_uncropped=j2d_full, seg=seg, seg_cropped=seg_c, boxes=boxes,
+                        seg_aug=seg_aug, joints2d_input=j2d_in)
         return out
 
     # ------------------------------------------------------------------ forward + loss + backward
@@ -235,26 +315,32 @@ class TrainStep:
         L, st, d, B = hipabi.lib(), hipabi.stream_ptr(), self.dev, self.B
         reg, smpl = self.reg, self.smpl
         assert reg.training, 'TrainStep needs the regressor in .train() mode'
-        self.flat_g.zero_()
+        hipabi.check(L.straps_memset_zero(hipabi.ptr(self.flat_g), self.flat_g.numel() * 4, st), 'straps_memset_zero(flat gradient)')
         enc_tape, ief_tape = {}, []
         reg.image_encoder.prepack(with_dgrad=True)          # every conv's forward + data-gradient weight layout, one launch
         if self.nbt_flat is not None:
-            self.nbt_flat.add_(1)                           # num_batches_tracked of every BatchNorm (encoder_exec defers to this)
+            # num_batches_tracked of every BatchNorm, one launch (encoder_exec defers to this)
+            hipabi.check(L.straps_counter_add(hipabi.ptr(self.nbt_flat), self.nbt_flat.numel(), 1, st), 'straps_counter_add(num_batches_tracked)')
         feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape, nzmask=batch.get('nzmask'))
         est = reg.ief_module.forward_estimate(feat, ief_tape)                      # [B,160]
         pose6d = est[:, 3:147]
         R = torch.empty(B, 24, 3, 3, device=d)
         hipabi.check(L.straps_rot6d_fwd(hipabi.ptr(pose6d), EST_LD, 24, hipabi.ptr(R), B, st), 'straps_rot6d_fwd')
-        pred_shape = est[:, 147:157].contiguous()
+        pred_shape = torch.empty(B, 10, device=d)
+        hipabi.check(L.straps_masked_copy(C.c_void_p(est.data_ptr() + 4 * 147), EST_LD, None, 0, hipabi.ptr(pred_shape), 10, B, 10, 0, st), 'pred_shape')
         verts, joints = smpl.forward_arrays(pred_shape, R)                         # SMPL #3
         eye = self._eye
         reposed, _ = smpl.forward_arrays(pred_shape, eye, want_joints=False)       # SMPL #4 (metrics only, train loop :206)
         # heads + loss + gradients
-        lv = self.crit.log_var_vector()
+        if self._lv_index is not None:                     # log-variances: flat-buffer (registration) order -> kernel task order
+            lv = torch.empty(5, device=d)
+            hipabi.check(L.straps_gather_f32(hipabi.ptr(self._lv_params_flat), hipabi.ptr(self._lv_index), hipabi.ptr(lv), 5, st), 'log-var gather')
+        else:
+            lv = self.crit.log_var_vector()
         loss = torch.empty(12, device=d)
         dverts, djoints = torch.empty_like(verts), torch.empty_like(joints)
         dest, drot = torch.empty(B, EST_LD, device=d), torch.empty(B, 24, 3, 3, device=d)
-        dlv = self._lv_flat if self._lv_flat is not None else torch.empty(5, device=d)
+        dlv = torch.empty(5, device=d)
         ws = torch.empty(L.straps_loss_workspace_bytes(B) // 4, device=d)
         hipabi.check(L.straps_loss_fwd_bwd(hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(est), EST_LD, hipabi.ptr(R), hipabi.ptr(batch['verts']),
                                            hipabi.ptr(batch['joints2d']), hipabi.ptr(batch['joints3d']), hipabi.ptr(batch['shape']),
@@ -273,12 +359,15 @@ class TrainStep:
                      'straps_rot6d_bwd')
         # regressor backward, gradients land in the flat buffer
         dfeat, _ = ief_backward(reg.ief_module, feat, ief_tape, dest, self.gviews)
-        if self._lv_flat is None:
-            for k, p in enumerate(self.logvar_params):        # (they sit at the very end of the flat buffer: part of the tail bucket)
+        # d(loss)/d(log-variances) -> their slots at the very end of the flat gradient buffer (part of the tail bucket)
+        if self._lv_index is not None:
+            hipabi.check(L.straps_gather_f32(hipabi.ptr(dlv), hipabi.ptr(self._lv_index_inv), hipabi.ptr(self._lv_grads_flat), 5, st), 'log-var gradient scatter')
+        else:
+            for k, p in enumerate(self.logvar_params):
                 if p.requires_grad:
                     self.gviews[p].copy_(dlv[k])
         encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews, self.side_stream, after_layer3)
-        self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed)
+        self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed, rot=R)
         if self.metrics is not None:
             from .cam_utils import orthographic_project_torch
             pred = {'verts': verts, 'joints3D': joints.index_select(1, self._h36m14), 'shape_params': pred_shape,
@@ -299,7 +388,7 @@ class TrainStep:
     def optimise(self):
         gscale = self.exchange.finish()
         self.steps += 1
-        self.step_t.add_(1)
+        hipabi.check(hipabi.lib().straps_counter_add(hipabi.ptr(self.step_t), 1, 1, hipabi.stream_ptr()), 'straps_counter_add(adam step)')
         hipabi.check(hipabi.lib().straps_adam_step(hipabi.ptr(self.flat_p), hipabi.ptr(self.flat_g), hipabi.ptr(self.exp_avg),
                                                    hipabi.ptr(self.exp_avg_sq), self.flat_p.numel(), self.steps, self.lr, 0.9, 0.999, 1e-8,
                                                    gscale, hipabi.ptr(self.step_t), hipabi.stream_ptr()), 'straps_adam_step')
@@ -337,8 +426,9 @@ class TrainStep:
         return loss
 
     def step(self):
-        """one full training step; returns the 12-float loss record (device tensor, no sync)."""
-        with torch.no_grad():
+        """one full training step; returns the 12-float loss record (device tensor, no sync).  Runs on the regressor's
+        device whatever the caller's current device is."""
+        with torch.cuda.device(self.dev), torch.no_grad():
             start_tail = self.exchange.start_tail if self.comm_overlap else None
             if not self.use_graph or self._warm < 2:
                 self._warm += 1
@@ -350,7 +440,9 @@ class TrainStep:
                 self._capture()
                 if not self.use_graph:
                     return self.step()
-            g1, g2, loss = self.graph[self._cur if self.pipeline else 0]
+            par = self._cur if self.pipeline else 0
+            g1, g2, loss = self.graph[par]
+            self.last = self._last_by_parity[par]          # the output buffers THIS graph writes (each capture has its own)
             g1.replay()
             if g2 is not None:
                 self.exchange.start_tail()       # layer3.. gradients are final: their all-reduce runs under the rest of backward
@@ -410,6 +502,7 @@ class TrainStep:
                 self.reg.image_encoder._cache.clear()
                 self.reg.ief_module._cache = {}
                 graphs[par] = self._capture_one()
+                self._last_by_parity[par] = self.last
             self._cur = start
             self.graph = graphs
             self.graph_tail = next(iter(graphs.values()))[1]
@@ -430,3 +523,41 @@ class TrainStep:
         group = {'lr': self.lr, 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
                  'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(self.params)))}
         return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        """restore the optimiser state written by `state_dict()` / torch.optim.Adam.state_dict() (checkpoint key
+        'optimiser_state_dict', run_train.py:204-209): per-parameter exp_avg / exp_avg_sq go back into the flat moment
+        buffers in `self.params` order, the step count into the host counter and the device-side Adam step."""
+        groups = sd.get('param_groups', [])
+        if len(groups) != 1:
+            raise ValueError('TrainStep.load_state_dict: expected one parameter group (run_train.py:200), got %d' % len(groups))
+        g = groups[0]
+        if len(g['params']) != len(self.params):
+            raise ValueError('TrainStep.load_state_dict: the state covers %d parameters, this step has %d' % (len(g['params']), len(self.params)))
+        if tuple(g.get('betas', (0.9, 0.999))) != (0.9, 0.999) or g.get('eps', 1e-8) != 1e-8 or g.get('weight_decay', 0) != 0 \
+                or g.get('amsgrad', False):
+            raise ValueError('TrainStep.load_state_dict: only torch.optim.Adam defaults (betas (0.9, 0.999), eps 1e-8, no weight decay, '
+                             'no amsgrad) are implemented by straps_adam_step')
+        self.lr = float(g.get('lr', self.lr))
+        state = sd.get('state', {})
+        steps = set()
+        with torch.cuda.device(self.dev), torch.no_grad():
+            off = 0
+            for i, p in zip(g['params'], self.params):
+                n = p.numel()
+                st = state.get(i, state.get(str(i)))
+                if st is None:                              # a parameter that never received a gradient has no state yet
+                    self.exp_avg[off:off + n].zero_()
+                    self.exp_avg_sq[off:off + n].zero_()
+                else:
+                    if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                        raise ValueError('TrainStep.load_state_dict: parameter %d has shape %s, the state %s' % (i, tuple(p.shape), tuple(st['exp_avg'].shape)))
+                    self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1).to(self.dev, torch.float32))
+                    self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1).to(self.dev, torch.float32))
+                    steps.add(int(float(st['step'])))
+                off += n
+            if len(steps) > 1:
+                raise ValueError('TrainStep.load_state_dict: per-parameter step counts differ (%s); one fused Adam launch keeps one count' % sorted(steps))
+            self.steps = steps.pop() if steps else 0
+            self.step_t.fill_(self.steps)
+

@@ -13,46 +13,47 @@ from straps_amd import hipabi
 pytestmark = pytest.mark.gpu
 
 
-def test_augment_seg_matches_reference_semantics():
+def test_augment_seg_bit_exact_vs_oracle():
+    """byte work -> bit-exact: the kernel and the oracle (pinned by the reference's own generator streams in
+    tests/test_oracle_golden.py) consume the SAME float32 draws."""
     dev = torch.device('cuda:0')
     L = hipabi.load()
-    B, wh, box = 6, 256, 48
+    B, wh, box = 64, 256, 48
     seg = np.floor(det_uniform((B, wh, wh), 50, 0.0, 6.999)).astype(np.float32)
     u = det_uniform((B, 9), 51, 0.0, 1.0)
     u[0, :7] = 0.0           # sample 0: every part removed and occluded
     u[1, :7] = 0.99          # sample 1: untouched
+    u[2, 6], u[2, 7], u[2, 8] = 0.0, 0.0, 1.0 - 2.0 ** -24          # extreme box centres
+    u[3, 6], u[3, 7], u[3, 8] = 0.0, 1.0 - 2.0 ** -24, 0.0
+    u[4, 6], u[4, 7] = 0.0, np.float32((166.4 - 152.0) / 76.8)      # centre - box/2 lands (almost) on an integer
+    u[5, 0] = np.float32(0.1)                                       # a draw equal to float32(prob): not removed
     probs = np.array([0.1, 0.1, 0.1, 0.1, 0.05, 0.05], np.float32)
-    # reference semantics with the same uniforms
-    want = seg.copy()
-    for c in range(6):
-        rm = u[:, c] < probs[c]
-        blk = want[rm]
-        blk[blk == c + 1] = 0
-        want[rm] = blk
-    centre = wh / 2
-    hi_, lo_ = centre - 0.3 * wh / 2, centre + 0.3 * wh / 2
-    for i in range(B):
-        if u[i, 6] < 0.5:
-            x = (hi_ - lo_) * u[i, 7] + lo_
-            y = (hi_ - lo_) * u[i, 8] + lo_
-            x1, x2, y1, y2 = int(np.float32(x - box / 2)), int(np.float32(x + box / 2)), int(np.float32(y - box / 2)), int(np.float32(y + box / 2))
-            want[i, x1:x2, y1:y2] = 0
+    want = O.augment_seg(seg, u, remove_probs=probs, occlude_probability=0.5, occlude_box_dim=box)
     segd, ud, pd = torch.from_numpy(seg).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(probs).to(dev)
     out = torch.empty_like(segd)
     hipabi.check(L.straps_augment_seg(hipabi.ptr(segd), hipabi.ptr(ud), hipabi.ptr(pd), 0.5, box, hipabi.ptr(out), B, wh, None), 'augment')
     got = out.cpu().numpy()
-    assert (got != want).mean() < 1e-4          # box edges may differ by float rounding of the centre on a pixel boundary
-    assert np.array_equal(got[1], seg[1]) and got[0].sum() == 0
-    # module-level entry point: inputs untouched, shapes kept
+    np.testing.assert_array_equal(got, want)
+    assert np.array_equal(got[1], seg[1]) and got[0].sum() == 0 and (got != seg).any(axis=(1, 2)).sum() > B // 2
+    # module-level entry point (reference signature): inputs untouched, same kernel, draws supplied or drawn on the device
     params = {'remove_appendages': True, 'deviate_joints2D': True, 'deviate_verts2D': True, 'occlude_seg': True,
               'remove_appendages_classes': [1, 2, 3, 4, 5, 6], 'remove_appendages_probabilities': [0.1, 0.1, 0.1, 0.1, 0.05, 0.05],
-              'delta_j2d_dev_range': [-8, 8], 'delta_j2d_hip_dev_range': [-8, 8], 'delta_verts2d_dev_range': [-0.01, 0.01],
+              'delta_j2d_dev_range': [-8, 8], 'delta_j2d_hip_dev_range': [-15, 15], 'delta_verts2d_dev_range': [-0.01, 0.01],
               'occlude_probability': 0.5, 'occlude_box_dim': 48}
     j = torch.from_numpy(det_uniform((B, 17, 2), 52, 20.0, 236.0)).to(dev)
     j0 = j.clone()
-    s2, j2 = straps_amd.augmentation.augment_proxy_representation(segd, j, params)
+    uj = det_uniform((B, 17, 2), 53, 0.0, 1.0)
+    s2, j2 = straps_amd.augmentation.augment_proxy_representation(segd, j, params, seg_uniforms=ud, joint_uniforms=torch.from_numpy(uj).to(dev))
     assert torch.equal(j, j0) and torch.equal(segd.cpu(), torch.from_numpy(seg))
-    assert float((j2 - j0).abs().max()) <= 8.0 and s2.shape == segd.shape
+    np.testing.assert_array_equal(s2.cpu().numpy(), want)
+    np.testing.assert_array_equal(j2.cpu().numpy(), O.random_joints2D_deviation(j0.cpu(), uj, [-8, 8], [-15, 15]).numpy())
+    straps_amd.device_rng.manual_seed(5, dev)
+    s3, j3 = straps_amd.augmentation.augment_proxy_representation(segd, j, params)
+    straps_amd.device_rng.manual_seed(5, dev)
+    s4, j4 = straps_amd.augmentation.augment_proxy_representation(segd, j, params)
+    assert torch.equal(s3, s4) and torch.equal(j3, j4) and not torch.equal(j3, j0)
+    d = (j3 - j0).abs()
+    assert float(d[:, [11, 12]].max()) <= 15.0 and float(d[:, [0, 5, 16]].max()) <= 8.0 and float(d[:, [11, 12]].max()) > 8.0
 
 
 def test_project_targets_vs_oracle():

@@ -72,7 +72,7 @@ def test_error_behaviour():
     with pytest.raises(RuntimeError, match='GPU tensor'):
         r(torch.zeros(1, 5, 3), torch.zeros(1, 3))
     L = hipabi.load()
-    assert L.straps_rasterize_parts(None, None, None, None, None, None, None, None, None, 1, 1, 1, 8, 0, 0.1, 100.0, None) != 0
+    assert L.straps_rasterize_parts(None, None, None, None, None, None, None, None, None, 1, 1, 1, 8, 0, 0.1, 100.0, None, 0.0, 0.0, None) != 0
     assert b'null pointer' in L.straps_last_error()
     r = r.to(DEV)
     out = r(torch.zeros(1, 5, 3, device=DEV), torch.tensor([[0.0, 0.0, 5.0]], device=DEV))      # all faces degenerate: empty image

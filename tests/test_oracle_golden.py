@@ -205,3 +205,89 @@ def test_crop_boxes_match_reference(small):
     np.testing.assert_allclose(cj0, small['crop0_joints'], rtol=0, atol=1e-9)
     out, oj, _ = O.crop_resize(seg, j, u)
     assert out.shape == (seg.shape[0], 256, 256) and set(np.unique(out)) <= set(range(7))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# augmentation with the draws supplied: fed with the REFERENCE's generator streams (same torch / numpy CPU generators,
+# same seeds, same call order as make_golden.py) the oracle must reproduce the reference's outputs exactly
+# ------------------------------------------------------------------------------------------------------------------
+def test_philox_known_answers():
+    """Random123 known-answer vectors of Philox4x32-10 (Salmon et al.): pins the generator restatement."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(np.array([ctr], np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == want
+    u = O.philox_uniform(1234, 5, 0, 200001)
+    n = O.philox_normal(1234, 5, 1, 200001)
+    assert u.dtype == np.float32 and u.shape == (200001,) and 0.0 <= u.min() and u.max() < 1.0
+    assert abs(float(u.mean()) - 0.5) < 3e-3 and abs(float(n.mean())) < 1e-2 and abs(float(n.std()) - 1.0) < 1e-2
+    # a draw is a pure function of (seed, step, sub-stream, index): prefixes agree, other steps / streams differ
+    assert np.array_equal(O.philox_uniform(1234, 5, 0, 10), u[:10]) and not np.array_equal(O.philox_uniform(1234, 6, 0, 10), u[:10])
+    assert not np.array_equal(O.philox_uniform(1234, 5, 1, 10), u[:10]) and not np.array_equal(O.philox_uniform(1235, 5, 0, 10), u[:10])
+
+
+def test_cam_and_shape_augmentation_match_reference_streams(small):
+    import straps_amd
+    torch.manual_seed(7)
+    n, u = torch.randn(6, 2), torch.rand(6)
+    mean_cam_t = torch.tensor([[0., 0.2, 42.0]]).expand(6, -1)
+    got = O.augment_cam_t(mean_cam_t, n, u, xy_std=0.05, delta_z_range=[-5, 5])
+    np.testing.assert_array_equal(got.numpy(), small['aug_cam_t'])
+    mean_shape = straps_amd.synthetic_mean_params(0)['shape']
+    torch.manual_seed(10)
+    got = O.sample_shape(mean_shape, torch.randn(5, 10), 'normal', std_vector=torch.full((10,), 1.5))
+    np.testing.assert_array_equal(got.numpy(), small['aug_shape_normal'])
+    torch.manual_seed(10)
+    got = O.sample_shape(mean_shape, torch.rand(5, 10), 'uniform', delta_betas_range=[-3., 3.])
+    np.testing.assert_array_equal(got.numpy(), small['aug_shape_uniform'])
+
+
+def test_proxy_augmentation_matches_reference_streams(small):
+    B = 6
+    segs = np.floor(det_uniform((B, 256, 256), 50, 0.0, 6.999))
+    j2 = det_uniform((B, 17, 2), 51, 20.0, 236.0)
+    np.random.seed(8)
+    torch.manual_seed(8)
+    u = np.zeros((B, 9), np.float64)
+    for c in range(6):                       # random_remove_bodyparts: one np.random.rand(B) per class (:65-70)
+        u[:, c] = np.random.rand(B)
+    u[:, 7] = np.random.rand(B)              # random_occlude: x, y, then the decision vector (:89-96)
+    u[:, 8] = np.random.rand(B)
+    u[:, 6] = np.random.rand(B)
+    nseg = O.augment_seg(segs, u)
+    np.testing.assert_array_equal(np.stack([(nseg == c).sum(axis=(1, 2)) for c in range(7)], 1), small['aug_seg_class_counts'])
+    np.testing.assert_array_equal(nseg.sum(axis=2), small['aug_seg_rowsum'])
+    np.testing.assert_array_equal(nseg.sum(axis=1), small['aug_seg_colsum'])
+    assert (nseg != segs).any()
+    other, hip = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16], [11, 12]
+    u17 = torch.zeros(B, 17, 2)
+    u17[:, other] = torch.rand(B, 15, 2)     # random_joints2D_deviation: the 15 other joints first, then the hips (:41-47)
+    u17[:, hip] = torch.rand(B, 2, 2)
+    got = O.random_joints2D_deviation(j2, u17, [-8, 8], [-8, 8])
+    np.testing.assert_array_equal(got.numpy(), small['aug_j2d'])
+    torch.manual_seed(9)
+    verts = det_uniform((2, 40, 3), 60, -1.0, 1.0)
+    got = O.random_verts2D_deviation(verts, torch.rand(2, 40, 2), [-0.01, 0.01])
+    np.testing.assert_array_equal(got.numpy(), small['aug_verts'])
+    assert np.array_equal(got.numpy()[:, :, 2], verts[:, :, 2]) and float(np.abs(got.numpy() - verts).max()) <= 0.01
+
+
+def test_standin_proxy_heatmaps_match_reference_numpy_routine():
+    """config 1 plumbing: the oracle's heat-maps on the committed stand-in equal the reference's NUMPY routine
+    (utils/label_conversions.py:58-87, called from predict_3D.py:67-76 with int16-truncated joints)."""
+    g = np.load(os.path.join(GOLD, 'predict_golden.npz'))
+    sil = np.unpackbits(g['sil_bits'])[:256 * 256].reshape(256, 256).astype(np.float32)
+    j = g['joints2D'][:, :2].astype(np.int16).astype(np.float32)
+    x = O.build_proxy_input(torch.from_numpy(sil)[None], torch.from_numpy(j)[None])[0].numpy()        # [18,256,256]
+    assert np.array_equal(x[0], sil) and 0.05 < sil.mean() < 0.5
+    heat = np.transpose(x[1:], (1, 2, 0)).reshape(-1)                                                  # reference layout [256,256,17]
+    assert np.array_equal(np.flatnonzero(heat), g['heat_idx'])
+    np.testing.assert_allclose(heat[g['heat_idx']], g['heat_val'], rtol=0, atol=2e-7)
+    assert abs(float(x.astype(np.float64).sum()) - float(g['proxy_sum'])) < 1e-3
+    assert x[1 + 16].sum() == 0 and x[1 + 4].sum() > 0 and x[1 + 3, :, 255].sum() == 0               # skipped / clipped / col 255 never written
+    for layers in (18, 50):
+        with torch.no_grad():
+            cam, pose, shape, est = O.regressor_forward(torch.from_numpy(x)[None], _sd(layers), _init(), layers, 3, training=False)
+        np.testing.assert_allclose(est.numpy()[:, :157], g['out_r%d' % layers], rtol=1e-5, atol=2e-6)
