@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- bodies/sec of the STRAPS hot path on MI355X (driver contract in the task prompt).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|fwd|smpl] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|fwd|smpl | --config 1..4] [--batch B] [--layers 18|50]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch; inputs are generated / resident in HBM:
@@ -10,7 +10,9 @@ A "step" is one pass of the hot path over one batch; inputs are generated / resi
         target SMPL x2, proxy construction + augmentation, forward (training-mode BN), heads +
         multi-task loss, backward, [N>1: one RCCL all-reduce of the flat gradient], Adam.
   fwd   (configs[1]): [B,18,256,256] -> resnet18 encoder -> 3-iter IEF -> rot6d -> SMPL, eval mode.
-  smpl  (configs[4]): SMPL-only forward, B bodies of random (theta, beta) per step.
+  smpl  (configs[4]): SMPL-only forward, 65 536 bodies of random (theta, beta) per step x 16 steps = the 1 M bodies BASELINE.json
+        names; blend contraction in the three-product fp16 split (--smpl-exact: exact-fp32 MFMA kernel, the A/B).
+  --config 3 = configs[3]'s per-GPU shape (train, resnet50, 32 bodies per GPU).
 Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel of the workload, its launches timed
 live with HIP events on the launch stream inside the timed region; `cpu_baseline` = the CPU oracle
 on a bounded sample on this host (rank 0, N = 1 only).
@@ -41,6 +43,8 @@ def pmc_traffic(args, kernel):
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
     tag = '%s_r%d_b%d' % (args.workload, args.layers, args.batch or (65536 if args.workload == 'smpl' else 64))
+    if args.workload == 'smpl' and args.smpl_exact:
+        tag += '_exact'
     try:
         rec = json.load(open(path)).get(tag)
     except (OSError, ValueError):
@@ -55,7 +59,7 @@ def pmc_traffic(args, kernel):
     if not n:
         return {}
     return {'traffic': round(byt / n), 'traffic_unit': 'HBM bytes per launch (read x2-corrected + write), launch-weighted mean',
-            'traffic_source': rec['source']}
+            'traffic_source': rec['source'], 'traffic_measured_in_run': False}
 
 
 def synthetic_proxy_batch(B, device, seed):
@@ -155,17 +159,26 @@ def instrument(timer):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=0, help='timed steps (default 20; smpl: 16 x 65 536 = the 1 M bodies of configs[4])')
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='train', choices=['train', 'fwd', 'smpl'])
     ap.add_argument('--batch', type=int, default=0, help='bodies per GPU per step (default 64; smpl: 65536)')
     ap.add_argument('--layers', type=int, default=18)
+    ap.add_argument('--config', type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help='BASELINE.json configs[N] alias: 1 = --workload fwd, 2 = --workload train, 3 = train --layers 50 --batch 32 (per GPU), 4 = --workload smpl')
+    ap.add_argument('--smpl-exact', action='store_true', help='smpl workload: exact-fp32 MFMA blend contraction instead of the three-product fp16 split')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
     ap.add_argument('--no-overlap', action='store_true', help='(default now) weight-gradient kernels stay on the main stream')
     ap.add_argument('--overlap-wgrad', action='store_true', help='A/B: run the weight-gradient kernels on a side stream (0.1 ms slower since the data pipeline)')
     args = ap.parse_args()
+    if args.config:
+        args.workload = {1: 'fwd', 2: 'train', 3: 'train', 4: 'smpl'}[args.config]
+        if args.config == 3:
+            args.layers, args.batch = 50, args.batch or 32
+    if not args.steps:
+        args.steps = 16 if args.workload == 'smpl' else 20
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -186,7 +199,15 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d needs WORLD_SIZE=%d (got %d): launch with python -m torch.distributed.run --nnodes=1 '
+                         '--nproc-per-node %d ... bench.py --gpus %d' % (args.gpus, args.gpus, world, args.gpus, args.gpus))
+    ranks_seen = 1
+    if dist is not None:           # every rank contributes a one: the sum is the number of ranks that really joined the job
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, 'only %d of %d ranks joined the process group' % (ranks_seen, world)
     hipabi.load()
 
     B = args.batch or (65536 if args.workload == 'smpl' else 64)
@@ -207,8 +228,8 @@ def main():
             init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}).to(dev)
         ts = TrainStep(reg, smpl, crit, B, lr=1e-4, rank=rank, world_size=world, seed=1234, mean_shape=mp['shape'], use_graph=not args.no_graph, overlap_wgrad=args.overlap_wgrad and not args.no_overlap)
         step = ts.step
-        workload = 'configs[2]: full synthetic OTF training step (augmentation + proxy construction + forward + multi-task loss ' \
-                   '+ backward + Adam), %s, 18x256x256 proxy' % net
+        workload = '%s: full synthetic OTF training step (augmentation + proxy construction + forward + multi-task loss ' \
+                   '+ backward + Adam), %s, 18x256x256 proxy' % ('configs[3] per-GPU shape' if args.layers == 50 else 'configs[2]', net)
         dominant = 'conv_igemm_kernel'
         par = 'data parallel: bodies sharded over %d rank(s), replicated weights, one RCCL sum all-reduce of the flat fp32 gradient per step' % world
         if ts.comm_overlap:
@@ -234,9 +255,12 @@ def main():
         aa = (torch.randn(B, 72, generator=g) * 0.3).to(dev)
         R = straps_amd.batch_rodrigues(aa.view(-1, 3)).view(B, 24, 3, 3).contiguous()
 
+        smpl_precision = 'fp32' if args.smpl_exact else 'fp16x3'
+
         def step():
-            return smpl.forward_arrays(betas, R, want_joints=True)[0]
-        workload = 'configs[4]: SMPL-only forward, %d random (theta,beta) per step -> 6890-vertex meshes + 90 joints' % B
+            return smpl.forward_arrays(betas, R, want_joints=True, precision=smpl_precision)[0]
+        workload = 'configs[4]: SMPL-only forward, %d random (theta,beta) per step x %d steps = %d bodies -> 6890-vertex meshes + 90 joints' % (
+            B, args.steps, B * args.steps)
         dominant = 'smpl_fwd'
         par = 'bodies sharded over %d rank(s), no collective (forward)' % world
 
@@ -273,6 +297,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.on = False
+    graph_captured = args.workload != 'train' or ts.graph is not None
     eager_ms = None
     if graph_mode:
         # same K steps launched eagerly with HIP-event pairs around the MFMA kernels (roofline section)
@@ -289,6 +314,25 @@ def main():
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
         timer.on = False
+    # A/B inside the same run: the stem kernels with their exact zero skipping defeated (every input cell marked non-zero = the
+    # plain dense convolution), 3 eager steps on every rank (the step's all-reduce is collective)
+    stem_ab = None
+    if args.workload == 'train' and not args.dense_stem:
+        if ts.use_graph:
+            ts.use_graph, ts.side_stream, ts.pipeline = False, None, False
+        saved, timer.recs = timer.recs, []
+        reg.image_encoder.dense_stem = True
+        step()
+        torch.cuda.synchronize()
+        timer.on = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        timer.on = False
+        dense = timer.summary()
+        timer.recs = saved
+        reg.image_encoder.dense_stem = False
+        stem_ab = {k: dense[k][2] / 3 * 1e3 for k in ('stem_kernel', 'stem_wgrad_kernel') if k in dense}
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -303,15 +347,27 @@ def main():
             n, flops, secs, abytes = agg[dominant]
             ach = flops / secs / 1e12
             roof = {'bound': 'mfma', 'kernel': dominant, 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
-                    'flops_per_launch': round(flops / n)}
+                    'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None, 'traffic_measured_in_run': False, 'launches': n,
+                    'avg_launch_us': round(secs / n * 1e6, 2), 'flops_per_launch': round(flops / n)}
             if abytes:
                 roof['algorithmic_bytes_per_launch'] = round(abytes / n)
-            roof.update(pmc_traffic(args, dominant))
             if args.workload == 'smpl':
-                byt = n * B * (6890 * 12 + 90 * 12 + 24 * 36 + 40)
-                roof['hbm_side'] = {'achieved': round(byt / secs / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                    'frac': round(byt / secs / 1e9 / HBM_PEAK_GBS, 4)}
+                # algorithmic bytes per body = 6890 x 12 (vertices) + 90 x 12 (joints) + 24 x 36 (rotation matrices) + 40 (betas)
+                per_body = 6890 * 12 + 90 * 12 + 24 * 36 + 40
+                byt = n * B * per_body
+                hbm = {'achieved': round(byt / secs / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(byt / secs / 1e9 / HBM_PEAK_GBS, 4)}
+                if args.smpl_exact:
+                    roof['hbm_side'] = hbm                # exact-fp32 blend: the fp32 matrix pipe binds long before HBM does
+                else:
+                    # three-product fp16 split: the contraction issues 3 x 2 x 224 x (tiles x 96) flops per body on the fp16 pipe
+                    issued = n * B * 3.0 * 2.0 * 224 * smpl.n_tiles * 96
+                    roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm['frac'],
+                            'traffic': None, 'traffic_measured_in_run': False, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
+                            'algorithmic_bytes_per_launch': B * per_body,
+                            'mfma_side': {'pipe': 'fp16 MFMA, fp32 accumulate (3 split products)', 'issued': round(issued / secs / 1e12, 1), 'peak': 2500.0,
+                                          'unit': 'TFLOP/s', 'frac': round(issued / secs / 1e12 / 2500.0, 4),
+                                          'fp32_equivalent_tflops': round(ach, 2)}}
+            roof.update(pmc_traffic(args, dominant))
         others = {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'avg_launch_us': round(v[2] / v[0] * 1e6, 2),
                       'ms_per_step': round(v[2] / args.steps * 1e3, 3)} for k, v in agg.items()}
         for k in others:
@@ -332,12 +388,20 @@ def main():
                'roofline': roof, 'kernels': others, 'cpu_baseline': cpu}
         if args.workload == 'train':
             out['final_loss'] = round(float(ts.last['loss'][0]), 5)
+            captured = graph_mode and graph_captured            # TrainStep falls back to eager launches if capture fails
             out['launch_mode'] = ('hipGraph replay of data-gen (next batch, second stream) + forward + loss + backward (all-reduce and Adam eager)'
-                                  if graph_mode else 'eager')
+                                  if captured else 'eager')
+            out['ranks_seen'] = ranks_seen
+            if stem_ab:
+                out['stem_dense_ms_per_step'] = round(sum(stem_ab.values()), 4)
+                out['stem_sparse_ms_per_step'] = round(sum(v[2] for k, v in agg.items() if k in stem_ab) / args.steps * 1e3, 4)
         else:
             out['launch_mode'] = 'hipGraph replay of the whole forward' if graph_mode else 'eager'
         if args.workload != 'smpl':
             out['stem_zero_skipping'] = not args.dense_stem
+        else:
+            out['smpl_blend_precision'] = smpl_precision
+            out['dtype'] = 'fp32' if args.smpl_exact else 'fp32 (blend contraction: 3-product fp16 split, fp32 accumulate)'
         if eager_ms is not None:
             out['eager_ms_per_step'] = round(eager_ms, 4)
             if roof is not None:
@@ -361,7 +425,7 @@ def cpu_baseline(args, mp, smpl_model):
         torch.manual_seed(1234)
         reg = straps_amd.SingleInputRegressor(18, args.layers, 3, mean_params=mp)
         sd = {k: v.detach().clone() for k, v in reg.state_dict().items()}
-        nb = 16
+        nb = args.batch or 64                      # the GPU run's batch (same B)
         x = synthetic_proxy_batch(nb, 'cpu', 99)
         if args.workload == 'fwd':
             def once():
@@ -396,14 +460,14 @@ def cpu_baseline(args, mp, smpl_model):
                 with torch.no_grad():
                     O.adam_step([p for p in ps], [p.grad for p in ps], m_, v_, stepno[0])
             what = 'training steps (forward + loss + backward + Adam; data generation excluded) of a %d-body batch'
-        once()
+        once()                                     # 1 warm-up + 3 timed iterations (more while the time budget lasts)
         t0, it = time.perf_counter(), 0
-        while time.perf_counter() - t0 < budget or it < 2:
+        while it < 3 or (time.perf_counter() - t0 < budget and it < 50):
             once()
             it += 1
         dt = time.perf_counter() - t0
-        return {'value': round(nb * it / dt, 2), 'unit': 'bodies/s', 'cores': ncores, 'kind': 'port',
-                'sample': ('%d ' + what + ' through the torch-CPU oracle (same net, synthetic input)') % (it, nb)}
+        return {'value': round(nb * it / dt, 2), 'unit': 'bodies/s', 'cores': ncores, 'kind': 'port', 'batch': nb,
+                'sample': ('1 warm-up + %d ' + what + ' through the torch-CPU oracle (same net, synthetic input)') % (it, nb)}
     nb = 64
     g = torch.Generator().manual_seed(0)
     betas = torch.randn(nb, 10, generator=g)

@@ -203,14 +203,28 @@ typedef struct {
     const int32_t* dj_ptr;     /* [54*24 + 1] */
     const int32_t* dj_code;
     const float* dj_w;
+    /* ---- split-precision forward (mode STRAPS_SMPL_SPLIT_F16; may be NULL / 0 otherwise) ----
+     * fp16 two-term split of the blend directions scaled by a power of two S_D: [tile][kstep 14][coord 3][hi|lo][lane 64][8],
+     * element = split(S_D * D[k = 16*kstep + 8*(lane>>5) + j][vertex = 32*tile + (lane&31)][coord]), hi = fp16(x),
+     * lo = fp16(x - hi); blend_h_unscale = 1 / (S_D * 64) (the kernel scales the features by 64).               */
+    const void* blend_frag_h;
+    float blend_h_unscale;
+    int32_t reserved1;
 } straps_smpl_model_t;
+
+/* arithmetic of the blend contraction (v_template + shapedirs + posedirs, K = 218) in straps_smpl_fwd */
+#define STRAPS_SMPL_EXACT_F32 0 /* fp32-input MFMA: exact fmaf chains (the reference's fp32 arithmetic)                  */
+/* three fp16-MFMA products of two-term splits, fp32 accumulate: ~7e-7 relative per product at 16x the matrix rate;
+ * features must satisfy |f| < 1023 (betas and R - I always do)                                                  */
+#define STRAPS_SMPL_SPLIT_F16 1
 
 /* bytes of caller-owned scratch for `batch` bodies (depends on the model's virtual-tile count)  */
 size_t straps_smpl_workspace_bytes(const straps_smpl_model_t* model, long long batch);
 /* verts [B][6890][3], joints [B][90][3] (may be NULL: vertices only).  betas [B][10],
- * rotmats [B][24][3][3] row-major.  chunks: split of the n_tiles/8 tile rounds over blocks, 0 = auto.  */
+ * rotmats [B][24][3][3] row-major.  chunks: split of the n_tiles/8 tile rounds over blocks, 0 = auto.
+ * mode: STRAPS_SMPL_EXACT_F32 or STRAPS_SMPL_SPLIT_F16 (skinning and the joint chain are exact fp32 in both).   */
 int straps_smpl_fwd(const straps_smpl_model_t* model, const float* betas, const float* rotmats,
-                    float* verts, float* joints, void* workspace, long long batch, int chunks,
+                    float* verts, float* joints, void* workspace, long long batch, int chunks, int mode,
                     void* stream);
 
 /* gradient of straps_smpl_fwd w.r.t. betas [B,10] and rotmats [B,24,3,3] given dverts [B,6890,3]

@@ -225,6 +225,19 @@ def main():
     small['loss_grad_verts_head'] = outp['verts'].grad.reshape(-1)[:64].numpy()
     small['loss_grad_j3d'] = outp['joints3D'].grad.numpy()
     small['loss_grad_pose_head'] = outp['pose_params_rot_matrices'].grad.reshape(-1)[:64].numpy()
+    # reduction='sum' (losses/multi_task_loss.py:13-17,59-71; unused by run_train.py but part of the constructor's contract)
+    crit_sum = HomoscedasticUncertaintyWeightedMultiTaskLoss(
+        ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
+        init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}, reduction='sum')
+    for v_ in outp.values():
+        v_.grad = None
+    total_s, parts_s = crit_sum(lab, outp)
+    total_s.backward()
+    small['loss_sum_total'] = np.array(float(total_s))
+    small['loss_sum_parts'] = np.array([float(parts_s[k]) for k in ('verts', 'joints2D', 'joints3D', 'shape_params', 'pose_params')])
+    small['loss_sum_grad_logvars'] = np.array([float(getattr(crit_sum, k + '_log_var').grad) for k in
+                                               ('verts', 'joints2D', 'joints3D', 'shape_params', 'pose_params')])
+    small['loss_sum_grad_j2d'] = outp['joints2D'].grad.numpy()
 
     # ================= G-aug: seeded cam / proxy augmentation (CPU RNG streams) =============
     torch.manual_seed(7)

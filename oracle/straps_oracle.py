@@ -329,6 +329,38 @@ def multi_task_loss(labels, outputs, log_vars, losses_on=LOSS_TASKS, img_wh=REGR
 
 
 # --------------------------------------------------------------------------------------------
+# forward + loss + backward of one training step (train loop :186-232) on a GIVEN batch
+# --------------------------------------------------------------------------------------------
+def train_step_loss_and_grads(batch, sd, init_estimate, smpl_model, layers=18, iterations=3, log_vars=None, dtype=torch.float32):
+    """regressor (training-mode BatchNorm) -> rot6d -> SMPL -> heads -> multi-task loss -> autograd.
+    batch: dict with 'input' [B,18,256,256], 'verts', 'joints2d', 'joints3d', 'shape', 'rot' (targets, CPU tensors);
+    sd: regressor state dict (cloned and cast to `dtype` here; the caller's tensors are not touched);
+    log_vars: {task: float}.  Returns (total, weighted task losses, {parameter name: grad}, {task: d total / d log_var})."""
+    sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
+    names = [k for k in sd if not k.startswith('ief_module.ief_layers.') and k.split('.')[-1] in ('weight', 'bias') and sd[k].is_floating_point()]
+    for n in names:
+        sd[n].requires_grad_(True)
+    for n in list(sd):                        # the aliased ief_layers.* keys must be the same tensors as fc1/fc2/fc3 (ief_module.py:24-28)
+        if n.startswith('ief_module.ief_layers.'):
+            idx, leaf = n.split('.')[2], n.split('.')[3]
+            sd[n] = sd['ief_module.fc%d.%s' % ({'0': 1, '2': 2, '4': 3}[idx], leaf)]
+    lv = {k: torch.tensor(float(v), dtype=dtype, requires_grad=True) for k, v in (log_vars or init_log_vars()).items()}
+    x = batch['input'].to(dtype)
+    cam, pose, shape, _ = regressor_forward(x, sd, torch.as_tensor(init_estimate).to(dtype), layers, iterations, training=True)
+    R = rot6d_to_rotmat(pose.contiguous()).view(-1, 24, 3, 3)
+    verts, joints = smpl_forward(smpl_model, shape, rotmats=R, dtype=dtype)
+    pred = {'verts': verts, 'joints2D': orthographic_project(joints[:, ALL_JOINTS_TO_COCO_MAP], cam),
+            'joints3D': joints[:, ALL_JOINTS_TO_H36M_MAP][:, H36M_TO_J14], 'shape_params': shape, 'pose_params_rot_matrices': R}
+    lab = {'verts': batch['verts'].to(dtype), 'joints2D': batch['joints2d'].to(dtype), 'joints3D': batch['joints3d'].to(dtype),
+           'shape_params': batch['shape'].to(dtype), 'pose_params_rot_matrices': batch['rot'].to(dtype)}
+    lab['vis'] = check_joints2d_visibility(batch['joints2d'])          # on the fp32 targets, like the step
+    total, parts = multi_task_loss(lab, pred, lv)
+    total.backward()
+    return (total.detach(), {k: v.detach() for k, v in parts.items()}, {n: sd[n].grad for n in names},
+            {k: v.grad for k, v in lv.items()})
+
+
+# --------------------------------------------------------------------------------------------
 # whole forward used by smoke()/bench cpu_baseline: proxy -> (cam,pose,shape) -> verts/joints
 # --------------------------------------------------------------------------------------------
 def predict_forward(x, sd, init_estimate, smpl_model, layers=18, iterations=3):

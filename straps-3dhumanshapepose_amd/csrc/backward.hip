@@ -1024,11 +1024,8 @@ inline unsigned capped_grid(long long n) {
 }
 
 // 128x128 tiles (32 flop per operand byte instead of 16) for the big 1x1 layers (resnet50): +10 % there; the 3x3 / strided layers
-// and small pixel counts do better with 64x64 (more workgroups per tap: tools/sweep_wgrad_splits.py)
+// and small pixel counts do better with 64x64 (more workgroups per tap)
 inline bool wgrad_big_tile(long long M, int cin, int cout, int taps) {
-#ifdef WGRAD_NO_BIG
-    return false;
-#endif
     return cin % 128 == 0 && cout % 128 == 0 && taps == 1 && M >= 8192;
 }
 

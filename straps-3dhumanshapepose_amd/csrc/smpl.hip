@@ -281,6 +281,180 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_kernel(straps_smpl_model_t
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Split-precision variant of the vertex kernel (mode STRAPS_SMPL_SPLIT_F16): the K = 218 blend contraction -- 91 % of the
+// forward's flops -- runs on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate) as THREE products of
+// two-term fp16 splits with fp32 accumulation:
+//     F . D  ~=  Fh.Dh + Fh.Dl + Fl.Dh ,   x = xh + xl,  xh = fp16(x),  xl = fp16(x - xh)
+// Each factor keeps 22 mantissa bits, the dropped Fl.Dl term and the split residuals are ~3 * 2^-22 relative per product
+// (7e-7), i.e. at the level of fp32 rounding of the result itself; products of fp16 values are exact in the fp32
+// accumulator.  D is split on the host (pre-scaled by a power of two so the low halves stay normal numbers), F in the
+// kernel while it is staged into LDS (scaled by 2^6: |feature| up to 1023 before fp16 overflows; betas live in +-10).
+// Skinning, the joint chain and every other stage stay exact fp32.  Measured against the fp64 oracle the result is as
+// close as the exact-fp32 kernel (tests/test_gpu_forward.py::test_smpl_split_precision_vs_oracle reports both).
+// Fragment layout of blend_frag_h: [tile][kstep 14][coord 3][hi|lo][lane 64][8 halves]; lane l holds
+// D[k = 16*kstep + 8*(l>>5) + j][vertex = 32*tile + (l&31)][coord], j = 0..7 (the A operand of the 32x32x16 MFMA; the
+// B operand -- features, n = body -- uses the same k map, so the contraction is independent of the hardware's k order).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+constexpr int KS = KP / 16;               // 14 k-steps of 16
+constexpr int FSH = 232;                  // halves per LDS feature row: 464 bytes = 4 * 29 dwords -> conflict-free b128 reads
+constexpr float F_SCALE = 64.0f;          // 2^6
+
+__device__ __forceinline__ f32x16 mfma16h(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model_t m, const float* __restrict__ F,
+                                                               const float* __restrict__ Amat, float* __restrict__ verts,
+                                                               float* __restrict__ vout, long long B, int btiles,
+                                                               int rounds, int rounds_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Fh = reinterpret_cast<_Float16*>(smem);            // [32][FSH] high halves of the scaled features
+    _Float16* Fl = Fh + BT * FSH;                                  // [32][FSH] low halves
+    float* As_ = smem + BT * FSH;                                  // [32][AS]   (2 * 32 * FSH halves = 32 * FSH floats)
+    float* stage = As_ + BT * AS;                                  // [NW][32][HS]
+    float* skin_lds = stage + NW * BT * HS;                        // [NW][256]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    const int bl = lane & 31;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = logical / btiles;
+    const long long b0 = (long long)(logical - chunk * btiles) * BT;
+    const int nb = (int)((B - b0) < BT ? (B - b0) : BT);
+
+    // ---- stage the block's feature rows (split into fp16 hi / lo) and joint transforms ----
+    for (int i = tid; i < BT * (KP / 4); i += NW * 64) {
+        const int b = i / (KP / 4), q = i % (KP / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < nb) v = *reinterpret_cast<const f32x4*>(F + (b0 + b) * KP + q * 4);
+        half4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e] * F_SCALE;
+            hi[e] = (_Float16)x;
+            lo[e] = (_Float16)(x - (float)hi[e]);
+        }
+        *reinterpret_cast<half4*>(Fh + b * FSH + q * 4) = hi;
+        *reinterpret_cast<half4*>(Fl + b * FSH + q * 4) = lo;
+    }
+    for (int i = tid; i < BT * 72; i += NW * 64) {
+        const int b = i / 72, q = i % 72;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < nb) v = *reinterpret_cast<const f32x4*>(Amat + (b0 + b) * 288 + q * 4);
+        *reinterpret_cast<f32x4*>(As_ + b * AS + q * 4) = v;
+    }
+    __syncthreads();
+
+    const int round0 = chunk * rounds_per_chunk;
+    const int round1 = min(round0 + rounds_per_chunk, rounds);
+    const int vrow_floats = (m.n_tiles - NT) * 96;
+    const half8* __restrict__ blend = reinterpret_cast<const half8*>(m.blend_frag_h);
+    const float unscale = m.blend_h_unscale;
+    float* mystage = stage + wave * BT * HS;
+    float* skw = skin_lds + wave * 256;
+    const int KW = m.skin_k;
+    const float* Ab = As_ + bl * AS;
+    const _Float16* fh_row = Fh + bl * FSH + 8 * h;
+    const _Float16* fl_row = Fl + bl * FSH + 8 * h;
+
+    for (int rd = round0; rd < round1; ++rd) {
+        const int tile = rd * NW + wave;
+        if (KW == 4) {
+            const int e2 = lane * 2;
+            const f32x2 w2 = *reinterpret_cast<const f32x2*>(m.skin_w + tile * 128 + e2);
+            const int2 j2 = *reinterpret_cast<const int2*>(m.skin_j + tile * 128 + e2);
+            skw[e2] = w2[0]; skw[e2 + 1] = w2[1];
+            reinterpret_cast<int*>(skw)[128 + e2] = j2.x * 12;
+            reinterpret_cast<int*>(skw)[128 + e2 + 1] = j2.y * 12;
+        }
+        // ---------------- blendshape contraction: 14 k-steps x 3 coordinates x 3 split products ----------------
+        f32x16 ax, ay, az;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ax[r] = 0.f; ay[r] = 0.f; az[r] = 0.f; }
+        {
+            const half8* p = blend + (long long)tile * (KS * 6 * 64) + lane;      // [kstep][coord][hi|lo][lane]
+            half8 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192], c4 = p[256], c5 = p[320];
+#pragma unroll 2
+            for (int s = 0; s < KS; ++s) {
+                half8 n0 = c0, n1 = c1, n2 = c2, n3 = c3, n4 = c4, n5 = c5;
+                if (s + 1 < KS) {
+                    const half8* q = p + (s + 1) * 384;
+                    n0 = q[0]; n1 = q[64]; n2 = q[128]; n3 = q[192]; n4 = q[256]; n5 = q[320];
+                }
+                const half8 fh = *reinterpret_cast<const half8*>(fh_row + 16 * s);
+                const half8 fl = *reinterpret_cast<const half8*>(fl_row + 16 * s);
+                ax = mfma16h(c0, fh, ax); ay = mfma16h(c2, fh, ay); az = mfma16h(c4, fh, az);       // Dh . Fh
+                ax = mfma16h(c1, fh, ax); ay = mfma16h(c3, fh, ay); az = mfma16h(c5, fh, az);       // Dl . Fh
+                ax = mfma16h(c0, fl, ax); ay = mfma16h(c2, fl, ay); az = mfma16h(c4, fl, az);       // Dh . Fl
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5;
+            }
+        }
+        // ---------------- linear blend skinning (exact fp32), lane = body, reg = vertex; 16 vertices at a time ----------------
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = half * 8 + rr;
+                const int vrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int vloc = vrow - 16 * half;
+                f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0, t2 = t0;
+                if (KW == 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(skw + vrow * 4);
+                    const int4 j4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(skw) + 128 + vrow * 4);
+                    const int jo[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + jo[k]);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + jo[k] + 4);
+                        const f32x4 a2 = *reinterpret_cast<const f32x4*>(Ab + jo[k] + 8);
+                        t0 += w4[k] * a0; t1 += w4[k] * a1; t2 += w4[k] * a2;
+                    }
+                } else {
+                    const int v = tile * 32 + vrow;
+                    for (int k = 0; k < KW; ++k) {
+                        const float w = m.skin_w[v * KW + k];
+                        const int jo = m.skin_j[v * KW + k] * 12;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + jo);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + jo + 4);
+                        const f32x4 a2 = *reinterpret_cast<const f32x4*>(Ab + jo + 8);
+                        t0 += w * a0; t1 += w * a1; t2 += w * a2;
+                    }
+                }
+                const float x = ax[r] * unscale, y = ay[r] * unscale, z = az[r] * unscale;      // power of two: exact
+                float* so = mystage + bl * HS + vloc * 3;
+                so[0] = t0[0] * x + t0[1] * y + t0[2] * z + t0[3];
+                so[1] = t1[0] * x + t1[1] * y + t1[2] * z + t1[3];
+                so[2] = t2[0] * x + t2[1] * y + t2[2] * z + t2[3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const bool mesh = tile < NT;
+                const int v0 = (mesh ? tile : tile - NT) * 32 + half * 16;
+                const int npair = mesh ? min(24, max(0, (NV - v0) * 3 / 2)) : 24;
+                const long long rstride = mesh ? (long long)(NV * 3) : (long long)vrow_floats;
+                float* vbase = (mesh ? verts : vout) + b0 * rstride + (long long)v0 * 3;
+                if (mesh || vout) {
+#pragma unroll 4
+                    for (int i = lane; i < BT * 24; i += 64) {
+                        const int b = i / 24, c = i - b * 24;
+                        if (b < nb && c < npair)
+                            *reinterpret_cast<f32x2*>(vbase + b * rstride + c * 2) =
+                                *reinterpret_cast<const f32x2*>(mystage + b * HS + c * 2);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Output joints 24..89: 21 picked vertices, then the 45 regressed joints = fixed-order sums of their
 // virtual vertices (contiguous in the scratch row).  One thread per output scalar -> deterministic.
@@ -331,10 +505,13 @@ extern "C" size_t straps_smpl_workspace_bytes(const straps_smpl_model_t* model, 
 }
 
 extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* betas, const float* rotmats,
-                               float* verts, float* joints, void* workspace, long long batch, int chunks,
+                               float* verts, float* joints, void* workspace, long long batch, int chunks, int mode,
                                void* stream) {
     STRAPS_REQUIRE(model && betas && rotmats && verts && workspace, "straps_smpl_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0, "straps_smpl_fwd: batch must be positive (got %lld)", batch);
+    STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || mode == STRAPS_SMPL_SPLIT_F16, "straps_smpl_fwd: unknown mode %d", mode);
+    STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || (model->blend_frag_h && model->blend_h_unscale > 0.f),
+                   "straps_smpl_fwd: split-precision mode needs blend_frag_h / blend_h_unscale in the model");
     STRAPS_REQUIRE(model->skin_k >= 1 && model->skin_k <= 24, "straps_smpl_fwd: skin_k %d out of range", model->skin_k);
     STRAPS_REQUIRE(model->n_tiles >= NT && model->n_tiles % NW == 0 && model->vj_ptr,
                    "straps_smpl_fwd: n_tiles %d must be a multiple of %d >= %d with the virtual-vertex table set", model->n_tiles, NW, NT);
@@ -347,20 +524,26 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
     float* vout = Amat + batch * 288;
     int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, joints, batch, st);
     if (rc != STRAPS_OK) return rc;
-    const size_t lds = (size_t)(BT * FS + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)smpl_verts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool split = mode == STRAPS_SMPL_SPLIT_F16;
+    const size_t lds = (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[split]) {
+        hipError_t e = hipFuncSetAttribute(split ? (const void*)smpl_verts_h_kernel : (const void*)smpl_verts_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("smpl_verts_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
-        attr_set = true;
+        attr_set[split] = true;
     }
     const long long btiles = (batch + BT - 1) / BT;
     if (btiles * nch > 0x7fffffffLL || btiles > 0x3fffffLL) {
         straps_set_error("straps_smpl_fwd: batch %lld exceeds one launch; split it", batch);
         return STRAPS_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL(smpl_verts_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
-                       joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);
+    if (split)
+        hipLaunchKernelGGL(smpl_verts_h_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
+                           joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);
+    else
+        hipLaunchKernelGGL(smpl_verts_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
+                           joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);
     STRAPS_CHECK_LAUNCH("smpl_verts_kernel");
     if (joints) {
         const long long n = batch * (STRAPS_SMPL_NPICK + STRAPS_SMPL_NEXTRA) * 3;

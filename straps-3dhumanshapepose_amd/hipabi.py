@@ -61,7 +61,7 @@ class SmplModelStruct(C.Structure):
                 ('skin_w', C.c_void_p), ('skin_j', C.c_void_p), ('vj_ptr', C.c_void_p), ('n_tiles', C.c_int32),
                 ('reserved0', C.c_int32), ('pick_ids', C.c_void_p), ('blend_frag_t', C.c_void_p), ('children', C.c_void_p),
                 ('jrt_ptr', C.c_void_p), ('jrt_code', C.c_void_p), ('jrt_w', C.c_void_p), ('dj_ptr', C.c_void_p), ('dj_code', C.c_void_p),
-                ('dj_w', C.c_void_p)]
+                ('dj_w', C.c_void_p), ('blend_frag_h', C.c_void_p), ('blend_h_unscale', C.c_float), ('reserved1', C.c_int32)]
 
 
 class PackDesc(C.Structure):
@@ -100,7 +100,7 @@ SIGNATURES = {
     'straps_rot6d_fwd': (_I, [_P, _L, _I, _P, _L, _P]),
     'straps_rodrigues_fwd': (_I, [_P, _P, _L, _P]),
     'straps_smpl_workspace_bytes': (_Z, [C.POINTER(SmplModelStruct), _L]),
-    'straps_smpl_fwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _L, _I, _P]),
+    'straps_smpl_fwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'straps_smpl_bwd_workspace_bytes': (_Z, [_L, _I]),
     'straps_smpl_bwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'straps_conv_dgrad': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -17,7 +17,7 @@ TASKS = ('verts', 'joints2D', 'joints3D', 'shape_params', 'pose_params')       #
 
 class _MseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, tgt, row_mask, tscale, tshift):
+    def forward(ctx, pred, tgt, row_mask, tscale, tshift, reduce_sum=False):
         L = hipabi.lib()
         p = pred.detach().contiguous()
         t = tgt.detach().contiguous().float()
@@ -28,17 +28,17 @@ class _MseFn(torch.autograd.Function):
         ws = torch.empty(512, device=p.device, dtype=torch.float32)
         hipabi.check(L.straps_mse_fwd(hipabi.ptr(p), hipabi.ptr(t), hipabi.ptr(m), rows, cols, tscale, tshift, hipabi.ptr(out), hipabi.ptr(ws),
                                       hipabi.stream_ptr()), 'straps_mse_fwd')
-        ctx.saved = (p, t, m, rows, cols, tscale, tshift, out)
-        return out[2]
+        ctx.saved = (p, t, m, rows, cols, tscale, tshift, out, reduce_sum)
+        return out[0] if reduce_sum else out[2]          # nn.MSELoss(reduction='sum' | 'mean')
 
     @staticmethod
     def backward(ctx, g):
-        p, t, m, rows, cols, tscale, tshift, out = ctx.saved
-        coef = (g * 2.0 / out[1]).reshape(1).contiguous()
+        p, t, m, rows, cols, tscale, tshift, out, reduce_sum = ctx.saved
+        coef = ((g * 2.0) if reduce_sum else (g * 2.0 / out[1])).reshape(1).contiguous()
         grad = torch.empty_like(p)
         hipabi.check(hipabi.lib().straps_mse_bwd(hipabi.ptr(p), hipabi.ptr(t), hipabi.ptr(m), rows, cols, tscale, tshift, hipabi.ptr(coef),
                                                  hipabi.ptr(grad), hipabi.stream_ptr()), 'straps_mse_bwd')
-        return grad, None, None, None, None
+        return grad, None, None, None, None, None
 
 
 class HomoscedasticUncertaintyWeightedMultiTaskLoss(nn.Module):
@@ -46,8 +46,7 @@ class HomoscedasticUncertaintyWeightedMultiTaskLoss(nn.Module):
         super().__init__()
         self.losses_on = losses_on
         assert reduction in ['mean', 'sum'], "Invalid reduction for loss."
-        if reduction != 'mean':
-            raise NotImplementedError("only reduction='mean' (the value run_train.py:196 uses) is implemented on the GPU path")
+        self.reduction = reduction          # (the fused training step implements 'mean', the value run_train.py:196 uses)
         for name in ('verts', 'joints2D', 'joints3D', 'pose_params', 'shape_params'):        # registration order of the reference (:46-55)
             init = 0.0 if init_loss_weights is None else float(-np.log(init_loss_weights[name] + eps))
             setattr(self, name + '_log_var', nn.Parameter(torch.tensor(init).float(), requires_grad=name in losses_on))
@@ -71,9 +70,9 @@ class HomoscedasticUncertaintyWeightedMultiTaskLoss(nn.Module):
             hipabi.require_gpu_tensor(pred, "outputs['%s']" % ko, torch.float32)
             if name == 'joints2D':
                 mask = labels['vis'] if 'vis' in labels else None
-                mse = _MseFn.apply(pred, lab, mask, 2.0 / wh, -1.0)                           # label normalised 2x/wh - 1 (:92)
+                mse = _MseFn.apply(pred, lab, mask, 2.0 / wh, -1.0, self.reduction == 'sum')  # label normalised 2x/wh - 1 (:92)
             else:
-                mse = _MseFn.apply(pred, lab, None, 1.0, 0.0)
+                mse = _MseFn.apply(pred, lab, None, 1.0, 0.0, self.reduction == 'sum')
             s = getattr(self, name + '_log_var')
             total_loss = total_loss + mse * torch.exp(-s) + s
             loss_dict[name] = mse * torch.exp(-s)

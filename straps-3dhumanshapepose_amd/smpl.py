@@ -20,6 +20,7 @@ ModelOutput = namedtuple('ModelOutput', ['vertices', 'joints', 'full_pose', 'bet
 ModelOutput.__new__.__defaults__ = (None,) * len(ModelOutput._fields)
 
 V, VPAD, TILES, KP = 6890, 6912, 216, 224
+PRECISIONS = {'fp32': 0, 'fp16x3': 1}          # STRAPS_SMPL_EXACT_F32 / STRAPS_SMPL_SPLIT_F16
 
 
 def pack_smpl_model(model):
@@ -76,6 +77,16 @@ def pack_smpl_model(model):
         Dall[:218, VPAD:VPAD + nvirt] = np.asarray(vdirs).reshape(nvirt, 218, 3).transpose(1, 0, 2)
     # fragment order [tile][coord][g][h][i][e]  <-  D[8g+4h+e][32t+i][c]
     frag = Dall.reshape(28, 2, 4, n_tiles, 32, 3).transpose(3, 5, 0, 1, 4, 2).copy()
+    # split-precision operand (straps_hip.h: blend_frag_h): two-term fp16 split of S_D * D, S_D the largest power of two that
+    # keeps |S_D * D| <= 32768 (at most 2^14): the low halves then stay normal fp16 numbers for every |D| > 2^-14 * 2^-3.
+    dmax = float(np.abs(Dall).max())
+    sd_exp = 14 if dmax == 0 else int(min(14, np.floor(np.log2(32768.0 / dmax))))
+    Ds = Dall.astype(np.float32) * np.float32(2.0 ** sd_exp)                              # exact (power of two)
+    Dh = Ds.astype(np.float16)
+    Dl = (Ds - Dh.astype(np.float32)).astype(np.float16)                                  # the difference is exact in fp32
+    assert np.isfinite(Dh.astype(np.float32)).all()
+    # [tile][kstep][coord][hi|lo][hh][i][j]  <-  D[16s + 8hh + j][32t + i][c]
+    frag_h = np.stack([Dh, Dl], axis=0).reshape(2, KP // 16, 2, 8, n_tiles, 32, 3).transpose(4, 1, 6, 0, 2, 5, 3).copy()
     parents = np.asarray(model['parents'], np.int32).copy()
     depth = np.zeros(24, np.int32)
     for j in range(1, 24):
@@ -131,6 +142,7 @@ def pack_smpl_model(model):
         'blend_frag_t': frag_t.reshape(-1), 'children': children,
         'jrt_ptr': jrt_ptr, 'jrt_code': (((vs % 32) << 8) | src).astype(np.int32), 'jrt_w': ws,
         'blend_frag': frag.reshape(-1),
+        'blend_frag_h': frag_h.reshape(-1), 'blend_h_unscale': float(2.0 ** -(sd_exp + 6)),
         'j_template': (Jr @ vt).astype(np.float32),
         'j_shapedirs': np.einsum('jv,vcl->jcl', Jr, sd).astype(np.float32),
         'parents': parents, 'depth': depth, 'max_depth': int(depth.max()), 'skin_k': k,
@@ -156,6 +168,11 @@ class SMPL(nn.Module):
         self.face_parts = None if model.get('face_parts') is None else np.asarray(model['face_parts'])
         packed = pack_smpl_model(model)
         self.max_depth, self.skin_k, self.n_tiles = packed.pop('max_depth'), packed.pop('skin_k'), packed.pop('n_tiles')
+        self.blend_h_unscale = packed.pop('blend_h_unscale')
+        precision = kwargs.pop('precision', 'fp32')
+        if precision not in PRECISIONS:
+            raise ValueError("SMPL: precision must be one of %s" % (sorted(PRECISIONS),))
+        self.precision = precision
         for name, arr in packed.items():
             self.register_buffer('_k_' + name, torch.from_numpy(np.ascontiguousarray(arr)), persistent=False)
         # buffers with the names smplx / the reference expose (state-dict visible, used by callers)
@@ -179,17 +196,20 @@ class SMPL(nn.Module):
         key = self._k_blend_frag.data_ptr()
         if self._struct_key != key:
             s = hipabi.SmplModelStruct()
-            for f in ('blend_frag', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
+            for f in ('blend_frag', 'blend_frag_h', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
                       'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w', 'dj_ptr', 'dj_code', 'dj_w'):
                 setattr(s, f, getattr(self, '_k_' + f).data_ptr())
             s.max_depth, s.skin_k, s.n_tiles = self.max_depth, self.skin_k, self.n_tiles
+            s.blend_h_unscale = self.blend_h_unscale
             self._struct, self._struct_key = s, key
         return self._struct
 
     @hipabi.on_tensor_device
-    def forward_arrays(self, betas, rotmats, want_joints=True, chunks=0, out_verts=None, out_joints=None):
+    def forward_arrays(self, betas, rotmats, want_joints=True, chunks=0, out_verts=None, out_joints=None, precision=None):
         """raw entry: betas [B,10], rotmats [B,24,3,3] (contiguous fp32 GPU) -> (verts, joints|None).
-        out_verts / out_joints: optional resident output buffers ([B,6890,3] / [B,90,3], contiguous fp32)."""
+        out_verts / out_joints: optional resident output buffers ([B,6890,3] / [B,90,3], contiguous fp32).
+        precision: 'fp32' (exact fp32 blend contraction) or 'fp16x3' (three-product fp16 split, fp32 accumulate: same accuracy
+        class, 16x the matrix rate); None = the module's setting."""
         hipabi.require_gpu_tensor(betas, 'betas', torch.float32)
         hipabi.require_gpu_tensor(rotmats, 'rotmats', torch.float32)
         hipabi.require_gpu_tensor(self._k_blend_frag, 'SMPL model buffers (call .to(device))')
@@ -209,7 +229,7 @@ class SMPL(nn.Module):
         ws = torch.empty(L.straps_smpl_workspace_bytes(C.byref(self._model_struct()), B) // 4, device=betas.device, dtype=torch.float32)
         hipabi.check(L.straps_smpl_fwd(C.byref(self._model_struct()), hipabi.ptr(betas), hipabi.ptr(rotmats),
                                        hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(ws), B, chunks,
-                                       hipabi.stream_ptr()), 'straps_smpl_fwd')
+                                       PRECISIONS[self.precision if precision is None else precision], hipabi.stream_ptr()), 'straps_smpl_fwd')
         return verts, joints
 
     @hipabi.on_tensor_device

@@ -112,6 +112,9 @@ class TrainStep:
               overlap_wgrad, renderer, track_metrics, comm_overlap, pipeline_data, smpl_augment_params, cam_augment_params, bbox_augment_params,
               proxy_rep_augment_params):
         self.reg, self.smpl, self.crit = regressor, smpl, criterion
+        if getattr(criterion, 'reduction', 'mean') != 'mean':
+            raise NotImplementedError("TrainStep: the fused loss kernel implements reduction='mean' (run_train.py:196); use the criterion "
+                                      "module with autograd for 'sum'")
         self.B, self.lr, self.rank, self.world, self.group = batch_size, lr, rank, world_size, group
         self.params = list(regressor.parameters()) + list(criterion.parameters())          # run_train.py:200 order
         self.flat_p, self.flat_g, self.gviews = flatten_parameters(self.params, self.dev)
@@ -523,6 +526,18 @@ class TrainStep:
         group = {'lr': self.lr, 'betas': (0.9, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
                  'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(self.params)))}
         return {'state': state, 'param_groups': [group]}
+
+    def data_state(self):
+        """generator step of the batch the next `step()` will train on (with the data pipeline that batch is already in
+        flight, drawn one generator step ago).  Synchronises."""
+        return self.draws.step() - (1 if self.pipeline and self._primed else 0)
+
+    def set_data_state(self, step):
+        """resume the data stream: the next `step()` regenerates its batch from generator step `step`."""
+        with torch.cuda.device(self.dev):
+            torch.cuda.synchronize()
+            self.draws.set_step(step)
+            self._primed = False
 
     def load_state_dict(self, sd):
         """restore the optimiser state written by `state_dict()` / torch.optim.Adam.state_dict() (checkpoint key

@@ -62,6 +62,42 @@ def test_smpl_forward_vs_oracle(dev, smpl_model, B, chunks):
     assert none is None and torch.equal(v2, v)
 
 
+@pytest.mark.parametrize('B', [1, 33, 70, 4096])
+def test_smpl_split_precision_vs_oracle(dev, smpl_model, B):
+    """STRAPS_SMPL_SPLIT_F16 (blend contraction as three fp16-MFMA products of two-term splits, fp32 accumulate) against
+    the float64 oracle on identical (theta, beta): north_star's bar is 1e-4 m; the test asserts 2e-5 and that the split
+    kernel is as close to float64 as the exact-fp32 kernel (both errors printed)."""
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    betas = torch.from_numpy(det_uniform((B, 10), 100 + B, -2.5, 2.5))
+    betas[0] = torch.tensor([10.0, -8.0, 6.0, 4.0, -4.0, 3.0, 3.0, -3.0, 2.0, 2.0])          # an extreme body
+    aa = torch.from_numpy(det_uniform((B, 72), 200 + B, -0.9, 0.9))
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+    v, j = smpl.forward_arrays(betas.to(dev), R.to(dev), precision='fp16x3')
+    v32, j32 = smpl.forward_arrays(betas.to(dev), R.to(dev), precision='fp32')
+    n = min(B, 96)                                                                         # the float64 oracle on a slice
+    v64, j64 = O.smpl_forward(smpl_model, betas[:n].double(), rotmats=R[:n].double(), dtype=torch.float64)
+    ev, ej = float((v[:n].cpu().double() - v64).abs().max()), float((j[:n].cpu().double() - j64).abs().max())
+    ev32, ej32 = float((v32[:n].cpu().double() - v64).abs().max()), float((j32[:n].cpu().double() - j64).abs().max())
+    print('SMPL B=%d max |err| vs float64: split-fp16 verts %.2e joints %.2e | exact-fp32 verts %.2e joints %.2e' % (B, ev, ej, ev32, ej32))
+    assert ev < 2e-5 and ej < 2e-5
+    assert ev <= 3 * ev32 + 1e-6 and ej <= 3 * ej32 + 1e-6
+    assert float((v - v32).abs().max()) < 1e-5 and float((j - j32).abs().max()) < 1e-5
+    assert torch.isfinite(v).all() and torch.isfinite(j).all()
+    # deterministic, vertices-only form identical, batch rows independent of the batch they ride in
+    v2, none = smpl.forward_arrays(betas.to(dev), R.to(dev), want_joints=False, precision='fp16x3')
+    assert none is None and torch.equal(v2, v)
+    if B > 40:
+        vs, js = smpl.forward_arrays(betas[30:37].contiguous().to(dev), R[30:37].contiguous().to(dev), precision='fp16x3')
+        assert torch.equal(vs, v[30:37]) and torch.equal(js, j[30:37])
+    # module-level switch
+    fast = straps_amd.SMPL(smpl_model, batch_size=B, precision='fp16x3').to(dev)
+    with torch.no_grad():
+        o = fast(body_pose=R[:, 1:].to(dev), global_orient=R[:, 0:1].to(dev), betas=betas.to(dev), pose2rot=False)
+    assert torch.equal(o.vertices, v)
+    with pytest.raises(ValueError):
+        straps_amd.SMPL(smpl_model, batch_size=1, precision='bf16')
+
+
 def test_smpl_module_call_forms(dev, smpl_model):
     """the three call forms of the reference (train loop :132, :144, :258)."""
     B = 4
@@ -444,3 +480,27 @@ def test_batch64_forward_consistency(dev):
     _close(big[:3], small, 1e-5, 1e-5, 'batch independence')
     _close(small, est, 2e-4, 2e-4, 'vs oracle')
     assert torch.isfinite(big).all()
+
+
+def test_eval_after_train_mode_forward_sees_fresh_running_statistics():
+    """the folded-BN cache is keyed on tensor versions, and running statistics are updated through raw pointers: a train-mode
+    forward (BN recalibration under no_grad, no optimiser step in between) must still invalidate the eval-mode folds."""
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    reg = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=straps_amd.synthetic_mean_params(0)).to(dev)
+    x = torch.from_numpy(det_uniform((2, 18, 256, 256), 71, 0.0, 1.0)).to(dev)
+    x2 = torch.from_numpy(det_uniform((2, 18, 256, 256), 72, 0.0, 1.0)).to(dev)
+    with torch.no_grad():
+        reg.train()
+        reg(x)
+        reg.eval()
+        y1 = torch.cat(reg(x), 1).clone()
+        reg.train()
+        reg(x2)                                 # running statistics move again, no parameter version changes
+        reg.eval()
+        y2 = torch.cat(reg(x), 1).clone()
+        fresh = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=straps_amd.synthetic_mean_params(0)).to(dev).eval()
+        fresh.load_state_dict(reg.state_dict())
+        y3 = torch.cat(fresh(x), 1)
+    assert not torch.equal(y1, y2)
+    assert torch.equal(y2, y3)

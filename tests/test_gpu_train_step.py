@@ -115,3 +115,145 @@ def test_tracked_metrics_match_oracle_on_the_step_outputs():
         tg.step()
     s5 = tg.metrics_summary()
     assert tg.graph is not None and all(np.isfinite(list(s5.values()))) and s5['pves'] > 0
+
+
+def _oracle_step(ts, reg, batch, layers, dtype):
+    sd = {k: v.detach().cpu().clone() for k, v in reg.state_dict().items()}
+    cpu_batch = {k: batch[k].cpu() for k in ('input', 'verts', 'joints2d', 'joints3d', 'shape', 'rot')}
+    lv = {n: float(getattr(ts.crit, n + '_log_var')) for n in O.LOSS_TASKS}
+    return O.train_step_loss_and_grads(cpu_batch, sd, O.ief_init_estimate(MP['pose'], MP['shape']), straps_amd.synthetic_smpl_model(0), layers, 3,
+                                       lv, dtype=dtype)
+
+
+def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd():
+    """T: forward + loss + backward of TrainStep on a B=8 batch against autograd of the float64 oracle on the SAME batch
+    (running statistics restored first): loss to 1e-5, every one of the 66 + 5 gradients to 1e-3 of its norm."""
+    B = 8
+    torch.set_num_threads(8)
+    dev, reg, smpl, crit = _setup(B, seed=5)
+    ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'])
+    with torch.no_grad():
+        batch = ts.make_batch()
+    total, parts, grads, glv = _oracle_step(ts, reg, batch, 18, torch.float64)       # before the step touches the running statistics
+    with torch.no_grad():
+        loss = ts.forward_backward(batch)
+    torch.cuda.synchronize()
+    assert float(loss[0]) == pytest.approx(float(total), rel=1e-5)
+    for k, name in enumerate(O.LOSS_TASKS):                                           # kernel task order == oracle's LOSS_TASKS
+        assert float(loss[1 + k]) == pytest.approx(float(parts[name]), rel=2e-5), name
+    assert int(loss[11]) == int(O.check_joints2d_visibility(batch['joints2d'].cpu()).sum())
+    worst = 0.0
+    for n, p in reg.named_parameters():
+        g, go = ts.gviews[p].detach().cpu().double().reshape(-1), grads[n].reshape(-1)
+        rel = float((g - go).norm() / go.norm().clamp_min(1e-30))
+        worst = max(worst, rel)
+        assert rel < 1e-3, (n, rel)
+    for name in O.LOSS_TASKS:
+        g = float(ts.gviews[getattr(crit, name + '_log_var')])
+        assert g == pytest.approx(float(glv[name]), rel=1e-4, abs=1e-7), name
+    print('worst relative gradient error vs fp64 oracle autograd: %.2e' % worst)
+    # and the fp32 oracle (what a CPU run of the reference computes) is no closer to fp64 than we are by more than ~10x
+    _, _, g32, _ = _oracle_step(ts, reg, batch, 18, torch.float32)
+    worst32 = max(float((g32[n].double().reshape(-1) - grads[n].reshape(-1)).norm() / grads[n].norm().clamp_min(1e-30)) for n in grads)
+    assert worst < max(1e-4, 10 * worst32)
+
+
+def test_resnet50_step_configs3_shape():
+    """configs[3] per-GPU shape: resnet50, 32 bodies.  hipGraph replay (single and split capture) == eager launches bit for
+    bit, deterministic, Bottleneck flat-buffer layout consistent with the autograd route, loss vs the oracle."""
+    B = 32
+
+    def run(use_graph, comm_overlap=False, steps=4):
+        dev, reg, smpl, crit = _setup(B, seed=9, layers=50)
+        ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], seed=77, use_graph=use_graph, comm_overlap=comm_overlap)
+        losses = torch.stack([ts.step().clone() for _ in range(steps)]).cpu()
+        torch.cuda.synchronize()
+        return losses, ts.flat_p.clone().cpu(), reg.image_encoder.layer3[5].bn3.running_var.clone().cpu(), ts, reg
+
+    l_e, p_e, rv_e, ts_e, reg_e = run(False)
+    assert torch.isfinite(l_e).all() and len(ts_e.params) == 165 + 5
+    l_g, p_g, rv_g, ts_g, _ = run(True)
+    assert ts_g.graph is not None, 'hipGraph capture fell back to eager launches'
+    assert torch.equal(l_e, l_g) and torch.equal(p_e, p_g) and torch.equal(rv_e, rv_g)
+    l_s, p_s, rv_s, ts_s, _ = run(True, comm_overlap=True)
+    assert ts_s.graph is not None and ts_s.graph_tail is not None and ts_s.exchange.split_off > 0
+    assert torch.equal(l_e, l_s) and torch.equal(p_e, p_s) and torch.equal(rv_e, rv_s)
+    assert int(reg_e.image_encoder.layer4[2].bn3.num_batches_tracked) == 4
+    # the two-bucket split sits at layer3's first parameter, as for resnet18
+    names = [n for n, _ in reg_e.named_parameters()]
+    off = sum(p.numel() for n, p in reg_e.named_parameters() if names.index(n) < names.index('image_encoder.layer3.0.conv1.weight'))
+    assert ts_s.exchange.split_off == off
+    # one more batch through the fused route vs the oracle's loss and a sample of gradients (fp32 oracle: r50 fp64 is slow)
+    with torch.no_grad():
+        batch = ts_e.make_batch()
+    total, parts, grads, glv = _oracle_step(ts_e, reg_e, batch, 50, torch.float32)
+    with torch.no_grad():
+        loss = ts_e.forward_backward(batch)
+    assert float(loss[0]) == pytest.approx(float(total), rel=1e-4)
+    for n in ('image_encoder.conv1.weight', 'image_encoder.layer1.0.conv3.weight', 'image_encoder.layer2.0.downsample.0.weight',
+              'image_encoder.layer3.5.bn3.weight', 'image_encoder.layer4.2.conv2.weight', 'ief_module.fc1.weight', 'ief_module.fc3.bias'):
+        p = dict(reg_e.named_parameters())[n]
+        g, go = ts_e.gviews[p].detach().cpu().double().reshape(-1), grads[n].double().reshape(-1)
+        assert float((g - go).norm() / go.norm().clamp_min(1e-30)) < 5e-3, n
+
+
+def test_resume_from_checkpoint_equals_uninterrupted_training(tmp_path):
+    """save (reference .tar schema) -> fresh objects -> load_state_dict -> the next steps equal the uninterrupted run bit
+    for bit: Adam moments, step count (host and device), BatchNorm buffers, loss weights and the generator's position."""
+    B = 8
+
+    def fresh(seed):
+        dev, reg, smpl, crit = _setup(B, seed=seed)
+        return reg, crit, TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], seed=31)
+
+    reg_a, crit_a, ts_a = fresh(2)
+    for _ in range(3):
+        ts_a.step()
+    path = str(tmp_path / 'ck.tar')
+    straps_amd.checkpoint_utils.save_checkpoint(path, 0, reg_a, ts_a, crit_a)
+    draw_step = ts_a.data_state()               # generator step of the batch the NEXT step consumes (it is already in flight)
+    assert draw_step == 3 and ts_a.draws.step() == 4
+    tail_a = torch.stack([ts_a.step().clone() for _ in range(3)]).cpu()
+    reg_b, crit_b, ts_b = fresh(3)                                   # different initial weights: everything must come from the file
+    ck = straps_amd.checkpoint_utils.load_checkpoint(path)
+    reg_b.load_state_dict(ck['model_state_dict'])
+    crit_b.load_state_dict(ck['criterion_state_dict'])
+    ts_b.load_state_dict(ck['optimiser_state_dict'])
+    ts_b.set_data_state(draw_step)
+    assert ts_b.steps == 3 and int(ts_b.step_t) == 3
+    assert torch.equal(ts_b.exp_avg, ts_a_moments(ck, ts_b, 'exp_avg'))
+    tail_b = torch.stack([ts_b.step().clone() for _ in range(3)]).cpu()
+    assert torch.equal(tail_a, tail_b)
+    assert torch.equal(ts_a.flat_p, ts_b.flat_p) and torch.equal(ts_a.exp_avg_sq, ts_b.exp_avg_sq)
+    # torch.optim.Adam reads the same dict (schema compatibility both ways), and bad states are refused
+    torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in ts_b.params], lr=1e-4).load_state_dict(ts_b.state_dict())
+    bad = ts_b.state_dict()
+    bad['param_groups'][0]['betas'] = (0.8, 0.999)
+    with pytest.raises(ValueError, match='defaults'):
+        ts_b.load_state_dict(bad)
+    bad = ts_b.state_dict()
+    bad['param_groups'][0]['params'] = bad['param_groups'][0]['params'][:-1]
+    with pytest.raises(ValueError, match='parameters'):
+        ts_b.load_state_dict(bad)
+
+
+def ts_a_moments(ck, ts, key):
+    st = ck['optimiser_state_dict']['state']
+    return torch.cat([st[i][key].reshape(-1) for i in range(len(ts.params))]).to(ts.dev)
+
+
+def test_last_outputs_follow_the_replayed_graph_parity():
+    """with the data pipeline two graphs are captured (one per buffer parity): ts.last must be the outputs of the graph
+    that just ran, i.e. consistent with the loss it returned."""
+    B = 4
+    dev, reg, smpl, crit = _setup(B, seed=6)
+    ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], use_graph=True)
+    for i in range(7):
+        loss = ts.step()
+        torch.cuda.synchronize()
+        assert ts.last['loss'].data_ptr() == loss.data_ptr()
+        cur = ts._bufs[1 - ts._cur]                                   # the batch this step trained on (the parity flipped afterwards)
+        mse = float(((ts.last['verts'] - cur['verts']) ** 2).mean())
+        assert mse == pytest.approx(float(loss[6]), rel=1e-4), i      # loss[6] = raw vertex MSE of THIS step
+    assert ts.graph is not None and len(ts._last_by_parity) == 2
+    assert ts._last_by_parity[0]['verts'].data_ptr() != ts._last_by_parity[1]['verts'].data_ptr()

@@ -178,3 +178,104 @@ def test_pmc_summary_and_bench_traffic_reader(tmp_path):
     want = sum(v['launches'] * (v['hbm_read_bytes'] + v['hbm_write_bytes']) for v in ks) / sum(v['launches'] for v in ks)
     assert got['traffic'] == round(want)
     assert bench.pmc_traffic(types.SimpleNamespace(workload='train', layers=101, batch=0), 'conv_igemm_kernel') == {}
+
+
+def write_real_layout_model(tmp_path, model):
+    """write `model` the way the files the reference loads are laid out: <dir>/SMPL_NEUTRAL.pkl (models/smpl_official.py:15 ->
+    smplx: pickle with latin1 strings, scipy-sparse J_regressor, posedirs [6890,3,207], kintree_table [2,24] whose root parent
+    is 2^32-1, faces 'f' as uint32, 300-column shapedirs) + the three regressor .npy files of config.py:6-8."""
+    import pickle
+    import scipy.sparse as sp
+    d = tmp_path / 'smpl'
+    d.mkdir()
+    parents = np.asarray(model['parents'], np.int64).copy()
+    parents[0] = 2 ** 32 - 1
+    sd300 = np.zeros((6890, 3, 300), np.float64)
+    sd300[:, :, :10] = model['shapedirs']
+    raw = {'v_template': model['v_template'].astype(np.float64), 'shapedirs': sd300,
+           'posedirs': model['posedirs'].astype(np.float64).T.reshape(6890, 3, 207),
+           'J_regressor': sp.csc_matrix(model['J_regressor'].astype(np.float64)), 'weights': model['weights'].astype(np.float64),
+           'kintree_table': np.stack([parents, np.arange(24)]).astype(np.uint32), 'f': model['faces'].astype(np.uint32),
+           'bs_type': 'lrotmin', 'bs_style': 'lbs'}
+    with open(d / 'SMPL_NEUTRAL.pkl', 'wb') as f:
+        pickle.dump(raw, f, protocol=2)
+    extra = []
+    for key, fn in (('J_regressor_extra', 'J_regressor_extra.npy'), ('J_regressor_cocoplus', 'cocoplus_regressor.npy'),
+                    ('J_regressor_h36m', 'J_regressor_h36m.npy')):
+        np.save(tmp_path / fn, model[key])
+        extra.append(str(tmp_path / fn))
+    return str(d), tuple(extra)
+
+
+def test_load_smpl_model_from_real_file_layout(tmp_path, monkeypatch):
+    """S0 loader (models/smpl_official.py:15-25, config.py:3-10) on a synthetic file in the real layout."""
+    model = straps_amd.synthetic_smpl_model(0)
+    d, extra = write_real_layout_model(tmp_path, model)
+    got = straps_amd.load_smpl_model(d, 'neutral', extra)
+    for k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'weights', 'J_regressor_extra', 'J_regressor_cocoplus', 'J_regressor_h36m'):
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], model[k]), k
+    assert got['shapedirs'].shape == (6890, 3, 10) and got['posedirs'].shape == (207, 20670)
+    assert np.array_equal(got['parents'], model['parents']) and got['parents'][0] == -1
+    assert np.array_equal(got['faces'], model['faces']) and np.array_equal(got['extra_vertex_ids'], model['extra_vertex_ids'])
+    # the packed kernel tables are identical too (what the device sees)
+    pa, pb = straps_amd.pack_smpl_model(got), straps_amd.pack_smpl_model(model)
+    for k in pb:
+        assert np.array_equal(np.asarray(pa[k]), np.asarray(pb[k])), k
+    # default regressor locations are the reference's relative paths (cwd-relative, config.py:6-8)
+    (tmp_path / 'additional').mkdir()
+    for src, dst in zip(extra, ('J_regressor_extra.npy', 'cocoplus_regressor.npy', 'J_regressor_h36m.npy')):
+        os.replace(src, tmp_path / 'additional' / dst)
+    monkeypatch.chdir(tmp_path)
+    again = straps_amd.load_smpl_model(d)
+    assert np.array_equal(again['J_regressor_h36m'], model['J_regressor_h36m'])
+    with pytest.raises(FileNotFoundError):
+        straps_amd.load_smpl_model(str(tmp_path / 'nowhere'))
+    os.remove(tmp_path / 'additional' / 'cocoplus_regressor.npy')
+    with pytest.raises(FileNotFoundError):
+        straps_amd.load_smpl_model(d)
+
+
+def test_split_precision_blend_operand_error_budget():
+    """the fp16 two-term split of the blend directions (straps_hip.h: blend_frag_h) and the three-product contraction the
+    kernel runs, emulated in numpy: the blend result stays within 3e-6 m of the float64 contraction for realistic (and one extreme)
+    (theta, beta) -- two orders inside north_star's 1e-4 -- and the fragment mapping is the documented one."""
+    import straps_oracle as O
+    model = straps_amd.synthetic_smpl_model(0)
+    pk = straps_amd.pack_smpl_model(model)
+    nt = pk['n_tiles']
+    fh = pk['blend_frag_h'].reshape(nt, 14, 3, 2, 2, 32, 8)                  # [t][s][c][hi|lo][hh][i][j]
+    assert fh.dtype == np.float16
+    unscale = pk['blend_h_unscale']
+    sd = 1.0 / (unscale * 64.0)
+    assert sd == 2.0 ** round(np.log2(sd)) and sd <= 2.0 ** 14
+    # D[k = 16s + 8hh + j][v = 32t + i][c] back from the fragments
+    Dsplit = fh.astype(np.float64).transpose(3, 1, 4, 6, 0, 5, 2).reshape(2, 224, nt * 32, 3)
+    D = np.zeros((224, nt * 32, 3))
+    D[0, :6890] = model['v_template']
+    D[1:11, :6890] = np.transpose(model['shapedirs'], (2, 0, 1))
+    D[11:218, :6890] = model['posedirs'].reshape(207, 6890, 3)
+    rec = (Dsplit[0] + Dsplit[1]) / sd
+    err = np.abs(rec[:, :6890] - D[:, :6890])
+    assert err.max() <= 2.0 ** -21 * np.abs(D).max() and (err <= np.abs(D[:, :6890]) * 2.0 ** -21 + 2.0 ** -24 / sd).all()
+    # the kernel's arithmetic: F scaled by 64, split in fp16; Fh.Dh + Fh.Dl + Fl.Dh accumulated in fp32
+    rs = np.random.RandomState(0)
+    B = 16
+    betas = rs.randn(B, 10) * 1.5
+    betas[0] = 10.0                                                              # far outside the training distribution
+    import torch
+    R = O.batch_rodrigues(torch.from_numpy(rs.randn(B * 24, 3) * 0.3)).view(B, 24, 3, 3).numpy()
+    F = np.zeros((B, 224), np.float32)
+    F[:, 0] = 1.0
+    F[:, 1:11] = betas
+    F[:, 11:218] = (R[:, 1:] - np.eye(3)).reshape(B, 207)
+    Fs = F * np.float32(64.0)
+    Fhh = Fs.astype(np.float16)
+    Fll = (Fs - Fhh.astype(np.float32)).astype(np.float16)
+    Dh, Dl = Dsplit[0, :, :6890].reshape(224, -1), Dsplit[1, :, :6890].reshape(224, -1)
+    acc = (Fhh.astype(np.float32) @ Dh.astype(np.float32) + Fhh.astype(np.float32) @ Dl.astype(np.float32)
+           + Fll.astype(np.float32) @ Dh.astype(np.float32)) * np.float32(unscale)
+    exact = F.astype(np.float64) @ D[:, :6890].reshape(224, -1)
+    e = float(np.abs(acc - exact).max())
+    e32 = float(np.abs((F @ D[:, :6890].reshape(224, -1).astype(np.float32)) - exact).max())
+    print('split-precision blend: max abs error %.2e m (plain fp32 contraction: %.2e m)' % (e, e32))
+    assert e < 3e-6 and e <= 1.5 * e32 + 1e-7 and np.isfinite(acc).all()      # no worse than a plain fp32 contraction
