@@ -623,23 +623,28 @@ __device__ __forceinline__ f32x4 pool_grad(const PoolSrc& ps, long long row, int
     return g;
 }
 
+// The three BatchNorm-backward kernels accumulate and subtract in DOUBLE: in the last stage the gradient that reaches a BatchNorm
+// is almost constant per channel (global average pooling broadcasts one value to the 64 positions), so dz - mean(dz) cancels to
+// rounding noise of fp32 sums -- measured 4e-4..2e-3 relative on the layer4 gradients against 2e-6 for the reference's CPU path,
+// whose BatchNorm backward accumulates in double (ATen acc_type<float, cpu>).  The passes are HBM-bound; the fp64 VALU work is free.
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ msc,
-                                                            const float* __restrict__ msh, float* __restrict__ part, long long rows,
+                                                            const float* __restrict__ msh, double* __restrict__ part, long long rows,
                                                             int C, int rows_per_block, PoolSrc ps) {
-    __shared__ float red[256][8];
+    __shared__ double red[256][8];
     constexpr int TR = 16;
     const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
     const int c4 = blockIdx.y * 16 + tc;
     const bool active = c4 * 4 < C;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};       // s2 = sum g * (x - mean); invstd is applied once at the end
+    f32x4 is = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
         f32x4 ksc = {0.f, 0.f, 0.f, 0.f}, ksh = ksc;
         if (msc) { ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4); ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4); }
         // 4 rows per trip: 8-12 independent float4 loads in flight per lane before the first use
@@ -663,8 +668,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[u][e] = fmaf(xr[u][e], ksc[e], ksh[e]) > 0.f ? g[u][e] : 0.f;
                 }
-                s1 += g[u];
-                s2 += g[u] * ((xr[u] - mu) * is);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += (double)g[u][e];
+                    s2[e] += (double)g[u][e] * ((double)xr[u][e] - (double)mu[e]);
+                }
             }
         }
         for (; r < r1; r += TR) {
@@ -681,50 +689,54 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = fmaf(xr[e], ksc[e], ksh[e]) > 0.f ? g[e] : 0.f;
             }
-            const f32x4 xh = (xr - mu) * is;
-            s1 += g;
-            s2 += g * xh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += (double)g[e];
+                s2[e] += (double)g[e] * ((double)xr[e] - (double)mu[e]);
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][4 + e] = s2[e]; }
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][4 + e] = s2[e] * (double)is[e]; }
     __syncthreads();
     if (tr == 0 && active) {
-        float t[8];
+        double t[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = red[tc][e];
         for (int q = 1; q < TR; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] += red[q * 16 + tc][e];
-        float* o = part + ((long long)blockIdx.x * C + c4 * 4) * 2;
+        double* o = part + ((long long)blockIdx.x * C + c4 * 4) * 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { o[e * 2 + 0] = t[e]; o[e * 2 + 1] = t[4 + e]; }
     }
 }
 
-// per channel: dbeta = S1, dgamma = S2; coefficients for the apply pass: k1 = gamma*invstd, m1 = S1/N, m2 = S2/N
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, double count,
+// per channel: dbeta = S1, dgamma = S2; coefficients for the apply pass: k1 = gamma*invstd (float), m1 = S1/N, m2 = S2/N (double)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, int C, double count,
                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ coef, int accumulate) {
+                                                             double* __restrict__ coefd, float* __restrict__ k1, int accumulate) {
     int c;
     double s1, s2;
     if (bn_partials_sum4(part, nblocks, C, s1, s2, c)) {
         dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
         dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
-        coef[c] = gamma[c] * invstd[c];
-        coef[C + c] = (float)(s1 / count);
-        coef[2 * C + c] = (float)(s2 / count);
+        k1[c] = gamma[c] * invstd[c];
+        coefd[c] = s1 / count;
+        coefd[C + c] = s2 / count;
     }
 }
 
-// pass 2: draw = k1 * (dz - m1 - xhat*m2);  optionally also writes dz (the gradient the skip connection receives)
+// pass 2: draw = k1 * (dz - m1 - xhat*m2), evaluated in double and rounded once;  optionally also writes dz (the gradient the
+// skip connection receives)
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                            const float* __restrict__ raw, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
-                                                           const float* __restrict__ msc, const float* __restrict__ msh,
-                                                           float* __restrict__ draw, float* dz_out, long long n4, int C, PoolSrc ps) {
+                                                           const float* __restrict__ invstd, const double* __restrict__ coefd,
+                                                           const float* __restrict__ k1p, const float* __restrict__ msc,
+                                                           const float* __restrict__ msh, float* __restrict__ draw, float* dz_out,
+                                                           long long n4, int C, PoolSrc ps) {
     const int C4 = C >> 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
         const int c4 = (int)(idx % C4);
@@ -744,12 +756,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         }
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-        const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
-        const f32x4 m1 = *reinterpret_cast<const f32x4*>(coef + C + c4 * 4);
-        const f32x4 m2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4 * 4);
-        const f32x4 xh = (xr - mu) * is;
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(k1p + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double m1 = coefd[c4 * 4 + e], m2 = coefd[C + c4 * 4 + e];
+            const double xh = ((double)xr[e] - (double)mu[e]) * (double)is[e];
+            o[e] = (float)((double)k1[e] * (((double)g[e] - m1) - xh * m2));
+        }
         if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = g;
-        *reinterpret_cast<f32x4*>(draw + idx * 4) = k1 * (g - m1 - xh * m2);
+        *reinterpret_cast<f32x4*>(draw + idx * 4) = o;
     }
 }
 
@@ -1201,14 +1217,15 @@ extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* ra
     hipStream_t st = (hipStream_t)stream;
     const int nblk = straps_bn_bwd_blocks(rows, c);
     const int rpb = (int)((rows + nblk - 1) / nblk);
-    float* part = (float*)workspace;                 // [nblk][c][2]
-    float* coef = part + (size_t)nblk * c * 2;       // [3][c]
+    double* part = (double*)workspace;               // [nblk][c][2]
+    double* coefd = part + (size_t)nblk * c * 2;     // [2][c]  m1, m2
+    float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coef, mask_scale, mask_shift, draw, dz_out, n4, c, PoolSrc{});
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, n4, c, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }
@@ -1225,15 +1242,16 @@ extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, co
     const long long rows = (long long)batch * h * w;
     const int nblk = straps_bn_bwd_blocks(rows, c);
     const int rpb = (int)((rows + nblk - 1) / nblk);
-    float* part = (float*)workspace;                 // [nblk][c][2]  (straps_bn_bwd_workspace_bytes(rows, c))
-    float* coef = part + (size_t)nblk * c * 2;       // [3][c]
+    double* part = (double*)workspace;               // [nblk][c][2]  (straps_bn_bwd_workspace_bytes(rows, c))
+    double* coefd = part + (size_t)nblk * c * 2;     // [2][c]  m1, m2
+    float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
     const PoolSrc ps{dy_pool, idx, h, w, (h - 1) / 2 + 1, (w - 1) / 2 + 1};
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, ps);
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel<pool>");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coef, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(capped_grid(n4)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coef, mask_scale, mask_shift, draw, nullptr, n4, c, ps);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(capped_grid(n4)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, n4, c, ps);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel<pool>");
     return STRAPS_OK;
 }
@@ -1249,7 +1267,7 @@ extern "C" int straps_bn_relu_maxpool_fwd(const float* raw, const float* scale, 
 }
 
 extern "C" size_t straps_bn_bwd_workspace_bytes(long long rows, int c) {
-    return ((size_t)straps_bn_bwd_blocks(rows, c) * c * 2 + 3 * (size_t)c) * sizeof(float);
+    return ((size_t)straps_bn_bwd_blocks(rows, c) * c * 2 + 2 * (size_t)c) * sizeof(double) + (size_t)c * sizeof(float);
 }
 
 extern "C" int straps_maxpool_fwd_idx(const float* x, float* y, uint8_t* idx, int batch, int h, int w, int c, void* stream) {

@@ -48,7 +48,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // BatchNorm finalize helper: fixed-order fp64 sum of the per-block (s1, s2) partials part[k][C][2], k < nblocks, for 4
 // consecutive channels per 256-thread block (grid = ceil(C/4)).  Lane group pl = tid>>2 walks k = pl, pl+64, ... with
 // 32-byte coalesced segments; the 64 group sums are then added in order by the pl == 0 threads, which get `true`.
-__device__ __forceinline__ bool bn_partials_sum4(const float* __restrict__ part, int nblocks, int C, double& s1, double& s2, int& c) {
+template <typename T>
+__device__ __forceinline__ bool bn_partials_sum4(const T* __restrict__ part, int nblocks, int C, double& s1, double& s2, int& c) {
     __shared__ double red[256][2];
     const int cl = threadIdx.x & 3, pl = threadIdx.x >> 2;
     c = blockIdx.x * 4 + cl;
@@ -56,7 +57,7 @@ __device__ __forceinline__ bool bn_partials_sum4(const float* __restrict__ part,
     if (c < C) {
 #pragma unroll 4
         for (int k = pl; k < nblocks; k += 64) {
-            const f32x2 v = *reinterpret_cast<const f32x2*>(part + ((long long)k * C + c) * 2);
+            const T* v = part + ((long long)k * C + c) * 2;      // (sum, second sum) pair of block k: one 8- or 16-byte access
             a1 += (double)v[0];
             a2 += (double)v[1];
         }

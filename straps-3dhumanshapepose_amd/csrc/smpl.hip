@@ -15,6 +15,8 @@
 //   3. smpl_joints_kernel : picked vertices + the 45 sparse-regressed joints, gathered from the
 //                           just-written vertices in a fixed order.
 // Everything is deterministic (no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -304,6 +306,7 @@ constexpr float F_SCALE = 64.0f;          // 2^6
 
 __device__ __forceinline__ f32x16 mfma16h(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+template <int PF>
 __global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model_t m, const float* __restrict__ F,
                                                                const float* __restrict__ Amat, float* __restrict__ verts,
                                                                float* __restrict__ vout, long long B, int btiles,
@@ -360,6 +363,15 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model
     const _Float16* fh_row = Fh + bl * FSH + 8 * h;
     const _Float16* fl_row = Fl + bl * FSH + 8 * h;
 
+    half8 ring[PF + 1][6];
+    if (round0 < round1) {
+        const half8* q = blend + (long long)(round0 * NW + wave) * (KS * 6 * 64) + lane;
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int f = 0; f < 6; ++f) ring[s][f] = q[s * 384 + f * 64];
+    }
+
     for (int rd = round0; rd < round1; ++rd) {
         const int tile = rd * NW + wave;
         if (KW == 4) {
@@ -371,26 +383,39 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model
             reinterpret_cast<int*>(skw)[128 + e2 + 1] = j2.y * 12;
         }
         // ---------------- blendshape contraction: 14 k-steps x 3 coordinates x 3 split products ----------------
+        // The fragments come from L2 (each wave streams its own tile: 84 KB): one k-step is only 9 x 32 = 288 MFMA cycles, far
+        // less than a loaded L2 round trip, so the loads run PF k-steps ahead in a register ring (fully unrolled: static
+        // indices), and the first PF steps of the NEXT tile are issued before this tile's skinning phase starts.
         f32x16 ax, ay, az;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ax[r] = 0.f; ay[r] = 0.f; az[r] = 0.f; }
         {
             const half8* p = blend + (long long)tile * (KS * 6 * 64) + lane;      // [kstep][coord][hi|lo][lane]
-            half8 c0 = p[0], c1 = p[64], c2 = p[128], c3 = p[192], c4 = p[256], c5 = p[320];
-#pragma unroll 2
+#pragma unroll
             for (int s = 0; s < KS; ++s) {
-                half8 n0 = c0, n1 = c1, n2 = c2, n3 = c3, n4 = c4, n5 = c5;
-                if (s + 1 < KS) {
-                    const half8* q = p + (s + 1) * 384;
-                    n0 = q[0]; n1 = q[64]; n2 = q[128]; n3 = q[192]; n4 = q[256]; n5 = q[320];
+                if (s + PF < KS) {
+                    const half8* q = p + (s + PF) * 384;
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) ring[(s + PF) % (PF + 1)][f] = q[f * 64];
                 }
+                // (the machine scheduler would otherwise sink every load to just before its first use -- register pressure --
+                //  and the ring would prefetch nothing: pin the issue point)
+                __builtin_amdgcn_sched_barrier(0);
                 const half8 fh = *reinterpret_cast<const half8*>(fh_row + 16 * s);
                 const half8 fl = *reinterpret_cast<const half8*>(fl_row + 16 * s);
-                ax = mfma16h(c0, fh, ax); ay = mfma16h(c2, fh, ay); az = mfma16h(c4, fh, az);       // Dh . Fh
-                ax = mfma16h(c1, fh, ax); ay = mfma16h(c3, fh, ay); az = mfma16h(c5, fh, az);       // Dl . Fh
-                ax = mfma16h(c0, fl, ax); ay = mfma16h(c2, fl, ay); az = mfma16h(c4, fl, az);       // Dh . Fl
-                c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5;
+                const half8* c = ring[s % (PF + 1)];
+                ax = mfma16h(c[0], fh, ax); ay = mfma16h(c[2], fh, ay); az = mfma16h(c[4], fh, az);       // Dh . Fh
+                ax = mfma16h(c[1], fh, ax); ay = mfma16h(c[3], fh, ay); az = mfma16h(c[5], fh, az);       // Dl . Fh
+                ax = mfma16h(c[0], fl, ax); ay = mfma16h(c[2], fl, ay); az = mfma16h(c[4], fl, az);       // Dh . Fl
             }
+            if (rd + 1 < round1) {                                                  // next tile's head: in flight during the skinning below
+                const half8* q = p + (long long)NW * (KS * 6 * 64);
+#pragma unroll
+                for (int s = 0; s < PF; ++s)
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) ring[s][f] = q[s * 384 + f * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---------------- linear blend skinning (exact fp32), lane = body, reg = vertex; 16 vertices at a time ----------------
 #pragma unroll
@@ -525,10 +550,14 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
     int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, joints, batch, st);
     if (rc != STRAPS_OK) return rc;
     const bool split = mode == STRAPS_SMPL_SPLIT_F16;
+    // prefetch depth of the split kernel's fragment ring (tuning knob, STRAPS_SMPL_PF = 1..4; default 3)
+    static int pf = 0;
+    if (!pf) { const char* e = getenv("STRAPS_SMPL_PF"); pf = e ? atoi(e) : 3; if (pf < 1 || pf > 4) pf = 3; }
+    auto h_kernel = pf == 1 ? smpl_verts_h_kernel<1> : pf == 2 ? smpl_verts_h_kernel<2> : pf == 4 ? smpl_verts_h_kernel<4> : smpl_verts_h_kernel<3>;
     const size_t lds = (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
     static bool attr_set[2] = {false, false};
     if (!attr_set[split]) {
-        hipError_t e = hipFuncSetAttribute(split ? (const void*)smpl_verts_h_kernel : (const void*)smpl_verts_kernel,
+        hipError_t e = hipFuncSetAttribute(split ? (const void*)h_kernel : (const void*)smpl_verts_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("smpl_verts_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
         attr_set[split] = true;
@@ -539,7 +568,7 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
         return STRAPS_EUNSUPPORTED;
     }
     if (split)
-        hipLaunchKernelGGL(smpl_verts_h_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
+        hipLaunchKernelGGL(h_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
                            joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);
     else
         hipLaunchKernelGGL(smpl_verts_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,

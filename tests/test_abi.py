@@ -60,4 +60,4 @@ def test_tile_choice_of_the_implicit_gemm(lib):
     for cfg, bm in ((1, 128), (2, 128), (3, 64), (3 | 16, 64)):
         assert lib.straps_conv_stat_blocks(2, 10, 10, 128, 1152, cfg) == -(-200 // bm)
     # BatchNorm-backward reduction grid and the workspace that goes with it
-    assert lib.straps_bn_bwd_workspace_bytes(4096, 64) == (lib.straps_bn_bwd_blocks(4096, 64) * 64 * 2 + 3 * 64) * 4
+    assert lib.straps_bn_bwd_workspace_bytes(4096, 64) == (lib.straps_bn_bwd_blocks(4096, 64) * 64 * 2 + 2 * 64) * 8 + 64 * 4

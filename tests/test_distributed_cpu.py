@@ -66,3 +66,73 @@ def test_flat_gradient_allreduce_two_ranks():
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def _worker_vis(rank, world, port, q, uneven):
+    """data-parallel semantics of the visibility-masked joints2D task (SURVEY 8e caveat): every rank takes the MEAN over ITS
+    visible joints, the exchange sums the gradients and Adam divides by the world size -- so the job optimises the average of
+    per-rank means.  That equals the single-process loss over the global batch exactly when every rank sees the same number of
+    visible joints, and differs from it by a (computable) reweighting of ranks otherwise."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import straps_oracle as O
+    from straps_amd.train_step import GradientExchange
+    Bl = 3
+    g = torch.Generator().manual_seed(7)
+    lab_all = torch.rand(world * Bl, 17, 2, generator=g) * 200 + 20           # all visible ...
+    if uneven:
+        for r in range(world):                                                # ... then rank r hides 4 r joints of each of its bodies
+            lab_all[r * Bl:(r + 1) * Bl, :4 * r] = 300.0
+    pred_all = torch.rand(world * Bl, 17, 2, generator=g) * 2 - 1
+    w = torch.tensor([0.7, -0.2], requires_grad=True)                          # a replicated "parameter": pred = w0 * pred + w1
+    lv = {k: torch.tensor(0.0) for k in O.LOSS_TASKS}
+
+    def j2d_loss(lab, pred):
+        labels = {'joints2D': lab, 'vis': O.check_joints2d_visibility(lab)}
+        total, parts = O.multi_task_loss(labels, {'joints2D': w[0] * pred + w[1]}, lv, losses_on=('joints2D',))
+        return total, int(labels['vis'].sum())
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    loss_r, nvis_r = j2d_loss(lab_all[sl], pred_all[sl])
+    (grad_r,) = torch.autograd.grad(loss_r, w)
+    flat = grad_r.clone()
+    ex = GradientExchange(flat, 0, world)
+    scale = ex.finish()
+    dp_grad = flat * scale                                                     # what straps_adam_step consumes (grad_scale = 1/world)
+    # single-process reference over the global batch, and the average of per-rank means computed directly
+    loss_g, nvis_g = j2d_loss(lab_all, pred_all)
+    (grad_g,) = torch.autograd.grad(loss_g, w)
+    means = []
+    for r in range(world):
+        l_r, _ = j2d_loss(lab_all[r * Bl:(r + 1) * Bl], pred_all[r * Bl:(r + 1) * Bl])
+        means.append(torch.autograd.grad(l_r, w)[0])
+    avg_of_means = sum(means) / world
+    ok_avg = bool(torch.allclose(dp_grad, avg_of_means, rtol=1e-6, atol=1e-8))
+    same_as_global = bool(torch.allclose(dp_grad, grad_g, rtol=1e-5, atol=1e-7))
+    counts = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([float(nvis_r)]))
+    q.put((rank, ok_avg, same_as_global, [int(c.item()) for c in counts], nvis_g))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('uneven', [False, True])
+def test_visibility_masked_mean_under_data_parallel_world4(uneven):
+    world = 4
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + (7 if uneven else 0)
+    procs = [ctx.Process(target=_worker_vis, args=(r, world, port, q, uneven)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(world)]
+    for rank, ok_avg, same_as_global, counts, nvis_g in res:
+        assert ok_avg                                              # the exchange implements exactly "average of per-rank means"
+        assert sum(counts) == nvis_g
+        if uneven:
+            assert len(set(counts)) == world and not same_as_global   # rank-dependent counts: NOT the global masked mean (documented)
+        else:
+            assert len(set(counts)) == 1 and same_as_global           # equal counts: identical to the single-process loss

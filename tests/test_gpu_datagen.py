@@ -119,7 +119,7 @@ def test_vertex_noise_materialised_and_fused_into_the_rasteriser():
     from_copy = r.render_arrays(noisy, cam_t)
     clean = r.render_arrays(verts, cam_t)
     assert torch.equal(fused, from_copy)
-    assert not torch.equal(fused, clean) and float((fused != clean).float().mean()) < 0.05          # only the edges move
+    assert not torch.equal(fused, clean) and float((fused != clean).float().mean()) < 0.15          # only silhouette / part edges move (+-1.2 px)
     want = O.rasterize_parts(want_noisy.numpy(), model['faces'], model['face_parts'], K, np.eye(3), cam_t.cpu().numpy())
     np.testing.assert_array_equal(fused.cpu().numpy(), want)
 

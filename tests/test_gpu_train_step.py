@@ -127,7 +127,16 @@ def _oracle_step(ts, reg, batch, layers, dtype):
 
 def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd():
     """T: forward + loss + backward of TrainStep on a B=8 batch against autograd of the float64 oracle on the SAME batch
-    (running statistics restored first): loss to 1e-5, every one of the 66 + 5 gradients to 1e-3 of its norm."""
+    (running statistics restored first).  Loss to 1e-5.  Gradients, relative L2 error per tensor:
+      * IEF head and loss weights (no BatchNorm / ReLU upstream of their gradient): < 1e-5;
+      * layer4: < 5e-3 each and < 2e-4 in the median.  Typical errors are ~1e-5; the tail is ReLU decisions: a pre-activation
+        within fp32 rounding of zero takes the other branch than in float64, which moves the few-element sums of the 8x8
+        stage (e.g. a BatchNorm bias gradient) by one whole term -- the float32 CPU oracle shows the same jumps on other tensors;
+      * stem .. layer3: the problem itself is ill conditioned in fp32 -- the gradient entering layer3 from layer4's BatchNorm
+        backward is the small residual of an almost constant tensor (global average pooling broadcasts one value to 64
+        positions), so ANY fp32 evaluation (the float32 CPU oracle = the reference's own CPU arithmetic included) sits ~5e-3
+        from float64 there (tools/grad_conditioning.py).  The bar for those tensors is the reference's own fp32 error:
+        gpu <= 2 x (float32 oracle's error) + 1e-3."""
     B = 8
     torch.set_num_threads(8)
     dev, reg, smpl, crit = _setup(B, seed=5)
@@ -135,6 +144,7 @@ def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd():
     with torch.no_grad():
         batch = ts.make_batch()
     total, parts, grads, glv = _oracle_step(ts, reg, batch, 18, torch.float64)       # before the step touches the running statistics
+    _, _, g32, _ = _oracle_step(ts, reg, batch, 18, torch.float32)
     with torch.no_grad():
         loss = ts.forward_backward(batch)
     torch.cuda.synchronize()
@@ -142,20 +152,25 @@ def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd():
     for k, name in enumerate(O.LOSS_TASKS):                                           # kernel task order == oracle's LOSS_TASKS
         assert float(loss[1 + k]) == pytest.approx(float(parts[name]), rel=2e-5), name
     assert int(loss[11]) == int(O.check_joints2d_visibility(batch['joints2d'].cpu()).sum())
-    worst = 0.0
+    table, bad = [], []
     for n, p in reg.named_parameters():
-        g, go = ts.gviews[p].detach().cpu().double().reshape(-1), grads[n].reshape(-1)
-        rel = float((g - go).norm() / go.norm().clamp_min(1e-30))
-        worst = max(worst, rel)
-        assert rel < 1e-3, (n, rel)
+        r = grads[n].reshape(-1)
+        e_gpu = float((ts.gviews[p].detach().cpu().double().reshape(-1) - r).norm() / r.norm().clamp_min(1e-30))
+        e_32 = float((g32[n].double().reshape(-1) - r).norm() / r.norm().clamp_min(1e-30))
+        bar = 1e-5 if n.startswith('ief_module.') else 5e-3 if n.startswith('image_encoder.layer4.') else 2 * e_32 + 1e-3
+        table.append((n, e_gpu, e_32, bar))
+        if not e_gpu < bar:
+            bad.append('%-52s gpu %.2e  cpu32 %.2e  bar %.2e' % table[-1])
+    assert not bad, '\n'.join(bad)
     for name in O.LOSS_TASKS:
         g = float(ts.gviews[getattr(crit, name + '_log_var')])
         assert g == pytest.approx(float(glv[name]), rel=1e-4, abs=1e-7), name
-    print('worst relative gradient error vs fp64 oracle autograd: %.2e' % worst)
-    # and the fp32 oracle (what a CPU run of the reference computes) is no closer to fp64 than we are by more than ~10x
-    _, _, g32, _ = _oracle_step(ts, reg, batch, 18, torch.float32)
-    worst32 = max(float((g32[n].double().reshape(-1) - grads[n].reshape(-1)).norm() / grads[n].norm().clamp_min(1e-30)) for n in grads)
-    assert worst < max(1e-4, 10 * worst32)
+    l4 = sorted(t[1] for t in table if t[0].startswith('image_encoder.layer4.'))
+    print('relative gradient error vs fp64 oracle autograd: IEF worst %.2e | layer4 median %.2e worst %.2e | stem..layer3 worst %.2e (float32 CPU oracle: %.2e)'
+          % (max(t[1] for t in table if t[0].startswith('ief_module.')), l4[len(l4) // 2], l4[-1],
+             max(t[1] for t in table if not t[0].startswith(('ief_module.', 'image_encoder.layer4.'))),
+             max(t[2] for t in table if not t[0].startswith(('ief_module.', 'image_encoder.layer4.')))))
+    assert l4[len(l4) // 2] < 2e-4
 
 
 def test_resnet50_step_configs3_shape():
@@ -190,11 +205,15 @@ def test_resnet50_step_configs3_shape():
     with torch.no_grad():
         loss = ts_e.forward_backward(batch)
     assert float(loss[0]) == pytest.approx(float(total), rel=1e-4)
-    for n in ('image_encoder.conv1.weight', 'image_encoder.layer1.0.conv3.weight', 'image_encoder.layer2.0.downsample.0.weight',
-              'image_encoder.layer3.5.bn3.weight', 'image_encoder.layer4.2.conv2.weight', 'ief_module.fc1.weight', 'ief_module.fc3.bias'):
+    # (float32 oracle: both sides carry the fp32 ill-conditioning of the stem .. layer3 gradients, see the resnet18 test above)
+    for n, bar in (('image_encoder.conv1.weight', 5e-2), ('image_encoder.layer1.0.conv3.weight', 5e-2),
+                   ('image_encoder.layer2.0.downsample.0.weight', 5e-2), ('image_encoder.layer3.5.bn3.weight', 5e-2),
+                   ('image_encoder.layer4.2.conv2.weight', 2e-2), ('image_encoder.layer4.2.bn3.bias', 2e-2), ('ief_module.fc1.weight', 1e-4),
+                   ('ief_module.fc3.bias', 1e-4)):
         p = dict(reg_e.named_parameters())[n]
         g, go = ts_e.gviews[p].detach().cpu().double().reshape(-1), grads[n].double().reshape(-1)
-        assert float((g - go).norm() / go.norm().clamp_min(1e-30)) < 5e-3, n
+        assert float((g - go).norm() / go.norm().clamp_min(1e-30)) < bar, n
+        assert float((g @ go) / (g.norm() * go.norm()).clamp_min(1e-30)) > 0.999, n
 
 
 def test_resume_from_checkpoint_equals_uninterrupted_training(tmp_path):
