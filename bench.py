@@ -43,8 +43,8 @@ def pmc_traffic(args, kernel):
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
     tag = '%s_r%d_b%d' % (args.workload, args.layers, args.batch or (65536 if args.workload == 'smpl' else 64))
-    if args.workload == 'smpl' and args.smpl_exact:
-        tag += '_exact'
+    if args.workload == 'smpl' and args.smpl_precision != 'fp16x3_lbs':
+        tag += '_' + args.smpl_precision
     try:
         rec = json.load(open(path)).get(tag)
     except (OSError, ValueError):
@@ -166,7 +166,9 @@ def main():
     ap.add_argument('--layers', type=int, default=18)
     ap.add_argument('--config', type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help='BASELINE.json configs[N] alias: 1 = --workload fwd, 2 = --workload train, 3 = train --layers 50 --batch 32 (per GPU), 4 = --workload smpl')
-    ap.add_argument('--smpl-exact', action='store_true', help='smpl workload: exact-fp32 MFMA blend contraction instead of the three-product fp16 split')
+    ap.add_argument('--smpl-exact', action='store_true', help='smpl workload: exact-fp32 MFMA blend contraction (= --smpl-precision fp32)')
+    ap.add_argument('--smpl-precision', default='fp16x3_lbs', choices=['fp32', 'fp16x3', 'fp16x3_lbs'],
+                    help='smpl workload: fp32 = exact, fp16x3 = blend contraction as a three-product fp16 split, fp16x3_lbs = skinning on the matrix pipe too')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
@@ -179,6 +181,9 @@ def main():
             args.layers, args.batch = 50, args.batch or 32
     if not args.steps:
         args.steps = 16 if args.workload == 'smpl' else 20
+    if args.smpl_exact:
+        args.smpl_precision = 'fp32'
+    args.smpl_exact = args.smpl_precision == 'fp32'
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -255,7 +260,7 @@ def main():
         aa = (torch.randn(B, 72, generator=g) * 0.3).to(dev)
         R = straps_amd.batch_rodrigues(aa.view(-1, 3)).view(B, 24, 3, 3).contiguous()
 
-        smpl_precision = 'fp32' if args.smpl_exact else 'fp16x3'
+        smpl_precision = args.smpl_precision
 
         def step():
             return smpl.forward_arrays(betas, R, want_joints=True, precision=smpl_precision)[0]
@@ -359,8 +364,9 @@ def main():
                 if args.smpl_exact:
                     roof['hbm_side'] = hbm                # exact-fp32 blend: the fp32 matrix pipe binds long before HBM does
                 else:
-                    # three-product fp16 split: the contraction issues 3 x 2 x 224 x (tiles x 96) flops per body on the fp16 pipe
-                    issued = n * B * 3.0 * 2.0 * 224 * smpl.n_tiles * 96
+                    # three-product fp16 split: the contraction issues 3 x 2 x 224 x (tiles x 96) flops per body on the fp16 pipe,
+                    # the matrix-pipe skinning another 3 x 2 x 32 x (tiles x 32 x 12)
+                    issued = n * B * 3.0 * 2.0 * smpl.n_tiles * (224 * 96 + (32 * 32 * 12 if args.smpl_precision == 'fp16x3_lbs' else 0))
                     roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm['frac'],
                             'traffic': None, 'traffic_measured_in_run': False, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
                             'algorithmic_bytes_per_launch': B * per_body,
@@ -401,7 +407,8 @@ def main():
             out['stem_zero_skipping'] = not args.dense_stem
         else:
             out['smpl_blend_precision'] = smpl_precision
-            out['dtype'] = 'fp32' if args.smpl_exact else 'fp32 (blend contraction: 3-product fp16 split, fp32 accumulate)'
+            out['dtype'] = {'fp32': 'fp32', 'fp16x3': 'fp32 (blend contraction: 3-product fp16 split, fp32 accumulate)',
+                            'fp16x3_lbs': 'fp32 (blend contraction and skinning transforms: 3-product fp16 splits, fp32 accumulate)'}[smpl_precision]
         if eager_ms is not None:
             out['eager_ms_per_step'] = round(eager_ms, 4)
             if roof is not None:

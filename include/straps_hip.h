@@ -210,6 +210,11 @@ typedef struct {
     const void* blend_frag_h;
     float blend_h_unscale;
     int32_t reserved1;
+    /* ---- skinning on the matrix pipe (mode STRAPS_SMPL_SPLIT_F16_LBS; may be NULL otherwise) ----
+     * fp16 two-term split of 2^14 * W, W = dense skinning weights [32*n_tiles][32] (24 joints + zero padding; the virtual
+     * vertices carry their single weight): [tile][kstep 2][hi|lo][lane 64][8], element = split(2^14 *
+     * W[vertex = 32*tile + (lane&31)][joint = 16*kstep + 8*(lane>>5) + j]).                                       */
+    const void* skin_frag_h;
 } straps_smpl_model_t;
 
 /* arithmetic of the blend contraction (v_template + shapedirs + posedirs, K = 218) in straps_smpl_fwd */
@@ -217,6 +222,9 @@ typedef struct {
 /* three fp16-MFMA products of two-term splits, fp32 accumulate: ~7e-7 relative per product at 16x the matrix rate;
  * features must satisfy |f| < 1023 (betas and R - I always do)                                                  */
 #define STRAPS_SMPL_SPLIT_F16 1
+/* as above, and the skinning transforms T[v][b] = sum_j W[v][j] A[b][j] as the same kind of split product on the matrix
+ * pipe (any number of weights per vertex); |A| < 63 (metres)                                                     */
+#define STRAPS_SMPL_SPLIT_F16_LBS 2
 
 /* bytes of caller-owned scratch for `batch` bodies (depends on the model's virtual-tile count)  */
 size_t straps_smpl_workspace_bytes(const straps_smpl_model_t* model, long long batch);

@@ -481,6 +481,267 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model
 }
 
 // ------------------------------------------------------------------------------------------
+// mode STRAPS_SMPL_SPLIT_F16_LBS: the skinning stage on the matrix pipe as well.  Measured on the kernel above (rocprofv3 PMC,
+// profiles/r02_smpl_*): with the blend contraction down to 18 % MFMA utilisation the wave time is the per-vertex VALU skinning
+// (~1200 VALU instructions and ~220 dependent LDS reads per 32-vertex tile) -- latency-bound with two waves per SIMD.
+// The per-vertex transform  T[v][b] = sum_j W[v][j] A[b][j]  (3x4 entries) is itself a small GEMM: M = 32 vertices,
+// N = 32 bodies (one 32x32 tile per entry e = 0..11), K = 24 joints padded to 32.  It runs as the same three-product fp16
+// split (weights scaled 2^14 and split on the host, joint transforms scaled 2^10 and split while they are staged into LDS),
+// its accumulators come out in the blend accumulators' layout (lane = body, register = vertex), so
+//     out_c = (T[4c]*x + T[4c+1]*y + T[4c+2]*z) + T[4c+3]
+// is 4 VALU operations per value: 72 MFMAs + ~250 VALU per tile instead of ~1200 VALU + the LDS gathers, any number of
+// non-zero weights per vertex, no joint-index table.  Error of the split products: 3 * 2^-22 relative per product.
+constexpr int ASH = 40;                   // halves per (entry, body) row of the split joint transforms: 80 bytes = 4 * 5 dwords
+constexpr float A_SCALE = 1024.0f;        // 2^10: |A| < 63 (metres) before fp16 overflows
+constexpr float W_UNSCALE = 1.0f / (16384.0f * 1024.0f);   // weights are scaled 2^14 on the host
+
+template <int NWV, int PF, int ABL>
+__global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_model_t m, const float* __restrict__ F,
+                                                                 const float* __restrict__ Amat, float* __restrict__ verts,
+                                                                 float* __restrict__ vout, long long B, int btiles,
+                                                                 int ntiles, int rounds, int rounds_per_chunk) {
+    // (ABL: compile-time measurement switches, 0 in production -- 1 = no output stores, 2 = no fragment loads after the first
+    //  k-step, 4 = no skinning MFMAs, 8 = no blend MFMAs; tools/smpl_ablate.sh)
+    constexpr int ablate = ABL;
+    // OPERAND ROLES ARE SWAPPED with respect to the two kernels above: the per-body operand (features, joint transforms) is the
+    // MFMA's A side (i = body) and the per-vertex operand (blend directions, skinning weights) its B side (n = vertex), so the
+    // accumulators hold lane = VERTEX, register = body row.  A lane's x,y,z of one (body, vertex) are then 12 contiguous bytes
+    // of the output and the 32 lanes of a half-wave cover 384 contiguous bytes of one body's row: the tile leaves as sixteen
+    // global_store_dwordx3 straight from the registers -- no LDS transpose, no staging buffer, no wave barrier.
+    // (The fragment packing is symmetric in the two sides: blend_frag_h / skin_frag_h are read exactly as before.)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Fh = reinterpret_cast<_Float16*>(smem);            // [32][FSH]
+    _Float16* Fl = Fh + BT * FSH;                                  // [32][FSH]
+    _Float16* Ah = Fl + BT * FSH;                                  // [12][32][ASH]  Ah[(e*32 + body)*ASH + joint]
+    _Float16* Al = Ah + 12 * BT * ASH;                             // [12][32][ASH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    const int bl = lane & 31;              // as A-side index: body; as output column: vertex within the tile
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = logical / btiles;
+    const long long b0 = (long long)(logical - chunk * btiles) * BT;
+    const int nb = (int)((B - b0) < BT ? (B - b0) : BT);
+
+    // ---- stage: feature rows and joint transforms, both split into fp16 hi / lo ----
+    // Every global load of the prologue is issued before the first value is converted (a load -> wait -> write loop had cost
+    // ~19 us per workgroup, a fifth of the kernel; loads are unconditional from a clamped row and zeroed afterwards: a load inside
+    // a divergent branch is followed by a full vmcnt(0) at the join).  Joint-transform items are (body, joint 0..31): the K
+    // padding columns 24..31 are written as zeros by their own items, so there is no separate clearing pass / barrier; lanes map
+    // to joints within a body row, which spreads the 2-byte LDS writes over the banks.
+    {
+        constexpr int FITEMS = BT * (KP / 4), FPER = (FITEMS + NWV * 64 - 1) / (NWV * 64);
+        constexpr int AITEMS = BT * 32, APER = (AITEMS + NWV * 64 - 1) / (NWV * 64);
+        f32x4 fv[FPER], av[APER][3];
+#pragma unroll
+        for (int t = 0; t < FPER; ++t) {
+            const int i = tid + t * NWV * 64;
+            const int b = i / (KP / 4), q = i % (KP / 4);
+            const bool ok = i < FITEMS && b < nb;
+            fv[t] = *reinterpret_cast<const f32x4*>(F + (b0 + (ok ? b : 0)) * KP + q * 4);
+            if (!ok) fv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < APER; ++t) {
+            const int i = tid + t * NWV * 64;
+            const int b = i >> 5, j = i & 31;
+            const bool ok = i < AITEMS && b < nb && j < 24;
+            const long long row = ok ? ((b0 + b) * 24 + j) : (b0 * 24);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                av[t][q] = *reinterpret_cast<const f32x4*>(Amat + row * 12 + q * 4);
+                if (!ok) av[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < FPER; ++t) {
+            const int i = tid + t * NWV * 64;
+            const int b = i / (KP / 4), q = i % (KP / 4);
+            if (i < FITEMS) {
+                half4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = fv[t][e] * F_SCALE;
+                    hi[e] = (_Float16)x;
+                    lo[e] = (_Float16)(x - (float)hi[e]);
+                }
+                *reinterpret_cast<half4*>(Fh + b * FSH + q * 4) = hi;
+                *reinterpret_cast<half4*>(Fl + b * FSH + q * 4) = lo;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < APER; ++t) {
+            const int i = tid + t * NWV * 64;
+            const int b = i >> 5, j = i & 31;
+            if (i < AITEMS) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    const float x = av[t][e >> 2][e & 3] * A_SCALE;
+                    const _Float16 hi = (_Float16)x;
+                    Ah[(e * BT + b) * ASH + j] = hi;
+                    Al[(e * BT + b) * ASH + j] = (_Float16)(x - (float)hi);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int round0 = chunk * rounds_per_chunk;
+    const int round1 = min(round0 + rounds_per_chunk, rounds);
+    const int vrow_floats = (m.n_tiles - NT) * 96;
+    const half8* __restrict__ blend = reinterpret_cast<const half8*>(m.blend_frag_h);
+    const half8* __restrict__ skin = reinterpret_cast<const half8*>(m.skin_frag_h);
+    const float us_blend = m.blend_h_unscale;
+    const _Float16* fh_row = Fh + bl * FSH + 8 * h;
+    const _Float16* fl_row = Fl + bl * FSH + 8 * h;
+    const _Float16* ah_row = Ah + bl * ASH + 8 * h;
+    const _Float16* al_row = Al + bl * ASH + 8 * h;
+
+    half8 ring[PF + 1][6];
+    {
+        const int t0 = round0 * NWV + wave;
+        if (round0 < round1 && t0 < ntiles) {
+            const half8* q = blend + (long long)t0 * (KS * 6 * 64) + lane;
+#pragma unroll
+            for (int s = 0; s < PF; ++s)
+#pragma unroll
+                for (int f = 0; f < 6; ++f) ring[s][f] = q[s * 384 + f * 64];
+        }
+    }
+    // The stores of tile t-1 are issued AFTER the blend phase of tile t and BEFORE its skinning phase: on gfx9 one in-order
+    // counter tracks loads and stores, so the first wait for a load issued behind stores drains the stores too (~1-2 us of
+    // write acknowledgements).  Placed here the drain has the whole LDS/MFMA-only skinning phase to complete in.
+    f32x16 outp[3];
+    int ptile = -1;
+    auto store_tile = [&](int t, const f32x16* o3) {
+        const bool mesh = t < NT;
+        const int v = (mesh ? t : t - NT) * 32 + bl;
+        const long long rstride = mesh ? (long long)(NV * 3) : (long long)vrow_floats;
+        float* vbase = (mesh ? verts : vout) + b0 * rstride + (long long)v * 3;
+        const bool vok = mesh ? v < NV : (vout != nullptr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int body = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if ((ablate & 1) && o3[0][r] != 12345.678f) continue;          // (never true: keeps the arithmetic alive)
+            if (vok && body < nb) {
+                float* o = vbase + body * rstride;
+                o[0] = o3[0][r]; o[1] = o3[1][r]; o[2] = o3[2][r];
+            }
+        }
+    };
+    for (int rd = round0; rd < round1; ++rd) {
+        const int tile = rd * NWV + wave;
+        if (tile >= ntiles) break;                           // (wave-uniform: the last round may be ragged)
+        // skinning-weight fragments of this tile [kstep 2][hi|lo][lane]: issued first, needed after the blend contraction
+        const half8* sp = skin + (long long)tile * 256 + lane;
+        const half8 wh0 = sp[0], wl0 = sp[64], wh1 = sp[128], wl1 = sp[192];
+        f32x16 ax, ay, az;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ax[r] = 0.f; ay[r] = 0.f; az[r] = 0.f; }
+        // LDS operands run one step ahead of the MFMAs that consume them (the wave would otherwise sit through an LDS round
+        // trip per k-step / per skinning tile: 26 exposed round trips per tile were ~40 % of the wave's time)
+        half8 fh = *reinterpret_cast<const half8*>(fh_row);
+        half8 fl = *reinterpret_cast<const half8*>(fl_row);
+        {
+            const half8* p = blend + (long long)tile * (KS * 6 * 64) + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + PF < KS && !(ablate & 2)) {
+                    const half8* q = p + (s + PF) * 384;
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) ring[(s + PF) % (PF + 1)][f] = q[f * 64];
+                }
+                half8 fhn = fh, fln = fl;
+                if (s + 1 < KS) {
+                    fhn = *reinterpret_cast<const half8*>(fh_row + 16 * (s + 1));
+                    fln = *reinterpret_cast<const half8*>(fl_row + 16 * (s + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const half8* c = ring[s % (PF + 1)];
+                if (!(ablate & 8)) {
+                ax = mfma16h(fh, c[0], ax); ay = mfma16h(fh, c[2], ay); az = mfma16h(fh, c[4], az);       // Fh . Dh
+                ax = mfma16h(fh, c[1], ax); ay = mfma16h(fh, c[3], ay); az = mfma16h(fh, c[5], az);       // Fh . Dl
+                ax = mfma16h(fl, c[0], ax); ay = mfma16h(fl, c[2], ay); az = mfma16h(fl, c[4], az);       // Fl . Dh
+                } else { ax[0] += (float)fh[0] + (float)c[0][0]; ay[0] += (float)fl[1] + (float)c[3][1]; az[0] += (float)c[5][2]; }
+                fh = fhn; fl = fln;
+            }
+            // the head of the NEXT tile's fragments is issued before this tile's stores: a load issued behind stores can only be
+            // waited for by draining the stores as well (one in-order counter for both on gfx9)
+            const int tnext = tile + NWV;
+            if (rd + 1 < round1 && tnext < ntiles) {
+                const half8* q = p + (long long)NWV * (KS * 6 * 64);
+#pragma unroll
+                for (int s = 0; s < PF; ++s)
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) ring[s][f] = q[s * 384 + f * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ptile >= 0) store_tile(ptile, outp);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- skinning on the matrix pipe: T_e[body][vertex] = sum_j A[body][j][e] W[vertex][j] ----------------
+        // Software pipeline over the twelve entries e: [LDS operands of e+1] -> [6-MFMA chain of e] -> [fold of e-1 on the VALU
+        // while that chain runs].  out_c = (T[4c] x + T[4c+1] y + T[4c+2] z) us_rot + T[4c+3] us_w.
+        f32x16 out[3];
+        const float us_rot = us_blend * W_UNSCALE;       // (T * blend) carries both scales, the translation column only the skin scale
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        half8 bh0 = *reinterpret_cast<const half8*>(ah_row), bh1 = *reinterpret_cast<const half8*>(ah_row + 16);
+        half8 bl0 = *reinterpret_cast<const half8*>(al_row), bl1 = *reinterpret_cast<const half8*>(al_row + 16);
+        f32x16 Tprev = zero16, acc = zero16;
+#pragma unroll
+        for (int e = 0; e <= 12; ++e) {
+            half8 nh0 = bh0, nh1 = bh1, nl0 = bl0, nl1 = bl1;
+            if (e + 1 < 12) {
+                nh0 = *reinterpret_cast<const half8*>(ah_row + (e + 1) * BT * ASH);
+                nh1 = *reinterpret_cast<const half8*>(ah_row + (e + 1) * BT * ASH + 16);
+                nl0 = *reinterpret_cast<const half8*>(al_row + (e + 1) * BT * ASH);
+                nl1 = *reinterpret_cast<const half8*>(al_row + (e + 1) * BT * ASH + 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 T = zero16;
+            if (e < 12 && !(ablate & 4)) {
+                T = mfma16h(bh0, wh0, zero16);
+                T = mfma16h(bh1, wh1, T);
+                T = mfma16h(bh0, wl0, T);
+                T = mfma16h(bh1, wl1, T);
+                T = mfma16h(bl0, wh0, T);
+                T = mfma16h(bl1, wh1, T);
+            } else if (e < 12) {
+                T[0] = (float)bh0[0] + (float)bl1[1];
+            }
+            if (e > 0) {                                  // fold entry e-1 (Tprev) while the chain above is in the pipe
+                const int pe = e - 1, c = pe >> 2, q = pe & 3;
+                if (q == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = Tprev[r] * ax[r];
+                } else if (q == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += Tprev[r] * ay[r];
+                } else if (q == 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += Tprev[r] * az[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[c][r] = acc[r] * us_rot + Tprev[r] * W_UNSCALE;
+                    asm volatile("" : "+v"(out[c]));
+                }
+                asm volatile("" : "+v"(acc));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            Tprev = T;
+            bh0 = nh0; bh1 = nh1; bl0 = nl0; bl1 = nl1;
+        }
+        // (lane = vertex, register r = body (r&3) + 8 (r>>2) + 4 h: stored after the NEXT tile's blend phase, see above)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) outp[c] = out[c];
+        ptile = tile;
+    }
+    if (ptile >= 0) store_tile(ptile, outp);
+}
+
+// ------------------------------------------------------------------------------------------
 // Output joints 24..89: 21 picked vertices, then the 45 regressed joints = fixed-order sums of their
 // virtual vertices (contiguous in the scratch row).  One thread per output scalar -> deterministic.
 __global__ __launch_bounds__(256) void smpl_joints_kernel(straps_smpl_model_t m, const float* __restrict__ verts,
@@ -505,10 +766,14 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(straps_smpl_model_t m,
     joints[b * (STRAPS_SMPL_NJOINTS_OUT * 3) + 72 + r] = v;
 }
 
-// rounds (of NW tiles) per block; chunks <= 0 -> auto: big batches take 8 rounds per block so the F / A staging
-// amortises, small ones 1 round so a 64-body step still puts 2 x n_tiles/8 blocks on the chip
+// rounds (of NW tiles) per block; chunks <= 0 -> auto: big batches take ~8 rounds per block so the F / A staging amortises -- split
+// EVENLY (28 rounds -> 4 x 7, not 8 + 8 + 8 + 4: the uneven split cost 8 % at 65 536 bodies) -- small ones 1 round so a 64-body
+// step still puts 2 x n_tiles/8 blocks on the chip
 inline int resolve_rpc(int rounds, long long batch, int chunks) {
-    if (chunks <= 0) return (batch >= 1024) ? 8 : 1;
+    if (chunks <= 0) {
+        if (batch < 1024) return 1;
+        chunks = (rounds + 7) / 8;
+    }
     if (chunks > rounds) chunks = rounds;
     return (rounds + chunks - 1) / chunks;
 }
@@ -534,7 +799,8 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                                void* stream) {
     STRAPS_REQUIRE(model && betas && rotmats && verts && workspace, "straps_smpl_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0, "straps_smpl_fwd: batch must be positive (got %lld)", batch);
-    STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || mode == STRAPS_SMPL_SPLIT_F16, "straps_smpl_fwd: unknown mode %d", mode);
+    STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || mode == STRAPS_SMPL_SPLIT_F16 || mode == STRAPS_SMPL_SPLIT_F16_LBS, "straps_smpl_fwd: unknown mode %d", mode);
+    STRAPS_REQUIRE(mode != STRAPS_SMPL_SPLIT_F16_LBS || model->skin_frag_h, "straps_smpl_fwd: mode STRAPS_SMPL_SPLIT_F16_LBS needs skin_frag_h in the model");
     STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || (model->blend_frag_h && model->blend_h_unscale > 0.f),
                    "straps_smpl_fwd: split-precision mode needs blend_frag_h / blend_h_unscale in the model");
     STRAPS_REQUIRE(model->skin_k >= 1 && model->skin_k <= 24, "straps_smpl_fwd: skin_k %d out of range", model->skin_k);
@@ -549,15 +815,27 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
     float* vout = Amat + batch * 288;
     int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, joints, batch, st);
     if (rc != STRAPS_OK) return rc;
-    const bool split = mode == STRAPS_SMPL_SPLIT_F16;
-    // prefetch depth of the split kernel's fragment ring (tuning knob, STRAPS_SMPL_PF = 1..4; default 3)
-    static int pf = 0;
-    if (!pf) { const char* e = getenv("STRAPS_SMPL_PF"); pf = e ? atoi(e) : 3; if (pf < 1 || pf > 4) pf = 3; }
+    const int split = mode == STRAPS_SMPL_SPLIT_F16 ? 1 : mode == STRAPS_SMPL_SPLIT_F16_LBS ? 2 : 0;
+    // measurement knobs (tools/smpl_ablate.sh; unset in production): STRAPS_SMPL_PF = depth of the fragment ring (default 3 for the
+    // blend-split kernel, 2 for the matrix-pipe-skinning kernel), STRAPS_SMPL_ABLATE (compile-time ablations of the latter),
+    // STRAPS_SMPL_RPC (rounds per workgroup)
+    static int pf_env = -1, ablate = -1, rpc_env = -1;
+    if (pf_env < 0) {
+        const char* e = getenv("STRAPS_SMPL_PF"); pf_env = e ? atoi(e) : 0;
+        e = getenv("STRAPS_SMPL_ABLATE"); ablate = e ? atoi(e) : 0;
+        e = getenv("STRAPS_SMPL_RPC"); rpc_env = e ? atoi(e) : 0;
+    }
+    const int pf = pf_env >= 1 && pf_env <= 4 ? pf_env : (split == 2 ? 2 : 3);
+    constexpr int nwv = 8;              // (12 / 16 waves per workgroup need <= 168 / 128 VGPRs: the kernel spills and runs 3.5x slower)
     auto h_kernel = pf == 1 ? smpl_verts_h_kernel<1> : pf == 2 ? smpl_verts_h_kernel<2> : pf == 4 ? smpl_verts_h_kernel<4> : smpl_verts_h_kernel<3>;
-    const size_t lds = (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
-    static bool attr_set[2] = {false, false};
+    auto hh_kernel = ablate == 1 ? smpl_verts_hh_kernel<8, 1, 1> : ablate == 2 ? smpl_verts_hh_kernel<8, 1, 2> : ablate == 3 ? smpl_verts_hh_kernel<8, 1, 3>
+                   : ablate == 7 ? smpl_verts_hh_kernel<8, 1, 7> : ablate == 15 ? smpl_verts_hh_kernel<8, 1, 15>
+                   : pf == 1 ? smpl_verts_hh_kernel<8, 1, 0> : smpl_verts_hh_kernel<8, 2, 0>;
+    const size_t lds = split == 2 ? (size_t)(BT * FSH + 12 * BT * ASH) * sizeof(float)
+                                  : (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
+    static bool attr_set[3] = {false, false, false};
     if (!attr_set[split]) {
-        hipError_t e = hipFuncSetAttribute(split ? (const void*)h_kernel : (const void*)smpl_verts_kernel,
+        hipError_t e = hipFuncSetAttribute(split == 2 ? (const void*)hh_kernel : split ? (const void*)h_kernel : (const void*)smpl_verts_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("smpl_verts_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
         attr_set[split] = true;
@@ -567,7 +845,15 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
         straps_set_error("straps_smpl_fwd: batch %lld exceeds one launch; split it", batch);
         return STRAPS_EUNSUPPORTED;
     }
-    if (split)
+    if (split == 2) {
+        // own round structure: nwv tiles per round, ragged last round
+        const int ntiles = joints ? model->n_tiles : NT;
+        const int rounds2 = (ntiles + nwv - 1) / nwv;
+        const int rpc2 = rpc_env > 0 ? (rpc_env > rounds2 ? rounds2 : rpc_env) : resolve_rpc(rounds2, batch, chunks);
+        const int nch2 = (rounds2 + rpc2 - 1) / rpc2;
+        hipLaunchKernelGGL(hh_kernel, dim3((unsigned)(btiles * nch2)), dim3(nwv * 64), lds, st, *model, F, Amat, verts, joints ? vout : nullptr,
+                           batch, (int)btiles, ntiles, rounds2, rpc2);
+    } else if (split)
         hipLaunchKernelGGL(h_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
                            joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);
     else

@@ -20,7 +20,8 @@ ModelOutput = namedtuple('ModelOutput', ['vertices', 'joints', 'full_pose', 'bet
 ModelOutput.__new__.__defaults__ = (None,) * len(ModelOutput._fields)
 
 V, VPAD, TILES, KP = 6890, 6912, 216, 224
-PRECISIONS = {'fp32': 0, 'fp16x3': 1}          # STRAPS_SMPL_EXACT_F32 / STRAPS_SMPL_SPLIT_F16
+# STRAPS_SMPL_EXACT_F32 / STRAPS_SMPL_SPLIT_F16 (blend contraction split) / STRAPS_SMPL_SPLIT_F16_LBS (blend + skinning split)
+PRECISIONS = {'fp32': 0, 'fp16x3': 1, 'fp16x3_lbs': 2}
 
 
 def pack_smpl_model(model):
@@ -102,6 +103,15 @@ def pack_smpl_model(model):
     if nvirt:
         sw[VPAD:VPAD + nvirt, 0] = np.asarray(vs_, np.float32)
         sj[VPAD:VPAD + nvirt, 0] = np.asarray(vk_, np.int32)
+    # dense skinning weights for the matrix-pipe skinning (straps_hip.h: skin_frag_h): two-term fp16 split of 2^14 * W,
+    # [tile][kstep][hi|lo][hh][i][j]  <-  W[32t + i][16 ks + 8 hh + j]   (24 joints + 8 columns of K padding)
+    Wd = np.zeros((n_tiles * 32, 32), np.float32)
+    np.add.at(Wd, (np.repeat(np.arange(n_tiles * 32), k), sj.reshape(-1)), sw.reshape(-1))
+    assert float(np.abs(Wd).max()) < 3.9, 'skinning weight too large for the fp16 split (|w| * 2^14 must stay below 65504)'
+    Ws = Wd * np.float32(2.0 ** 14)
+    Wh = Ws.astype(np.float16)
+    Wl = (Ws - Wh.astype(np.float32)).astype(np.float16)
+    skin_frag_h = np.stack([Wh, Wl], axis=0).reshape(2, n_tiles, 32, 2, 2, 8).transpose(1, 3, 0, 4, 2, 5).copy()
     jj, vv = np.nonzero(R45)                                                 # (backward tables below)
     o = np.lexsort((vv, jj))
     jj, vv = jj[o], vv[o]
@@ -142,7 +152,7 @@ def pack_smpl_model(model):
         'blend_frag_t': frag_t.reshape(-1), 'children': children,
         'jrt_ptr': jrt_ptr, 'jrt_code': (((vs % 32) << 8) | src).astype(np.int32), 'jrt_w': ws,
         'blend_frag': frag.reshape(-1),
-        'blend_frag_h': frag_h.reshape(-1), 'blend_h_unscale': float(2.0 ** -(sd_exp + 6)),
+        'blend_frag_h': frag_h.reshape(-1), 'blend_h_unscale': float(2.0 ** -(sd_exp + 6)), 'skin_frag_h': skin_frag_h.reshape(-1),
         'j_template': (Jr @ vt).astype(np.float32),
         'j_shapedirs': np.einsum('jv,vcl->jcl', Jr, sd).astype(np.float32),
         'parents': parents, 'depth': depth, 'max_depth': int(depth.max()), 'skin_k': k,
@@ -196,7 +206,7 @@ class SMPL(nn.Module):
         key = self._k_blend_frag.data_ptr()
         if self._struct_key != key:
             s = hipabi.SmplModelStruct()
-            for f in ('blend_frag', 'blend_frag_h', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
+            for f in ('blend_frag', 'blend_frag_h', 'skin_frag_h', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
                       'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w', 'dj_ptr', 'dj_code', 'dj_w'):
                 setattr(s, f, getattr(self, '_k_' + f).data_ptr())
             s.max_depth, s.skin_k, s.n_tiles = self.max_depth, self.skin_k, self.n_tiles
@@ -208,8 +218,9 @@ class SMPL(nn.Module):
     def forward_arrays(self, betas, rotmats, want_joints=True, chunks=0, out_verts=None, out_joints=None, precision=None):
         """raw entry: betas [B,10], rotmats [B,24,3,3] (contiguous fp32 GPU) -> (verts, joints|None).
         out_verts / out_joints: optional resident output buffers ([B,6890,3] / [B,90,3], contiguous fp32).
-        precision: 'fp32' (exact fp32 blend contraction) or 'fp16x3' (three-product fp16 split, fp32 accumulate: same accuracy
-        class, 16x the matrix rate); None = the module's setting."""
+        precision: 'fp32' (exact fp32 everywhere), 'fp16x3' (blend contraction as a three-product fp16 split with fp32
+        accumulate: same accuracy class, 16x the matrix rate) or 'fp16x3_lbs' (the skinning transforms on the matrix pipe as
+        well); None = the module's setting."""
         hipabi.require_gpu_tensor(betas, 'betas', torch.float32)
         hipabi.require_gpu_tensor(rotmats, 'rotmats', torch.float32)
         hipabi.require_gpu_tensor(self._k_blend_frag, 'SMPL model buffers (call .to(device))')

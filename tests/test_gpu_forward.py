@@ -62,35 +62,37 @@ def test_smpl_forward_vs_oracle(dev, smpl_model, B, chunks):
     assert none is None and torch.equal(v2, v)
 
 
+@pytest.mark.parametrize('mode', ['fp16x3', 'fp16x3_lbs'])
 @pytest.mark.parametrize('B', [1, 33, 70, 4096])
-def test_smpl_split_precision_vs_oracle(dev, smpl_model, B):
-    """STRAPS_SMPL_SPLIT_F16 (blend contraction as three fp16-MFMA products of two-term splits, fp32 accumulate) against
-    the float64 oracle on identical (theta, beta): north_star's bar is 1e-4 m; the test asserts 2e-5 and that the split
-    kernel is as close to float64 as the exact-fp32 kernel (both errors printed)."""
+def test_smpl_split_precision_vs_oracle(dev, smpl_model, B, mode):
+    """STRAPS_SMPL_SPLIT_F16 (blend contraction as three fp16-MFMA products of two-term splits, fp32 accumulate) and
+    STRAPS_SMPL_SPLIT_F16_LBS (the skinning transforms as split products too) against the float64 oracle on identical
+    (theta, beta): north_star's bar is 1e-4 m; the test asserts 2e-5 and that the split kernels are as close to float64 as
+    the exact-fp32 kernel (both errors printed)."""
     smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
     betas = torch.from_numpy(det_uniform((B, 10), 100 + B, -2.5, 2.5))
     betas[0] = torch.tensor([10.0, -8.0, 6.0, 4.0, -4.0, 3.0, 3.0, -3.0, 2.0, 2.0])          # an extreme body
     aa = torch.from_numpy(det_uniform((B, 72), 200 + B, -0.9, 0.9))
     R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
-    v, j = smpl.forward_arrays(betas.to(dev), R.to(dev), precision='fp16x3')
+    v, j = smpl.forward_arrays(betas.to(dev), R.to(dev), precision=mode)
     v32, j32 = smpl.forward_arrays(betas.to(dev), R.to(dev), precision='fp32')
     n = min(B, 96)                                                                         # the float64 oracle on a slice
     v64, j64 = O.smpl_forward(smpl_model, betas[:n].double(), rotmats=R[:n].double(), dtype=torch.float64)
     ev, ej = float((v[:n].cpu().double() - v64).abs().max()), float((j[:n].cpu().double() - j64).abs().max())
     ev32, ej32 = float((v32[:n].cpu().double() - v64).abs().max()), float((j32[:n].cpu().double() - j64).abs().max())
-    print('SMPL B=%d max |err| vs float64: split-fp16 verts %.2e joints %.2e | exact-fp32 verts %.2e joints %.2e' % (B, ev, ej, ev32, ej32))
+    print('SMPL B=%d max |err| vs float64: %s verts %.2e joints %.2e | exact-fp32 verts %.2e joints %.2e' % (B, mode, ev, ej, ev32, ej32))
     assert ev < 2e-5 and ej < 2e-5
     assert ev <= 3 * ev32 + 1e-6 and ej <= 3 * ej32 + 1e-6
     assert float((v - v32).abs().max()) < 1e-5 and float((j - j32).abs().max()) < 1e-5
     assert torch.isfinite(v).all() and torch.isfinite(j).all()
     # deterministic, vertices-only form identical, batch rows independent of the batch they ride in
-    v2, none = smpl.forward_arrays(betas.to(dev), R.to(dev), want_joints=False, precision='fp16x3')
+    v2, none = smpl.forward_arrays(betas.to(dev), R.to(dev), want_joints=False, precision=mode)
     assert none is None and torch.equal(v2, v)
     if B > 40:
-        vs, js = smpl.forward_arrays(betas[30:37].contiguous().to(dev), R[30:37].contiguous().to(dev), precision='fp16x3')
+        vs, js = smpl.forward_arrays(betas[30:37].contiguous().to(dev), R[30:37].contiguous().to(dev), precision=mode)
         assert torch.equal(vs, v[30:37]) and torch.equal(js, j[30:37])
     # module-level switch
-    fast = straps_amd.SMPL(smpl_model, batch_size=B, precision='fp16x3').to(dev)
+    fast = straps_amd.SMPL(smpl_model, batch_size=B, precision=mode).to(dev)
     with torch.no_grad():
         o = fast(body_pose=R[:, 1:].to(dev), global_orient=R[:, 0:1].to(dev), betas=betas.to(dev), pose2rot=False)
     assert torch.equal(o.vertices, v)
