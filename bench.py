@@ -53,7 +53,13 @@ def pmc_traffic(args, kernel):
         return {}
     n = byt = 0.0
     for name, k in rec['kernels'].items():
-        if name.replace('void ', '').startswith(kernel):
+        nm = name.replace('void ', '')
+        if kernel == 'smpl_fwd':          # one straps_smpl_fwd call = pose + vertex + joint kernels: traffic of all three per call
+            if nm.startswith('smpl_'):
+                byt += k['launches'] * (k['hbm_read_bytes'] + k['hbm_write_bytes'])
+                if nm.startswith('smpl_verts'):
+                    n += k['launches']
+        elif nm.startswith(kernel):
             n += k['launches']
             byt += k['launches'] * (k['hbm_read_bytes'] + k['hbm_write_bytes'])
     if not n:
