@@ -179,6 +179,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
     ap.add_argument('--no-overlap', action='store_true', help='(default now) weight-gradient kernels stay on the main stream')
+    ap.add_argument('--no-stem-ab', action='store_true', help='skip the dense-stem A/B steps after the timed region (profiling runs: keeps the kernel stats clean)')
     ap.add_argument('--overlap-wgrad', action='store_true', help='A/B: run the weight-gradient kernels on a side stream (0.1 ms slower since the data pipeline)')
     args = ap.parse_args()
     if args.config:
@@ -328,7 +329,7 @@ def main():
     # A/B inside the same run: the stem kernels with their exact zero skipping defeated (every input cell marked non-zero = the
     # plain dense convolution), 3 eager steps on every rank (the step's all-reduce is collective)
     stem_ab = None
-    if args.workload == 'train' and not args.dense_stem:
+    if args.workload == 'train' and not args.dense_stem and not args.no_stem_ab:
         if ts.use_graph:
             ts.use_graph, ts.side_stream, ts.pipeline = False, None, False
         saved, timer.recs = timer.recs, []
