@@ -538,6 +538,8 @@ class TrainStep:
             torch.cuda.synchronize()
             self.draws.set_step(step)
             self._primed = False
+            if self.graph is not None:             # captured graphs consume the batch that was in flight: re-prime eagerly, capture again
+                self.graph, self.graph_tail, self._warm, self._last_by_parity = None, None, 0, {}
 
     def load_state_dict(self, sd):
         """restore the optimiser state written by `state_dict()` / torch.optim.Adam.state_dict() (checkpoint key

@@ -276,3 +276,27 @@ def test_last_outputs_follow_the_replayed_graph_parity():
         assert mse == pytest.approx(float(loss[6]), rel=1e-4), i      # loss[6] = raw vertex MSE of THIS step
     assert ts.graph is not None and len(ts._last_by_parity) == 2
     assert ts._last_by_parity[0]['verts'].data_ptr() != ts._last_by_parity[1]['verts'].data_ptr()
+
+
+def test_set_data_state_with_captured_graphs_recaptures():
+    """re-seating the data stream after the hipGraphs were captured drops them (they would consume the batch that was in flight)
+    and the run continues exactly like an uninterrupted one."""
+    B = 4
+
+    def run(reseat):
+        dev, reg, smpl, crit = _setup(B, seed=8)
+        ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], seed=5, use_graph=True)
+        out = []
+        for i in range(8):
+            if reseat and i == 4:
+                assert ts.graph is not None
+                ts.set_data_state(ts.data_state())
+                assert ts.graph is None
+            out.append(ts.step().clone())
+        torch.cuda.synchronize()
+        assert ts.graph is not None
+        return torch.stack(out).cpu(), ts.flat_p.clone().cpu()
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert torch.equal(la, lb) and torch.equal(pa, pb)
