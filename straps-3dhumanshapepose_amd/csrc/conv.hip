@@ -356,16 +356,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // tile choice from the per-layer sweeps (tools/sweep_conv.py, tools/sweep_igemm_staging.py, B=64): the larger the tile the fewer
 // operand bytes per flop go through L2 -> LDS, but a size only pays while it still yields >= 2 workgroups per CU and the
 // reduction is long enough (K >= 512 / 1024) to amortise its heavier prologue / epilogue: 128x128 first (layer2: 124 vs 111 TFLOP/s),
-// then 128x64 (layer3: 122 vs 113), otherwise 64x64 whose 5 resident workgroups per CU hide each other's barrier / refill
-// bubbles (layer1's short K, layer4's 4096 pixels).
+// then 128x64 (layer3: 122 vs 113; layer1's 64-channel 3x3 layers: 98 vs 90), otherwise 64x64 whose 5 resident workgroups per CU hide
+// each other's barrier / refill bubbles (layer4's 4096 pixels, the 1x1 down-sampling layers' short K).
 inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
     cfg &= 15;               // bit 4 selects the register-staged operand path (A/B tools only)
     const long long mt128 = (M + 127) / 128;
     if (cfg == 1) { bm = 128; bn = 128; }
     else if (cfg == 2) { bm = 128; bn = 64; }
     else if (cfg == 3) { bm = 64; bn = 64; }
-    else if (cout % 128 == 0 && kdim >= 512 && mt128 * (cout / 128) >= 512) { bm = 128; bn = 128; }
+    else if (cout % 128 == 0 && kdim >= 512 && mt128 * (cout / 128) >= 512) { bm = 128; bn = 128; }   // (>= 256 would give layer3 128x128 tiles: +3.5 % in isolation, -0.3 % inside the step)
     else if (kdim >= 1024 && mt128 * (cout / 64) >= 512) { bm = 128; bn = 64; }
+    else if (cout == 64 && kdim >= 512 && mt128 >= 1024) { bm = 128; bn = 64; }   // layer1: only 64 output channels but 262 144 rows (round 2: 98 vs 90 TFLOP/s forward, 98 vs 94 data gradient, step -0.6 %)
     else { bm = 64; bn = 64; }
     if (cout % bn != 0) bn = 64;
 }

@@ -50,9 +50,11 @@ def test_version_and_error_channel(lib):
 
 def test_tile_choice_of_the_implicit_gemm(lib):
     """straps_conv_stat_blocks = ceil(M / BM) exposes the tile rule (host arithmetic only): 128x128 for layer2, 128x64 for
-    layer3, 64x64 for layer1's short K and layer4's 4096 pixels (resnet18, B=64), and the explicit tile_cfg overrides."""
+    layer3 and layer1's 64-channel 3x3 layers, 64x64 for layer4's 4096 pixels and short-K 1x1 layers (resnet18, B=64), and the
+    explicit tile_cfg overrides."""
     B = 64
-    assert lib.straps_conv_stat_blocks(B, 64, 64, 64, 576, 0) == B * 64 * 64 // 64          # layer1: 64x64 tiles
+    assert lib.straps_conv_stat_blocks(B, 64, 64, 64, 576, 0) == B * 64 * 64 // 128         # layer1: 128x64 tiles
+    assert lib.straps_conv_stat_blocks(2, 64, 64, 64, 576, 0) == 2 * 64 * 64 // 64          # ... only with enough rows to fill the chip
     assert lib.straps_conv_stat_blocks(B, 32, 32, 128, 1152, 0) == B * 32 * 32 // 128       # layer2: 128x128
     assert lib.straps_conv_stat_blocks(B, 16, 16, 256, 2304, 0) == B * 16 * 16 // 128       # layer3: 128x64
     assert lib.straps_conv_stat_blocks(B, 8, 8, 512, 4608, 0) == B * 8 * 8 // 64            # layer4: 64x64
