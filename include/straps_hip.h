@@ -73,6 +73,11 @@ int straps_pack_stem_weight(const float* w_oihw, float* w_frag, int cin, void* s
 int straps_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                    float eps, float* scale, float* shift, int c, void* stream);
 
+/* diagnostics: with tile_cfg bit 5 set, straps_conv_fwd / straps_conv_dgrad run a build of the implicit-GEMM kernel whose
+ * wave 0 of every workgroup writes 8 shader-clock sums (copy wait, barrier, copy issue, MFMA burst, chunks, total, prologue,
+ * epilogue) to trace[workgroup][8] (device int64; NULL switches the writes off).  tools/igemm_trace.py.                 */
+int straps_conv_trace_buffer(long long* trace);
+
 /* conv7x7/s2/p3 over the NCHW network input, fused y = relu?(conv*scale+shift) -> NHWC.
  * scale/shift may be NULL (raw conv output, used in training mode).  If stats_partial != NULL it
  * receives per-block per-channel (sum, sum of squares) of the RAW conv output:

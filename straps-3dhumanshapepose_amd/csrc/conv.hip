@@ -48,6 +48,17 @@ struct ConvP {
 
 constexpr int LS = 36;   // LDS row stride in floats (32 data + 4 pad)
 
+// diagnostic trace (tile_cfg bit 5 + straps_conv_trace_buffer): wave 0 of every workgroup accumulates shader-clock intervals of the
+// four segments of its chunk loop -- [0] waiting for its own operand copies (s_waitcnt vmcnt(0)), [1] in the barrier, [2] issuing
+// the next chunk's copies (+ the per-tap set-up), [3] fragment reads + MFMA burst -- plus [4] chunks, [5] whole kernel, [6] prologue,
+// [7] epilogue, and writes them to trace[workgroup][8].  tools/igemm_trace.py.
+__device__ long long* g_conv_trace = nullptr;
+__device__ __forceinline__ long long clk() {
+    long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+}
+
 __device__ __attribute__((aligned(16))) float k_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // source of the padding pixels (LDS-DMA path)
 
 // NS = 2 (default): operands copied global -> LDS directly (global_load_lds_dwordx4, two stages of unpadded 128-byte rows): no
@@ -61,8 +72,11 @@ __device__ __attribute__((aligned(16))) float k_zero16[4] = {0.f, 0.f, 0.f, 0.f}
 // each parity must land in eight different slots.  Bits 1,2 and 4 of the row number separate them in every group.
 __device__ __forceinline__ int swz(int r) { return ((r >> 1) & 3) | ((r >> 2) & 4); }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool TRACE = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_start = 0, t_a = 0, t_b = 0;
+    if constexpr (TRACE) t_start = clk();
     const ConvP::Class& c = p.cls[blockIdx.y];
     const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, coah = c.oah, coaw = c.oaw, cntaps = c.ntaps;
     if ((int)blockIdx.x >= cMT * p.NT) return;                 // a smaller class of the same launch
@@ -137,6 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     };
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool abl_a = TRACE && (((unsigned long long)g_conv_trace) & 1ull);
     // LDS-DMA copies of the NEXT chunk.  Chunks run tap-major: inside a tap the source pointers just move 32 channels on, so the
     // tap table, the halo test and the 64-bit address arithmetic are done once per tap, not once per chunk.
     const float* a_src[AP];
@@ -162,8 +177,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         for (int i = 0; i < BP; ++i) b_src[i] = wrow[i] + tw * p.Cin;
     };
     auto dma_next = [&](int stage) {
+        // (TRACE build only, when the trace pointer's low bit is set: skip the A copies of two taps out of three -- wrong results,
+        //  it prices what a halo-patch A operand, each input pixel copied once per channel chunk instead of once per tap, would buy)
+        const bool skip_a = TRACE && abl_a && (n_tap % 3) != 0;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
+            if (skip_a) break;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_src[i],
                                              (__attribute__((address_space(3))) void*)(As + (stage * BM + 32 * i + 8 * wave_u) * 32), 16, 0, 0);
             a_src[i] += a_inc[i];
@@ -195,14 +214,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         int fo[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ swz(lane & 31)) << 2);
+        if constexpr (TRACE) { t_a = clk(); tr[6] = t_a - t_start; }
         for (int q = 0; q < nchunks; ++q) {
             const int stage = q & 1;
             // my copies of chunk q have landed, then everybody's have -- and every wave is done reading the other stage.
             // (raw s_barrier: __syncthreads() would be the same wait here, but the explicit count documents the protocol)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (TRACE) { t_b = clk(); tr[0] += t_b - t_a; t_a = t_b; }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if constexpr (TRACE) { t_b = clk(); tr[1] += t_b - t_a; t_a = t_b; }
             if (q + 1 < nchunks) dma_next(stage ^ 1);
+            if constexpr (TRACE) { t_b = clk(); tr[2] += t_b - t_a; t_a = t_b; }
             const float* Ab = As + (stage * BM + wm * WTM) * 32;
             const float* Bb = Bs + (stage * BN + wn * WTN) * 32;
             __builtin_amdgcn_s_setprio(1);
@@ -221,6 +244,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
                         for (int j = 0; j < NI; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
             }
             __builtin_amdgcn_s_setprio(0);
+            if constexpr (TRACE) { asm volatile("s_nop 0" ::: "memory"); t_b = clk(); tr[3] += t_b - t_a; t_a = t_b; tr[4] += 1; }
         }
     } else {
     if (nchunks > 0) {
@@ -330,6 +354,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
     };
     if (full) rows(std::true_type{}); else rows(std::false_type{});
+    if constexpr (TRACE) {
+        long long* trp = (long long*)(((unsigned long long)g_conv_trace) & ~1ull);
+        if (trp && tid == 0 && blockIdx.y == 0) {
+            const long long t_end = clk();
+            tr[5] = t_end - t_start;
+            tr[7] = t_end - t_a;
+            for (int k = 0; k < 8; ++k) trp[(long long)blockIdx.x * 8 + k] = tr[k];
+        }
+    }
     if (p.stats) {
         // lanes l and l+32 hold the same channel; the two M-waves are combined through LDS
         __syncthreads();   // all fragment reads of the last chunk are done: LDS is free
@@ -359,11 +392,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // then 128x64 (layer3: 122 vs 113; layer1's 64-channel 3x3 layers: 98 vs 90), otherwise 64x64 whose 5 resident workgroups per CU hide
 // each other's barrier / refill bubbles (layer4's 4096 pixels, the 1x1 down-sampling layers' short K).
 inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
-    cfg &= 15;               // bit 4 selects the register-staged operand path (A/B tools only)
+    cfg &= 15;               // bit 4 selects the register-staged operand path (A/B tools only), bit 5 the traced build
     const long long mt128 = (M + 127) / 128;
     if (cfg == 1) { bm = 128; bn = 128; }
     else if (cfg == 2) { bm = 128; bn = 64; }
     else if (cfg == 3) { bm = 64; bn = 64; }
+    else if (cfg == 4) { bm = 256; bn = 64; }
     else if (cout % 128 == 0 && kdim >= 512 && mt128 * (cout / 128) >= 512) { bm = 128; bn = 128; }   // (>= 256 would give layer3 128x128 tiles: +3.5 % in isolation, -0.3 % inside the step)
     else if (kdim >= 1024 && mt128 * (cout / 64) >= 512) { bm = 128; bn = 64; }
     else if (cout == 64 && kdim >= 512 && mt128 >= 1024) { bm = 128; bn = 64; }   // layer1: only 64 output channels but 262 144 rows (round 2: 98 vs 90 TFLOP/s forward, 98 vs 94 data gradient, step -0.6 %)
@@ -371,7 +405,7 @@ inline void pick_tile(int cfg, long long M, int cout, int kdim, int& bm, int& bn
     if (cout % bn != 0) bn = 64;
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool TRACE = false>
 int launch(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     p.NT = p.Cout / BN;
@@ -383,11 +417,11 @@ int launch(const ConvP& p0, hipStream_t st) {
     const size_t lds = NS ? (size_t)NS * (BM + BN) * 32 * sizeof(float) : (size_t)2 * (BM + BN) * LS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, NS, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("conv_igemm_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NS>), dim3(maxblk, p.ncls), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NS, TRACE>), dim3(maxblk, p.ncls), dim3(256), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_kernel");
     return STRAPS_OK;
 }
@@ -401,17 +435,30 @@ int dispatch(const ConvP& p, int tile_cfg, hipStream_t st) {
         if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
     }
     pick_tile(tile_cfg, M, p.Cout, kdim, bm, bn);
+    if (tile_cfg & 32) {        // diagnostic build of the LDS-DMA kernel with the shader-clock trace
+        if (bm == 256) return launch<256, 64, 2, true>(p, st);
+        if (bm == 128 && bn == 128) return launch<128, 128, 2, true>(p, st);
+        if (bm == 128 && bn == 64) return launch<128, 64, 2, true>(p, st);
+        return launch<64, 64, 2, true>(p, st);
+    }
     if (tile_cfg & 16) {
         if (bm == 128 && bn == 128) return launch<128, 128, 0>(p, st);
         if (bm == 128 && bn == 64) return launch<128, 64, 0>(p, st);
         return launch<64, 64, 0>(p, st);
     }
+    if (bm == 256) return launch<256, 64, 2>(p, st);
     if (bm == 128 && bn == 128) return launch<128, 128, 2>(p, st);
     if (bm == 128 && bn == 64) return launch<128, 64, 2>(p, st);
     return launch<64, 64, 2>(p, st);
 }
 
 }  // namespace
+
+extern "C" int straps_conv_trace_buffer(long long* trace) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_conv_trace), &trace, sizeof(trace));
+    if (e != hipSuccess) { straps_set_error("straps_conv_trace_buffer: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+    return STRAPS_OK;
+}
 
 extern "C" int straps_conv_stat_blocks(int batch, int ho, int wo, int cout, int kdim, int tile_cfg) {
     int bm, bn;

@@ -88,6 +88,7 @@ SIGNATURES = {
     'straps_stem_nzmask_words': (_Z, [_I, _I, _I, _I]),
     'straps_stem_nzmask': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_stem_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_conv_trace_buffer': (_I, [_P]),
     'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I, _I]),
     'straps_conv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_maxpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),

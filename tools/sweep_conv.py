@@ -50,7 +50,7 @@ for name, H, Cin, Cout, k, stride in SHAPES:
     dx = torch.empty_like(x)
     flops = 2.0 * B * Ho * Ho * Cout * Cin * k * k
     row = '%-18s M=%7d N=%3d K=%4d |' % (name, B * Ho * Ho, Cout, Cin * k * k)
-    for cfg in (1, 2, 3):
+    for cfg in (1, 2, 3, 4):
         if cfg == 1 and Cout % 128:
             row += ' fwd%d   n/a ' % cfg
             continue
@@ -58,7 +58,7 @@ for name, H, Cin, Cout, k, stride in SHAPES:
         t = timeit(lambda: L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wp), None, None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, H, H, Cin, Cout, k, k, stride, pad, cfg, None))
         row += ' fwd%d %5.1f' % (cfg, flops / t / 1e12)
     row += ' |'
-    for cfg in (1, 2, 3):
+    for cfg in (1, 2, 3, 4):
         if cfg == 1 and Cin % 128:
             row += ' dg%d   n/a ' % cfg
             continue
