@@ -258,6 +258,46 @@ int straps_smpl_bwd(const straps_smpl_model_t* model, const float* betas, const 
 int straps_conv_dgrad(const float* dy_nhwc, const float* w_crsk, const float* addend,
                       float* dx_nhwc, int batch, int h, int w, int cin, int cout, int kh, int kw,
                       int stride, int pad, int tile_cfg, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The same implicit-GEMM convolution on the bf16 matrix pipe at fp32 accuracy (csrc/conv_x3.hip):
+ * every fp32 operand is carried as three bf16 planes x = x1 + x2 + x3 (exact, round-to-nearest
+ * splits) and a product is the six bf16 products of weight >= 2^-16, accumulated in fp32 --
+ * relative error <= ~2^-23 per product, the accuracy class of the fp32 chain, at 2.67x its
+ * matrix-pipe rate.  planes: [3][plane_stride] bf16 bit patterns (uint16), plane_stride >= n,
+ * a multiple of 8.  Geometry / epilogue arguments exactly as straps_conv_fwd /
+ * straps_conv_dgrad; x3 / dy3 are the planes of the NHWC tensor, w3 the planes of the packed
+ * weights (straps_pack_conv_weight / straps_pack_conv_weight_dgrad output).
+ * tile_cfg: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128.
+ * ------------------------------------------------------------------------------------------ */
+int straps_split3_bf16(const float* x, unsigned short* planes, long long n, long long plane_stride,
+                       void* stream);
+int straps_conv_x3_stat_blocks(int batch, int ho, int wo, int cout, int kdim, int tile_cfg);
+int straps_conv_fwd_x3(const unsigned short* x3, long long x_plane_stride,
+                       const unsigned short* w3_krsc, long long w_plane_stride, const float* scale,
+                       const float* shift, const float* residual, int relu, float* y_nhwc,
+                       float* stats_partial, int batch, int h, int w, int cin, int cout, int kh,
+                       int kw, int stride, int pad, int tile_cfg, void* stream);
+int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plane_stride,
+                         const unsigned short* w3_crsk, long long w_plane_stride,
+                         const float* addend, float* dx_nhwc, int batch, int h, int w, int cin,
+                         int cout, int kh, int kw, int stride, int pad, int tile_cfg, void* stream);
+/* producers of the bf16x3 route that write their fp32 output AND its three planes in one pass (instead of a
+ * straps_split3_bf16 pass over the output): straps_bn_apply / straps_bn_relu_maxpool_fwd / straps_bn_bwd with
+ * two more arguments (planes [3][plane_stride], plane_stride >= element count, a multiple of 8; draw_planes
+ * may be NULL).                                                                                             */
+int straps_bn_apply_x3(const float* raw, const float* scale, const float* shift, const float* residual,
+                       int relu, float* y, unsigned short* y_planes, long long plane_stride,
+                       long long rows, int c, void* stream);
+int straps_bn_relu_maxpool_fwd_x3(const float* raw, const float* scale, const float* shift,
+                                  float* y_pool, uint8_t* idx, unsigned short* y_planes,
+                                  long long plane_stride, int batch, int h, int w, int c, void* stream);
+int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const float* save_mean,
+                     const float* save_invstd, const float* gamma, const float* mask_scale,
+                     const float* mask_shift, float* dgamma, float* dbeta, float* draw, float* dz_out,
+                     unsigned short* draw_planes, long long plane_stride, void* workspace,
+                     long long rows, int c, int accumulate, void* stream);
+
 /* weight gradient in the parameter's own OIHW layout: dw (+)= sum_pixels dy (x) x.                */
 size_t straps_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int kh,
                                          int kw, int stride, int pad);

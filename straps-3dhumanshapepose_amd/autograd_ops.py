@@ -64,8 +64,9 @@ def _packed_dgrad_weight(net, conv):
     return net._cached(('wd', id(conv)), [w], make)
 
 
-def _bn_bwd(L, rec, dy, masked, want_dz, grads):
-    """BatchNorm(train) + ReLU backward of one tape record; returns (draw, dz|None)."""
+def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None):
+    """BatchNorm(train) + ReLU backward of one tape record; returns (draw, dz|None).
+    planes_sink (bf16x3 route): dict that receives id(draw) -> (draw, planes, plane stride), written by the same kernel pass."""
     bn = rec['bn']
     raw, ss = rec['raw'], rec['stats']
     rows, Cc = raw.numel() // raw.shape[-1], raw.shape[-1]
@@ -76,10 +77,15 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads):
     # ReLU mask: without a residual the activation is relu(raw*scale + shift), so the kernel re-derives it from raw (one
     # tensor read less); with a residual it has to read the stored activation
     from_raw = masked and rec.get('residual') is None
-    hipabi.check(L.straps_bn_bwd(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked and not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
-                                 hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
-                                 hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw),
-                                 hipabi.ptr(dz), hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
+    planes, ps = None, 0
+    if planes_sink is not None:
+        ps = (draw.numel() + 7) // 8 * 8
+        planes = torch.empty(3, ps, device=draw.device, dtype=torch.int16)
+        planes_sink[id(draw)] = (draw, planes, ps)
+    hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked and not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
+                                    hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
+                                    hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw),
+                                    hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
     grads[bn.weight] = dgamma
     grads[bn.bias] = dbeta
     return draw, dz
@@ -95,10 +101,21 @@ def _conv_wgrad(L, rec, draw, grads):
     grads[conv.weight] = dw
 
 
-def _conv_dgrad(L, net, rec, draw, addend):
+def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None):
     conv = rec['conv']
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     dx = torch.empty(B, H, W, Cin, device=draw.device, dtype=torch.float32)
+    if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
+        hit = planes_sink.pop(id(draw), None) if planes_sink is not None else None
+        if hit is not None and hit[0] is draw:
+            g3, gps = hit[1], hit[2]
+        else:
+            from .encoder_exec import split3
+            g3, gps = split3(L, draw)
+        w3, wps = net._packed_weight_x3(conv, dgrad=True)
+        hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(dx), B, H, W, Cin, Cout,
+                                            k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_dgrad_x3')
+        return dx
     hipabi.check(L.straps_conv_dgrad(hipabi.ptr(draw), hipabi.ptr(_packed_dgrad_weight(net, conv)), hipabi.ptr(addend), hipabi.ptr(dx), B, H, W,
                                      Cin, Cout, k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_dgrad')
     return dx
@@ -112,6 +129,7 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
     L = hipabi.lib()
     grads = GradSink(views)
     side = _SideStream(side_stream)
+    sink = {} if getattr(net, 'conv_precision', 'fp32') == 'bf16x3' else None      # planes of the gradients the data-gradient kernels read
     rec = tape['gap']
     B, HW, Cf = rec['geom']
     dy = _empty_like(rec['x'])
@@ -120,21 +138,21 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
         for unit in reversed(list(getattr(net, 'layer%d' % li))):
             pairs = unit.conv_bn_pairs()
             rec = tape[id(pairs[-1][0])]
-            draw, dz = _bn_bwd(L, rec, dy, True, True, grads)          # ReLU(out) mask; dz feeds the skip connection
+            draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink)    # ReLU(out) mask; dz feeds the skip connection
             side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads), draw)
             if unit.downsample is not None:
                 recd = tape[id(unit.downsample[0])]
-                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads)
+                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink)
                 side.run(lambda recd=recd, drawd=drawd: _conv_wgrad(L, recd, drawd, grads), drawd)
-                dskip = _conv_dgrad(L, net, recd, drawd, None)
+                dskip = _conv_dgrad(L, net, recd, drawd, None, sink)
             else:
                 dskip = dz
             for ci in range(len(pairs) - 1, 0, -1):
-                dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None)
+                dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None, sink)
                 rec = tape[id(pairs[ci - 1][0])]
-                draw, _ = _bn_bwd(L, rec, dt, True, False, grads)
+                draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink)
                 side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads), draw)
-            dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip)   # + skip gradient fused in the epilogue
+            dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink)   # + skip gradient fused in the epilogue
         if li == 3 and after_layer3 is not None:
             side.join()
             after_layer3()

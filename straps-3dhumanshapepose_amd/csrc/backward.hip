@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const double* __restrict__ coefd,
                                                            const float* __restrict__ k1p, const float* __restrict__ msc,
                                                            const float* __restrict__ msh, float* __restrict__ draw, float* dz_out,
-                                                           long long n4, int C, PoolSrc ps) {
+                                                           u16* __restrict__ planes, long long pstride, long long n4, int C, PoolSrc ps) {
     const int C4 = C >> 2;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
         const int c4 = (int)(idx % C4);
@@ -766,6 +766,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         }
         if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = g;
         *reinterpret_cast<f32x4*>(draw + idx * 4) = o;
+        if (planes) store_planes4(planes, pstride, idx * 4, o);      // bf16x3 route: the data-gradient kernel's operand
     }
 }
 
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(256) void maxpool_idx_kernel(const float* __restric
 // sequence as straps_bn_apply followed by straps_maxpool_fwd_idx: bit-identical outputs and arg-max taps.
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ y, uint8_t* __restrict__ idx,
-                                                              int B, int H, int W, int C, int Ho, int Wo) {
+                                                              u16* __restrict__ planes, long long pstride, int B, int H, int W, int C, int Ho, int Wo) {
     const int C4 = C >> 2;
     const long long n = (long long)B * Ho * Wo * C4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -844,6 +845,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
         }
         *reinterpret_cast<f32x4*>(y + i * 4) = m;
         *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4((unsigned char)am[0], (unsigned char)am[1], (unsigned char)am[2], (unsigned char)am[3]);
+        if (planes) store_planes4(planes, pstride, i * 4, m);
     }
 }
 
@@ -1207,9 +1209,11 @@ extern "C" int straps_bn_bwd_blocks(long long rows, int c) {
     return (int)(b < 1 ? 1 : b);
 }
 
-extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
-                             const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
-                             float* dz_out, void* workspace, long long rows, int c, int accumulate, void* stream) {
+extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
+                                const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
+                                float* dz_out, unsigned short* draw_planes, long long plane_stride, void* workspace, long long rows, int c,
+                                int accumulate, void* stream) {
+    STRAPS_REQUIRE(!draw_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "straps_bn_bwd_x3: plane_stride must be >= rows*c and a multiple of 8");
     STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && draw && workspace, "straps_bn_bwd: null pointer");
     STRAPS_REQUIRE(rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd: bad shape rows=%lld c=%d", rows, c);
     const int C4 = c >> 2;
@@ -1225,9 +1229,16 @@ extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* ra
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, n4, c, PoolSrc{});
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
+}
+
+extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
+                             const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
+                             float* dz_out, void* workspace, long long rows, int c, int accumulate, void* stream) {
+    return straps_bn_bwd_x3(dy, yact, raw, save_mean, save_invstd, gamma, mask_scale, mask_shift, dgamma, dbeta, draw, dz_out, nullptr, 0, workspace,
+                            rows, c, accumulate, stream);
 }
 
 extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, const float* raw, const float* save_mean, const float* save_invstd,
@@ -1251,19 +1262,25 @@ extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, co
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(capped_grid(n4)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, n4, c, ps);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(capped_grid(n4)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel<pool>");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_relu_maxpool_fwd_x3(const float* raw, const float* scale, const float* shift, float* y_pool, uint8_t* idx,
+                                             unsigned short* y_planes, long long plane_stride, int batch, int h, int w, int c, void* stream) {
+    STRAPS_REQUIRE(raw && scale && shift && y_pool && idx && batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0, "straps_bn_relu_maxpool_fwd: bad arguments");
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const long long n = (long long)batch * Ho * Wo * (c >> 2);
+    STRAPS_REQUIRE(!y_planes || (plane_stride >= n * 4 && plane_stride % 8 == 0), "straps_bn_relu_maxpool_fwd_x3: plane_stride must be >= the output size and a multiple of 8");
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, y_pool, idx, y_planes, plane_stride, batch, h, w, c, Ho, Wo);
+    STRAPS_CHECK_LAUNCH("bn_relu_maxpool_kernel");
     return STRAPS_OK;
 }
 
 extern "C" int straps_bn_relu_maxpool_fwd(const float* raw, const float* scale, const float* shift, float* y_pool, uint8_t* idx, int batch, int h,
                                           int w, int c, void* stream) {
-    STRAPS_REQUIRE(raw && scale && shift && y_pool && idx && batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0, "straps_bn_relu_maxpool_fwd: bad arguments");
-    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
-    const long long n = (long long)batch * Ho * Wo * (c >> 2);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, y_pool, idx, batch, h, w, c, Ho, Wo);
-    STRAPS_CHECK_LAUNCH("bn_relu_maxpool_kernel");
-    return STRAPS_OK;
+    return straps_bn_relu_maxpool_fwd_x3(raw, scale, shift, y_pool, idx, nullptr, 0, batch, h, w, c, stream);
 }
 
 extern "C" size_t straps_bn_bwd_workspace_bytes(long long rows, int c) {

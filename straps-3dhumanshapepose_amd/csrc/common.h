@@ -71,4 +71,33 @@ __device__ __forceinline__ bool bn_partials_sum4(const T* __restrict__ part, int
     return true;
 }
 
+// ---- three-plane bf16 representation of an fp32 value (csrc/conv_x3.hip): x = b1 + b2 + b3 exactly, round-to-nearest-even splits
+typedef unsigned short u16;
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u16 bf16_rn(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ void split3(float x, u16& b1, u16& b2, u16& b3) {
+    b1 = bf16_rn(x);
+    const float r1 = x - __uint_as_float((unsigned)b1 << 16);       // exact
+    b2 = bf16_rn(r1);
+    const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);      // exact; at most 8 significant bits are left
+    b3 = bf16_rn(r2);
+}
+// four consecutive values -> the three planes at element offset i (i % 4 == 0, planes 8-byte aligned)
+__device__ __forceinline__ void store_planes4(u16* __restrict__ planes, long long ps, long long i, const f32x4& v) {
+    u16x4 q1, q2, q3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u16 b1, b2, b3;
+        split3(v[e], b1, b2, b3);
+        q1[e] = b1; q2[e] = b2; q3[e] = b3;
+    }
+    *reinterpret_cast<u16x4*>(planes + i) = q1;
+    *reinterpret_cast<u16x4*>(planes + ps + i) = q2;
+    *reinterpret_cast<u16x4*>(planes + 2 * ps + i) = q3;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -16,35 +16,10 @@
 //   Epilogue (C layout: lane = output channel, reg = pixel row): BN scale/shift, residual/addend, ReLU fused;
 //   raw output + per-channel (sum, sumsq) partials in training mode.
 //   Block ids are remapped so that consecutive tiles (same A rows / neighbouring halos) share an XCD's L2.
-#include "common.h"
-#include <type_traits>
+#include "conv_igemm.h"
 
 namespace {
 
-struct ConvP {
-    const float* x;
-    const float* w;
-    const float* scale;
-    const float* shift;
-    const float* res;
-    float* y;
-    float* stats;
-    int H, W, Cin, Cout, relu;      // source tensor [B][H][W][Cin]
-    int stride;                     // source pixel of logical (ho,wo) before the tap offset: (ho*stride, wo*stride)
-    int OH, OW, omul;               // physical output pixel = (b, ho*omul + oah, wo*omul + oaw) in [B][OH][OW][Cout]
-    int NT, wtaps;                  // N tiles; taps stored per output channel in w
-    // Up to four independent sub-problems per launch (blockIdx.y): the output-parity classes of a stride-2 data gradient
-    // are GEMMs over a quarter of the pixels each with their own tap subset -- launched together they fill the chip
-    // instead of queueing as four small grids.  A forward conv / stride-1 gradient is the single class 0.
-    struct Class {
-        int Mh, Mw;                 // logical output grid enumerated by M = B*Mh*Mw
-        int M, MT;
-        int oah, oaw;
-        int ntaps;                  // taps used
-        int tap_w[9], tap_dh[9], tap_dw[9];
-    } cls[4];
-    int ncls;
-};
 
 constexpr int LS = 36;   // LDS row stride in floats (32 data + 4 pad)
 
@@ -283,77 +258,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
 
     // ---------------- epilogue ----------------
-    const bool remap = p.omul != 1 || coah != 0 || coaw != 0 || p.OH != cMh || p.OW != cMw;
-    float s1[NI], s2[NI], sc[NI], sh[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-        sc[j] = p.scale ? p.scale[n] : 1.f;
-        sh[j] = p.shift ? p.shift[n] : 0.f;
-        s1[j] = 0.f;
-        s2[j] = 0.f;
-    }
-    // (32-bit element offsets, see the launcher's size check; an M tile that lies inside the problem skips the per-row test)
-    const bool full = m0 + BM <= cM;
-    auto rows = [&](auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            // the lane's 16 rows are m = mb + (r & 3) + 8 * (r >> 2): the physical pixel of a remapped output (a parity class of
-            // a stride-2 data gradient) is found by division once and then walked row by row
-            const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
-            int b_ = 0, ho_ = 0, wo_ = 0;
-            if (remap) {
-                b_ = mb / MhMw;
-                const int rem = mb - b_ * MhMw;
-                ho_ = rem / cMw;
-                wo_ = rem - ho_ * cMw;
-            }
-            int pixr[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pixr[r] = mb + (r & 3) + 8 * (r >> 2);
-                if (remap) {
-                    pixr[r] = (b_ * p.OH + ho_ * p.omul + coah) * p.OW + wo_ * p.omul + coaw;
-                    wo_ += (r & 3) == 3 ? 5 : 1;
-                    while (wo_ >= cMw) {
-                        wo_ -= cMw;
-                        if (++ho_ == cMh) { ho_ = 0; ++b_; }
-                    }
-                }
-            }
-            // the residual / skip-gradient values of all 16 rows are fetched before the first store: p.res may alias p.y (in
-            // place), so the compiler would otherwise serialise load -> store -> load through 16 memory round trips
-            float rv[16][NI];
-            if (p.res) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int m = mb + (r & 3) + 8 * (r >> 2);
-                        rv[r][j] = (FULL || m < cM) ? p.res[pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31)] : 0.f;
-                    }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (FULL || m < cM) {
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int o = pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
-                        float v = acc[i][j][r];
-                        s1[j] += v;
-                        s2[j] = fmaf(v, v, s2[j]);
-                        if (p.scale) v = fmaf(v, sc[j], sh[j]);
-                        if (p.res) v += rv[r][j];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        p.y[o] = v;
-                    }
-                }
-            }
-        }
-    };
-    if (full) rows(std::true_type{}); else rows(std::false_type{});
+    float s1[NI], s2[NI];
+    igemm_store_rows<BM, BN>(p, c, acc, m0, n0, s1, s2);
     if constexpr (TRACE) {
         long long* trp = (long long*)(((unsigned long long)g_conv_trace) & ~1ull);
         if (trp && tid == 0 && blockIdx.y == 0) {
@@ -363,27 +269,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
             for (int k = 0; k < 8; ++k) trp[(long long)blockIdx.x * 8 + k] = tr[k];
         }
     }
-    if (p.stats) {
-        // lanes l and l+32 hold the same channel; the two M-waves are combined through LDS
-        __syncthreads();   // all fragment reads of the last chunk are done: LDS is free
-        float* red = smem;   // [2 (wm)][BN][2]
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const float u1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-            const float u2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-            if (lane < 32) {
-                const int c = wn * WTN + j * 32 + lane;
-                red[(wm * BN + c) * 2 + 0] = u1;
-                red[(wm * BN + c) * 2 + 1] = u2;
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            float* o = p.stats + ((long long)mt * p.Cout + n0 + tid) * 2;
-            o[0] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
-            o[1] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-        }
-    }
+    igemm_store_stats<BM, BN>(p, s1, s2, mt, n0, smem);
 }
 
 // tile choice from the per-layer sweeps (tools/sweep_conv.py, tools/sweep_igemm_staging.py, B=64): the larger the tile the fewer
@@ -476,20 +362,9 @@ extern "C" int straps_conv_fwd(const float* x, const float* w, const float* scal
     STRAPS_REQUIRE(kh >= 1 && kw >= 1 && kh * kw <= 9 && stride >= 1 && pad >= 0, "straps_conv_fwd: bad filter geometry");
     STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_conv_fwd: scale and shift must be given together");
     ConvP p;
-    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
-    p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
-    ConvP::Class& c = p.cls[0];
-    p.ncls = 1;
-    c.Mh = (h + 2 * pad - kh) / stride + 1;
-    c.Mw = (wdt + 2 * pad - kw) / stride + 1;
-    p.OH = c.Mh; p.OW = c.Mw; p.omul = 1; c.oah = 0; c.oaw = 0;
-    c.ntaps = p.wtaps = kh * kw;
-    for (int r = 0; r < kh; ++r)
-        for (int s = 0; s < kw; ++s) { c.tap_w[r * kw + s] = r * kw + s; c.tap_dh[r * kw + s] = r - pad; c.tap_dw[r * kw + s] = s - pad; }
-    const long long M = (long long)batch * c.Mh * c.Mw;
-    STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 31) && M * cout < (1LL << 31),
-                   "straps_conv_fwd: tensors must stay below 2^31 elements (32-bit offsets)");
-    c.M = (int)M;
+    p.x = x; p.w = w;
+    const int rc = conv_fwd_problem(p, scale, shift, residual, relu, y, stats_partial, batch, h, wdt, cin, cout, kh, kw, stride, pad);
+    if (rc != STRAPS_OK) return rc;
     return dispatch(p, tile_cfg, (hipStream_t)stream);
 }
 
@@ -504,52 +379,10 @@ extern "C" int straps_conv_dgrad(const float* dy, const float* w_crsk, const flo
     STRAPS_REQUIRE(cout % 32 == 0 && cin % 64 == 0, "straps_conv_dgrad: need cout%%32==0 and cin%%64==0 (cin=%d cout=%d)", cin, cout);
     STRAPS_REQUIRE(stride == 1 || stride == 2, "straps_conv_dgrad: stride must be 1 or 2");
     STRAPS_REQUIRE(kh * kw <= 9 && kh - 1 - pad >= 0 && kw - 1 - pad >= 0, "straps_conv_dgrad: unsupported filter geometry");
-    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (wdt + 2 * pad - kw) / stride + 1;
-    const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     hipStream_t st = (hipStream_t)stream;
     ConvP p;
-    p.x = dy; p.w = w_crsk; p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
-    p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
-    p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
-    p.omul = stride;
-    p.ncls = 0;
-    for (int ph = 0; ph < stride; ++ph) {
-        for (int pw = 0; pw < stride; ++pw) {
-            ConvP::Class& c = p.cls[p.ncls];
-            c.Mh = (h - ph + stride - 1) / stride;
-            c.Mw = (wdt - pw + stride - 1) / stride;
-            if (c.Mh <= 0 || c.Mw <= 0) continue;
-            c.oah = ph; c.oaw = pw;
-            c.ntaps = 0;
-            for (int r = 0; r < kh; ++r) {
-                const int nh = ph - padh + r;                 // source row numerator of logical row 0
-                if (((nh % stride) + stride) % stride) continue;
-                for (int s = 0; s < kw; ++s) {
-                    const int nw = pw - padw + s;
-                    if (((nw % stride) + stride) % stride) continue;
-                    c.tap_w[c.ntaps] = r * kw + s;
-                    c.tap_dh[c.ntaps] = (nh - (((nh % stride) + stride) % stride)) / stride;   // exact: nh divisible
-                    c.tap_dw[c.ntaps] = (nw - (((nw % stride) + stride) % stride)) / stride;
-                    // floor division for negative numerators
-                    if (nh < 0) c.tap_dh[c.ntaps] = -((-nh) / stride);
-                    if (nw < 0) c.tap_dw[c.ntaps] = -((-nw) / stride);
-                    ++c.ntaps;
-                }
-            }
-            const long long M = (long long)batch * c.Mh * c.Mw;
-            STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * ho * wo * cout < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 31),
-                           "straps_conv_dgrad: tensors must stay below 2^31 elements (32-bit offsets)");
-            c.M = (int)M;
-            ++p.ncls;
-        }
-    }
-    // heaviest class first (blockIdx.y = 0 is dispatched first): the 4-tap class of a 3x3/s2 gradient runs four times as long per
-    // workgroup as the 1-tap one -- started last it would be the launch's tail
-    for (int a = 1; a < p.ncls; ++a)
-        for (int b = a; b > 0 && (long long)p.cls[b].ntaps * p.cls[b].M > (long long)p.cls[b - 1].ntaps * p.cls[b - 1].M; --b) {
-            const ConvP::Class t = p.cls[b];
-            p.cls[b] = p.cls[b - 1];
-            p.cls[b - 1] = t;
-        }
+    p.x = dy; p.w = w_crsk;
+    const int rc = conv_dgrad_problem(p, addend, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad);
+    if (rc != STRAPS_OK) return rc;
     return p.ncls ? dispatch(p, tile_cfg, st) : STRAPS_OK;
 }

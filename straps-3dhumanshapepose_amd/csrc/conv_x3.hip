@@ -1,0 +1,351 @@
+// conv_x3.hip -- the implicit-GEMM convolution of conv.hip on the bf16 matrix pipe at fp32 accuracy.
+//
+//   Every fp32 operand value is carried as three bf16 planes  x = x1 + x2 + x3  (round-to-nearest splits: the sum is EXACT, 3 x 8
+//   significand bits cover fp32's 24; bf16 has fp32's exponent, so no scaling and no range analysis is needed; only below 2^-110 do
+//   the last bits fall under bf16's smallest subnormal: absolute error <= 2^-133 there), and a product
+//   a*b is evaluated as the six bf16 products of weight >= 2^-16
+//        a1*b1 + a1*b2 + a2*b1 + a1*b3 + a3*b1 + a2*b2          (dropped: a2*b3 + a3*b2 + a3*b3 <= 2^-23 |a*b|)
+//   each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Six 32-cycle instructions do the work of eight 64-cycle
+//   v_mfma_f32_32x32x2_f32: 2.67x the exact-fp32 pipe at the same accuracy class (measured error vs float64: tests/test_gpu_conv_x3.py).
+//   The planes are separate [pixels][C] bf16 tensors (straps_split3_bf16 writes them; 6 bytes per element instead of 4).
+//
+//   Same structure as conv.hip: tap table, LDS-DMA operand copies (a 32-channel K chunk of one plane is 64 contiguous bytes of one
+//   pixel -> 4 lanes x 16 bytes), two stages, one barrier per chunk, XOR-swizzled 64-byte rows read back as one ds_read_b128 per
+//   (32-row block, plane, 16-wide k step), the shared epilogue of conv_igemm.h.  The copies of chunk q+1 are issued between the
+//   MFMAs of chunk q (a chunk's matrix work is only 6 x 2 x MI x NI x 32 cycles: issued in front of it they would cost as much
+//   as the burst itself).
+#include "conv_igemm.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+__device__ __attribute__((aligned(16))) float k_zero16_x3[4] = {0.f, 0.f, 0.f, 0.f};   // source of the padding pixels
+
+// slot swizzle of a 64-byte row (four 16-byte K groups): ds_read_b128 is serviced in groups of 16 lanes -- rows {0-3,12-15,20-27},
+// {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS table) -- over 64 banks = four rows: the four rows of a group that share r & 3 must
+// use four different slots; bits 3 and 4 of the row number separate them in both groups.
+__device__ __forceinline__ int swz3(int r) { return (r >> 3) & 3; }
+
+// ABL (tools only, wrong results): 1 = no MFMAs and no fragment reads (prices the operand copies alone), 2 = no operand copies
+//   (prices the matrix work + fragment reads alone), 3 = neither copies nor fragment reads (the MFMA stream + barriers alone)
+template <int BM, int BN, int WGM, int WGN, int NST, int ABL = 0>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) {
+    const ConvP::Class& c = p.cls[blockIdx.y];
+    const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, cntaps = c.ntaps;
+    if ((int)blockIdx.x >= cMT * p.NT) return;                 // a smaller class of the same launch
+    constexpr int NW = WGM * WGN, RPP = 16 * NW;               // waves; rows per copy pass (4 lanes x 16 bytes per 64-byte row)
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
+    constexpr int AP = BM / RPP, BP = BN / RPP;                // copy passes
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile / wave grid mismatch");
+    constexpr int NPIECE = 3 * (AP + BP);                      // LDS-DMA instructions per thread and chunk
+    constexpr int NMFMA = 2 * 6 * MI * NI;
+    constexpr int GAP = NMFMA / NPIECE > 0 ? NMFMA / NPIECE : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* As = reinterpret_cast<u16*>(smem);       // [NST stages][3 planes][BM][32]
+    u16* Bs = As + NST * 3 * BM * 32;             // [NST stages][3 planes][BN][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int bid = xcd_remap(blockIdx.x, cMT * p.NT);
+    const int nt = bid % p.NT, mt = bid / p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int lr = tid >> 2;                                   // row of the RPP-row pass this thread copies
+    const int lc = (tid & 3) ^ swz3(lr);                       // 16-byte K group it fetches for its slot tid & 3
+    const u16* xg = reinterpret_cast<const u16*>(p.x);
+    const u16* wg = reinterpret_cast<const u16*>(p.w);
+
+    int a_hi0[AP], a_wi0[AP], a_base[AP];
+    const int MhMw = cMh * cMw;
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int m = m0 + lr + RPP * q;
+        if (m < cM) {
+            const int b = m / MhMw;
+            const int rem = m - b * MhMw;
+            const int ho = rem / cMw, wo = rem - ho * cMw;
+            a_hi0[q] = ho * p.stride;
+            a_wi0[q] = wo * p.stride;
+            a_base[q] = ((b * p.H + a_hi0[q]) * p.W + a_wi0[q]) * p.Cin + lc * 8;
+        } else {
+            a_hi0[q] = -(1 << 28);
+            a_wi0[q] = 0;
+            a_base[q] = 0;
+        }
+    }
+    const u16* wrow[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) wrow[q] = wg + (long long)(n0 + lr + RPP * q) * p.wtaps * p.Cin + lc * 8;
+
+    const int cchunks = p.Cin >> 5;
+    const int nchunks = cntaps * cchunks;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    const u16* a_src[AP];
+    long long a_ps[AP];            // plane stride, 0 for a padding pixel (all three planes read the zero constant)
+    int a_inc[AP];
+    const u16* b_src[BP];
+    int n_tap = 0, n_cc = 0;
+    const int tl = lane < 9 ? lane : 0;
+    const int v_dh = c.tap_dh[tl], v_dw = c.tap_dw[tl], v_tw = c.tap_w[tl];
+    const u16* zsrc = reinterpret_cast<const u16*>(k_zero16_x3);
+    asm volatile("" : "+s"(zsrc));
+    auto setup_tap = [&](int tap) {
+        const int dh = __builtin_amdgcn_readlane(v_dh, tap), dw = __builtin_amdgcn_readlane(v_dw, tap), tw = __builtin_amdgcn_readlane(v_tw, tap);
+        const int toff = (dh * p.W + dw) * p.Cin;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            a_src[i] = ok ? xg + (a_base[i] + toff) : zsrc;
+            a_ps[i] = ok ? p.xps : 0;
+            a_inc[i] = ok ? 32 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) b_src[i] = wrow[i] + tw * p.Cin;
+    };
+    // copy piece `idx` (compile-time after unrolling) of the next chunk: planes outermost, A passes then B passes
+    auto piece = [&](int stage, int idx) {
+        if constexpr (ABL == 2 || ABL == 3) return;
+        const int plane = idx / (AP + BP), r = idx % (AP + BP);
+        if (r < AP) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[r] + plane * a_ps[r]),
+                                             (__attribute__((address_space(3))) void*)(As + ((stage * 3 + plane) * BM + RPP * r + 16 * wave_u) * 32), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[r - AP] + plane * p.wps),
+                                             (__attribute__((address_space(3))) void*)(Bs + ((stage * 3 + plane) * BN + RPP * (r - AP) + 16 * wave_u) * 32), 16, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) a_src[i] += a_inc[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i) b_src[i] += 32;
+        if (++n_cc == cchunks) {
+            n_cc = 0;
+            if (++n_tap < cntaps) setup_tap(n_tap);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // chunk q lives in stage q % NST; the copies run NST - 1 chunks ahead of the matrix work
+    if (nchunks > 0) setup_tap(0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nchunks) {
+#pragma unroll
+            for (int idx = 0; idx < NPIECE; ++idx) piece(s, idx);
+            advance();
+        }
+    int fo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ swz3(lane & 31)) << 3);
+
+    // plane pairs of the six products, smallest terms first
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+
+    // MORE: chunk q + NST - 1 exists and is issued between this chunk's MFMAs into the stage that chunk q - 1 was read from.
+    // INFLIGHT: copies of younger chunks that may stay outstanding while this chunk's are awaited (the counter retires in order).
+    auto chunk = [&](int stage, int nstage, auto more_c, auto inflight_c) {
+        constexpr bool MORE = decltype(more_c)::value;
+        constexpr int INFLIGHT = decltype(inflight_c)::value;
+        // my copies of this chunk have landed, then everybody's have -- and every wave is done reading the stage refilled next
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const u16* Ab = As + (stage * 3 * BM + wm * WTM) * 32;
+        const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
+        int cnt = 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[MI][3], b[NI][3];
+            if constexpr (ABL == 3) {      // no fragment reads either: the matrix work on whatever the registers hold
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) asm volatile("" : "=v"(a[i][pl]));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) asm volatile("" : "=v"(b[j][pl]));
+                }
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3 && ABL != 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + (pl * BM + i * 32) * 32 + fo[kk]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + (pl * BN + j * 32) * 32 + fo[kk]);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        if constexpr (ABL != 1) acc[i][j] = mfma_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j]);
+                        if (MORE && cnt % GAP == GAP - 1 && cnt / GAP < NPIECE) piece(nstage, cnt / GAP);
+                        ++cnt;
+                    }
+        }
+        if (MORE) {
+#pragma unroll
+            for (int idx = NMFMA / GAP; idx < NPIECE; ++idx) piece(nstage, idx);
+            advance();
+        }
+    };
+    int stage = 0, nstage = NST - 1;
+    auto next = [&]() {
+        stage = stage + 1 == NST ? 0 : stage + 1;
+        nstage = nstage + 1 == NST ? 0 : nstage + 1;
+    };
+    int q = 0;
+    for (; q + NST - 1 < nchunks; ++q) { chunk(stage, nstage, std::true_type{}, std::integral_constant<int, (NST - 2) * NPIECE>{}); next(); }
+    if constexpr (NST == 3) {
+        if (q + 1 < nchunks) { chunk(stage, nstage, std::false_type{}, std::integral_constant<int, NPIECE>{}); next(); ++q; }
+    }
+    if (q < nchunks) chunk(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{});
+
+    float s1[NI], s2[NI];
+    igemm_store_rows<BM, BN, WGM, WGN>(p, c, acc, m0, n0, s1, s2);
+    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, int ABL = 0>
+int launch_x3(const ConvP& p0, hipStream_t st) {
+    ConvP p = p0;
+    p.NT = p.Cout / BN;
+    int maxblk = 0;
+    for (int i = 0; i < p.ncls; ++i) {
+        p.cls[i].MT = (p.cls[i].M + BM - 1) / BM;
+        if (p.cls[i].MT * p.NT > maxblk) maxblk = p.cls[i].MT * p.NT;
+    }
+    const size_t lds = (size_t)NST * 3 * (BM + BN) * 32 * sizeof(u16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { straps_set_error("conv_igemm_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL>), dim3(maxblk, p.ncls), dim3(64 * WGM * WGN), lds, st, p);
+    STRAPS_CHECK_LAUNCH("conv_igemm_x3_kernel");
+    return STRAPS_OK;
+}
+
+// tile_cfg & 15: 0 = auto, 1 = 128x128 (8 waves, 3 stages), 2 = 128x64 (4 waves, 2 stages, two workgroups per CU), 3 = 64x64 (4 waves, 3 stages),
+// 4 = 256x128 (8 waves, 2 stages), 5 = 128x128 (4 waves, 3 stages), 6 = 256x128 (4 waves, 2 stages), 7 = 128x64 (4 waves, 3 stages)
+// auto rule from tools/sweep_conv_x3.py (resnet18 shapes, B = 64): 64-channel outputs take 128x64 tiles, two workgroups per CU; otherwise
+// the largest tile that still gives every CU a workgroup: 256x128 from 512 128x128-tiles on (layer2: 63 vs 68 us), 128x128 from 256
+// (layer3: 97 vs 108), else 128x64 with the three-stage ring (layer4's 4096 pixels: 113 vs 150).
+inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
+    (void)kdim;
+    cfg &= 15;
+    if (cfg == 0) {
+        const long long t128 = ((M + 127) / 128) * (cout / 128);
+        cfg = cout % 128 != 0 ? 2 : t128 >= 512 ? 4 : t128 >= 256 ? 5 : 7;
+    }
+    if (cout % 128 != 0 && cfg != 3 && cfg != 7) cfg = 2;
+    bm = (cfg == 4 || cfg == 6) ? 256 : cfg == 3 ? 64 : 128;
+    bn = (cfg == 2 || cfg == 3 || cfg == 7) ? 64 : 128;
+    return cfg;
+}
+
+template <int ABL>
+int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 1: return launch_x3<128, 128, 4, 2, 3, ABL>(p, st);
+        case 2: return launch_x3<128, 64, 2, 2, 2, ABL>(p, st);
+        case 3: return launch_x3<64, 64, 2, 2, 3, ABL>(p, st);
+        case 4: return launch_x3<256, 128, 4, 2, 2, ABL>(p, st);
+        case 5: return launch_x3<128, 128, 2, 2, 3, ABL>(p, st);
+        case 6: return launch_x3<256, 128, 2, 2, 2, ABL>(p, st);
+        default: return launch_x3<128, 64, 2, 2, 3, ABL>(p, st);
+    }
+}
+
+int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
+    int bm, bn, kdim = 0;
+    long long M = 0;
+    for (int i = 0; i < p.ncls; ++i) {
+        M += p.cls[i].M;
+        if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
+    }
+    const int cfg = pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn);
+    if ((tile_cfg & 192) == 192) return dispatch_x3_abl<3>(p, cfg, st);      // ablations (tools)
+    if (tile_cfg & 64) return dispatch_x3_abl<1>(p, cfg, st);
+    if (tile_cfg & 128) return dispatch_x3_abl<2>(p, cfg, st);
+    return dispatch_x3_abl<0>(p, cfg, st);
+}
+
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, u16* __restrict__ o, long long n, long long ps) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        store_planes4(o, ps, i4, *reinterpret_cast<const f32x4*>(x + i4));
+    } else {
+        for (long long i = i4; i < n; ++i) {
+            u16 b1, b2, b3;
+            split3(x[i], b1, b2, b3);
+            o[i] = b1; o[ps + i] = b2; o[2 * ps + i] = b3;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int straps_split3_bf16(const float* x, unsigned short* planes, long long n, long long plane_stride, void* stream) {
+    STRAPS_REQUIRE(x && planes, "straps_split3_bf16: null pointer");
+    STRAPS_REQUIRE(n >= 0 && plane_stride >= n && plane_stride % 8 == 0, "straps_split3_bf16: plane_stride must be >= n and a multiple of 8");
+    if (n == 0) return STRAPS_OK;
+    STRAPS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15) == 0, "straps_split3_bf16: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(split3_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, planes, n, plane_stride);
+    STRAPS_CHECK_LAUNCH("split3_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_conv_fwd_x3(const unsigned short* x3, long long x_plane_stride, const unsigned short* w3, long long w_plane_stride,
+                                  const float* scale, const float* shift, const float* residual, int relu, float* y, float* stats_partial,
+                                  int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg, void* stream) {
+    STRAPS_REQUIRE(x3 && w3 && y, "straps_conv_fwd_x3: null pointer");
+    STRAPS_REQUIRE(batch > 0 && h > 0 && wdt > 0, "straps_conv_fwd_x3: empty input %dx%dx%d", batch, h, wdt);
+    STRAPS_REQUIRE(cin % 32 == 0 && cout % 64 == 0, "straps_conv_fwd_x3: need cin%%32==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
+    STRAPS_REQUIRE(kh >= 1 && kw >= 1 && kh * kw <= 9 && stride >= 1 && pad >= 0, "straps_conv_fwd_x3: bad filter geometry");
+    STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_conv_fwd_x3: scale and shift must be given together");
+    STRAPS_REQUIRE(x_plane_stride % 8 == 0 && w_plane_stride % 8 == 0, "straps_conv_fwd_x3: plane strides must be multiples of 8 elements");
+    ConvP p;
+    p.x = reinterpret_cast<const float*>(x3); p.w = reinterpret_cast<const float*>(w3);
+    p.xps = x_plane_stride; p.wps = w_plane_stride;
+    const int rc = conv_fwd_problem(p, scale, shift, residual, relu, y, stats_partial, batch, h, wdt, cin, cout, kh, kw, stride, pad);
+    if (rc != STRAPS_OK) return rc;
+    return dispatch_x3(p, tile_cfg, (hipStream_t)stream);
+}
+
+extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                                    const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
+                                    int pad, int tile_cfg, void* stream) {
+    STRAPS_REQUIRE(dy3 && w3_crsk && dx, "straps_conv_dgrad_x3: null pointer");
+    STRAPS_REQUIRE(cout % 32 == 0 && cin % 64 == 0, "straps_conv_dgrad_x3: need cout%%32==0 and cin%%64==0 (cin=%d cout=%d)", cin, cout);
+    STRAPS_REQUIRE(stride == 1 || stride == 2, "straps_conv_dgrad_x3: stride must be 1 or 2");
+    STRAPS_REQUIRE(kh * kw <= 9 && kh - 1 - pad >= 0 && kw - 1 - pad >= 0, "straps_conv_dgrad_x3: unsupported filter geometry");
+    STRAPS_REQUIRE(dy_plane_stride % 8 == 0 && w_plane_stride % 8 == 0, "straps_conv_dgrad_x3: plane strides must be multiples of 8 elements");
+    ConvP p;
+    p.x = reinterpret_cast<const float*>(dy3); p.w = reinterpret_cast<const float*>(w3_crsk);
+    p.xps = dy_plane_stride; p.wps = w_plane_stride;
+    const int rc = conv_dgrad_problem(p, addend, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad);
+    if (rc != STRAPS_OK) return rc;
+    return p.ncls ? dispatch_x3(p, tile_cfg, (hipStream_t)stream) : STRAPS_OK;
+}
+
+extern "C" int straps_conv_x3_stat_blocks(int batch, int ho, int wo, int cout, int kdim, int tile_cfg) {
+    int bm, bn;
+    const long long M = (long long)batch * ho * wo;
+    pick_tile_x3(tile_cfg, M, cout, kdim, bm, bn);
+    return (int)((M + bm - 1) / bm);
+}

@@ -23,9 +23,16 @@ class _Ctx:
         self.training = training
         self.tape = tape
         self.defer_nbt = False        # True: the caller bumps every BatchNorm's num_batches_tracked itself (one fused add)
+        self.x3 = False               # bf16x3 convolution route (net.conv_precision)
+        self.planes = {}              # bf16x3 route: id(tensor) -> (tensor, planes, plane stride) of the activations split so far
 
     def empty(self, *shape):
         return torch.empty(*shape, device=self.device, dtype=torch.float32)
+
+
+def _new_planes(t):
+    ps = (t.numel() + 7) // 8 * 8
+    return torch.empty(3, ps, device=t.device, dtype=torch.int16), ps
 
 
 def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=True):
@@ -45,11 +52,59 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=
             rec.update(raw=raw, stats=ss, out=None)
         return ss
     y = torch.empty_like(raw)
-    hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
-                                   hipabi.ptr(y), rows, C, hipabi.stream_ptr()), 'straps_bn_apply')
+    if ctx.x3 and relu:
+        # bf16x3 route: every ReLU output of the residual stages feeds a convolution -- its planes are written here, not by a split pass
+        planes, ps = _new_planes(y)
+        hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
+                                          hipabi.ptr(y), hipabi.ptr(planes), ps, rows, C, hipabi.stream_ptr()), 'straps_bn_apply_x3')
+        ctx.planes[id(y)] = (y, planes, ps)
+    else:
+        hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
+                                       hipabi.ptr(y), rows, C, hipabi.stream_ptr()), 'straps_bn_apply')
     if rec is not None:
         rec.update(raw=raw, stats=ss, out=y)
     return y
+
+
+def split3(L, t):
+    """fp32 tensor -> its three bf16 planes [3][ps] (t = p1 + p2 + p3 exactly; csrc/conv_x3.hip), ps = numel rounded up to 8."""
+    n = t.numel()
+    ps = (n + 7) // 8 * 8
+    planes = torch.empty(3, ps, device=t.device, dtype=torch.int16)
+    hipabi.check(L.straps_split3_bf16(hipabi.ptr(t), hipabi.ptr(planes), n, ps, hipabi.stream_ptr()), 'straps_split3_bf16')
+    return planes, ps
+
+
+def _planes_of(ctx, t):
+    hit = ctx.planes.get(id(t))
+    if hit is None or hit[0] is not t:
+        hit = (t,) + split3(ctx.L, t)
+        ctx.planes[id(t)] = hit
+    return hit[1], hit[2]
+
+
+def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile_cfg):
+    """the convolution itself on the route net.conv_precision selects: 'fp32' = exact-fp32 MFMA chain (csrc/conv.hip),
+    'bf16x3' = three-plane bf16 operands, six products per term, fp32 accumulate (csrc/conv_x3.hip)."""
+    L = ctx.L
+    B, H, W, Cin, Cout, k, stride, pad = geom
+    s0, s1 = (hipabi.ptr(ss[0]), hipabi.ptr(ss[1])) if ss is not None else (None, None)
+    if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
+        x3, xps = _planes_of(ctx, x)
+        w3, wps = net._packed_weight_x3(conv)
+        hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, s0, s1, hipabi.ptr(residual), int(relu), hipabi.ptr(y),
+                                          hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg, hipabi.stream_ptr()),
+                     'straps_conv_fwd_x3')
+    else:
+        hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wpk), s0, s1, hipabi.ptr(residual), int(relu), hipabi.ptr(y),
+                                       hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg, hipabi.stream_ptr()),
+                     'straps_conv_fwd')
+
+
+def conv_stat_blocks(L, net, B, Ho, Wo, Cout, kdim, tile_cfg):
+    if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
+        return L.straps_conv_x3_stat_blocks(B, Ho, Wo, Cout, kdim, tile_cfg)
+    return L.straps_conv_stat_blocks(B, Ho, Wo, Cout, kdim, tile_cfg)
 
 
 def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
@@ -67,14 +122,11 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
         ctx.tape[id(conv)] = rec
     if not ctx.training:
         ss = net._folded_bn(bn)
-        hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wpk), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual),
-                                       int(relu), hipabi.ptr(y), None, B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg,
-                                       hipabi.stream_ptr()), 'straps_conv_fwd')
+        _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, None, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
         return y, Ho, Wo
-    nblk = L.straps_conv_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
+    nblk = conv_stat_blocks(L, net, B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
     part = ctx.empty(nblk, Cout, 2)
-    hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wpk), None, None, None, 0, hipabi.ptr(y), hipabi.ptr(part), B, H, W,
-                                   Cin, Cout, k, k, stride, pad, tile_cfg, hipabi.stream_ptr()), 'straps_conv_fwd')
+    _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
     out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec)
     return out, Ho, Wo
 
@@ -90,6 +142,7 @@ def encoder_forward(net, x, tape=None, nzmask=None):
     x = x.contiguous()
     B, C, H, W = x.shape
     ctx = _Ctx(x.device, net.training, tape)
+    ctx.x3 = getattr(net, 'conv_precision', 'fp32') == 'bf16x3'
     if net.training:
         net._bn_epoch = getattr(net, '_bn_epoch', 0) + 1      # running statistics are about to change: folded-BN cache entries expire
     ctx.defer_nbt = getattr(net, '_nbt_flat', None) is not None
@@ -132,8 +185,15 @@ def encoder_forward(net, x, tape=None, nzmask=None):
             Hp, Wp = _conv_out(H, 3, 2, 1), _conv_out(W, 3, 2, 1)
             p = ctx.empty(B, Hp, Wp, 64)
             idx = torch.empty(B, Hp, Wp, 64, device=x.device, dtype=torch.uint8)
-            hipabi.check(L.straps_bn_relu_maxpool_fwd(hipabi.ptr(y), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(p), hipabi.ptr(idx),
-                                                      B, H, W, 64, hipabi.stream_ptr()), 'straps_bn_relu_maxpool_fwd')
+            if ctx.x3:
+                planes, pstride = _new_planes(p)
+                hipabi.check(L.straps_bn_relu_maxpool_fwd_x3(hipabi.ptr(y), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(p), hipabi.ptr(idx),
+                                                             hipabi.ptr(planes), pstride, B, H, W, 64, hipabi.stream_ptr()),
+                             'straps_bn_relu_maxpool_fwd_x3')
+                ctx.planes[id(p)] = (p, planes, pstride)
+            else:
+                hipabi.check(L.straps_bn_relu_maxpool_fwd(hipabi.ptr(y), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(p), hipabi.ptr(idx),
+                                                          B, H, W, 64, hipabi.stream_ptr()), 'straps_bn_relu_maxpool_fwd')
             tape['maxpool'] = dict(kind='maxpool_fused', out=p, idx=idx, geom=(B, H, W, 64, Hp, Wp))
             return _residual_stages(ctx, net, p, B, Hp, Wp, tape)
         y = _bn_train_finish(ctx, net.bn1, y, part, nblk, B * Ho * Wo, None, True, rec)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
-SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'stem.hip', 'smpl.hip',
+SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'conv_x3.hip', 'stem.hip', 'smpl.hip',
            'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip', 'raster.hip']
 
 _lib = None
@@ -89,6 +89,13 @@ SIGNATURES = {
     'straps_stem_nzmask': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_stem_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_conv_trace_buffer': (_I, [_P]),
+    'straps_split3_bf16': (_I, [_P, _P, _L, _L, _P]),
+    'straps_conv_fwd_x3': (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'straps_conv_dgrad_x3': (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'straps_conv_x3_stat_blocks': (_I, [_I, _I, _I, _I, _I, _I]),
+    'straps_bn_apply_x3': (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _P]),
+    'straps_bn_relu_maxpool_fwd_x3': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    'straps_bn_bwd_x3': (_I, [_P] * 13 + [_L, _P, _L, _I, _I, _P]),
     'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I, _I]),
     'straps_conv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_maxpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),

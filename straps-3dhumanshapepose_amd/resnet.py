@@ -106,6 +106,20 @@ class ResNet(nn.Module):
             return out
         return self._cached(('w', id(conv)), [w], make)
 
+    def _packed_weight_x3(self, conv, dgrad=False):
+        """(planes, plane stride) of the packed forward (KRSC) / data-gradient (CRSK) weights for the bf16x3 convolution route."""
+        w = conv.weight
+
+        def make():
+            from .encoder_exec import split3
+            if dgrad:
+                from .autograd_ops import _packed_dgrad_weight
+                pk = _packed_dgrad_weight(self, conv)
+            else:
+                pk = self._packed_weight(conv)
+            return split3(hipabi.lib(), pk)
+        return self._cached(('wd3' if dgrad else 'w3', id(conv)), [w], make)
+
     def prepack(self, with_dgrad=True):
         """(re)pack the weights of every non-stem conv for the forward (KRSC) and data-gradient (flipped CRSK) kernels in
         ONE launch and seed the caches `_packed_weight` / autograd_ops._packed_dgrad_weight read.  The training step
@@ -113,7 +127,7 @@ class ResNet(nn.Module):
         import ctypes as C
         import numpy as np
         convs = [m for m in self.modules() if isinstance(m, nn.Conv2d) and m is not self.conv1]
-        key = tuple(c.weight.data_ptr() for c in convs) + (with_dgrad,)
+        key = tuple(c.weight.data_ptr() for c in convs) + (with_dgrad, getattr(self, 'conv_precision', 'fp32'))
         st = getattr(self, '_prepack_state', None)
         if st is None or st['key'] != key:
             dev = convs[0].weight.device
@@ -133,9 +147,22 @@ class ResNet(nn.Module):
                 off += w.numel()
             table = torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()).to(dev)
             st = dict(key=key, krsc=krsc, crsk=crsk, table=table, total=total, convs=convs)
+            if getattr(self, 'conv_precision', 'fp32') == 'bf16x3':
+                ps = (total + 7) // 8 * 8
+                st['ps'] = ps
+                st['krsc3'] = torch.empty(3, ps, device=dev, dtype=torch.int16)
+                st['crsk3'] = torch.empty(3, ps, device=dev, dtype=torch.int16) if with_dgrad else None
             self._prepack_state = st
         hipabi.check(hipabi.lib().straps_pack_conv_weights_batched(hipabi.ptr(st['table']), len(st['convs']), st['total'],
                                                                    hipabi.stream_ptr()), 'straps_pack_conv_weights_batched')
+        x3 = st.get('krsc3') is not None
+        if x3:      # one split launch per packed buffer: every conv's planes are slices with the common plane stride
+            L = hipabi.lib()
+            hipabi.check(L.straps_split3_bf16(hipabi.ptr(st['krsc']), hipabi.ptr(st['krsc3']), st['total'], st['ps'], hipabi.stream_ptr()),
+                         'straps_split3_bf16')
+            if with_dgrad:
+                hipabi.check(L.straps_split3_bf16(hipabi.ptr(st['crsk']), hipabi.ptr(st['crsk3']), st['total'], st['ps'], hipabi.stream_ptr()),
+                             'straps_split3_bf16')
         off = 0
         for c in st['convs']:
             w, n = c.weight, c.weight.numel()
@@ -143,6 +170,10 @@ class ResNet(nn.Module):
             self._cache[('w', id(c))] = (sig, st['krsc'][off:off + n])
             if with_dgrad:
                 self._cache[('wd', id(c))] = (sig, st['crsk'][off:off + n])
+            if x3:
+                self._cache[('w3', id(c))] = (sig, (st['krsc3'][0, off:], st['ps']))
+                if with_dgrad:
+                    self._cache[('wd3', id(c))] = (sig, (st['crsk3'][0, off:], st['ps']))
             off += n
 
     def _folded_bn(self, bn):

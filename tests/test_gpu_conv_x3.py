@@ -1,0 +1,254 @@
+"""GPU parity tests of the bf16x3 convolution route (csrc/conv_x3.hip): fp32 operands carried as three bf16 planes, six bf16
+products per term, fp32 accumulate -- the replacement of the exact-fp32 MFMA chain for the forward convolution and its data
+gradient (models/resnet.py:61-77, 101-121 and their backward).
+
+Bars (written where used): the split is EXACT (bit-for-bit reconstruction); the convolutions meet the same bars against the
+float64 convolution as the exact-fp32 kernels do in test_gpu_forward.py / test_gpu_backward.py (2e-5 abs + 2e-5 rel; data gradient
+2e-5 of the maximum), and their error is compared with the fp32 kernels' on the same inputs; fused plane outputs equal a split
+pass over the fp32 output bit for bit; the training step on this route stays inside the bars of the fp32 route against the
+float64 oracle (tests/test_gpu_train_step.py, parametrised there).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import straps_amd
+from detgen import det_uniform
+from straps_amd import hipabi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    hipabi.load()
+    return torch.device('cuda:0')
+
+
+def _split(t):
+    L = hipabi.lib()
+    n = t.numel()
+    ps = (n + 7) // 8 * 8
+    planes = torch.zeros(3, ps, device=t.device, dtype=torch.int16)
+    hipabi.check(L.straps_split3_bf16(hipabi.ptr(t), hipabi.ptr(planes), n, ps, None), 'split3')
+    return planes, ps
+
+
+def _planes_to_f64(planes, n):
+    """bf16 bit patterns [3][ps] -> float64 sum of the three planes (exact: 24 significant bits)."""
+    bits = planes[:, :n].cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+    return bits.view(np.float32).astype(np.float64).sum(0)
+
+
+def test_split_is_exact(dev):
+    """x == p1 + p2 + p3 bit for bit (|x| >= 2^-110): normal range, tiny / huge magnitudes, zeros, exact powers of two, an odd element count."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.standard_normal(100003).astype(np.float32),
+                        (rng.standard_normal(4096) * 1e-25).astype(np.float32), (rng.standard_normal(4096) * 1e30).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -126, 2.0 ** 100, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0, 255.0, 257.0], np.float32)])
+    t = torch.from_numpy(x).to(dev)
+    planes, ps = _split(t)
+    torch.cuda.synchronize()
+    got = _planes_to_f64(planes, x.size)
+    assert np.array_equal(got, x.astype(np.float64)), 'three-plane split is not exact'
+    # the planes are ordered by magnitude: |p2| <= 2^-8 |p1|, |p3| <= 2^-16 |p1| (up to rounding of the leading plane)
+    b = (planes[:, :x.size].cpu().numpy().view(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    nz = np.abs(b[0]) > 0
+    assert np.all(np.abs(b[1][nz]) <= np.abs(b[0][nz]) * 2.0 ** -8 * 1.01)
+    assert np.all(np.abs(b[2][nz]) <= np.abs(b[0][nz]) * 2.0 ** -16 * 1.01)
+    # below 2^-110 the last bits of an fp32 value lie under bf16's smallest subnormal (2^-133): the split is then within 2^-133
+    tiny = (rng.standard_normal(4096) * 1e-36).astype(np.float32)
+    planes, ps = _split(torch.from_numpy(tiny).to(dev))
+    torch.cuda.synchronize()
+    assert np.abs(_planes_to_f64(planes, tiny.size) - tiny.astype(np.float64)).max() <= 2.0 ** -133
+
+
+def _pack(dev, w, dgrad=False):
+    L = hipabi.lib()
+    Cout, Cin, k, _ = w.shape
+    wd = w.float().contiguous().to(dev)
+    wp = torch.empty_like(wd)
+    fn = L.straps_pack_conv_weight_dgrad if dgrad else L.straps_pack_conv_weight
+    hipabi.check(fn(hipabi.ptr(wd), hipabi.ptr(wp), Cout, Cin, k, k, None), 'pack')
+    return wp
+
+
+def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_nchw=None, relu=False, stats=False):
+    L = hipabi.lib()
+    B, Cin, H, W = x_nchw.shape
+    Cout, _, k, _ = w.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = x_nchw.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = _pack(dev, w)
+    y = torch.full((B, Ho, Wo, Cout), float('nan'), device=dev)
+    res = res_nchw.float().permute(0, 2, 3, 1).contiguous().to(dev) if res_nchw is not None else None
+    sc = scale.float().to(dev) if scale is not None else None
+    sh = shift.float().to(dev) if shift is not None else None
+    part = None
+    if x3:
+        if stats:
+            part = torch.empty(L.straps_conv_x3_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, cfg), Cout, 2, device=dev)
+        xp, xps = _split(x)
+        wp3, wps = _split(wp)
+        hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(xp), xps, hipabi.ptr(wp3), wps, hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), int(relu),
+                                          hipabi.ptr(y), hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, cfg, None), 'conv_fwd_x3')
+    else:
+        hipabi.check(L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wp), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), int(relu), hipabi.ptr(y),
+                                       None, B, H, W, Cin, Cout, k, k, stride, pad, 0, None), 'conv_fwd')
+    torch.cuda.synchronize()
+    return y.permute(0, 3, 1, 2).cpu().double(), part
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
+    (2, 64, 64, 16, 16, 3, 1, 0), (2, 64, 64, 16, 16, 3, 1, 3), (2, 64, 64, 16, 16, 3, 1, 7), (2, 64, 128, 16, 16, 3, 2, 1),
+    (3, 128, 128, 8, 8, 3, 1, 5), (5, 128, 128, 24, 24, 3, 1, 4), (5, 128, 128, 24, 24, 3, 1, 6), (2, 64, 128, 16, 16, 1, 2, 0),
+    (1, 256, 512, 8, 8, 3, 2, 0), (1, 512, 512, 8, 8, 3, 1, 0), (5, 64, 64, 7, 7, 3, 1, 2), (2, 256, 64, 16, 16, 1, 1, 0),
+    (2, 64, 64, 10, 24, 3, 1, 0), (3, 96, 128, 7, 13, 3, 2, 0), (1, 32, 64, 3, 3, 3, 1, 0), (2, 2048, 512, 4, 4, 1, 1, 0)])
+def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
+    """all tile configurations (4- and 8-wave, 2- and 3-stage rings), ragged M, stride 1 / 2, 3x3 and 1x1, non-square maps, the
+    fused epilogue and the training-mode statistics; the bar is the exact-fp32 kernel's (test_gpu_forward.py)."""
+    pad = 1 if k == 3 else 0
+    x = torch.from_numpy(det_uniform((B, Cin, H, W), 1, -1, 1))
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 2, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    y, part = _fwd(dev, x, w, stride, pad, cfg, stats=True)
+    err = (y - ref).abs()
+    assert float((err - (2e-5 + 2e-5 * ref.abs())).max()) <= 0, 'raw conv: max abs err %.3e' % float(err.max())
+    y32, _ = _fwd(dev, x, w, stride, pad, 0, x3=False)
+    e32 = float((y32 - ref).abs().max())
+    assert float(err.max()) <= 3.0 * e32 + 1e-7, 'bf16x3 error %.3e vs exact-fp32 chain %.3e' % (float(err.max()), e32)
+    s = part.double().sum(0).cpu()
+    np.testing.assert_allclose(s[:, 0].numpy(), ref.sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    sc = torch.from_numpy(det_uniform((Cout,), 3, 0.5, 1.5))
+    sh = torch.from_numpy(det_uniform((Cout,), 4, -0.5, 0.5))
+    res = torch.from_numpy(det_uniform(tuple(ref.shape), 5, -1, 1))
+    want = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + res.double())
+    y2, _ = _fwd(dev, x, w, stride, pad, cfg, scale=sc, shift=sh, res_nchw=res, relu=True)
+    err2 = (y2 - want).abs()
+    assert float((err2 - (3e-5 + 3e-5 * want.abs())).max()) <= 0, 'fused epilogue: max abs err %.3e' % float(err2.max())
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
+    (2, 64, 64, 16, 16, 3, 1, 0), (2, 64, 128, 16, 16, 3, 2, 0), (3, 128, 64, 9, 9, 3, 1, 0), (2, 64, 128, 16, 16, 1, 2, 0),
+    (1, 256, 512, 8, 8, 3, 2, 0), (2, 256, 64, 8, 8, 1, 1, 0), (2, 128, 128, 15, 15, 3, 2, 1), (4, 128, 128, 20, 12, 3, 1, 4),
+    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3)])
+def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
+    """data gradient on the bf16x3 route (stride-2 parity classes, odd sizes, the skip-gradient addend) vs float64 autograd."""
+    L = hipabi.lib()
+    pad = 1 if k == 3 else 0
+    x = torch.from_numpy(det_uniform((B, Cin, H, W), 1, -1, 1)).double().requires_grad_()
+    w = (torch.from_numpy(det_uniform((Cout, Cin, k, k), 2, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5).double()
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = torch.from_numpy(det_uniform(tuple(y.shape), 3, -1, 1)).double() * 1e-3          # gradient-sized values
+    y.backward(dy)
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    g3, gps = _split(dyd)
+    wd = _pack(dev, w, dgrad=True)
+    w3, wps = _split(wd)
+    add = torch.from_numpy(det_uniform((B, H, W, Cin), 4, -1, 1)).to(dev) * 1e-3
+    dx = torch.full((B, H, W, Cin), float('nan'), device=dev)
+    hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(add), hipabi.ptr(dx), B, H, W, Cin, Cout, k, k,
+                                        stride, pad, cfg, None), 'dgrad_x3')
+    want = x.grad.permute(0, 2, 3, 1) + add.cpu().double()
+    err = float((dx.cpu().double() - want).abs().max() / want.abs().max())
+    assert err < 2e-5, 'dgrad_x3 relative-to-max error %.3e' % err
+
+
+def test_error_budget_of_the_six_products(dev):
+    """long reductions (K = 4608, layer4) of same-sign terms -- where a systematic bias of the dropped low-order products would
+    show -- stay at the exact-fp32 chain's error against float64, and so do operands spread over 12 orders of magnitude."""
+    B, Cin, Cout, H, k = 2, 512, 512, 8, 3
+    x = torch.from_numpy(det_uniform((B, Cin, H, H), 11, 0.0, 1.0))                       # all positive: errors cannot cancel
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 12, 0.0, 1.0)) * (2.0 / (Cin * k * k)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    y3, _ = _fwd(dev, x, w, 1, 1, 0)
+    y32, _ = _fwd(dev, x, w, 1, 1, 0, x3=False)
+    r3 = float(((y3 - ref).abs() / ref.abs()).max())
+    r32 = float(((y32 - ref).abs() / ref.abs()).max())
+    # (fp32 accumulation of 4608 same-sign terms: the exact-fp32 chain itself sits at ~4e-6 here)
+    assert r3 < 1.5 * r32 + 1e-7 and r3 < 1e-5, 'relative error %.3e of a same-sign K=4608 reduction (exact-fp32 chain: %.3e)' % (r3, r32)
+    scale = torch.from_numpy(10.0 ** det_uniform((1, Cin, 1, 1), 13, -6, 6)).float()     # per-channel magnitudes 1e-6 .. 1e6
+    xs, ws = x * scale, w / scale
+    refs = F.conv2d(xs.double(), ws.double(), None, 1, 1)
+    ys, _ = _fwd(dev, xs, ws, 1, 1, 0)
+    ys32, _ = _fwd(dev, xs, ws, 1, 1, 0, x3=False)
+    rs = float(((ys - refs).abs() / refs.abs()).max())
+    rs32 = float(((ys32 - refs).abs() / refs.abs()).max())
+    assert rs < 1.5 * rs32 + 1e-7 and rs < 1e-5, ('relative error %.3e with operand magnitudes over 12 decades (exact-fp32 chain: %.3e; no scaling is '
+                                                   'involved: bf16 has the fp32 exponent)' % (rs, rs32))
+    print('same-sign K=4608: bf16x3 %.2e  fp32 chain %.2e | 12 decades: bf16x3 %.2e  fp32 chain %.2e' % (r3, r32, rs, rs32))
+
+
+def test_fused_plane_outputs_equal_a_split_pass(dev):
+    """straps_bn_apply_x3 / straps_bn_relu_maxpool_fwd_x3 / straps_bn_bwd_x3 write the same fp32 outputs as their plain forms and the
+    planes a straps_split3_bf16 pass over that output would (bit for bit)."""
+    L = hipabi.lib()
+    B, H, W, C = 3, 10, 14, 64
+    rows = B * H * W
+    raw = torch.from_numpy(det_uniform((B, H, W, C), 21, -2, 2)).to(dev)
+    sc = torch.from_numpy(det_uniform((C,), 22, 0.5, 1.5)).to(dev)
+    sh = torch.from_numpy(det_uniform((C,), 23, -0.5, 0.5)).to(dev)
+    res = torch.from_numpy(det_uniform((B, H, W, C), 24, -1, 1)).to(dev)
+    y0, y1 = torch.empty_like(raw), torch.empty_like(raw)
+    ps = (raw.numel() + 7) // 8 * 8
+    pl = torch.zeros(3, ps, device=dev, dtype=torch.int16)
+    hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, hipabi.ptr(y0), rows, C, None), 'bn_apply')
+    hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, hipabi.ptr(y1), hipabi.ptr(pl), ps, rows, C, None), 'bn_apply_x3')
+    want, _ = _split(y0)
+    assert torch.equal(y0, y1) and torch.equal(pl, want)
+    # stem tail
+    Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    p0, p1 = torch.empty(B, Hp, Wp, C, device=dev), torch.empty(B, Hp, Wp, C, device=dev)
+    i0, i1 = torch.empty(B, Hp, Wp, C, device=dev, dtype=torch.uint8), torch.empty(B, Hp, Wp, C, device=dev, dtype=torch.uint8)
+    pps = (p0.numel() + 7) // 8 * 8
+    ppl = torch.zeros(3, pps, device=dev, dtype=torch.int16)
+    hipabi.check(L.straps_bn_relu_maxpool_fwd(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(p0), hipabi.ptr(i0), B, H, W, C, None), 'pool')
+    hipabi.check(L.straps_bn_relu_maxpool_fwd_x3(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(p1), hipabi.ptr(i1), hipabi.ptr(ppl), pps,
+                                                 B, H, W, C, None), 'pool_x3')
+    want, _ = _split(p0)
+    assert torch.equal(p0, p1) and torch.equal(i0, i1) and torch.equal(ppl, want)
+    # BatchNorm backward
+    dy = torch.from_numpy(det_uniform((B, H, W, C), 25, -1, 1)).to(dev) * 1e-3
+    mean = raw.mean(dim=(0, 1, 2)).contiguous()
+    invstd = (raw.var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt().contiguous()
+    gamma = torch.from_numpy(det_uniform((C,), 26, 0.5, 1.5)).to(dev)
+    ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, C) // 4, device=dev)
+    outs = []
+    for planes in (None, torch.zeros(3, ps, device=dev, dtype=torch.int16)):
+        dg, db, draw, dz = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty_like(raw), torch.empty_like(raw)
+        hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dy), hipabi.ptr(y0), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma), None, None,
+                                        hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(dz), hipabi.ptr(planes), ps if planes is not None else 0,
+                                        hipabi.ptr(ws), rows, C, 0, None), 'bn_bwd_x3')
+        outs.append((dg, db, draw, dz, planes))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    want, _ = _split(outs[0][2])
+    assert torch.equal(outs[1][4], want)
+
+
+@pytest.mark.parametrize('layers', [18, 50])
+def test_regressor_forward_on_the_x3_route_vs_fp32_route(dev, layers):
+    """eval- and train-mode forward of the whole regressor with conv_precision = 'bf16x3' against the exact-fp32 route: the 85 outputs
+    agree to 2e-5 (the bar of the fp32 route against the reference golden is 2e-4)."""
+    torch.manual_seed(3)
+    reg = straps_amd.SingleInputRegressor(18, layers, 3, mean_params=straps_amd.synthetic_mean_params(0)).to(dev)
+    x = torch.zeros(4, 18, 256, 256, device=dev)
+    x[:, 0, 60:200, 80:180] = 1.0
+    g = torch.Generator(device='cpu').manual_seed(5)
+    for b in range(4):
+        for j in range(17):
+            cy, cx = (int(v) for v in torch.randint(20, 236, (2,), generator=g))
+            x[b, 1 + j, cy - 3:cy + 4, cx - 3:cx + 4] = 0.8
+    for mode in ('eval', 'train'):
+        getattr(reg, mode)()
+        outs = {}
+        for prec in ('fp32', 'bf16x3'):
+            reg.image_encoder.conv_precision = prec
+            reg.image_encoder._cache.clear()
+            with torch.no_grad():
+                outs[prec] = torch.cat([t.reshape(4, -1) for t in reg(x)], 1).double().cpu()
+        err = float((outs['fp32'] - outs['bf16x3']).abs().max())
+        assert err < 2e-5, '%s-mode forward, resnet%d: routes differ by %.3e' % (mode, layers, err)

@@ -15,10 +15,11 @@ W = {'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'jo
 LOSSES = ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D']
 
 
-def _setup(B, seed=0, layers=18):
+def _setup(B, seed=0, layers=18, conv_precision='fp32'):
     dev = torch.device('cuda:0')
     torch.manual_seed(seed)
     reg = straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP).to(dev).train()
+    reg.image_encoder.conv_precision = conv_precision          # 'fp32': exact-fp32 MFMA chain; 'bf16x3': three-plane bf16 operands (csrc/conv_x3.hip)
     smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=B).to(dev)
     crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(LOSSES, init_loss_weights=W, reduction='mean').to(dev)
     return dev, reg, smpl, crit
@@ -125,8 +126,10 @@ def _oracle_step(ts, reg, batch, layers, dtype):
                                        lv, dtype=dtype)
 
 
-def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd():
-    """T: forward + loss + backward of TrainStep on a B=8 batch against autograd of the float64 oracle on the SAME batch
+@pytest.mark.parametrize('conv_precision', ['fp32', 'bf16x3'])
+def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd(conv_precision):
+    """(both convolution routes meet the same bars)
+    T: forward + loss + backward of TrainStep on a B=8 batch against autograd of the float64 oracle on the SAME batch
     (running statistics restored first).  Loss to 1e-5.  Gradients, relative L2 error per tensor:
       * IEF head and loss weights (no BatchNorm / ReLU upstream of their gradient): < 1e-5;
       * layer4: < 5e-3 each and < 2e-4 in the median.  Typical errors are ~1e-5; the tail is ReLU decisions: a pre-activation
@@ -139,7 +142,7 @@ def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd():
         gpu <= 2 x (float32 oracle's error) + 1e-3."""
     B = 8
     torch.set_num_threads(8)
-    dev, reg, smpl, crit = _setup(B, seed=5)
+    dev, reg, smpl, crit = _setup(B, seed=5, conv_precision=conv_precision)
     ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'])
     with torch.no_grad():
         batch = ts.make_batch()
@@ -166,20 +169,21 @@ def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd():
         g = float(ts.gviews[getattr(crit, name + '_log_var')])
         assert g == pytest.approx(float(glv[name]), rel=1e-4, abs=1e-7), name
     l4 = sorted(t[1] for t in table if t[0].startswith('image_encoder.layer4.'))
-    print('relative gradient error vs fp64 oracle autograd: IEF worst %.2e | layer4 median %.2e worst %.2e | stem..layer3 worst %.2e (float32 CPU oracle: %.2e)'
+    print(conv_precision, 'relative gradient error vs fp64 oracle autograd: IEF worst %.2e | layer4 median %.2e worst %.2e | stem..layer3 worst %.2e (float32 CPU oracle: %.2e)'
           % (max(t[1] for t in table if t[0].startswith('ief_module.')), l4[len(l4) // 2], l4[-1],
              max(t[1] for t in table if not t[0].startswith(('ief_module.', 'image_encoder.layer4.'))),
              max(t[2] for t in table if not t[0].startswith(('ief_module.', 'image_encoder.layer4.')))))
     assert l4[len(l4) // 2] < 2e-4
 
 
-def test_resnet50_step_configs3_shape():
+@pytest.mark.parametrize('conv_precision', ['fp32', 'bf16x3'])
+def test_resnet50_step_configs3_shape(conv_precision):
     """configs[3] per-GPU shape: resnet50, 32 bodies.  hipGraph replay (single and split capture) == eager launches bit for
     bit, deterministic, Bottleneck flat-buffer layout consistent with the autograd route, loss vs the oracle."""
     B = 32
 
     def run(use_graph, comm_overlap=False, steps=4):
-        dev, reg, smpl, crit = _setup(B, seed=9, layers=50)
+        dev, reg, smpl, crit = _setup(B, seed=9, layers=50, conv_precision=conv_precision)
         ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], seed=77, use_graph=use_graph, comm_overlap=comm_overlap)
         losses = torch.stack([ts.step().clone() for _ in range(steps)]).cpu()
         torch.cuda.synchronize()
