@@ -182,7 +182,7 @@ def main():
     ap.add_argument('--smpl-exact', action='store_true', help='smpl workload: exact-fp32 MFMA blend contraction (= --smpl-precision fp32)')
     ap.add_argument('--smpl-precision', default='fp16x3_lbs', choices=['fp32', 'fp16x3', 'fp16x3_lbs'],
                     help='smpl workload: fp32 = exact, fp16x3 = blend contraction as a three-product fp16 split, fp16x3_lbs = skinning on the matrix pipe too')
-    ap.add_argument('--conv-precision', default='fp32', choices=['fp32', 'bf16x3'],
+    ap.add_argument('--conv-precision', default='bf16x3', choices=['fp32', 'bf16x3'],
                     help="encoder convolutions (forward + data gradient): 'fp32' = exact-fp32 MFMA chain, 'bf16x3' = three bf16 planes per fp32 "
                          "operand, six products per term, fp32 accumulate (same accuracy class, bf16 matrix pipe)")
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -78,6 +78,11 @@ class ResNet(nn.Module):
                 if isinstance(m, ResidualUnit):
                     nn.init.constant_((m.bn3 if m.kind == 'bottleneck' else m.bn2).weight, 0)
         self._cache = {}
+        # route of the 3x3 / 1x1 convolutions (forward + data gradient): 'bf16x3' = every fp32 operand as three exact bf16 planes, six
+        # products per term, fp32 accumulate on the bf16 matrix pipe (csrc/conv_x3.hip; same error class against float64 as the fp32
+        # chain: tests/test_gpu_conv_x3.py), 'fp32' = the exact-fp32 MFMA chain (csrc/conv.hip).  The weight gradients and the stem
+        # are fp32 MFMA on both routes.
+        self.conv_precision = 'bf16x3'
         self._bn_epoch = 0          # bumped by every training-mode forward (running statistics change behind torch's back)
 
     # ---- packed-weight / folded-BN caches, refreshed when a parameter's version changes ----
