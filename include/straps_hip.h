@@ -297,6 +297,14 @@ int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const
                      const float* mask_shift, float* dgamma, float* dbeta, float* draw, float* dz_out,
                      unsigned short* draw_planes, long long plane_stride, void* workspace,
                      long long rows, int c, int accumulate, void* stream);
+/* weight gradient on the bf16x3 route: straps_conv_wgrad's arguments plus the planes of x and dy; 3x3 / stride 1 /
+ * pad 1 layers (power-of-two width >= 8) run on the planes (halo-patch kernel, ds_read_b64_tr_b16 operand gathers),
+ * every other shape -- or NULL planes -- uses the fp32 kernels on (x, dy).  Workspace as for straps_conv_wgrad.      */
+int straps_conv_wgrad_x3(const float* x_nhwc, const float* dy_nhwc, const unsigned short* x3,
+                         long long x_plane_stride, const unsigned short* dy3, long long dy_plane_stride,
+                         float* dw_oihw, void* workspace, int batch, int h, int w, int cin, int cout,
+                         int kh, int kw, int stride, int pad, int accumulate, void* stream);
+
 
 /* weight gradient in the parameter's own OIHW layout: dw (+)= sum_pixels dy (x) x.                */
 size_t straps_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int kh,

@@ -315,6 +315,205 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_kernel(Wgrad3P p) {
         }
 }
 
+// ---- the same weight gradient on the bf16 matrix pipe (bf16x3 route, see conv_x3.hip) -------------------------------------------
+// Operands are the three bf16 planes of x and dy (x = x1 + x2 + x3 exactly); a term dy * x is the six bf16 products of weight >= 2^-16
+// in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  The reduction index of this GEMM is the PIXEL, but both operands are stored
+// pixel-major / channel-minor, so a lane's eight consecutive k values are eight different LDS rows: they are gathered by the
+// hardware transpose read ds_read_b64_tr_b16 -- in a 16-lane group, lanes 4j .. 4j+3 each name 4 contiguous channels of pixel j
+// and lane t receives channel t of pixels 0..3 (tools/tr_probe.hip prints the lane map) -- two reads per plane and operand.
+// LDS image per stage and plane: dy tile [32 pixels][64 channels] and input patch [128 pixel slots][64 channels], rows of 128 bytes
+// copied by the LDS-DMA; the two 64-byte halves of a row are swapped when bit 1 of the pixel (slot) number is set, so four
+// consecutive rows -- whatever the tap shift -- touch all 64 banks once per 32-lane read group.
+struct Wgrad3XP {
+    const u16* x3;
+    const u16* dy3;
+    long long xps, dps;
+    float* part;
+    int H, W, Cin, Cout;
+    int cw, cw_log2, rpc;
+    int chunks_per_row, chunk_rows_per_img, nchunks, chunks_per_split, it;
+};
+
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef short short4w __attribute__((ext_vector_type(4)));
+typedef short short8w __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(16))) float k_zero16x[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr int W3X_DPX = 32, W3X_XPX = 128;                              // pixel rows per stage and plane: dy tile, input patch slots
+#ifndef W3X_TG
+#define W3X_TG 2          // taps whose MFMA chains are interleaved
+#endif
+constexpr int W3X_STAGE = 3 * (W3X_DPX + W3X_XPX) * 64;                 // u16 elements per stage (61 440 bytes)
+
+// eight k values (pixels) of one channel: two transpose reads of four pixels each
+__device__ __forceinline__ bf16x8w tr_frag(const u16* lo, const u16* hi) {
+    const short4w a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4w*)lo);
+    const short4w b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4w*)hi);
+    const short8w v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8w, v);
+}
+
+// NG = 2: two 4-wave groups share every stage; group g takes k step g (pixels 16g .. 16g+15) of each chunk and the two accumulator
+// sets are added through LDS at the end (fixed order) -- two waves per SIMD cover each other's LDS latency and barrier waits.
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    u16* smem = reinterpret_cast<u16*>(smem_f);
+    const int pw = p.cw + 2;
+    const int npatch = (p.rpc + 2) * pw;                 // <= 102 pixels
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;           // wave inside its 4-wave group
+    const int grp = NG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int itile = blockIdx.x % p.it, ctile = blockIdx.x / p.it;
+    const int co0 = ctile * 64, ci0 = itile * 64;
+    const int cbeg = blockIdx.y * p.chunks_per_split;
+    const int cend = min(cbeg + p.chunks_per_split, p.nchunks);
+    const u16* zsrc = reinterpret_cast<const u16*>(k_zero16x);
+    asm volatile("" : "+s"(zsrc));
+
+    // ---- copies: thread -> (pixel slot of a 32-slot round, 16-byte slot tid & 7 of its row); it fetches channel group slot ^ swap.
+    // The five rounds of a chunk (dy tile, four patch rounds) alternate between the groups when NG = 2.
+    const int lp = (tid & 255) >> 3, ls = tid & 7;
+    const int d_g = ls ^ (((lp >> 1) & 1) << 2);
+    const int d_off = ((lp >> p.cw_log2) * p.W + (lp & (p.cw - 1))) * p.Cout + co0 + d_g * 8;
+    int x_pr[4], x_pc[4], x_g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pp = lp + 32 * q;
+        x_pr[q] = pp / pw - 1;
+        x_pc[q] = pp - (x_pr[q] + 1) * pw - 1;
+        x_g[q] = ls ^ (((pp >> 1) & 1) << 2);
+    }
+    auto dma_chunk = [&](int c, int stage) {
+        const int per_img = p.chunk_rows_per_img * p.chunks_per_row;
+        const int b = c / per_img;
+        const int rem = c - b * per_img;
+        const int cr = rem / p.chunks_per_row, cc = rem - cr * p.chunks_per_row;
+        const int ho0 = cr * p.rpc, wo0 = cc * p.cw;
+        u16* D = smem + stage * W3X_STAGE;
+        u16* X = D + 3 * W3X_DPX * 64;
+        const u16* dsrc = p.dy3 + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cout + d_off;
+        const u16* xsrc = p.x3 + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cin + ci0;
+        if (grp == 0) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + pl * p.dps),
+                                                 (__attribute__((address_space(3))) void*)(D + (pl * W3X_DPX + 8 * wave_u) * 64), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q * 32 >= npatch) break;                 // wave-uniform
+            if (NG > 1 && ((q + 1) & 1) != grp) continue;   // rounds 1..4 of the chunk alternate between the groups
+            const int hi = ho0 + x_pr[q], wi = wo0 + x_pc[q];
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;     // (slots past the patch read anything)
+            const u16* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin + x_g[q] * 8 : zsrc;
+            const long long ps = ok ? p.xps : 0;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pl * ps),
+                                                 (__attribute__((address_space(3))) void*)(X + (pl * W3X_XPX + 32 * q + 8 * wave_u) * 64), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses (u16 element offsets inside a stage, plane 0), fixed for the whole kernel.
+    // lane: t = lane & 15 (row j = t >> 2 of the 4-pixel group, channel quad t & 3), 16-channel half (lane >> 4) & 1, k half lane >> 5.
+    const int t = lane & 15, ch16 = (lane >> 4) & 1, kh = lane >> 5;
+    auto row_off = [&](int slot_px, int c4) {            // element offset of 4 contiguous channels c4 .. c4+3 (of 64) in pixel slot slot_px
+        const int g = (c4 >> 3) ^ (((slot_px >> 1) & 1) << 2);
+        return slot_px * 64 + g * 8 + (c4 & 4);
+    };
+    int d_fo[2][2], x_fo[2][2];                          // [k step][read]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int px = ks * 16 + kh * 8 + r * 4 + (t >> 2);
+            d_fo[ks][r] = row_off(px, wm * 32 + ch16 * 16 + (t & 3) * 4);
+            x_fo[ks][r] = (px >> p.cw_log2) * pw + (px & (p.cw - 1));          // patch slot of tap (0,0); the channel part is added per tap
+        }
+    const int x_c4 = wn * 32 + ch16 * 16 + (t & 3) * 4;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[tp][q] = 0.f;
+    if (cbeg < cend) dma_chunk(cbeg, 0);
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0};            // plane pairs (dy, x) of the six products, smallest terms first
+    constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+    for (int c = cbeg; c < cend; ++c) {
+        const int stage = (c - cbeg) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies of chunk c have landed ...
+        __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
+        asm volatile("" ::: "memory");
+        if (c + 1 < cend) dma_chunk(c + 1, stage ^ 1);
+        const u16* D = smem + stage * W3X_STAGE;
+        const u16* X = D + 3 * W3X_DPX * 64;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (NG > 1 && ks != grp) continue;
+            bf16x8w a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = tr_frag(D + pl * W3X_DPX * 64 + d_fo[ks][0], D + pl * W3X_DPX * 64 + d_fo[ks][1]);
+            // taps in pairs: the six products of a tap accumulate into one tile, so two taps' chains are interleaved (a dependent
+            // MFMA issued back to back waits for its predecessor's last pass)
+#pragma unroll
+            for (int tp0 = 0; tp0 < 9; tp0 += W3X_TG) {
+                bf16x8w b[W3X_TG][3];
+#pragma unroll
+                for (int u = 0; u < W3X_TG; ++u) {
+                    const int tp = tp0 + u;
+                    if (tp >= 9) break;
+                    const int sh = (tp / 3) * pw + (tp % 3);
+                    const int o0 = row_off(x_fo[ks][0] + sh, x_c4), o1 = row_off(x_fo[ks][1] + sh, x_c4);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) b[u][pl] = tr_frag(X + pl * W3X_XPX * 64 + o0, X + pl * W3X_XPX * 64 + o1);
+                }
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+#pragma unroll
+                    for (int u = 0; u < W3X_TG; ++u)
+                        if (tp0 + u < 9) acc[tp0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[e]], b[u][TB[e]], acc[tp0 + u], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (NG > 1) {
+        // group 1 -> LDS -> group 0, three taps per round (48 KB), fixed order: acc(group 0) + acc(group 1)
+        float* R = smem_f + ((wave * 3) * 16) * 64 + lane;
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) {
+            __syncthreads();                                  // the stages (round 0) / the previous round's values are no longer needed
+            if (grp == 1) {
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) R[(tp * 16 + q) * 64] = acc[rd * 3 + tp][q];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[rd * 3 + tp][q] += R[(tp * 16 + q) * 64];
+            }
+        }
+        if (grp != 0) return;
+    }
+    const int i = lane & 31;
+    float* o = p.part + (long long)blockIdx.y * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = co0 + wm * 32 + mfma_row(q, lane);
+            o[((long long)co * 9 + tp) * p.Cin + ci0 + wn * 32 + i] = acc[tp][q];
+        }
+}
+
 // dW_oihw[co][ci][r][s] = sum_split part[split][co][tap][ci]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
                                                            int Cout, int Cin, int RS, int accumulate) {
@@ -1157,6 +1356,43 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
 // row blocks of tiles (grid.x): enough for 4-5 resident workgroups per CU across the channel groups, few enough that the
 // per-block partials stay small
 static int stem_wgrad_blocks(int ntiles) { return ntiles < 256 ? ntiles : 256; }
+
+// weight gradient on the bf16x3 route: the 3x3 / stride 1 layers that fit the halo-patch plan run on the planes (x3, dy3: [3][plane
+// stride] bf16, see straps_split3_bf16); every other shape falls through to the fp32 kernels of straps_conv_wgrad on (x, dy).
+extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsigned short* x3, long long x_plane_stride, const unsigned short* dy3,
+                                    long long dy_plane_stride, float* dw_oihw, void* workspace, int batch, int h, int w, int cin, int cout, int kh,
+                                    int kw, int stride, int pad, int accumulate, void* stream) {
+    STRAPS_REQUIRE(x && dy && dw_oihw && workspace, "straps_conv_wgrad_x3: null pointer");
+    STRAPS_REQUIRE(cin % 64 == 0 && cout % 64 == 0, "straps_conv_wgrad_x3: need cin%%64==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
+    Wgrad3P p3;
+    int splits3;
+    if (x3 && dy3 && wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) {
+        STRAPS_REQUIRE(x_plane_stride % 8 == 0 && dy_plane_stride % 8 == 0, "straps_conv_wgrad_x3: plane strides must be multiples of 8 elements");
+        Wgrad3XP q;
+        q.x3 = x3; q.dy3 = dy3; q.xps = x_plane_stride; q.dps = dy_plane_stride; q.part = (float*)workspace;
+        q.H = p3.H; q.W = p3.W; q.Cin = p3.Cin; q.Cout = p3.Cout; q.cw = p3.cw; q.cw_log2 = p3.cw_log2; q.rpc = p3.rpc;
+        q.chunks_per_row = p3.chunks_per_row; q.chunk_rows_per_img = p3.chunk_rows_per_img; q.nchunks = p3.nchunks;
+        q.chunks_per_split = p3.chunks_per_split; q.it = p3.it;
+#ifndef W3X_NG
+#define W3X_NG 2
+#endif
+        const size_t lds = (size_t)2 * W3X_STAGE * sizeof(u16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_x3_kernel<W3X_NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+            attr_set = true;
+        }
+        hipStream_t st3 = (hipStream_t)stream;
+        hipLaunchKernelGGL(conv_wgrad3x3_x3_kernel<W3X_NG>, dim3((cout / 64) * (cin / 64), splits3), dim3(256 * W3X_NG), lds, st3, q);
+        STRAPS_CHECK_LAUNCH("conv_wgrad3x3_x3_kernel");
+        const long long n3 = (long long)cout * 9 * cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n3 / 256)), dim3(256), 0, st3, q.part, dw_oihw, splits3, cout, cin, 9, accumulate);
+        STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+        return STRAPS_OK;
+    }
+    return straps_conv_wgrad(x, dy, dw_oihw, workspace, batch, h, w, cin, cout, kh, kw, stride, pad, accumulate, stream);
+}
 
 extern "C" size_t straps_stem_wgrad_workspace_bytes(int batch, int cin, int h, int w) {
     const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
