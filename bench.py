@@ -151,6 +151,9 @@ def instrument(timer):
         def straps_conv_wgrad(self, *a):
             return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a))
 
+        def straps_conv_wgrad_x3(self, *a):
+            return timer.wrap('conv_wgrad_x3_kernel', conv_flops(*a[8:17]), lambda: L.straps_conv_wgrad_x3(*a))
+
         def straps_stem_fwd(self, *a):
             B, C, H, W = a[8:12]
             return timer.wrap('stem_kernel', 2.0 * B * _out(H, 7, 2, 3) * _out(W, 7, 2, 3) * 64 * C * 49, lambda: L.straps_stem_fwd(*a))

@@ -91,13 +91,21 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None):
     return draw, dz
 
 
-def _conv_wgrad(L, rec, draw, grads):
+def _conv_wgrad(L, rec, draw, grads, planes_sink=None):
     conv = rec['conv']
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=draw.device, dtype=torch.float32)
     dw = grads.buf(conv.weight)
-    hipabi.check(L.straps_conv_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride,
-                                     pad, 0, hipabi.stream_ptr()), 'straps_conv_wgrad')
+    xh = rec.get('x3')
+    gh = planes_sink.get(id(draw)) if planes_sink is not None else None
+    if xh is not None and gh is not None and xh[0] is rec['x'] and gh[0] is draw:
+        # bf16x3 route: the planes the forward convolution / the data gradient read anyway (3x3 stride-1 layers; other shapes fall
+        # through to the fp32 kernels inside the entry point)
+        hipabi.check(L.straps_conv_wgrad_x3(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(xh[1]), xh[2], hipabi.ptr(gh[1]), gh[2], hipabi.ptr(dw),
+                                            hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_wgrad_x3')
+    else:
+        hipabi.check(L.straps_conv_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride,
+                                         pad, 0, hipabi.stream_ptr()), 'straps_conv_wgrad')
     grads[conv.weight] = dw
 
 
@@ -106,7 +114,7 @@ def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None):
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     dx = torch.empty(B, H, W, Cin, device=draw.device, dtype=torch.float32)
     if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
-        hit = planes_sink.pop(id(draw), None) if planes_sink is not None else None
+        hit = planes_sink.get(id(draw)) if planes_sink is not None else None      # (kept until the backward ends: the weight gradient may still be reading them on the side stream)
         if hit is not None and hit[0] is draw:
             g3, gps = hit[1], hit[2]
         else:
@@ -139,11 +147,11 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
             pairs = unit.conv_bn_pairs()
             rec = tape[id(pairs[-1][0])]
             draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink)    # ReLU(out) mask; dz feeds the skip connection
-            side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads), draw)
+            side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             if unit.downsample is not None:
                 recd = tape[id(unit.downsample[0])]
                 drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink)
-                side.run(lambda recd=recd, drawd=drawd: _conv_wgrad(L, recd, drawd, grads), drawd)
+                side.run(lambda recd=recd, drawd=drawd: _conv_wgrad(L, recd, drawd, grads, sink), drawd)
                 dskip = _conv_dgrad(L, net, recd, drawd, None, sink)
             else:
                 dskip = dz
@@ -151,7 +159,7 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
                 dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None, sink)
                 rec = tape[id(pairs[ci - 1][0])]
                 draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink)
-                side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads), draw)
+                side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink)   # + skip gradient fused in the epilogue
         if li == 3 and after_layer3 is not None:
             side.join()

@@ -127,6 +127,8 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
     nblk = conv_stat_blocks(L, net, B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
     part = ctx.empty(nblk, Cout, 2)
     _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
+    if rec is not None and ctx.x3:
+        rec['x3'] = ctx.planes.get(id(x))          # (x, planes, plane stride): the weight gradient reads the same planes
     out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec)
     return out, Ho, Wo
 

@@ -157,6 +157,33 @@ def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     assert err < 2e-5, 'dgrad_x3 relative-to-max error %.3e' % err
 
 
+@pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 64, 64, 16, 16), (3, 128, 64, 8, 8), (2, 64, 128, 4, 32), (1, 128, 128, 6, 64), (5, 64, 64, 12, 8),
+                                            (2, 64, 64, 9, 16), (2, 64, 64, 10, 24)])
+def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W):
+    """3x3 / stride-1 weight gradient on the planes (halo-patch kernel, transpose-read operand gathers): every chunk geometry the plan
+    produces (W = 8 .. 64: 4 x 8 .. 1 x 32 pixel chunks), image borders, several splits, accumulate; the last two shapes do not fit
+    the plan (odd row count / non-power-of-two width) and must fall through to the fp32 kernels.  Bar: 2e-5 of the maximum, the
+    fp32 kernel's bar in test_gpu_backward.py."""
+    L = hipabi.lib()
+    k, stride, pad = 3, 1, 1
+    x = torch.from_numpy(det_uniform((B, Cin, H, W), 31, -1, 1)).double()
+    dy = torch.from_numpy(det_uniform((B, Cout, H, W), 32, -1, 1)).double() * 1e-3
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=stride, padding=pad)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    gd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    x3, xps = _split(xd)
+    g3, gps = _split(gd)
+    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=dev)
+    dw = torch.full((Cout, Cin, k, k), float('nan'), device=dev)
+    args = (hipabi.ptr(xd), hipabi.ptr(gd), hipabi.ptr(x3), xps, hipabi.ptr(g3), gps, hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride, pad)
+    hipabi.check(L.straps_conv_wgrad_x3(*args, 0, None), 'wgrad_x3')
+    err = float((dw.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, 'wgrad_x3 relative-to-max error %.3e' % err
+    hipabi.check(L.straps_conv_wgrad_x3(*args, 1, None), 'wgrad_x3 accumulate')
+    err = float((dw.cpu().double() - 2 * ref).abs().max() / ref.abs().max())
+    assert err < 4e-5, 'wgrad_x3 accumulate: %.3e' % err
+
+
 def test_error_budget_of_the_six_products(dev):
     """long reductions (K = 4608, layer4) of same-sign terms -- where a systematic bias of the dropped low-order products would
     show -- stay at the exact-fp32 chain's error against float64, and so do operands spread over 12 orders of magnitude."""
