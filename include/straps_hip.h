@@ -268,11 +268,15 @@ int straps_conv_dgrad(const float* dy_nhwc, const float* w_crsk, const float* ad
  * a multiple of 8.  Geometry / epilogue arguments exactly as straps_conv_fwd /
  * straps_conv_dgrad; x3 / dy3 are the planes of the NHWC tensor, w3 the planes of the packed
  * weights (straps_pack_conv_weight / straps_pack_conv_weight_dgrad output).
- * tile_cfg: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128.
+ * tile_cfg: 0 = auto (incl. the halo-patch kernel for 3x3 / stride-1 layers: the tile's input patch is
+ * copied once per channel chunk and the nine taps are shifted LDS addresses), 1..7 = explicit tiles
+ * of the im2col kernel (csrc/conv_x3.hip), + 256 = auto without the halo-patch kernel.
  * ------------------------------------------------------------------------------------------ */
 int straps_split3_bf16(const float* x, unsigned short* planes, long long n, long long plane_stride,
                        void* stream);
-int straps_conv_x3_stat_blocks(int batch, int ho, int wo, int cout, int kdim, int tile_cfg);
+/* statistics partials of straps_conv_fwd_x3 for this geometry: [blocks][cout][2]                          */
+int straps_conv_x3_stat_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride,
+                               int pad, int tile_cfg);
 int straps_conv_fwd_x3(const unsigned short* x3, long long x_plane_stride,
                        const unsigned short* w3_krsc, long long w_plane_stride, const float* scale,
                        const float* shift, const float* residual, int relu, float* y_nhwc,

@@ -219,6 +219,228 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
 }
 
+// ---- halo-patch variant for the 3x3 / stride-1 layers (forward, and the data gradient, which is the same convolution over dy) ----
+// The im2col A operand above copies every input pixel nine times per channel chunk (once per tap) from L2; here a tile's input patch
+// -- its BM output pixels are whole image rows (or whole images), so the patch is (rows + 2) x (W + 2) pixels per image -- is copied
+// ONCE per 32-channel chunk into a double-buffered LDS image and the nine taps are nine shifted fragment addresses into it.  The
+// reduction runs channel-chunk-major / tap-minor; the weights keep their NST-stage ring (one (tap, chunk) slice per step).
+// L2 -> LDS bytes per step: (BM + BN) x 192  ->  (BN + patch / 9) x 192: 2.0x fewer for layer1 (128x64), 1.7-2.2x for the others.
+// PS = patch slot capacity.  Slot swizzle: 16-byte group g of slot s sits at g ^ ((s >> 2) & 3), conflict-free for the 16-lane
+// groups of ds_read_b128 over consecutive slots at any tap shift.
+template <int BM, int BN, int WGM, int WGN, int NST, int PS>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p) {
+    const ConvP::Class& c = p.cls[0];
+    const int cntaps = c.ntaps;
+    constexpr int NW = WGM * WGN, NTH = 64 * NW, RPP = 16 * NW;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
+    constexpr int BP = BN / RPP;
+    static_assert(BN % RPP == 0 && WTM % 32 == 0 && WTN % 32 == 0 && PS % 16 == 0, "tile / wave grid mismatch");
+    constexpr int NPB = 3 * BP;                                // weight copies per thread and step
+    constexpr int NPA = (PS * 4 + NTH - 1) / NTH;              // patch copy rounds per plane (the last one may cover only some waves)
+    constexpr int NMFMA = 2 * 6 * MI * NI;
+    constexpr int GAP = NMFMA / NPB > 0 ? NMFMA / NPB : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u16* As = reinterpret_cast<u16*>(smem);       // [2 patch buffers][3 planes][PS slots][32]
+    u16* Bs = As + 2 * 3 * PS * 32;               // [NST stages][3 planes][BN][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int bid = xcd_remap(blockIdx.x, c.MT * p.NT);
+    const int nt = bid % p.NT, mt = bid / p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const u16* xg = reinterpret_cast<const u16*>(p.x);
+    const u16* wg = reinterpret_cast<const u16*>(p.w);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // ---- tile geometry: nimg images x rows_t rows x W columns; patch (rows_t + 2) x (W + 2) slots per image
+    const int HW = p.H * p.W, PW = p.W + 2;
+    const int nimg = BM >= HW ? BM / HW : 1;
+    const int rows_t = BM >= HW ? p.H : BM / p.W;
+    const int pslots = (rows_t + 2) * PW;                      // per image
+    const int nslots = nimg * pslots;
+    const int b0 = m0 / HW, row0 = (m0 - b0 * HW) / p.W;
+
+    // ---- patch copies: round pi covers slots pi*NTH/4 + (tid >> 2), 16-byte slot tid & 3 <- channel group (tid & 3) ^ ((slot >> 2) & 3)
+    int poff[NPA];
+#pragma unroll
+    for (int pi = 0; pi < NPA; ++pi) {
+        const int slot = pi * (NTH / 4) + (tid >> 2);
+        const int im = slot / pslots, rem = slot - im * pslots;
+        const int py = rem / PW, px = rem - py * PW;
+        const int sr = row0 + py - 1, sc = px - 1;
+        const bool ok = slot < nslots && (unsigned)sr < (unsigned)p.H && (unsigned)sc < (unsigned)p.W;
+        poff[pi] = ok ? (((b0 + im) * p.H + sr) * p.W + sc) * p.Cin + (((tid & 3) ^ ((slot >> 2) & 3)) << 3) : -1;
+    }
+    const u16* zsrc = reinterpret_cast<const u16*>(k_zero16_x3);
+    asm volatile("" : "+s"(zsrc));
+    auto patch_dma = [&](int cc) {
+        u16* dst = As + (cc & 1) * (3 * PS * 32);
+#pragma unroll
+        for (int pi = 0; pi < NPA; ++pi) {
+            if (pi * (NTH / 4) + 16 * wave_u >= nslots) break;                 // wave-uniform: nothing of this round lies inside the patch
+            if (pi * (NTH / 4) + 16 * wave_u >= PS) break;
+            const bool ok = poff[pi] >= 0;
+            const u16* src = ok ? xg + (poff[pi] + cc * 32) : zsrc;
+            const long long ps = ok ? p.xps : 0;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pl * ps),
+                                                 (__attribute__((address_space(3))) void*)(dst + (pl * PS + pi * (NTH / 4) + 16 * wave_u) * 32), 16, 0, 0);
+        }
+    };
+
+    // ---- weight copies (as in the im2col kernel), issue stream runs NST - 1 steps ahead: step = (chunk cc, tap), tap fastest
+    const int lr = tid >> 2;
+    const int lc = (tid & 3) ^ swz3(lr);
+    const u16* wrow[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) wrow[q] = wg + (long long)(n0 + lr + RPP * q) * p.wtaps * p.Cin + lc * 8;
+    const int cchunks = p.Cin >> 5;
+    const int nsteps = cntaps * cchunks;
+    const int tl = lane < 9 ? lane : 0;
+    const int v_tw = c.tap_w[tl];
+    const int v_sh = (c.tap_dh[tl] + 1) * PW + c.tap_dw[tl] + 1;              // slot shift of the tap
+    int i_tap = 0, i_cc = 0;                                                   // issue stream position
+    auto piece = [&](int stage, int idx) {
+        const int plane = idx / BP, r = idx % BP;
+        const int tw = __builtin_amdgcn_readlane(v_tw, i_tap);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[r] + (tw * p.Cin + i_cc * 32) + plane * p.wps),
+                                         (__attribute__((address_space(3))) void*)(Bs + ((stage * 3 + plane) * BN + RPP * r + 16 * wave_u) * 32), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        if (++i_tap == cntaps) { i_tap = 0; ++i_cc; }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addresses
+    int a_slot[MI];                                             // patch slot of the lane's output pixel at tap shift 0
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int il = wm * WTM + i * 32 + (lane & 31);
+        const int im = il / (rows_t * p.W), rem = il - im * (rows_t * p.W);
+        const int y = rem / p.W, x = rem - y * p.W;
+        a_slot[i] = im * pslots + y * PW + x;
+    }
+    int fo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ swz3(lane & 31)) << 3);
+    const int kh2 = lane >> 5;
+
+    if (nsteps > 0) patch_dma(0);
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nsteps) {
+#pragma unroll
+            for (int idx = 0; idx < NPB; ++idx) piece(s, idx);
+            advance();
+        }
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+    int c_tap = 0, c_cc = 0;                                    // compute stream position
+    auto step = [&](int stage, int nstage, auto more_c, auto inflight_c) {
+        constexpr bool MORE = decltype(more_c)::value;
+        constexpr int INFLIGHT = decltype(inflight_c)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // first tap of a chunk: every wave is past the previous chunk, its patch buffer is free -> the next chunk's patch is copied
+        // into it (issued before this step's weight copies: the in-order counter then retires it before any later weights)
+        if (c_tap == 0 && c_cc + 1 < cchunks) patch_dma(c_cc + 1);
+        const u16* Ap = As + (c_cc & 1) * (3 * PS * 32);
+        const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
+        const int tsh = __builtin_amdgcn_readlane(v_sh, c_tap);
+        int ao[MI][2];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int sl = a_slot[i] + tsh;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) ao[i][kk] = sl * 32 + (((kk * 2 + kh2) ^ ((sl >> 2) & 3)) << 3);
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[MI][3], b[NI][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(Ap + pl * PS * 32 + ao[i][kk]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + (pl * BN + j * 32) * 32 + fo[kk]);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = mfma_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j]);
+                        if (MORE && cnt % GAP == GAP - 1 && cnt / GAP < NPB) piece(nstage, cnt / GAP);
+                        ++cnt;
+                    }
+        }
+        if (MORE) {
+#pragma unroll
+            for (int idx = NMFMA / GAP; idx < NPB; ++idx) piece(nstage, idx);
+            advance();
+        }
+        if (++c_tap == cntaps) { c_tap = 0; ++c_cc; }
+    };
+    int stage = 0, nstage = NST - 1;
+    auto next = [&]() {
+        stage = stage + 1 == NST ? 0 : stage + 1;
+        nstage = nstage + 1 == NST ? 0 : nstage + 1;
+    };
+    int q = 0;
+    for (; q + NST - 1 < nsteps; ++q) { step(stage, nstage, std::true_type{}, std::integral_constant<int, (NST - 2) * NPB>{}); next(); }
+    if constexpr (NST == 3) {
+        if (q + 1 < nsteps) { step(stage, nstage, std::false_type{}, std::integral_constant<int, NPB>{}); next(); ++q; }
+    }
+    if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{});
+
+    float s1[NI], s2[NI];
+    igemm_store_rows<BM, BN, WGM, WGN>(p, c, acc, m0, n0, s1, s2);
+    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, int PS>
+int launch_x3h(const ConvP& p0, hipStream_t st) {
+    ConvP p = p0;
+    p.NT = p.Cout / BN;
+    p.cls[0].MT = p.cls[0].M / BM;
+    const size_t lds = ((size_t)2 * 3 * PS + (size_t)NST * 3 * BN) * 32 * sizeof(u16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { straps_set_error("conv_igemm_x3h_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS>), dim3(p.cls[0].MT * p.NT, 1), dim3(64 * WGM * WGN), lds, st, p);
+    STRAPS_CHECK_LAUNCH("conv_igemm_x3h_kernel");
+    return STRAPS_OK;
+}
+
+// does the halo-patch kernel (BM = 128) cover this problem?  3x3 / stride 1 / pad 1 as ONE class over the full map, tiles of whole rows
+// inside one image or of whole images, no ragged tile, patch within the slot capacity
+inline int halo_patch_slots(const ConvP& p) {
+    constexpr int BM = 128;
+    if (p.ncls != 1 || p.stride != 1 || p.omul != 1) return 0;
+    const ConvP::Class& c = p.cls[0];
+    if (c.ntaps != 9 || c.Mh != p.H || c.Mw != p.W || p.OH != p.H || p.OW != p.W || c.oah != 0 || c.oaw != 0 || c.M % BM != 0) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (c.tap_dh[t] < -1 || c.tap_dh[t] > 1 || c.tap_dw[t] < -1 || c.tap_dw[t] > 1) return 0;
+    const int HW = p.H * p.W;
+    if (BM >= HW) { if (BM % HW != 0) return 0; return (BM / HW) * (p.H + 2) * (p.W + 2); }
+    if (BM % p.W != 0 || HW % BM != 0) return 0;
+    return (BM / p.W + 2) * (p.W + 2);
+}
+
 template <int BM, int BN, int WGM, int WGN, int NST, int ABL = 0>
 int launch_x3(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
@@ -258,6 +480,20 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
     return cfg;
 }
 
+// auto tile choice only (tile_cfg & 15 == 0; bit 8 = im2col kernel only, bit 9 = halo kernel wherever it applies: A/B tools):
+// 1 = halo kernel 128x128, 2 = halo kernel 128x64, 0 = no.  Measured (tools/sweep_conv_x3.py, B = 64): halving the L2 -> LDS bytes
+// buys only 4-5 % where the grid still fills the chip with 128x128 tiles (layer2: 104 vs 108 us, layer3: 96 vs 101) and loses
+// against the smaller / two-per-CU tiles of layer1 (154 vs 135) and layer4 (157 vs 111): operand bytes are not what limits
+// these kernels (the barrier-per-step skeleton is: DESIGN.md section 9).
+inline int halo_choice(const ConvP& p, int tile_cfg) {
+    if ((tile_cfg & 15) != 0 || (tile_cfg & 256)) return 0;
+    const int slots = halo_patch_slots(p);
+    const bool all = (tile_cfg & 512) != 0;
+    if (slots > 0 && p.Cout % 128 == 0 && slots <= 208 && (all || (p.cls[0].M / 128) * (p.Cout / 128) >= 256)) return 1;
+    if (slots > 0 && p.Cout % 128 != 0 && slots <= 272 && all) return 2;
+    return 0;
+}
+
 template <int ABL>
 int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
     switch (cfg) {
@@ -278,6 +514,9 @@ int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
         M += p.cls[i].M;
         if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
     }
+    const int halo = halo_choice(p, tile_cfg);
+    if (halo == 1) return launch_x3h<128, 128, 2, 2, 3, 208>(p, st);
+    if (halo == 2) return launch_x3h<128, 64, 2, 2, 3, 272>(p, st);
     const int cfg = pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn);
     if ((tile_cfg & 192) == 192) return dispatch_x3_abl<3>(p, cfg, st);      // ablations (tools)
     if (tile_cfg & 64) return dispatch_x3_abl<1>(p, cfg, st);
@@ -343,9 +582,14 @@ extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plan
     return p.ncls ? dispatch_x3(p, tile_cfg, (hipStream_t)stream) : STRAPS_OK;
 }
 
-extern "C" int straps_conv_x3_stat_blocks(int batch, int ho, int wo, int cout, int kdim, int tile_cfg) {
+// number of [cout][2] statistics partials straps_conv_fwd_x3 writes for this geometry (= its M tiles)
+extern "C" int straps_conv_x3_stat_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg) {
+    ConvP p;
+    p.x = nullptr; p.w = nullptr; p.xps = p.wps = 0;
+    if (conv_fwd_problem(p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, batch, h, w, cin, cout, kh, kw, stride, pad) != STRAPS_OK) return -1;
+    const long long M = p.cls[0].M;
+    if (halo_choice(p, tile_cfg)) return (int)(M / 128);
     int bm, bn;
-    const long long M = (long long)batch * ho * wo;
-    pick_tile_x3(tile_cfg, M, cout, kdim, bm, bn);
+    pick_tile_x3(tile_cfg, M, cout, kh * kw * cin, bm, bn);
     return (int)((M + bm - 1) / bm);
 }

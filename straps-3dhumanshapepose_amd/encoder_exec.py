@@ -101,10 +101,11 @@ def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile
                      'straps_conv_fwd')
 
 
-def conv_stat_blocks(L, net, B, Ho, Wo, Cout, kdim, tile_cfg):
+def conv_stat_blocks(L, net, geom, Ho, Wo, tile_cfg):
+    B, H, W, Cin, Cout, k, stride, pad = geom
     if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
-        return L.straps_conv_x3_stat_blocks(B, Ho, Wo, Cout, kdim, tile_cfg)
-    return L.straps_conv_stat_blocks(B, Ho, Wo, Cout, kdim, tile_cfg)
+        return L.straps_conv_x3_stat_blocks(B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg)
+    return L.straps_conv_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
 
 
 def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
@@ -124,7 +125,7 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
         ss = net._folded_bn(bn)
         _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, None, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
         return y, Ho, Wo
-    nblk = conv_stat_blocks(L, net, B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
+    nblk = conv_stat_blocks(L, net, (B, H, W, Cin, Cout, k, stride, pad), Ho, Wo, tile_cfg)
     part = ctx.empty(nblk, Cout, 2)
     _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
     if rec is not None and ctx.x3:

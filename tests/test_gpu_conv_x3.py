@@ -89,7 +89,7 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
     part = None
     if x3:
         if stats:
-            part = torch.empty(L.straps_conv_x3_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, cfg), Cout, 2, device=dev)
+            part = torch.empty(L.straps_conv_x3_stat_blocks(B, H, W, Cin, Cout, k, k, stride, pad, cfg), Cout, 2, device=dev)
         xp, xps = _split(x)
         wp3, wps = _split(wp)
         hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(xp), xps, hipabi.ptr(wp3), wps, hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), int(relu),
@@ -105,7 +105,13 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
     (2, 64, 64, 16, 16, 3, 1, 0), (2, 64, 64, 16, 16, 3, 1, 3), (2, 64, 64, 16, 16, 3, 1, 7), (2, 64, 128, 16, 16, 3, 2, 1),
     (3, 128, 128, 8, 8, 3, 1, 5), (5, 128, 128, 24, 24, 3, 1, 4), (5, 128, 128, 24, 24, 3, 1, 6), (2, 64, 128, 16, 16, 1, 2, 0),
     (1, 256, 512, 8, 8, 3, 2, 0), (1, 512, 512, 8, 8, 3, 1, 0), (5, 64, 64, 7, 7, 3, 1, 2), (2, 256, 64, 16, 16, 1, 1, 0),
-    (2, 64, 64, 10, 24, 3, 1, 0), (3, 96, 128, 7, 13, 3, 2, 0), (1, 32, 64, 3, 3, 3, 1, 0), (2, 2048, 512, 4, 4, 1, 1, 0)])
+    (2, 64, 64, 10, 24, 3, 1, 0), (3, 96, 128, 7, 13, 3, 2, 0), (1, 32, 64, 3, 3, 3, 1, 0), (2, 2048, 512, 4, 4, 1, 1, 0),
+    # shapes the halo-patch kernel takes (cfg 0): two rows of 64, four rows of 32, eight rows of 16, two whole 8x8 images, 128-row
+    # tiles inside taller maps, 64 / 128 output channels (cfg 512 = halo kernel wherever it applies) -- the same through the im2col
+    # kernel (cfg 256) -- and a full-size layer3 launch, which the auto rule gives to the halo kernel
+    (1, 64, 64, 64, 64, 3, 1, 512), (1, 128, 128, 32, 32, 3, 1, 512), (2, 256, 256, 16, 16, 3, 1, 512), (4, 512, 512, 8, 8, 3, 1, 512),
+    (2, 64, 128, 8, 16, 3, 1, 512), (1, 64, 64, 8, 32, 3, 1, 512), (2, 64, 64, 16, 16, 3, 1, 256), (4, 512, 512, 8, 8, 3, 1, 256),
+    (64, 256, 256, 16, 16, 3, 1, 0)])
 def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """all tile configurations (4- and 8-wave, 2- and 3-stage rings), ragged M, stride 1 / 2, 3x3 and 1x1, non-square maps, the
     fused epilogue and the training-mode statistics; the bar is the exact-fp32 kernel's (test_gpu_forward.py)."""
