@@ -31,7 +31,11 @@ __device__ __forceinline__ int swz3(int r) { return (r >> 3) & 3; }
 
 // ABL (tools only, wrong results): 1 = no MFMAs and no fragment reads (prices the operand copies alone), 2 = no operand copies
 //   (prices the matrix work + fragment reads alone), 3 = neither copies nor fragment reads (the MFMA stream + barriers alone)
-template <int BM, int BN, int WGM, int WGN, int NST, int ABL = 0>
+// PIPE: software-pipelined chunk loop.  The fragments of the two 16-wide k steps of a chunk live in two register sets; the barrier that
+//   publishes chunk q+1 sits BETWEEN the two MFMA blocks of chunk q: k step 1 of chunk q is read before it, k step 0 of chunk q+1
+//   right after it, each half a chunk ahead of its MFMAs (no LDS latency in front of an MFMA block), and the stage of chunk q --
+//   dead once every wave is past that barrier -- is refilled with chunk q+NST during the second block (copies run NST chunks ahead).
+template <int BM, int BN, int WGM, int WGN, int NST, int ABL = 0, bool PIPE = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) {
     const ConvP::Class& c = p.cls[blockIdx.y];
     const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, cntaps = c.ntaps;
@@ -137,10 +141,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // chunk q lives in stage q % NST; the copies run NST - 1 chunks ahead of the matrix work
+    // chunk q lives in stage q % NST; the copies run NST - 1 (PIPE: NST) chunks ahead of the matrix work
     if (nchunks > 0) setup_tap(0);
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
+    for (int s = 0; s < (PIPE ? NST : NST - 1); ++s)
         if (s < nchunks) {
 #pragma unroll
             for (int idx = 0; idx < NPIECE; ++idx) piece(s, idx);
@@ -202,6 +206,68 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
             advance();
         }
     };
+    if constexpr (PIPE) {
+        bf16x8 fa[2][MI][3], fb[2][NI][3];
+        auto load_frags = [&](int stage, int kk, int set) {
+            const u16* Ab = As + (stage * 3 * BM + wm * WTM) * 32;
+            const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[set][i][pl] = *reinterpret_cast<const bf16x8*>(Ab + (pl * BM + i * 32) * 32 + fo[kk]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[set][j][pl] = *reinterpret_cast<const bf16x8*>(Bb + (pl * BN + j * 32) * 32 + fo[kk]);
+            }
+        };
+        constexpr int HALF = NMFMA / 2, GAP2 = HALF / NPIECE > 0 ? HALF / NPIECE : 1;
+        auto mfma_block = [&](int set, int nstage, bool more) {
+            int cnt = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = mfma_bf16(fa[set][i][TA[t]], fb[set][j][TB[t]], acc[i][j]);
+                        if (set == 1 && cnt % GAP2 == GAP2 - 1 && cnt / GAP2 < NPIECE) { if (more) piece(nstage, cnt / GAP2); }
+                        ++cnt;
+                    }
+            if (set == 1 && more) {
+#pragma unroll
+                for (int idx = HALF / GAP2; idx < NPIECE; ++idx) piece(nstage, idx);
+                advance();
+            }
+        };
+        if (nchunks > 0) {
+            // chunk 0 has landed (up to NST - 1 younger chunks may stay in flight), then everybody's has
+            if (nchunks >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            load_frags(0, 0, 0);
+        }
+        int stage = 0;
+        for (int q = 0; q < nchunks; ++q) {
+            const int nxt = stage + 1 == NST ? 0 : stage + 1;
+            load_frags(stage, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(0, 0, false);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < nchunks) {
+                // chunk q+1 (issued NST chunks ago) has landed -- the NST - 2 chunks after it may still be in flight
+                if (q + NST - 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NPIECE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (my reads of this chunk's stage are done before anyone may refill it)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load_frags(nxt, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(1, stage, q + NST < nchunks);          // refill this chunk's stage: no wave reads it any more
+            __builtin_amdgcn_sched_barrier(0);
+            stage = nxt;
+        }
+    } else {
     int stage = 0, nstage = NST - 1;
     auto next = [&]() {
         stage = stage + 1 == NST ? 0 : stage + 1;
@@ -213,6 +279,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
         if (q + 1 < nchunks) { chunk(stage, nstage, std::false_type{}, std::integral_constant<int, NPIECE>{}); next(); ++q; }
     }
     if (q < nchunks) chunk(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{});
+    }
 
     float s1[NI], s2[NI];
     igemm_store_rows<BM, BN, WGM, WGN>(p, c, acc, m0, n0, s1, s2);
@@ -441,7 +508,7 @@ inline int halo_patch_slots(const ConvP& p) {
     return (BM / p.W + 2) * (p.W + 2);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int NST, int ABL = 0, bool PIPE = false>
 int launch_x3(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     p.NT = p.Cout / BN;
@@ -453,17 +520,18 @@ int launch_x3(const ConvP& p0, hipStream_t st) {
     const size_t lds = (size_t)NST * 3 * (BM + BN) * 32 * sizeof(u16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("conv_igemm_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL>), dim3(maxblk, p.ncls), dim3(64 * WGM * WGN), lds, st, p);
+    hipLaunchKernelGGL((conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL, PIPE>), dim3(maxblk, p.ncls), dim3(64 * WGM * WGN), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_x3_kernel");
     return STRAPS_OK;
 }
 
 // tile_cfg & 15: 0 = auto, 1 = 128x128 (8 waves, 3 stages), 2 = 128x64 (4 waves, 2 stages, two workgroups per CU), 3 = 64x64 (4 waves, 3 stages),
-// 4 = 256x128 (8 waves, 2 stages), 5 = 128x128 (4 waves, 3 stages), 6 = 256x128 (4 waves, 2 stages), 7 = 128x64 (4 waves, 3 stages)
+// 4 = 256x128 (8 waves, 2 stages), 5 = 128x128 (4 waves, 3 stages), 6 = 256x128 (4 waves, 2 stages), 7 = 128x64 (4 waves, 3 stages);
+// software-pipelined loop (PIPE): 8 = as 5, 9 = as 1, 10 = as 7, 11 = as 2, 12 = as 4
 // auto rule from tools/sweep_conv_x3.py (resnet18 shapes, B = 64): 64-channel outputs take 128x64 tiles, two workgroups per CU; otherwise
 // the largest tile that still gives every CU a workgroup: 256x128 from 512 128x128-tiles on (layer2: 63 vs 68 us), 128x128 from 256
 // (layer3: 97 vs 108), else 128x64 with the three-stage ring (layer4's 4096 pixels: 113 vs 150).
@@ -472,24 +540,26 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
     cfg &= 15;
     if (cfg == 0) {
         const long long t128 = ((M + 127) / 128) * (cout / 128);
-        cfg = cout % 128 != 0 ? 2 : t128 >= 512 ? 4 : t128 >= 256 ? 5 : 7;
+        cfg = cout % 128 != 0 ? 11 : t128 >= 512 ? 12 : t128 >= 256 ? 5 : 7;       // (11 / 12: the pipelined loop pays with two-stage rings: -7 %)
     }
-    if (cout % 128 != 0 && cfg != 3 && cfg != 7) cfg = 2;
-    bm = (cfg == 4 || cfg == 6) ? 256 : cfg == 3 ? 64 : 128;
-    bn = (cfg == 2 || cfg == 3 || cfg == 7) ? 64 : 128;
+    if (cout % 128 != 0 && cfg != 3 && cfg != 7 && cfg != 10 && cfg != 11) cfg = 2;
+    bm = (cfg == 4 || cfg == 6 || cfg == 12) ? 256 : cfg == 3 ? 64 : 128;
+    bn = (cfg == 2 || cfg == 3 || cfg == 7 || cfg == 10 || cfg == 11) ? 64 : 128;
     return cfg;
 }
 
 // auto tile choice only (tile_cfg & 15 == 0; bit 8 = im2col kernel only, bit 9 = halo kernel wherever it applies: A/B tools):
 // 1 = halo kernel 128x128, 2 = halo kernel 128x64, 0 = no.  Measured (tools/sweep_conv_x3.py, B = 64): halving the L2 -> LDS bytes
-// buys only 4-5 % where the grid still fills the chip with 128x128 tiles (layer2: 104 vs 108 us, layer3: 96 vs 101) and loses
+// buys only 4-5 % where the grid still fills the chip with 128x128 tiles (layer2: 104 vs 108 us -- 98 with the pipelined 256x128 tile,
+// which is what layer2 uses --, layer3: 96 vs 101) and loses
 // against the smaller / two-per-CU tiles of layer1 (154 vs 135) and layer4 (157 vs 111): operand bytes are not what limits
 // these kernels (the barrier-per-step skeleton is: DESIGN.md section 9).
 inline int halo_choice(const ConvP& p, int tile_cfg) {
     if ((tile_cfg & 15) != 0 || (tile_cfg & 256)) return 0;
     const int slots = halo_patch_slots(p);
     const bool all = (tile_cfg & 512) != 0;
-    if (slots > 0 && p.Cout % 128 == 0 && slots <= 208 && (all || (p.cls[0].M / 128) * (p.Cout / 128) >= 256)) return 1;
+    const long long t128 = (long long)(p.cls[0].M / 128) * (p.Cout / 128);
+    if (slots > 0 && p.Cout % 128 == 0 && slots <= 208 && (all || (t128 >= 256 && t128 < 512))) return 1;
     if (slots > 0 && p.Cout % 128 != 0 && slots <= 272 && all) return 2;
     return 0;
 }
@@ -503,6 +573,11 @@ int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
         case 4: return launch_x3<256, 128, 4, 2, 2, ABL>(p, st);
         case 5: return launch_x3<128, 128, 2, 2, 3, ABL>(p, st);
         case 6: return launch_x3<256, 128, 2, 2, 2, ABL>(p, st);
+        case 8: return launch_x3<128, 128, 2, 2, 3, 0, true>(p, st);
+        case 9: return launch_x3<128, 128, 4, 2, 3, 0, true>(p, st);
+        case 10: return launch_x3<128, 64, 2, 2, 3, 0, true>(p, st);
+        case 11: return launch_x3<128, 64, 2, 2, 2, 0, true>(p, st);
+        case 12: return launch_x3<256, 128, 4, 2, 2, 0, true>(p, st);
         default: return launch_x3<128, 64, 2, 2, 3, ABL>(p, st);
     }
 }

@@ -111,7 +111,10 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
     # kernel (cfg 256) -- and a full-size layer3 launch, which the auto rule gives to the halo kernel
     (1, 64, 64, 64, 64, 3, 1, 512), (1, 128, 128, 32, 32, 3, 1, 512), (2, 256, 256, 16, 16, 3, 1, 512), (4, 512, 512, 8, 8, 3, 1, 512),
     (2, 64, 128, 8, 16, 3, 1, 512), (1, 64, 64, 8, 32, 3, 1, 512), (2, 64, 64, 16, 16, 3, 1, 256), (4, 512, 512, 8, 8, 3, 1, 256),
-    (64, 256, 256, 16, 16, 3, 1, 0)])
+    (64, 256, 256, 16, 16, 3, 1, 0),
+    # software-pipelined chunk loop (barrier between the two k steps, register double buffer): every such configuration
+    (3, 128, 128, 8, 8, 3, 1, 8), (5, 128, 128, 24, 24, 3, 1, 9), (2, 64, 64, 16, 16, 3, 1, 10), (5, 64, 64, 7, 7, 3, 1, 11),
+    (5, 128, 128, 24, 24, 3, 1, 12), (2, 64, 128, 16, 16, 1, 2, 8), (1, 32, 64, 3, 3, 3, 1, 11), (2, 64, 128, 16, 16, 3, 2, 9)])
 def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """all tile configurations (4- and 8-wave, 2- and 3-stage rings), ragged M, stride 1 / 2, 3x3 and 1x1, non-square maps, the
     fused epilogue and the training-mode statistics; the bar is the exact-fp32 kernel's (test_gpu_forward.py)."""

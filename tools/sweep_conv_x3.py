@@ -87,15 +87,15 @@ for name, H, Cin, Cout, k, stride in SHAPES:
     t32 = timeit(lambda: L.straps_conv_fwd(hipabi.ptr(x), hipabi.ptr(wp), None, None, None, 0, hipabi.ptr(y), None, B, H, H, Cin, Cout, k, k, stride, pad, 0, None))
     row = '%-13s M=%6d N=%3d K=%4d | fwd err/max: fp32 %.1e  x3 %s | dgrad err: fp32 %.1e x3 %.1e | fwd fp32 %6.1f us (%5.1f TF) | x3' % (
         name, B * Ho * Ho, Cout, Cin * k * k, e32, ' '.join('%.1e' % e for e in errs), ed32, ed3, t32 * 1e6, flops / t32 / 1e12)
-    for cfg in (0, 256, 1, 2, 4, 5, 7):
-        if (cfg & 15) in (1, 4, 5, 6) and Cout % 128:
+    for cfg in (0, 2, 4, 5, 7, 8, 9, 10, 11, 12):
+        if (cfg & 15) in (1, 4, 5, 6, 8, 9, 12) and Cout % 128:
             continue
         t = timeit(lambda: L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(wp3), wps, None, None, None, 0, hipabi.ptr(y3), None, B, H, H, Cin, Cout, k, k, stride, pad, cfg, None))
         row += ' c%d %5.1f' % (cfg, t * 1e6)
     td32 = timeit(lambda: L.straps_conv_dgrad(hipabi.ptr(g), hipabi.ptr(wd), None, hipabi.ptr(dx), B, H, H, Cin, Cout, k, k, stride, pad, 0, None))
     row += ' us | dgrad fp32 %6.1f us, x3' % (td32 * 1e6)
-    for cfg in (0, 256, 1, 2, 4, 5, 7):
-        if (cfg & 15) in (1, 4, 5, 6) and Cin % 128:
+    for cfg in (0, 2, 4, 5, 7, 8, 9, 10, 11, 12):
+        if (cfg & 15) in (1, 4, 5, 6, 8, 9, 12) and Cin % 128:
             continue
         t = timeit(lambda: L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(wd3), wdps, None, hipabi.ptr(dx3), B, H, H, Cin, Cout, k, k, stride, pad, cfg, None))
         row += ' c%d %5.1f' % (cfg, t * 1e6)
