@@ -46,6 +46,8 @@ def pmc_traffic(args, kernel):
     tag = '%s_r%d_b%d' % (args.workload, args.layers, args.batch or (65536 if args.workload == 'smpl' else 64))
     if args.workload == 'smpl' and args.smpl_precision != 'fp16x3_lbs':
         tag += '_' + args.smpl_precision
+    if args.workload != 'smpl' and args.conv_precision != 'bf16x3':
+        tag += '_' + args.conv_precision + 'conv'
     try:
         rec = json.load(open(path)).get(tag)
     except (OSError, ValueError):
@@ -60,7 +62,7 @@ def pmc_traffic(args, kernel):
                 byt += k['launches'] * (k['hbm_read_bytes'] + k['hbm_write_bytes'])
                 if nm.startswith('smpl_verts'):
                     n += k['launches']
-        elif nm.startswith(kernel):
+        elif nm.startswith(kernel) or (kernel == 'conv_igemm_x3_kernel' and nm.startswith('conv_igemm_x3h_kernel')):
             n += k['launches']
             byt += k['launches'] * (k['hbm_read_bytes'] + k['hbm_write_bytes'])
     if not n:

@@ -21,12 +21,14 @@ pmc() {  # json tag, summary name, source text, bench args...
 }
 cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 prof train_b64 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
+prof train_b64_fp32conv --conv-precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
 prof fwd_b64 --workload fwd --steps 10 --warmup 3 --no-cpu-baseline --no-graph
 prof smpl_65536 --workload smpl --steps 5 --warmup 2 --no-cpu-baseline --no-graph
 prof smpl_65536_fp32 --workload smpl --smpl-precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-graph
 prof train_r50_b32 --config 3 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
 S='rocprofv3 --kernel-trace --pmc MfmaUtil | FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py'
 pmc train_r18_b64 train_b64 "$S --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
+pmc train_r18_b64_fp32conv train_b64_fp32conv "$S --conv-precision fp32 --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --conv-precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
 pmc fwd_r18_b64 fwd_b64 "$S --workload fwd --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload fwd --steps 2 --warmup 1 --no-cpu-baseline --no-graph
 pmc smpl_r18_b65536 smpl_65536 "$S --workload smpl --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload smpl --steps 2 --warmup 1 --no-cpu-baseline --no-graph
 pmc smpl_r18_b65536_fp32 smpl_65536_fp32 "$S --workload smpl --smpl-precision fp32 --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload smpl --smpl-precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --no-graph
@@ -34,7 +36,9 @@ pmc train_r50_b32 train_r50_b32 "$S --config 3 --steps 2 --warmup 1 --no-graph; 
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json      # bench.py reports roofline.traffic from this file
 cd $R
 python bench.py 2>/dev/null | tail -1 > $O/${RND}_bench_train_b64.json
+python bench.py --conv-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_train_b64_fp32conv.json
 python bench.py --config 1 2>/dev/null | tail -1 > $O/${RND}_bench_fwd_b64.json
+python bench.py --config 1 --conv-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_fwd_b64_fp32conv.json
 python bench.py --config 4 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M.json
 python bench.py --config 4 --smpl-precision fp16x3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp16x3.json
 python bench.py --config 4 --smpl-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp32.json
