@@ -172,12 +172,18 @@ def test_pmc_summary_and_bench_traffic_reader(tmp_path):
     spec.loader.exec_module(bench)
     prof = os.path.join(root, 'profiles', 'pmc_traffic.json')
     committed = json.load(open(prof))
-    assert 'train_r18_b64' in committed and any(n.replace('void ', '').startswith('conv_igemm_kernel') for n in committed['train_r18_b64']['kernels'])
-    got = bench.pmc_traffic(types.SimpleNamespace(workload='train', layers=18, batch=0), 'conv_igemm_kernel')
-    ks = [v for n, v in committed['train_r18_b64']['kernels'].items() if n.replace('void ', '').startswith('conv_igemm_kernel')]
-    want = sum(v['launches'] * (v['hbm_read_bytes'] + v['hbm_write_bytes']) for v in ks) / sum(v['launches'] for v in ks)
-    assert got['traffic'] == round(want)
-    assert bench.pmc_traffic(types.SimpleNamespace(workload='train', layers=101, batch=0), 'conv_igemm_kernel') == {}
+    def match(n, kernel):
+        n = n.replace('void ', '')
+        return n.startswith(kernel) or (kernel == 'conv_igemm_x3_kernel' and n.startswith('conv_igemm_x3h_kernel'))
+
+    for tag, prec, kernel in (('train_r18_b64', 'bf16x3', 'conv_igemm_x3_kernel'), ('train_r18_b64_fp32conv', 'fp32', 'conv_igemm_kernel')):
+        assert tag in committed and any(match(n, kernel) for n in committed[tag]['kernels']), tag
+        got = bench.pmc_traffic(types.SimpleNamespace(workload='train', layers=18, batch=0, conv_precision=prec, smpl_precision='fp16x3_lbs'), kernel)
+        ks = [v for n, v in committed[tag]['kernels'].items() if match(n, kernel)]
+        want = sum(v['launches'] * (v['hbm_read_bytes'] + v['hbm_write_bytes']) for v in ks) / sum(v['launches'] for v in ks)
+        assert got['traffic'] == round(want)
+    assert bench.pmc_traffic(types.SimpleNamespace(workload='train', layers=101, batch=0, conv_precision='bf16x3', smpl_precision='fp16x3_lbs'),
+                             'conv_igemm_x3_kernel') == {}
 
 
 def write_real_layout_model(tmp_path, model):
