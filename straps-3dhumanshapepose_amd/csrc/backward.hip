@@ -10,6 +10,7 @@
 //   gemm_strided_kernel    small generic C[M,N] (+)= A.B with arbitrary strides (IEF linear dgrad / wgrad)
 //   rot6d_bwd_kernel       Gram-Schmidt backward
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -352,6 +353,181 @@ __device__ __forceinline__ bf16x8w tr_frag(const u16* lo, const u16* hi) {
     const short4w b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4w*)hi);
     const short8w v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8w, v);
+}
+
+// per-tap weight gradient (stride-2 / 1x1 / any shape the halo plan does not take) on the planes: conv_wgrad_kernel's structure -- one tap
+// x a BCO x BCI channel block x one split of the pixels per workgroup, 32 pixels per step, LDS-DMA copies, two stages -- with the
+// operand gathers of the kernel below (ds_read_b64_tr_b16).  Rows are BCO (BCI) bf16 channels; their 64-byte segments are permuted
+// by the pixel number so four consecutive pixel rows cover all 64 banks (2 segments per row: swap on bit 1; 4 or more: xor with
+// the low two bits).
+struct WgradXP {
+    const u16* x3;
+    const u16* dy3;
+    long long xps, dps;
+    float* part;
+    int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
+    int M, rows_per_split, ct, it;
+};
+
+template <int BC>
+__device__ __forceinline__ int seg_swz(int px) { return BC == 64 ? ((px >> 1) & 1) : (px & 3); }
+
+template <int BCO, int BCI>
+__global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
+    constexpr int PLD = 32 * BCO, PLX = 32 * BCI;                 // u16 elements per plane of a stage: [32 px][BCO], [32 px][BCI]
+    constexpr int STG = 3 * (PLD + PLX);
+    constexpr int LPD = BCO / 8, PWD = 64 / LPD, RDD = 8 / PWD;   // dy: lanes per pixel, pixels per wave-copy, copy rounds per wave
+    constexpr int LPX = BCI / 8, PWX = 64 / LPX, RDX = 8 / PWX;
+    constexpr int MI = BCO / 64, NI = BCI / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    u16* smem = reinterpret_cast<u16*>(smem_f);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = blockIdx.x;
+    const int itile = t % p.it; t /= p.it;
+    const int ctile = t % p.ct; t /= p.ct;
+    const int tap = t;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int split = blockIdx.y;
+    const int co0 = ctile * BCO, ci0 = itile * BCI;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(mbeg + p.rows_per_split, p.M);
+    const int nsteps = (mend - mbeg + 31) >> 5;
+    const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+    const u16* zsrc = reinterpret_cast<const u16*>(k_zero16w);
+    asm volatile("" : "+s"(zsrc));
+
+    // copy slots at step 0: round q of this wave copies pixels (q*4 + wave) * PW .. of the tile; a lane's 16-byte slot j = lane % LP
+    // of pixel row px receives channel group ((j >> 2) ^ swz(px)) * 4 + (j & 3)
+    int md[RDD], gd[RDD];
+    int mx[RDX], gx[RDX], wo_[RDX], ho_[RDX], b_[RDX];
+#pragma unroll
+    for (int q = 0; q < RDD; ++q) {
+        const int px = (q * 4 + wave) * PWD + lane / LPD, j = lane % LPD;
+        md[q] = mbeg + px;
+        gd[q] = ((((j >> 2) ^ seg_swz<BCO>(px)) << 2) | (j & 3)) * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < RDX; ++q) {
+        const int px = (q * 4 + wave) * PWX + lane / LPX, j = lane % LPX;
+        const int m = mbeg + px;
+        mx[q] = m;
+        gx[q] = ((((j >> 2) ^ seg_swz<BCI>(px)) << 2) | (j & 3)) * 8;
+        const int HoWo = p.Ho * p.Wo;
+        b_[q] = m / HoWo;
+        const int rem = m - b_[q] * HoWo;
+        ho_[q] = rem / p.Wo;
+        wo_[q] = rem - ho_[q] * p.Wo;
+    }
+    const int adv_h = 32 / p.Wo, adv_w = 32 - adv_h * p.Wo;      // a step moves every slot 32 pixels on
+    auto dma_step = [&](int stage) {
+        u16* D = smem + stage * STG;
+        u16* X = D + 3 * PLD;
+#pragma unroll
+        for (int q = 0; q < RDD; ++q) {
+            const bool in = md[q] < mend;
+            const u16* src = in ? p.dy3 + (long long)md[q] * p.Cout + co0 + gd[q] : zsrc;
+            const long long ps = in ? p.dps : 0;
+            md[q] += 32;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pl * ps),
+                                                 (__attribute__((address_space(3))) void*)(D + pl * PLD + (q * 4 + wave_u) * PWD * BCO), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < RDX; ++q) {
+            bool in = mx[q] < mend;
+            const u16* src = zsrc;
+            if (pointwise) {
+                if (in) src = p.x3 + (long long)mx[q] * p.Cin + ci0 + gx[q];
+            } else {
+                const int hi = ho_[q] * p.stride - p.pad + r, wi = wo_[q] * p.stride - p.pad + s;
+                in = in && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                if (in) src = p.x3 + (((long long)b_[q] * p.H + hi) * p.W + wi) * p.Cin + ci0 + gx[q];
+                wo_[q] += adv_w; ho_[q] += adv_h;
+                if (wo_[q] >= p.Wo) { wo_[q] -= p.Wo; ++ho_[q]; }
+                if (ho_[q] >= p.Ho) { const int k = ho_[q] / p.Ho; ho_[q] -= k * p.Ho; b_[q] += k; }
+            }
+            const long long ps = in ? p.xps : 0;
+            mx[q] += 32;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pl * ps),
+                                                 (__attribute__((address_space(3))) void*)(X + pl * PLX + (q * 4 + wave_u) * PWX * BCI), 16, 0, 0);
+        }
+    };
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NI; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][c][q] = 0.f;
+    if (nsteps > 0) dma_step(0);
+    // fragment addresses: lane t = lane & 15 names row t >> 2 of a 4-pixel group and channel quad t & 3 of its 16-channel half
+    const int tt = lane & 15, ch16 = (lane >> 4) & 1, kh = lane >> 5;
+    int fd[2][2][MI], fx[2][2][NI];                               // [k step][read][32-channel block]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int px = ks * 16 + kh * 8 + rd * 4 + (tt >> 2);
+#pragma unroll
+            for (int a = 0; a < MI; ++a) {
+                const int c4 = wm * (BCO / 2) + a * 32 + ch16 * 16 + (tt & 3) * 4;
+                fd[ks][rd][a] = px * BCO + (((c4 >> 5) ^ seg_swz<BCO>(px)) << 5) + (c4 & 31);
+            }
+#pragma unroll
+            for (int c = 0; c < NI; ++c) {
+                const int c4 = wn * (BCI / 2) + c * 32 + ch16 * 16 + (tt & 3) * 4;
+                fx[ks][rd][c] = px * BCI + (((c4 >> 5) ^ seg_swz<BCI>(px)) << 5) + (c4 & 31);
+            }
+        }
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+    for (int st = 0; st < nsteps; ++st) {
+        const int stage = st & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies of step st have landed ...
+        __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
+        asm volatile("" ::: "memory");
+        if (st + 1 < nsteps) dma_step(stage ^ 1);
+        const u16* D = smem + stage * STG;
+        const u16* X = D + 3 * PLD;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8w av[MI][3], bv[NI][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) av[a][pl] = tr_frag(D + pl * PLD + fd[ks][0][a], D + pl * PLD + fd[ks][1][a]);
+#pragma unroll
+                for (int c = 0; c < NI; ++c) bv[c][pl] = tr_frag(X + pl * PLX + fx[ks][0][c], X + pl * PLX + fx[ks][1][c]);
+            }
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+#pragma unroll
+                for (int a = 0; a < MI; ++a)
+#pragma unroll
+                    for (int c = 0; c < NI; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a][TA[e]], bv[c][TB[e]], acc[a][c], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    // C layout: lane -> ci (col), reg -> co (row).  partial[split][co][tap][ci]
+    const int i = lane & 31;
+    const long long RS = (long long)p.R * p.S;
+    float* o = p.part + (long long)split * p.Cout * RS * p.Cin;
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NI; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = co0 + wm * (BCO / 2) + a * 32 + mfma_row(q, lane);
+                o[((long long)co * RS + tap) * p.Cin + ci0 + wn * (BCI / 2) + c * 32 + i] = acc[a][c][q];
+            }
 }
 
 // NG = 2: two 4-wave groups share every stage; group g takes k step g (pixels 16g .. 16g+15) of each chunk and the two accumulator
@@ -1388,6 +1564,46 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         STRAPS_CHECK_LAUNCH("conv_wgrad3x3_x3_kernel");
         const long long n3 = (long long)cout * 9 * cin;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n3 / 256)), dim3(256), 0, st3, q.part, dw_oihw, splits3, cout, cin, 9, accumulate);
+        STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+        return STRAPS_OK;
+    }
+    // per-tap kernel on the planes where it beats the fp32 one (tools/sweep_wgrad_x3.py: 3x3 / stride 2: 87-93 vs 115-125 us; 1x1 with at
+    // least 128 channels on both sides: +0..29 %; with a 64-channel side the fp32 kernel's 4-byte rows win: 52 vs 60 us).  Both stream
+    // their operands from memory once per tile of the other channel dimension: bytes, not the matrix pipe, set their rate.
+    static const bool tap_x3 = !(getenv("STRAPS_WGRAD_TAP_FP32") && atoi(getenv("STRAPS_WGRAD_TAP_FP32")));      // (A/B switch for tools)
+    if (tap_x3 && x3 && dy3 && (kh * kw > 1 || (cin >= 128 && cout >= 128))) {
+        // same tiles, splits and partial layout as the fp32 kernel (the workspace size is shared)
+        STRAPS_REQUIRE(x_plane_stride % 8 == 0 && dy_plane_stride % 8 == 0, "straps_conv_wgrad_x3: plane strides must be multiples of 8 elements");
+        WgradXP q;
+        q.x3 = x3; q.dy3 = dy3; q.xps = x_plane_stride; q.dps = dy_plane_stride; q.part = (float*)workspace;
+        q.B = batch; q.H = h; q.W = w; q.Cin = cin; q.Cout = cout; q.R = kh; q.S = kw; q.stride = stride; q.pad = pad;
+        q.Ho = (h + 2 * pad - kh) / stride + 1;
+        q.Wo = (w + 2 * pad - kw) / stride + 1;
+        const long long M = (long long)batch * q.Ho * q.Wo;
+        STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_wgrad_x3: problem too large");
+        q.M = (int)M;
+        const bool big = wgrad_big_tile(M, cin, cout, kh * kw);
+        const int tile = big ? 128 : 64;
+        q.ct = cout / tile; q.it = cin / tile;
+        const int tiles = kh * kw * q.ct * q.it;
+        const int splits = wgrad_splits(M, tiles, big);
+        q.rows_per_split = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
+        hipStream_t st = (hipStream_t)stream;
+        if (big) {
+            constexpr int LDSB = 2 * 3 * 32 * 256 * 2;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+                if (e != hipSuccess) { straps_set_error("conv_wgrad_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128>), dim3(tiles, splits), dim3(256), LDSB, st, q);
+        } else {
+            hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 64>), dim3(tiles, splits), dim3(256), 2 * 3 * 32 * 128 * 2, st, q);
+        }
+        STRAPS_CHECK_LAUNCH("conv_wgrad_x3_kernel");
+        const long long n = (long long)cout * kh * kw * cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, st, q.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);
         STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
         return STRAPS_OK;
     }

@@ -166,17 +166,21 @@ def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     assert err < 2e-5, 'dgrad_x3 relative-to-max error %.3e' % err
 
 
-@pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 64, 64, 16, 16), (3, 128, 64, 8, 8), (2, 64, 128, 4, 32), (1, 128, 128, 6, 64), (5, 64, 64, 12, 8),
-                                            (2, 64, 64, 9, 16), (2, 64, 64, 10, 24)])
-def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W):
-    """3x3 / stride-1 weight gradient on the planes (halo-patch kernel, transpose-read operand gathers): every chunk geometry the plan
-    produces (W = 8 .. 64: 4 x 8 .. 1 x 32 pixel chunks), image borders, several splits, accumulate; the last two shapes do not fit
-    the plan (odd row count / non-power-of-two width) and must fall through to the fp32 kernels.  Bar: 2e-5 of the maximum, the
-    fp32 kernel's bar in test_gpu_backward.py."""
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride', [
+    (2, 64, 64, 16, 16, 3, 1), (3, 128, 64, 8, 8, 3, 1), (2, 64, 128, 4, 32, 3, 1), (1, 128, 128, 6, 64, 3, 1), (5, 64, 64, 12, 8, 3, 1),
+    # shapes outside the halo plan (odd row count, non-power-of-two width), stride 2, 1x1 (stride 1 and 2), the 128x128 channel tile
+    # of the big 1x1 layers (M >= 8192), ragged last step, zero-padded borders: the per-tap kernel on the planes
+    (2, 64, 64, 9, 16, 3, 1), (2, 64, 64, 10, 24, 3, 1), (2, 64, 128, 16, 16, 3, 2), (2, 128, 128, 15, 15, 3, 2), (2, 64, 128, 16, 16, 1, 2),
+    (2, 256, 64, 8, 8, 1, 1), (3, 128, 256, 56, 56, 1, 1), (1, 256, 128, 96, 96, 1, 1), (1, 256, 512, 8, 8, 3, 2), (3, 64, 192, 7, 5, 1, 1)])
+def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride):
+    """weight gradient on the planes: the halo-patch kernel (3x3 / stride 1, every chunk geometry the plan produces: W = 8 .. 64) and
+    the per-tap kernel (everything else), transpose-read operand gathers, several splits, accumulate.  Bar: 2e-5 of the maximum,
+    the fp32 kernels' bar in test_gpu_backward.py."""
     L = hipabi.lib()
-    k, stride, pad = 3, 1, 1
+    pad = 1 if k == 3 else 0
     x = torch.from_numpy(det_uniform((B, Cin, H, W), 31, -1, 1)).double()
-    dy = torch.from_numpy(det_uniform((B, Cout, H, W), 32, -1, 1)).double() * 1e-3
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = torch.from_numpy(det_uniform((B, Cout, Ho, Wo), 32, -1, 1)).double() * 1e-3
     ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, k, k), dy, stride=stride, padding=pad)
     xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
     gd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
@@ -191,6 +195,11 @@ def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W):
     hipabi.check(L.straps_conv_wgrad_x3(*args, 1, None), 'wgrad_x3 accumulate')
     err = float((dw.cpu().double() - 2 * ref).abs().max() / ref.abs().max())
     assert err < 4e-5, 'wgrad_x3 accumulate: %.3e' % err
+    # without planes the entry point is the fp32 weight gradient
+    hipabi.check(L.straps_conv_wgrad_x3(hipabi.ptr(xd), hipabi.ptr(gd), None, 0, None, 0, hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k,
+                                        stride, pad, 0, None), 'wgrad_x3 (no planes)')
+    err = float((dw.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5
 
 
 def test_error_budget_of_the_six_products(dev):

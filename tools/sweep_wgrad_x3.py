@@ -13,7 +13,12 @@ from straps_amd import hipabi  # noqa: E402
 L = hipabi.load()
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-SHAPES = [('l1 3x3 s1', 64, 64, 64), ('l2 3x3 s1', 32, 128, 128), ('l3 3x3 s1', 16, 256, 256), ('l4 3x3 s1', 8, 512, 512)]
+SHAPES = [('l1 3x3 s1', 64, 64, 64, 3, 1), ('l2 3x3 s1', 32, 128, 128, 3, 1), ('l3 3x3 s1', 16, 256, 256, 3, 1), ('l4 3x3 s1', 8, 512, 512, 3, 1),
+          ('l2.0 3x3 s2', 64, 64, 128, 3, 2), ('l2 ds 1x1 s2', 64, 64, 128, 1, 2), ('l3.0 3x3 s2', 32, 128, 256, 3, 2), ('l3 ds 1x1 s2', 32, 128, 256, 1, 2),
+          ('l4.0 3x3 s2', 16, 256, 512, 3, 2), ('l4 ds 1x1 s2', 16, 256, 512, 1, 2),
+          ('r50 l1 64>256', 56, 64, 256, 1, 1), ('r50 l1 256>64', 56, 256, 64, 1, 1), ('r50 l2 256>128', 56, 256, 128, 1, 1), ('r50 l2 128>512', 28, 128, 512, 1, 1),
+          ('r50 l2 512>128', 28, 512, 128, 1, 1), ('r50 l3 256>1024', 14, 256, 1024, 1, 1), ('r50 l3 1024>256', 14, 1024, 256, 1, 1),
+          ('r50 l4 512>2048', 7, 512, 2048, 1, 1), ('r50 l4 2048>512', 7, 2048, 512, 1, 1), ('r50 l3 3x3 s2', 28, 256, 256, 3, 2)]
 
 
 def timeit(fn, iters=20):
@@ -37,26 +42,28 @@ def split3(t):
     return out, ps
 
 
-for name, H, Cin, Cout in SHAPES:
-    k, stride, pad = 3, 1, 1
+for name, H, Cin, Cout, k, stride in SHAPES:
+    pad = 1 if k == 3 else 0
+    Bn = B if not name.startswith('r50') else B // 2
+    Ho = (H + 2 * pad - k) // stride + 1
     torch.manual_seed(0)
-    x = torch.randn(B, H, H, Cin, device=dev).relu_()
-    g = torch.randn(B, H, H, Cout, device=dev) * 1e-3
+    x = torch.randn(Bn, H, H, Cin, device=dev).relu_()
+    g = torch.randn(Bn, Ho, Ho, Cout, device=dev) * 1e-3
     x3, xps = split3(x)
     g3, gps = split3(g)
-    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, k, k, stride, pad) // 4, device=dev)
+    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(Bn, H, H, Cin, Cout, k, k, stride, pad) // 4, device=dev)
     dw32 = torch.empty(Cout, Cin, k, k, device=dev)
     dw3 = torch.full((Cout, Cin, k, k), float('nan'), device=dev)
-    hipabi.check(L.straps_conv_wgrad(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(dw32), hipabi.ptr(ws), B, H, H, Cin, Cout, k, k, stride, pad, 0, None), 'wgrad')
-    hipabi.check(L.straps_conv_wgrad_x3(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(x3), xps, hipabi.ptr(g3), gps, hipabi.ptr(dw3), hipabi.ptr(ws), B, H, H, Cin,
+    hipabi.check(L.straps_conv_wgrad(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(dw32), hipabi.ptr(ws), Bn, H, H, Cin, Cout, k, k, stride, pad, 0, None), 'wgrad')
+    hipabi.check(L.straps_conv_wgrad_x3(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(x3), xps, hipabi.ptr(g3), gps, hipabi.ptr(dw3), hipabi.ptr(ws), Bn, H, H, Cin,
                                         Cout, k, k, stride, pad, 0, None), 'wgrad_x3')
     ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, k, k), g.permute(0, 3, 1, 2).double(), stride=stride, padding=pad)
     sc = ref.abs().max().item()
     e32 = (dw32.double() - ref).abs().max().item() / sc
     e3 = (dw3.double() - ref).abs().max().item() / sc
-    flops = 2.0 * B * H * H * Cout * Cin * 9
-    t32 = timeit(lambda: L.straps_conv_wgrad(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(dw32), hipabi.ptr(ws), B, H, H, Cin, Cout, k, k, stride, pad, 0, None))
-    t3 = timeit(lambda: L.straps_conv_wgrad_x3(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(x3), xps, hipabi.ptr(g3), gps, hipabi.ptr(dw3), hipabi.ptr(ws), B, H, H,
+    flops = 2.0 * Bn * Ho * Ho * Cout * Cin * k * k
+    t32 = timeit(lambda: L.straps_conv_wgrad(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(dw32), hipabi.ptr(ws), Bn, H, H, Cin, Cout, k, k, stride, pad, 0, None))
+    t3 = timeit(lambda: L.straps_conv_wgrad_x3(hipabi.ptr(x), hipabi.ptr(g), hipabi.ptr(x3), xps, hipabi.ptr(g3), gps, hipabi.ptr(dw3), hipabi.ptr(ws), Bn, H, H,
                                                Cin, Cout, k, k, stride, pad, 0, None))
-    print('%-10s err/max vs float64: fp32 %.1e  x3 %.1e | fp32 %6.1f us (%5.1f TF)  x3 %6.1f us (%5.1f TF fp32-equivalent)' % (
+    print('%-16s err/max vs float64: fp32 %.1e  x3 %.1e | fp32 %6.1f us (%5.1f TF)  x3 %6.1f us (%5.1f TF fp32-equivalent)' % (
         name, e32, e3, t32 * 1e6, flops / t32 / 1e12, t3 * 1e6, flops / t3 / 1e12), flush=True)
