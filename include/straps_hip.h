@@ -289,7 +289,8 @@ int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plane_stride,
 /* producers of the bf16x3 route that write their fp32 output AND its three planes in one pass (instead of a
  * straps_split3_bf16 pass over the output): straps_bn_apply / straps_bn_relu_maxpool_fwd / straps_bn_bwd with
  * two more arguments (planes [3][plane_stride], plane_stride >= element count, a multiple of 8; draw_planes
- * may be NULL).                                                                                             */
+ * may be NULL).  The fp32 output of straps_bn_apply_x3 (y) and of straps_bn_bwd_x3 (draw) may be NULL when only
+ * bf16x3 kernels consume it: 4 of the 10 bytes per element are then not written.                            */
 int straps_bn_apply_x3(const float* raw, const float* scale, const float* shift, const float* residual,
                        int relu, float* y, unsigned short* y_planes, long long plane_stride,
                        long long rows, int c, void* stream);
@@ -304,6 +305,10 @@ int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const
 /* weight gradient on the bf16x3 route: straps_conv_wgrad's arguments plus the planes of x and dy; 3x3 / stride 1 /
  * pad 1 layers (power-of-two width >= 8) run on the planes (halo-patch kernel, ds_read_b64_tr_b16 operand gathers),
  * every other shape -- or NULL planes -- uses the fp32 kernels on (x, dy).  Workspace as for straps_conv_wgrad.      */
+/* 1 if straps_conv_wgrad_x3 handles this geometry on the planes alone (x_nhwc / dy_nhwc may then be NULL, and the producers
+ * -- straps_bn_apply_x3's y, straps_bn_bwd_x3's draw -- need not write their fp32 copies), 0 if it needs the fp32 tensors.      */
+int straps_conv_wgrad_x3_on_planes(int batch, int h, int w, int cin, int cout, int kh, int kw,
+                                   int stride, int pad);
 int straps_conv_wgrad_x3(const float* x_nhwc, const float* dy_nhwc, const unsigned short* x3,
                          long long x_plane_stride, const unsigned short* dy3, long long dy_plane_stride,
                          float* dw_oihw, void* workspace, int batch, int h, int w, int cin, int cout,

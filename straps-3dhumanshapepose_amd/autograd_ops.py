@@ -64,7 +64,7 @@ def _packed_dgrad_weight(net, conv):
     return net._cached(('wd', id(conv)), [w], make)
 
 
-def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None):
+def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True):
     """BatchNorm(train) + ReLU backward of one tape record; returns (draw, dz|None).
     planes_sink (bf16x3 route): dict that receives id(draw) -> (draw, planes, plane stride), written by the same kernel pass."""
     bn = rec['bn']
@@ -72,19 +72,22 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None):
     rows, Cc = raw.numel() // raw.shape[-1], raw.shape[-1]
     ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, Cc) // 4, device=raw.device, dtype=torch.float32)
     dgamma, dbeta = grads.buf(bn.weight), grads.buf(bn.bias)
-    draw = _empty_like(raw)
+    # keep_fp32 = False (bf16x3 route): both consumers of this gradient -- the data gradient and the weight gradient of the layer --
+    # read its planes, so the fp32 tensor is not written; `draw` is then an empty tensor that only carries the identity
+    keep_fp32 = keep_fp32 or planes_sink is None
+    draw = _empty_like(raw) if keep_fp32 else raw.new_empty(0)
     dz = _empty_like(raw) if want_dz else None
     # ReLU mask: without a residual the activation is relu(raw*scale + shift), so the kernel re-derives it from raw (one
     # tensor read less); with a residual it has to read the stored activation
     from_raw = masked and rec.get('residual') is None
     planes, ps = None, 0
     if planes_sink is not None:
-        ps = (draw.numel() + 7) // 8 * 8
-        planes = torch.empty(3, ps, device=draw.device, dtype=torch.int16)
+        ps = (raw.numel() + 7) // 8 * 8
+        planes = torch.empty(3, ps, device=raw.device, dtype=torch.int16)
         planes_sink[id(draw)] = (draw, planes, ps)
     hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked and not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
                                     hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
-                                    hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw),
+                                    hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw if keep_fp32 else None),
                                     hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
     grads[bn.weight] = dgamma
     grads[bn.bias] = dbeta
@@ -96,12 +99,13 @@ def _conv_wgrad(L, rec, draw, grads, planes_sink=None):
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=draw.device, dtype=torch.float32)
     dw = grads.buf(conv.weight)
+    fp = lambda t: hipabi.ptr(t if t is not None and t.numel() else None)      # (an empty tensor = "fp32 copy not materialised")
     xh = rec.get('x3')
     gh = planes_sink.get(id(draw)) if planes_sink is not None else None
     if xh is not None and gh is not None and xh[0] is rec['x'] and gh[0] is draw:
         # bf16x3 route: the planes the forward convolution / the data gradient read anyway (3x3 stride-1 layers; other shapes fall
         # through to the fp32 kernels inside the entry point)
-        hipabi.check(L.straps_conv_wgrad_x3(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(xh[1]), xh[2], hipabi.ptr(gh[1]), gh[2], hipabi.ptr(dw),
+        hipabi.check(L.straps_conv_wgrad_x3(fp(rec['x']), fp(draw), hipabi.ptr(xh[1]), xh[2], hipabi.ptr(gh[1]), gh[2], hipabi.ptr(dw),
                                             hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_wgrad_x3')
     else:
         hipabi.check(L.straps_conv_wgrad(hipabi.ptr(rec['x']), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(ws), B, H, W, Cin, Cout, k, k, stride,
@@ -114,6 +118,8 @@ def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None):
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     dx = torch.empty(B, H, W, Cin, device=draw.device, dtype=torch.float32)
     if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
+        if not draw.numel() and (planes_sink is None or planes_sink.get(id(draw)) is None):
+            raise RuntimeError('data gradient: neither the fp32 gradient nor its planes exist')
         hit = planes_sink.get(id(draw)) if planes_sink is not None else None      # (kept until the backward ends: the weight gradient may still be reading them on the side stream)
         if hit is not None and hit[0] is draw:
             g3, gps = hit[1], hit[2]
@@ -138,6 +144,12 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
     grads = GradSink(views)
     side = _SideStream(side_stream)
     sink = {} if getattr(net, 'conv_precision', 'fp32') == 'bf16x3' else None      # planes of the gradients the data-gradient kernels read
+
+    def keep(rec):      # does anything read the fp32 gradient of this layer's raw output?  (its weight gradient, unless that runs on planes)
+        if sink is None or rec.get('x3') is None:
+            return True
+        B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
+        return not L.straps_conv_wgrad_x3_on_planes(B, H, W, Cin, Cout, k, k, stride, pad)
     rec = tape['gap']
     B, HW, Cf = rec['geom']
     dy = _empty_like(rec['x'])
@@ -146,11 +158,11 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
         for unit in reversed(list(getattr(net, 'layer%d' % li))):
             pairs = unit.conv_bn_pairs()
             rec = tape[id(pairs[-1][0])]
-            draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink)    # ReLU(out) mask; dz feeds the skip connection
+            draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink, keep(rec))    # ReLU(out) mask; dz feeds the skip connection
             side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             if unit.downsample is not None:
                 recd = tape[id(unit.downsample[0])]
-                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink)
+                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink, keep(recd))
                 side.run(lambda recd=recd, drawd=drawd: _conv_wgrad(L, recd, drawd, grads, sink), drawd)
                 dskip = _conv_dgrad(L, net, recd, drawd, None, sink)
             else:
@@ -158,7 +170,7 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
             for ci in range(len(pairs) - 1, 0, -1):
                 dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None, sink)
                 rec = tape[id(pairs[ci - 1][0])]
-                draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink)
+                draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink, keep(rec))
                 side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink)   # + skip gradient fused in the epilogue
         if li == 3 and after_layer3 is not None:

@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o[e] = (float)((double)k1[e] * (((double)g[e] - m1) - xh * m2));
         }
         if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = g;
-        *reinterpret_cast<f32x4*>(draw + idx * 4) = o;
+        if (draw) *reinterpret_cast<f32x4*>(draw + idx * 4) = o;      // (NULL: only the planes are consumed, see straps_bn_bwd_x3)
         if (planes) store_planes4(planes, pstride, idx * 4, o);      // bf16x3 route: the data-gradient kernel's operand
     }
 }
@@ -1535,14 +1535,33 @@ static int stem_wgrad_blocks(int ntiles) { return ntiles < 256 ? ntiles : 256; }
 
 // weight gradient on the bf16x3 route: the 3x3 / stride 1 layers that fit the halo-patch plan run on the planes (x3, dy3: [3][plane
 // stride] bf16, see straps_split3_bf16); every other shape falls through to the fp32 kernels of straps_conv_wgrad on (x, dy).
+// which kernel straps_conv_wgrad_x3 runs when planes are given: 1 = halo-patch kernel on the planes, 2 = per-tap kernel on the planes,
+// 0 = the fp32 kernels on (x, dy)
+static int wgrad_x3_route(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+    Wgrad3P p3;
+    int splits3;
+    if (wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) return 1;
+    static const bool tap_x3 = !(getenv("STRAPS_WGRAD_TAP_FP32") && atoi(getenv("STRAPS_WGRAD_TAP_FP32")));      // (A/B switch for tools)
+    // per-tap kernel on the planes where it beats the fp32 one (tools/sweep_wgrad_x3.py: 3x3 / stride 2: 87-93 vs 115-125 us; 1x1 with at
+    // least 128 channels on both sides: +0..29 %; with a 64-channel side the fp32 kernel's 4-byte rows win: 52 vs 60 us).  Both stream
+    // their operands from memory once per tile of the other channel dimension: bytes, not the matrix pipe, set their rate.
+    return tap_x3 && (kh * kw > 1 || (cin >= 128 && cout >= 128)) ? 2 : 0;
+}
+
+extern "C" int straps_conv_wgrad_x3_on_planes(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+    return wgrad_x3_route(batch, h, w, cin, cout, kh, kw, stride, pad) != 0;
+}
+
 extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsigned short* x3, long long x_plane_stride, const unsigned short* dy3,
                                     long long dy_plane_stride, float* dw_oihw, void* workspace, int batch, int h, int w, int cin, int cout, int kh,
                                     int kw, int stride, int pad, int accumulate, void* stream) {
-    STRAPS_REQUIRE(x && dy && dw_oihw && workspace, "straps_conv_wgrad_x3: null pointer");
+    STRAPS_REQUIRE(dw_oihw && workspace, "straps_conv_wgrad_x3: null pointer");
+    const int route = (x3 && dy3) ? wgrad_x3_route(batch, h, w, cin, cout, kh, kw, stride, pad) : 0;
+    STRAPS_REQUIRE(route != 0 || (x && dy), "straps_conv_wgrad_x3: this shape runs on the fp32 tensors, which are NULL (see straps_conv_wgrad_x3_on_planes)");
     STRAPS_REQUIRE(cin % 64 == 0 && cout % 64 == 0, "straps_conv_wgrad_x3: need cin%%64==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
     Wgrad3P p3;
     int splits3;
-    if (x3 && dy3 && wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) {
+    if (route == 1 && wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) {
         STRAPS_REQUIRE(x_plane_stride % 8 == 0 && dy_plane_stride % 8 == 0, "straps_conv_wgrad_x3: plane strides must be multiples of 8 elements");
         Wgrad3XP q;
         q.x3 = x3; q.dy3 = dy3; q.xps = x_plane_stride; q.dps = dy_plane_stride; q.part = (float*)workspace;
@@ -1567,11 +1586,7 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
         return STRAPS_OK;
     }
-    // per-tap kernel on the planes where it beats the fp32 one (tools/sweep_wgrad_x3.py: 3x3 / stride 2: 87-93 vs 115-125 us; 1x1 with at
-    // least 128 channels on both sides: +0..29 %; with a 64-channel side the fp32 kernel's 4-byte rows win: 52 vs 60 us).  Both stream
-    // their operands from memory once per tile of the other channel dimension: bytes, not the matrix pipe, set their rate.
-    static const bool tap_x3 = !(getenv("STRAPS_WGRAD_TAP_FP32") && atoi(getenv("STRAPS_WGRAD_TAP_FP32")));      // (A/B switch for tools)
-    if (tap_x3 && x3 && dy3 && (kh * kw > 1 || (cin >= 128 && cout >= 128))) {
+    if (route == 2) {
         // same tiles, splits and partial layout as the fp32 kernel (the workspace size is shared)
         STRAPS_REQUIRE(x_plane_stride % 8 == 0 && dy_plane_stride % 8 == 0, "straps_conv_wgrad_x3: plane strides must be multiples of 8 elements");
         WgradXP q;
@@ -1666,7 +1681,7 @@ extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float*
                                 float* dz_out, unsigned short* draw_planes, long long plane_stride, void* workspace, long long rows, int c,
                                 int accumulate, void* stream) {
     STRAPS_REQUIRE(!draw_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "straps_bn_bwd_x3: plane_stride must be >= rows*c and a multiple of 8");
-    STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && draw && workspace, "straps_bn_bwd: null pointer");
+    STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && (draw || draw_planes) && workspace, "straps_bn_bwd: null pointer");
     STRAPS_REQUIRE(rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd: bad shape rows=%lld c=%d", rows, c);
     const int C4 = c >> 2;
     STRAPS_REQUIRE(C4 <= 256 ? (256 % C4 == 0) : (C4 % 256 == 0), "straps_bn_bwd: channel count %d not supported", c);

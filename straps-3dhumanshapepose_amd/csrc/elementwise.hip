@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         for (int q = 0; q < 4; ++q) v[q] = fmaf(v[q], sc[q], sh[q]);
         if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+        if (y) *reinterpret_cast<f32x4*>(y + i * 4) = v;        // (NULL: only the planes are consumed -- bf16x3 route, see straps_bn_apply_x3)
         if (planes) store_planes4(planes, ps, i * 4, v);       // bf16x3 route: the next convolution's operand, written here instead of by a split pass
     }
 }
@@ -260,7 +260,7 @@ extern "C" int straps_bn_apply(const float* x, const float* scale, const float* 
 
 extern "C" int straps_bn_apply_x3(const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
                                   unsigned short* y_planes, long long plane_stride, long long rows, int c, void* stream) {
-    STRAPS_REQUIRE(x && scale && shift && y && y_planes && rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_apply_x3: bad arguments (c%%4 must be 0)");
+    STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_apply_x3: bad arguments (c%%4 must be 0)");
     STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "straps_bn_apply_x3: plane_stride must be >= rows*c and a multiple of 8");
     const long long n4 = rows * (c >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, y_planes, plane_stride, n4, c >> 2);

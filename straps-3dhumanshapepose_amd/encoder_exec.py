@@ -35,7 +35,7 @@ def _new_planes(t):
     return torch.empty(3, ps, device=t.device, dtype=torch.int16), ps
 
 
-def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=True):
+def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=True, keep_fp32=True):
     C = bn.weight.shape[0]
     L = ctx.L
     ss = ctx.empty(4, C)          # scale, shift, save_mean, save_invstd
@@ -51,16 +51,23 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=
         if rec is not None:
             rec.update(raw=raw, stats=ss, out=None)
         return ss
-    y = torch.empty_like(raw)
     if ctx.x3 and relu:
-        # bf16x3 route: every ReLU output of the residual stages feeds a convolution -- its planes are written here, not by a split pass
-        planes, ps = _new_planes(y)
+        # bf16x3 route: every ReLU output of the residual stages feeds a convolution -- its planes are written here, not by a split pass.
+        # keep_fp32 = False: nothing reads the fp32 activation (its only consumers, the next convolution and that layer's weight
+        # gradient, run on the planes; the ReLU mask of the backward is re-derived from raw): it is not written -- y is then an
+        # empty tensor that only carries the identity the planes are looked up by.
+        y = torch.empty_like(raw) if keep_fp32 else raw.new_empty(0)
+        planes, ps = _new_planes(raw)
         hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
-                                          hipabi.ptr(y), hipabi.ptr(planes), ps, rows, C, hipabi.stream_ptr()), 'straps_bn_apply_x3')
+                                          hipabi.ptr(y if keep_fp32 else None), hipabi.ptr(planes), ps, rows, C, hipabi.stream_ptr()),
+                     'straps_bn_apply_x3')
         ctx.planes[id(y)] = (y, planes, ps)
-    else:
-        hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
-                                       hipabi.ptr(y), rows, C, hipabi.stream_ptr()), 'straps_bn_apply')
+        if rec is not None:
+            rec.update(raw=raw, stats=ss, out=y if keep_fp32 else None)
+        return y
+    y = torch.empty_like(raw)
+    hipabi.check(L.straps_bn_apply(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
+                                   hipabi.ptr(y), rows, C, hipabi.stream_ptr()), 'straps_bn_apply')
     if rec is not None:
         rec.update(raw=raw, stats=ss, out=y)
     return y
@@ -108,7 +115,7 @@ def conv_stat_blocks(L, net, geom, Ho, Wo, tile_cfg):
     return L.straps_conv_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
 
 
-def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
+def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, keep_fp32=True):
     """x NHWC [B,H,W,Cin] -> NHWC [B,Ho,Wo,Cout] through conv + BatchNorm (+residual) (+ReLU)."""
     L = ctx.L
     Cout, Cin, k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
@@ -130,7 +137,7 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0):
     _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
     if rec is not None and ctx.x3:
         rec['x3'] = ctx.planes.get(id(x))          # (x, planes, plane stride): the weight gradient reads the same planes
-    out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec)
+    out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec, keep_fp32=keep_fp32)
     return out, Ho, Wo
 
 
@@ -226,7 +233,14 @@ def _residual_stages(ctx, net, y, B, H, W, tape):
             t, h, w = y, H, W
             for ci, (conv, bn) in enumerate(pairs):
                 last = ci == len(pairs) - 1
-                t, h, w = conv_bn(ctx, net, t, B, h, w, conv, bn, relu=True, residual=idt if last else None)
+                keep = True
+                if ctx.x3 and ctx.training and tape is not None and not last:
+                    # the fp32 activation between two convolutions of a unit is dead when the next layer's weight gradient reads planes
+                    nc = pairs[ci + 1][0]
+                    k2, s2, p2 = nc.weight.shape[2], nc.stride[0], nc.padding[0]
+                    ho2, wo2 = _conv_out(h, conv.weight.shape[2], conv.stride[0], conv.padding[0]), _conv_out(w, conv.weight.shape[2], conv.stride[0], conv.padding[0])
+                    keep = not L.straps_conv_wgrad_x3_on_planes(B, ho2, wo2, nc.weight.shape[1], nc.weight.shape[0], k2, k2, s2, p2)
+                t, h, w = conv_bn(ctx, net, t, B, h, w, conv, bn, relu=True, residual=idt if last else None, keep_fp32=keep)
             y, H, W = t, h, w
     # ---- global average pool + flatten (:213-214) ----
     Cf = y.shape[3]

@@ -244,6 +244,9 @@ def test_fused_plane_outputs_equal_a_split_pass(dev):
     hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, hipabi.ptr(y1), hipabi.ptr(pl), ps, rows, C, None), 'bn_apply_x3')
     want, _ = _split(y0)
     assert torch.equal(y0, y1) and torch.equal(pl, want)
+    pl.zero_()          # y = NULL: the planes alone (the fp32 copy is dead when only bf16x3 kernels consume it)
+    hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, None, hipabi.ptr(pl), ps, rows, C, None), 'bn_apply_x3')
+    assert torch.equal(pl, want)
     # stem tail
     Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     p0, p1 = torch.empty(B, Hp, Wp, C, device=dev), torch.empty(B, Hp, Wp, C, device=dev)
@@ -272,6 +275,11 @@ def test_fused_plane_outputs_equal_a_split_pass(dev):
         assert torch.equal(a, b)
     want, _ = _split(outs[0][2])
     assert torch.equal(outs[1][4], want)
+    planes = torch.zeros(3, ps, device=dev, dtype=torch.int16)      # draw = NULL: planes only
+    dg, db, dz = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty_like(raw)
+    hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dy), hipabi.ptr(y0), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma), None, None,
+                                    hipabi.ptr(dg), hipabi.ptr(db), None, hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(ws), rows, C, 0, None), 'bn_bwd_x3')
+    assert torch.equal(planes, want) and torch.equal(dg, outs[0][0]) and torch.equal(dz, outs[0][3])
 
 
 @pytest.mark.parametrize('layers', [18, 50])
