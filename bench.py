@@ -44,7 +44,7 @@ def pmc_traffic(args, kernel):
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
     tag = '%s_r%d_b%d' % (args.workload, args.layers, args.batch or (65536 if args.workload == 'smpl' else 64))
-    if args.workload == 'smpl' and args.smpl_precision != 'fp16x3_lbs':
+    if args.workload == 'smpl' and args.smpl_precision != 'fp16x3_lbs_p16':
         tag += '_' + args.smpl_precision
     if args.workload != 'smpl' and args.conv_precision != 'bf16x3':
         tag += '_' + args.conv_precision + 'conv'
@@ -185,7 +185,7 @@ def main():
     ap.add_argument('--config', type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help='BASELINE.json configs[N] alias: 1 = --workload fwd, 2 = --workload train, 3 = train --layers 50 --batch 32 (per GPU), 4 = --workload smpl')
     ap.add_argument('--smpl-exact', action='store_true', help='smpl workload: exact-fp32 MFMA blend contraction (= --smpl-precision fp32)')
-    ap.add_argument('--smpl-precision', default='fp16x3_lbs', choices=['fp32', 'fp16x3', 'fp16x3_lbs'],
+    ap.add_argument('--smpl-precision', default='fp16x3_lbs_p16', choices=['fp32', 'fp16x3', 'fp16x3_lbs', 'fp16x3_lbs_pd16', 'fp16x3_lbs_p16'],
                     help='smpl workload: fp32 = exact, fp16x3 = blend contraction as a three-product fp16 split, fp16x3_lbs = skinning on the matrix pipe too')
     ap.add_argument('--conv-precision', default='bf16x3', choices=['fp32', 'bf16x3'],
                     help="encoder convolutions (forward + data gradient): 'fp32' = exact-fp32 MFMA chain, 'bf16x3' = three bf16 planes per fp32 "
@@ -390,11 +390,13 @@ def main():
                 else:
                     # three-product fp16 split: the contraction issues 3 x 2 x 224 x (tiles x 96) flops per body on the fp16 pipe,
                     # the matrix-pipe skinning another 3 x 2 x 32 x (tiles x 32 x 12)
-                    issued = n * B * 3.0 * 2.0 * smpl.n_tiles * (224 * 96 + (32 * 32 * 12 if args.smpl_precision == 'fp16x3_lbs' else 0))
+                    # products per term: 3 everywhere; the pd16 / p16 modes use 2 / 1 from the second 16-column k step on (13 of 14 steps)
+                    npose = {'fp16x3_lbs_pd16': 2.0, 'fp16x3_lbs_p16': 1.0}.get(args.smpl_precision, 3.0)
+                    issued = n * B * 2.0 * smpl.n_tiles * (96 * 16 * (3.0 + 13.0 * npose) + (3.0 * 32 * 32 * 12 if args.smpl_precision.startswith('fp16x3_lbs') else 0))
                     roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm['frac'],
                             'traffic': None, 'traffic_measured_in_run': False, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
                             'algorithmic_bytes_per_launch': B * per_body,
-                            'mfma_side': {'pipe': 'fp16 MFMA, fp32 accumulate (3 split products)', 'issued': round(issued / secs / 1e12, 1), 'peak': 2500.0,
+                            'mfma_side': {'pipe': 'fp16 MFMA, fp32 accumulate (split products)', 'issued': round(issued / secs / 1e12, 1), 'peak': 2500.0,
                                           'unit': 'TFLOP/s', 'frac': round(issued / secs / 1e12 / 2500.0, 4),
                                           'fp32_equivalent_tflops': round(ach, 2)}}
             if dominant == 'conv_igemm_x3_kernel':
@@ -414,7 +416,7 @@ def main():
                 others[k]['zero_skipping'] = True
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, mp, smpl_model)
+            cpu = cpu_baseline(args, mp, smpl_model, (smpl, smpl_precision) if args.workload == 'smpl' else None)
         out = {'metric': 'bodies/sec', 'value': round(bodies / elapsed, 1), 'unit': 'bodies/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -440,7 +442,9 @@ def main():
         else:
             out['smpl_blend_precision'] = smpl_precision
             out['dtype'] = {'fp32': 'fp32', 'fp16x3': 'fp32 (blend contraction: 3-product fp16 split, fp32 accumulate)',
-                            'fp16x3_lbs': 'fp32 (blend contraction and skinning transforms: 3-product fp16 splits, fp32 accumulate)'}[smpl_precision]
+                            'fp16x3_lbs': 'fp32 (blend contraction and skinning transforms: 3-product fp16 splits, fp32 accumulate)',
+                            'fp16x3_lbs_p16': 'fp32 results; template / shape blend and skinning as 3-product fp16 splits, pose-corrective blend in plain fp16 (1 product)',
+                            'fp16x3_lbs_pd16': 'fp32 results; template / shape blend and skinning as 3-product fp16 splits, pose-corrective directions as plain fp16 (2 products)'}[smpl_precision]
         if eager_ms is not None:
             out['eager_ms_per_step'] = round(eager_ms, 4)
             if roof is not None:
@@ -451,7 +455,7 @@ def main():
     return out
 
 
-def cpu_baseline(args, mp, smpl_model):
+def cpu_baseline(args, mp, smpl_model, gpu_smpl=None):
     """the CPU oracle (torch-CPU port of the reference path, oracle/straps_oracle.py) on this host:
     bounded sample, `cores` = the torch thread count actually used."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -518,8 +522,20 @@ def cpu_baseline(args, mp, smpl_model):
             O.smpl_forward(smpl_model, betas, rotmats=R)
             it += 1
         dt = time.perf_counter() - t0
-    return {'value': round(nb * it / dt, 2), 'unit': 'bodies/s', 'cores': ncores, 'kind': 'port',
-            'sample': '%d passes of %d bodies through the torch-CPU SMPL oracle' % (it, nb)}
+    out = {'value': round(nb * it / dt, 2), 'unit': 'bodies/s', 'cores': ncores, 'kind': 'port',
+           'sample': '%d passes of %d bodies through the torch-CPU SMPL oracle' % (it, nb)}
+    if gpu_smpl is not None:
+        # the checker's other job in this leg: the timed kernel's vertices / joints against the float64 oracle on the same 64 bodies
+        # (north_star: <= 1e-4 m)
+        smpl_mod, prec = gpu_smpl
+        dev = next(smpl_mod.buffers()).device
+        with torch.no_grad():
+            v, j = smpl_mod.forward_arrays(betas.to(dev), R.to(dev), precision=prec)
+            v64, j64 = O.smpl_forward(smpl_model, betas.double(), rotmats=R.double(), dtype=torch.float64)
+        out['gpu_max_abs_err_vs_float64_m'] = {'vertices': float('%.3g' % float((v.cpu().double() - v64).abs().max())),
+                                               'joints': float('%.3g' % float((j.cpu().double() - j64).abs().max())),
+                                               'bodies': nb, 'precision': prec, 'north_star_tolerance_m': 1e-4}
+    return out
 
 
 if __name__ == '__main__':

@@ -230,6 +230,12 @@ typedef struct {
 /* as above, and the skinning transforms T[v][b] = sum_j W[v][j] A[b][j] as the same kind of split product on the matrix
  * pipe (any number of weights per vertex); |A| < 63 (metres)                                                     */
 #define STRAPS_SMPL_SPLIT_F16_LBS 2
+/* as STRAPS_SMPL_SPLIT_F16_LBS with the pose-corrective directions from column 16 on as plain fp16 (two products per term,
+ * their low halves are not fetched): ~2^-12 of the pose-corrective displacement (measured: tests/test_gpu_forward.py),
+ * inside north_star's 1e-4 m; template and shape directions keep the three-product split                          */
+#define STRAPS_SMPL_SPLIT_F16_LBS_PD16 3
+/* and the pose features of those columns as plain fp16 too (one product per term)                                  */
+#define STRAPS_SMPL_SPLIT_F16_LBS_P16 4
 
 /* bytes of caller-owned scratch for `batch` bodies (depends on the model's virtual-tile count)  */
 size_t straps_smpl_workspace_bytes(const straps_smpl_model_t* model, long long batch);

@@ -495,7 +495,13 @@ constexpr int ASH = 40;                   // halves per (entry, body) row of the
 constexpr float A_SCALE = 1024.0f;        // 2^10: |A| < 63 (metres) before fp16 overflows
 constexpr float W_UNSCALE = 1.0f / (16384.0f * 1024.0f);   // weights are scaled 2^14 on the host
 
-template <int NWV, int PF, int ABL>
+// PD16 (mode STRAPS_SMPL_SPLIT_F16_LBS_PD16): from the second k step on -- columns 16.. of the contraction, all of them pose-corrective
+// directions, whose summed contribution to a vertex is centimetres -- the directions are taken as plain fp16 (their low halves are
+// neither fetched nor multiplied): two products (Fh.Dh + Fl.Dh) instead of three for 13 of the 14 k steps, 45 % fewer fragment
+// bytes from L2 (the fragment stream, 19 MB per 32 bodies, is what bounds this kernel).  Template + shape (+ the first five pose
+// features, k step 0) keep the three-product split.  Error: ~2^-12 of the pose-corrective sum -- measured in the tests.
+// PD16 = 2 (mode STRAPS_SMPL_SPLIT_F16_LBS_P16): additionally the pose FEATURES of those columns as plain fp16 -- one product.
+template <int NWV, int PF, int ABL, int PD16 = 0>
 __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_model_t m, const float* __restrict__ F,
                                                                  const float* __restrict__ Amat, float* __restrict__ verts,
                                                                  float* __restrict__ vout, long long B, int btiles,
@@ -607,7 +613,8 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
 #pragma unroll
             for (int s = 0; s < PF; ++s)
 #pragma unroll
-                for (int f = 0; f < 6; ++f) ring[s][f] = q[s * 384 + f * 64];
+                for (int f = 0; f < 6; ++f)
+                    if (!(PD16 && s >= 1 && (f & 1))) ring[s][f] = q[s * 384 + f * 64];
         }
     }
     // The stores of tile t-1 are issued AFTER the blend phase of tile t and BEFORE its skinning phase: on gfx9 one in-order
@@ -651,7 +658,8 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
                 if (s + PF < KS && !(ablate & 2)) {
                     const half8* q = p + (s + PF) * 384;
 #pragma unroll
-                    for (int f = 0; f < 6; ++f) ring[(s + PF) % (PF + 1)][f] = q[f * 64];
+                    for (int f = 0; f < 6; ++f)
+                        if (!(PD16 && (f & 1))) ring[(s + PF) % (PF + 1)][f] = q[f * 64];          // (s + PF >= 1)
                 }
                 half8 fhn = fh, fln = fl;
                 if (s + 1 < KS) {
@@ -662,8 +670,8 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
                 const half8* c = ring[s % (PF + 1)];
                 if (!(ablate & 8)) {
                 ax = mfma16h(fh, c[0], ax); ay = mfma16h(fh, c[2], ay); az = mfma16h(fh, c[4], az);       // Fh . Dh
-                ax = mfma16h(fh, c[1], ax); ay = mfma16h(fh, c[3], ay); az = mfma16h(fh, c[5], az);       // Fh . Dl
-                ax = mfma16h(fl, c[0], ax); ay = mfma16h(fl, c[2], ay); az = mfma16h(fl, c[4], az);       // Fl . Dh
+                if (!(PD16 && s >= 1)) { ax = mfma16h(fh, c[1], ax); ay = mfma16h(fh, c[3], ay); az = mfma16h(fh, c[5], az); }       // Fh . Dl
+                if (!(PD16 == 2 && s >= 1)) { ax = mfma16h(fl, c[0], ax); ay = mfma16h(fl, c[2], ay); az = mfma16h(fl, c[4], az); }       // Fl . Dh
                 } else { ax[0] += (float)fh[0] + (float)c[0][0]; ay[0] += (float)fl[1] + (float)c[3][1]; az[0] += (float)c[5][2]; }
                 fh = fhn; fl = fln;
             }
@@ -675,7 +683,8 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
 #pragma unroll
                 for (int s = 0; s < PF; ++s)
 #pragma unroll
-                    for (int f = 0; f < 6; ++f) ring[s][f] = q[s * 384 + f * 64];
+                    for (int f = 0; f < 6; ++f)
+                        if (!(PD16 && s >= 1 && (f & 1))) ring[s][f] = q[s * 384 + f * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -812,7 +821,11 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                                void* stream) {
     STRAPS_REQUIRE(model && betas && rotmats && verts && workspace, "straps_smpl_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0, "straps_smpl_fwd: batch must be positive (got %lld)", batch);
-    STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || mode == STRAPS_SMPL_SPLIT_F16 || mode == STRAPS_SMPL_SPLIT_F16_LBS, "straps_smpl_fwd: unknown mode %d", mode);
+    STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || mode == STRAPS_SMPL_SPLIT_F16 || mode == STRAPS_SMPL_SPLIT_F16_LBS || mode == STRAPS_SMPL_SPLIT_F16_LBS_PD16 ||
+                   mode == STRAPS_SMPL_SPLIT_F16_LBS_P16,
+                   "straps_smpl_fwd: unknown mode %d", mode);
+    const int pd16 = mode == STRAPS_SMPL_SPLIT_F16_LBS_PD16 ? 1 : mode == STRAPS_SMPL_SPLIT_F16_LBS_P16 ? 2 : 0;
+    if (pd16) mode = STRAPS_SMPL_SPLIT_F16_LBS;
     STRAPS_REQUIRE(mode != STRAPS_SMPL_SPLIT_F16_LBS || model->skin_frag_h, "straps_smpl_fwd: mode STRAPS_SMPL_SPLIT_F16_LBS needs skin_frag_h in the model");
     STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || (model->blend_frag_h && model->blend_h_unscale > 0.f),
                    "straps_smpl_fwd: split-precision mode needs blend_frag_h / blend_h_unscale in the model");
@@ -843,15 +856,17 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
     auto h_kernel = pf == 1 ? smpl_verts_h_kernel<1> : pf == 2 ? smpl_verts_h_kernel<2> : pf == 4 ? smpl_verts_h_kernel<4> : smpl_verts_h_kernel<3>;
     auto hh_kernel = ablate == 1 ? smpl_verts_hh_kernel<8, 1, 1> : ablate == 2 ? smpl_verts_hh_kernel<8, 1, 2> : ablate == 3 ? smpl_verts_hh_kernel<8, 1, 3>
                    : ablate == 7 ? smpl_verts_hh_kernel<8, 1, 7> : ablate == 15 ? smpl_verts_hh_kernel<8, 1, 15>
+                   : pd16 == 1 ? (pf == 1 ? smpl_verts_hh_kernel<8, 1, 0, 1> : smpl_verts_hh_kernel<8, 2, 0, 1>)
+                   : pd16 == 2 ? (pf == 1 ? smpl_verts_hh_kernel<8, 1, 0, 2> : smpl_verts_hh_kernel<8, 2, 0, 2>)
                    : pf == 1 ? smpl_verts_hh_kernel<8, 1, 0> : smpl_verts_hh_kernel<8, 2, 0>;
     const size_t lds = split == 2 ? (size_t)(BT * FSH + 12 * BT * ASH) * sizeof(float)
                                   : (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[split]) {
+    static bool attr_set[5] = {false, false, false, false, false};
+    if (!attr_set[split + pd16]) {
         hipError_t e = hipFuncSetAttribute(split == 2 ? (const void*)hh_kernel : split ? (const void*)h_kernel : (const void*)smpl_verts_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("smpl_verts_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
-        attr_set[split] = true;
+        attr_set[split + pd16] = true;
     }
     const long long btiles = (batch + BT - 1) / BT;
     if (btiles * nch > 0x7fffffffLL || btiles > 0x3fffffLL) {

@@ -100,6 +100,33 @@ def test_smpl_split_precision_vs_oracle(dev, smpl_model, B, mode):
         straps_amd.SMPL(smpl_model, batch_size=1, precision='bf16')
 
 
+@pytest.mark.parametrize('mode', ['fp16x3_lbs_pd16', 'fp16x3_lbs_p16'])
+@pytest.mark.parametrize('B', [1, 70, 4096])
+def test_smpl_pd16_mode_vs_oracle(dev, smpl_model, B, mode):
+    """STRAPS_SMPL_SPLIT_F16_LBS_PD16: pose-corrective directions as plain fp16 (two products), template / shape / skinning as the
+    three-product splits.  Not as close to float64 as fp32 arithmetic -- the point of the mode is throughput inside north_star's
+    1e-4 m: asserted < 2e-5 m (the bar of every SMPL test here), measured error printed; everything else as the other modes."""
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    betas = torch.from_numpy(det_uniform((B, 10), 100 + B, -2.5, 2.5))
+    betas[0] = torch.tensor([10.0, -8.0, 6.0, 4.0, -4.0, 3.0, 3.0, -3.0, 2.0, 2.0])
+    aa = torch.from_numpy(det_uniform((B, 72), 200 + B, -0.9, 0.9))
+    aa[-1] = torch.from_numpy(det_uniform((72,), 7, -3.0, 3.0))                             # rotations up to pi per axis component
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+    v, j = smpl.forward_arrays(betas.to(dev), R.to(dev), precision=mode)
+    n = min(B, 96)
+    idx = list(range(n - 1)) + [B - 1]
+    v64, j64 = O.smpl_forward(smpl_model, betas[idx].double(), rotmats=R[idx].double(), dtype=torch.float64)
+    ev, ej = float((v[idx].cpu().double() - v64).abs().max()), float((j[idx].cpu().double() - j64).abs().max())
+    print('SMPL B=%d %s max |err| vs float64: verts %.2e joints %.2e' % (B, mode, ev, ej))
+    assert ev < 2e-5 and ej < 2e-5
+    assert torch.isfinite(v).all() and torch.isfinite(j).all()
+    v2, none = smpl.forward_arrays(betas.to(dev), R.to(dev), want_joints=False, precision=mode)
+    assert none is None and torch.equal(v2, v)
+    if B > 40:
+        vs, js = smpl.forward_arrays(betas[30:37].contiguous().to(dev), R[30:37].contiguous().to(dev), precision=mode)
+        assert torch.equal(vs, v[30:37]) and torch.equal(js, j[30:37])
+
+
 def test_smpl_module_call_forms(dev, smpl_model):
     """the three call forms of the reference (train loop :132, :144, :258)."""
     B = 4

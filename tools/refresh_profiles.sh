@@ -41,6 +41,8 @@ python bench.py --config 1 2>/dev/null | tail -1 > $O/${RND}_bench_fwd_b64.json
 python bench.py --config 1 --conv-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_fwd_b64_fp32conv.json
 python bench.py --config 4 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M.json
 python bench.py --config 4 --smpl-precision fp16x3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp16x3.json
+python bench.py --config 4 --smpl-precision fp16x3_lbs --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp16x3_lbs.json
+python bench.py --config 4 --smpl-precision fp16x3_lbs_pd16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp16x3_lbs_pd16.json
 python bench.py --config 4 --smpl-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp32.json
 python bench.py --config 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_train_r50_b32.json
 rm -rf $O/prof_*/ $O/pmc_*/
