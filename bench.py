@@ -190,6 +190,8 @@ def main():
     ap.add_argument('--conv-precision', default='bf16x3', choices=['fp32', 'bf16x3'],
                     help="encoder convolutions (forward + data gradient): 'fp32' = exact-fp32 MFMA chain, 'bf16x3' = three bf16 planes per fp32 "
                          "operand, six products per term, fp32 accumulate (same accuracy class, bf16 matrix pipe)")
+    ap.add_argument('--smpl-in-step', default='fp16x3_lbs', choices=['fp32', 'fp16x3', 'fp16x3_lbs'],
+                    help='train / fwd workloads: arithmetic of the SMPL forward calls inside the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
@@ -240,7 +242,9 @@ def main():
     B = args.batch or (65536 if args.workload == 'smpl' else 64)
     mp = straps_amd.synthetic_mean_params(0)
     smpl_model = straps_amd.synthetic_smpl_model(0)
-    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    # train / forward workloads: the SMPL calls inside them run the fully split kernel (every product three ways: 7e-7 m from float64,
+    # closer than fp32 arithmetic -- not the reduced pose-corrective modes of configs[4]); --smpl-in-step fp32 gives the exact-fp32 chain
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B, precision=args.smpl_in_step if args.workload != 'smpl' else 'fp32').to(dev)
     timer = KernelTimer()
     instrument(timer)
     net = 'resnet%d' % args.layers
@@ -432,6 +436,7 @@ def main():
             out['launch_mode'] = ('hipGraph replay of data-gen (next batch, second stream) + forward + loss + backward (all-reduce and Adam eager)'
                                   if captured else 'eager')
             out['ranks_seen'] = ranks_seen
+            out['smpl_in_step'] = args.smpl_in_step
             if stem_ab:
                 out['stem_dense_ms_per_step'] = round(sum(stem_ab.values()), 4)
                 out['stem_sparse_ms_per_step'] = round(sum(v[2] for k, v in agg.items() if k in stem_ab) / args.steps * 1e3, 4)

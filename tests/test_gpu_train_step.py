@@ -20,7 +20,8 @@ def _setup(B, seed=0, layers=18, conv_precision='fp32'):
     torch.manual_seed(seed)
     reg = straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP).to(dev).train()
     reg.image_encoder.conv_precision = conv_precision          # 'fp32': exact-fp32 MFMA chain; 'bf16x3': three-plane bf16 operands (csrc/conv_x3.hip)
-    smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=B).to(dev)
+    # (the bf16x3 parametrisations also run the step's SMPL forwards on the fully split matrix-pipe kernel: bench.py's default pairing)
+    smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=B, precision='fp16x3_lbs' if conv_precision == 'bf16x3' else 'fp32').to(dev)
     crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(LOSSES, init_loss_weights=W, reduction='mean').to(dev)
     return dev, reg, smpl, crit
 
