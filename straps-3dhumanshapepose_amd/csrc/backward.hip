@@ -341,11 +341,9 @@ typedef short short8w __attribute__((ext_vector_type(8)));
 
 __device__ __attribute__((aligned(16))) float k_zero16x[4] = {0.f, 0.f, 0.f, 0.f};
 
-constexpr int W3X_DPX = 32, W3X_XPX = 128;                              // pixel rows per stage and plane: dy tile, input patch slots
 #ifndef W3X_TG
 #define W3X_TG 2          // taps whose MFMA chains are interleaved
 #endif
-constexpr int W3X_STAGE = 3 * (W3X_DPX + W3X_XPX) * 64;                 // u16 elements per stage (61 440 bytes)
 
 // eight k values (pixels) of one channel: two transpose reads of four pixels each
 __device__ __forceinline__ bf16x8w tr_frag(const u16* lo, const u16* hi) {
@@ -530,14 +528,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
             }
 }
 
-// NG = 2: two 4-wave groups share every stage; group g takes k step g (pixels 16g .. 16g+15) of each chunk and the two accumulator
+// NG = 2: two 4-wave groups share every stage; group g takes the k steps g, g + 2, .. (16 pixels each) of each chunk and the two accumulator
 // sets are added through LDS at the end (fixed order) -- two waves per SIMD cover each other's LDS latency and barrier waits.
-template <int NG>
+// CP = pixels per chunk (32 or 64; the plan's cw x rpc): 64 halves the barriers per MFMA and the halo overhead of the patch
+// ((rpc + 2) x (cw + 2) slots per chunk: 3.2 -> 2.1 per pixel at cw = 32); a group then runs two k steps per chunk.
+template <int NG, int CP>
 __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) {
+    constexpr int DPX = CP, XPX = CP == 32 ? 128 : 136;          // pixel rows per stage and plane: dy tile, input patch slots
+    constexpr int STAGE = 3 * (DPX + XPX) * 64;                   // u16 elements per stage
+    constexpr int DR = CP / 32, XR = (XPX + 31) / 32;             // copy rounds of 32 pixel slots: dy tile, patch
+    constexpr int KSG = CP / 16 / NG;                             // k steps per group and chunk
+    static_assert(CP % (16 * NG) == 0, "chunk / group mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     u16* smem = reinterpret_cast<u16*>(smem_f);
     const int pw = p.cw + 2;
-    const int npatch = (p.rpc + 2) * pw;                 // <= 102 pixels
+    const int npatch = (p.rpc + 2) * pw;                 // <= 102 (CP = 32) / 136 (CP = 64) pixels
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;           // wave inside its 4-wave group
     const int grp = NG > 1 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -552,11 +557,16 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
     // ---- copies: thread -> (pixel slot of a 32-slot round, 16-byte slot tid & 7 of its row); it fetches channel group slot ^ swap.
     // The five rounds of a chunk (dy tile, four patch rounds) alternate between the groups when NG = 2.
     const int lp = (tid & 255) >> 3, ls = tid & 7;
-    const int d_g = ls ^ (((lp >> 1) & 1) << 2);
-    const int d_off = ((lp >> p.cw_log2) * p.W + (lp & (p.cw - 1))) * p.Cout + co0 + d_g * 8;
-    int x_pr[4], x_pc[4], x_g[4];
+    const int d_g = ls ^ (((lp >> 1) & 1) << 2);           // (bit 1 of lp + 32 q is bit 1 of lp)
+    int d_off[DR];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < DR; ++q) {
+        const int px = lp + 32 * q;
+        d_off[q] = ((px >> p.cw_log2) * p.W + (px & (p.cw - 1))) * p.Cout + co0 + d_g * 8;
+    }
+    int x_pr[XR], x_pc[XR], x_g[XR];
+#pragma unroll
+    for (int q = 0; q < XR; ++q) {
         const int pp = lp + 32 * q;
         x_pr[q] = pp / pw - 1;
         x_pc[q] = pp - (x_pr[q] + 1) * pw - 1;
@@ -568,20 +578,22 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
         const int rem = c - b * per_img;
         const int cr = rem / p.chunks_per_row, cc = rem - cr * p.chunks_per_row;
         const int ho0 = cr * p.rpc, wo0 = cc * p.cw;
-        u16* D = smem + stage * W3X_STAGE;
-        u16* X = D + 3 * W3X_DPX * 64;
-        const u16* dsrc = p.dy3 + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cout + d_off;
+        u16* D = smem + stage * STAGE;
+        u16* X = D + 3 * DPX * 64;
+        const u16* dbase = p.dy3 + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cout;
         const u16* xsrc = p.x3 + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cin + ci0;
-        if (grp == 0) {
+#pragma unroll
+        for (int q = 0; q < DR; ++q) {
+            if (NG > 1 && (q & 1) != grp) continue;          // the copy rounds of a chunk (dy rounds, then patch rounds) alternate between the groups
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + pl * p.dps),
-                                                 (__attribute__((address_space(3))) void*)(D + (pl * W3X_DPX + 8 * wave_u) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dbase + d_off[q] + pl * p.dps),
+                                                 (__attribute__((address_space(3))) void*)(D + (pl * DPX + 32 * q + 8 * wave_u) * 64), 16, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q * 32 >= npatch) break;                 // wave-uniform
-            if (NG > 1 && ((q + 1) & 1) != grp) continue;   // rounds 1..4 of the chunk alternate between the groups
+        for (int q = 0; q < XR; ++q) {
+            if (q * 32 + 8 * wave_u >= npatch || q * 32 + 8 * wave_u >= XPX) break;     // wave-uniform: nothing of this round lies inside the patch
+            if (NG > 1 && ((q + DR) & 1) != grp) continue;
             const int hi = ho0 + x_pr[q], wi = wo0 + x_pc[q];
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;     // (slots past the patch read anything)
             const u16* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin + x_g[q] * 8 : zsrc;
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pl * ps),
-                                                 (__attribute__((address_space(3))) void*)(X + (pl * W3X_XPX + 32 * q + 8 * wave_u) * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(X + (pl * XPX + 32 * q + 8 * wave_u) * 64), 16, 0, 0);
         }
     };
 
@@ -600,12 +612,12 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
         const int g = (c4 >> 3) ^ (((slot_px >> 1) & 1) << 2);
         return slot_px * 64 + g * 8 + (c4 & 4);
     };
-    int d_fo[2][2], x_fo[2][2];                          // [k step][read]
+    int d_fo[KSG][2], x_fo[KSG][2];     // [this group's k step][read]; group g takes k steps g, g + NG, ...
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KSG; ++ks)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int px = ks * 16 + kh * 8 + r * 4 + (t >> 2);
+            const int px = (grp + NG * ks) * 16 + kh * 8 + r * 4 + (t >> 2);
             d_fo[ks][r] = row_off(px, wm * 32 + ch16 * 16 + (t & 3) * 4);
             x_fo[ks][r] = (px >> p.cw_log2) * pw + (px & (p.cw - 1));          // patch slot of tap (0,0); the channel part is added per tap
         }
@@ -625,15 +637,14 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
         __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
         asm volatile("" ::: "memory");
         if (c + 1 < cend) dma_chunk(c + 1, stage ^ 1);
-        const u16* D = smem + stage * W3X_STAGE;
-        const u16* X = D + 3 * W3X_DPX * 64;
+        const u16* D = smem + stage * STAGE;
+        const u16* X = D + 3 * DPX * 64;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (NG > 1 && ks != grp) continue;
+        for (int ks = 0; ks < KSG; ++ks) {
             bf16x8w a[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[pl] = tr_frag(D + pl * W3X_DPX * 64 + d_fo[ks][0], D + pl * W3X_DPX * 64 + d_fo[ks][1]);
+            for (int pl = 0; pl < 3; ++pl) a[pl] = tr_frag(D + pl * DPX * 64 + d_fo[ks][0], D + pl * DPX * 64 + d_fo[ks][1]);
             // taps in pairs: the six products of a tap accumulate into one tile, so two taps' chains are interleaved (a dependent
             // MFMA issued back to back waits for its predecessor's last pass)
 #pragma unroll
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
                     const int sh = (tp / 3) * pw + (tp % 3);
                     const int o0 = row_off(x_fo[ks][0] + sh, x_c4), o1 = row_off(x_fo[ks][1] + sh, x_c4);
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) b[u][pl] = tr_frag(X + pl * W3X_XPX * 64 + o0, X + pl * W3X_XPX * 64 + o1);
+                    for (int pl = 0; pl < 3; ++pl) b[u][pl] = tr_frag(X + pl * XPX * 64 + o0, X + pl * XPX * 64 + o1);
                 }
 #pragma unroll
                 for (int e = 0; e < 6; ++e)
@@ -1433,10 +1444,10 @@ inline int wgrad_splits(long long M, int tiles, bool big = false) {
 
 // ------------------------------------------------------------------------------------------ C ABI
 // plan of the halo-patch kernel; returns false when the layer must use the per-tap kernel
-static bool wgrad3_plan(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, Wgrad3P* p, int* splits) {
+static bool wgrad3_plan(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, Wgrad3P* p, int* splits, int cp = 32) {
     if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1)) return false;
     if (w < 8 || (w & (w - 1)) != 0) return false;              // chunk columns must tile the row exactly
-    const int cw = w < 32 ? w : 32, rpc = 32 / cw;
+    const int cw = w < 32 ? w : 32, rpc = cp / cw;              // cp pixels per chunk (32; the bf16x3 kernel also 64)
     if (h % rpc != 0) return false;
     int lg = 0;
     while ((1 << lg) < cw) ++lg;
@@ -1571,15 +1582,33 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
 #ifndef W3X_NG
 #define W3X_NG 2
 #endif
-        const size_t lds = (size_t)2 * W3X_STAGE * sizeof(u16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_x3_kernel<W3X_NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-            attr_set = true;
-        }
         hipStream_t st3 = (hipStream_t)stream;
-        hipLaunchKernelGGL(conv_wgrad3x3_x3_kernel<W3X_NG>, dim3((cout / 64) * (cin / 64), splits3), dim3(256 * W3X_NG), lds, st3, q);
+        // 64-pixel chunks where the rows allow it (fewer splits than the 32-pixel plan at most: the shared workspace size covers both)
+        Wgrad3P p64;
+        int splits64;
+        const bool c64 = wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p64, &splits64, 64) && splits64 <= splits3;
+        if (c64) {
+            q.rpc = p64.rpc; q.chunks_per_row = p64.chunks_per_row; q.chunk_rows_per_img = p64.chunk_rows_per_img; q.nchunks = p64.nchunks;
+            q.chunks_per_split = p64.chunks_per_split;
+            splits3 = splits64;
+            const size_t lds = (size_t)2 * 3 * (64 + 136) * 64 * sizeof(u16);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_x3_kernel<W3X_NG, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), dim3((cout / 64) * (cin / 64), splits3), dim3(256 * W3X_NG), lds, st3, q);
+        } else {
+            const size_t lds = (size_t)2 * 3 * (32 + 128) * 64 * sizeof(u16);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_x3_kernel<W3X_NG, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((conv_wgrad3x3_x3_kernel<W3X_NG, 32>), dim3((cout / 64) * (cin / 64), splits3), dim3(256 * W3X_NG), lds, st3, q);
+        }
         STRAPS_CHECK_LAUNCH("conv_wgrad3x3_x3_kernel");
         const long long n3 = (long long)cout * 9 * cin;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n3 / 256)), dim3(256), 0, st3, q.part, dw_oihw, splits3, cout, cin, 9, accumulate);
