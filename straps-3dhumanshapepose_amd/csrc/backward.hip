@@ -1098,6 +1098,66 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
+// The same sums for the fused stem tail (bn1 + ReLU + max-pool), taken over the POOLED grid: every pooled element routes its gradient to
+// exactly one un-pooled position (its arg-max tap), so  S1 = sum_q mask * dy_q,  S2 = sum_q mask * dy_q * (x[argmax(q)] - mean) --
+// a quarter of the elements of the un-pooled sweep, one gathered raw value each, no four-window search per element.
+// (mask = the ReLU derivative at the arg-max position, re-derived from raw like everywhere else.)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const float* __restrict__ raw, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ msc,
+                                                                   const float* __restrict__ msh, double* __restrict__ part, long long prows,
+                                                                   int C, int rows_per_block, PoolSrc ps) {
+    __shared__ double red[256][8];
+    constexpr int TR = 16;
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c4 = blockIdx.y * 16 + tc;
+    const bool active = c4 * 4 < C;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < prows ? r0 + rows_per_block : prows;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 is = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        const f32x4 ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4), ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4);
+        for (long long r = r0 + tr; r < r1; r += TR) {
+            const int wo = (int)(r % ps.Wo);
+            const long long t = r / ps.Wo;
+            const int ho = (int)(t % ps.Ho);
+            const long long b = t / ps.Ho;
+            const long long o = r * C + c4 * 4;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(ps.dyp + o);
+            const uchar4 k4 = *reinterpret_cast<const uchar4*>(ps.idx + o);
+            const int k[4] = {k4.x, k4.y, k4.z, k4.w};
+            float xr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hi = 2 * ho - 1 + k[e] / 3, wi = 2 * wo - 1 + k[e] % 3;          // (the recorded tap lies inside the image)
+                xr[e] = raw[((b * ps.H + hi) * ps.W + wi) * C + c4 * 4 + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = fmaf(xr[e], ksc[e], ksh[e]) > 0.f ? d[e] : 0.f;
+                s1[e] += (double)g;
+                s2[e] += (double)g * ((double)xr[e] - (double)mu[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][4 + e] = s2[e] * (double)is[e]; }
+    __syncthreads();
+    if (tr == 0 && active) {
+        double t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = red[tc][e];
+        for (int q = 1; q < TR; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += red[q * 16 + tc][e];
+        double* o = part + ((long long)blockIdx.x * C + c4 * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e * 2 + 0] = t[e]; o[e * 2 + 1] = t[4 + e]; }
+    }
+}
+
 // per channel: dbeta = S1, dgamma = S2; coefficients for the apply pass: k1 = gamma*invstd (float), m1 = S1/N, m2 = S2/N (double)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, int C, double count,
                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
@@ -1753,8 +1813,11 @@ extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, co
     double* coefd = part + (size_t)nblk * c * 2;     // [2][c]  m1, m2
     float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
     const PoolSrc ps{dy_pool, idx, h, w, (h - 1) / 2 + 1, (w - 1) / 2 + 1};
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, ps);
-    STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel<pool>");
+    const long long prows = (long long)batch * ps.Ho * ps.Wo;
+    const int prpb = (int)((prows + nblk - 1) / nblk);
+    (void)rpb;
+    hipLaunchKernelGGL(bn_bwd_reduce_pooled_kernel, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, raw, save_mean, save_invstd, mask_scale, mask_shift, part, prows, c, prpb, ps);
+    STRAPS_CHECK_LAUNCH("bn_bwd_reduce_pooled_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;

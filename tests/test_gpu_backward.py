@@ -282,8 +282,8 @@ def test_regressor_param_grads_vs_reference_golden(dev, layers):
 def test_fused_stem_tail_equals_unfused(dev):
     """bn1 + relu + maxpool fused (straps_bn_relu_maxpool_fwd / straps_bn_bwd_pooled: the stem activation and its gradient are
     never materialised) against the unfused calls (straps_bn_apply, straps_maxpool_fwd_idx, straps_maxpool_bwd, straps_bn_bwd):
-    same arithmetic in the same order, so features and every parameter gradient agree bit for bit; also an odd-sized input
-    (pool windows clipped at the border)."""
+    same arithmetic in the same order, so features, running statistics and every parameter gradient behind the stem agree bit for
+    bit (the stem's own three gradients to 1e-5: see below); also an odd-sized input (pool windows clipped at the border)."""
     for shape in ((3, 18, 256, 256), (2, 18, 120, 88)):
         outs = []
         for unfused in (False, True):
@@ -300,7 +300,13 @@ def test_fused_stem_tail_equals_unfused(dev):
         (ya, ga, ba), (yb, gb, bb) = outs
         assert torch.equal(ya, yb)
         for n in ga:
-            assert torch.equal(ga[n], gb[n]), n
+            if n in ('image_encoder.conv1.weight', 'image_encoder.bn1.weight', 'image_encoder.bn1.bias'):
+                # the fused tail takes bn1's two backward sums over the POOLED grid (one term per pooled element, in double) instead of
+                # over the un-pooled gradient: the same numbers in another summation order
+                err = float((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-30))
+                assert err < 1e-5, (n, err)
+            else:
+                assert torch.equal(ga[n], gb[n]), n
         for n in ba:
             assert torch.equal(ba[n], bb[n]), n
 
