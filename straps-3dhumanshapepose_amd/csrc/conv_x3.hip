@@ -220,7 +220,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
             }
         };
         constexpr int HALF = NMFMA / 2, GAP2 = HALF / NPIECE > 0 ? HALF / NPIECE : 1;
-        auto mfma_block = [&](int set, int nstage, bool more) {
+        auto mfma_block = [&](int set, int nstage, auto more_c) {
+            constexpr bool more = decltype(more_c)::value;      // (compile-time: a run-time test per copy splits the block at every MFMA)
             int cnt = 0;
 #pragma unroll
             for (int t = 0; t < 6; ++t)
@@ -247,11 +248,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
             load_frags(0, 0, 0);
         }
         int stage = 0;
-        for (int q = 0; q < nchunks; ++q) {
+        auto body = [&](int q, auto more_c) {
             const int nxt = stage + 1 == NST ? 0 : stage + 1;
             load_frags(stage, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_block(0, 0, false);
+            mfma_block(0, 0, std::false_type{});
             __builtin_amdgcn_sched_barrier(0);
             if (q + 1 < nchunks) {
                 // chunk q+1 (issued NST chunks ago) has landed -- the NST - 2 chunks after it may still be in flight
@@ -263,10 +264,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
                 load_frags(nxt, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma_block(1, stage, q + NST < nchunks);          // refill this chunk's stage: no wave reads it any more
+            mfma_block(1, stage, more_c);                     // refill this chunk's stage (chunk q + NST): no wave reads it any more
             __builtin_amdgcn_sched_barrier(0);
             stage = nxt;
-        }
+        };
+        int q = 0;
+        for (; q + NST < nchunks; ++q) body(q, std::true_type{});
+        for (; q < nchunks; ++q) body(q, std::false_type{});
     } else {
     int stage = 0, nstage = NST - 1;
     auto next = [&]() {
