@@ -63,3 +63,27 @@ def test_tile_choice_of_the_implicit_gemm(lib):
         assert lib.straps_conv_stat_blocks(2, 10, 10, 128, 1152, cfg) == -(-200 // bm)
     # BatchNorm-backward reduction grid and the workspace that goes with it
     assert lib.straps_bn_bwd_workspace_bytes(4096, 64) == (lib.straps_bn_bwd_blocks(4096, 64) * 64 * 2 + 2 * 64) * 8 + 64 * 4
+
+
+def test_tile_choice_and_routes_of_the_bf16x3_kernels(lib):
+    """host arithmetic only: straps_conv_x3_stat_blocks exposes which kernel / tile straps_conv_fwd_x3 uses for a geometry (resnet18 at
+    B = 64: layer1 128x64 two-stage tiles, layer2 256x128, layer3 the halo-patch kernel (128 rows), layer4 128x64 three-stage; the
+    halo-patch kernel only for 3x3 / stride 1 maps whose 128-pixel tiles are whole rows or whole images), and
+    straps_conv_wgrad_x3_on_planes which weight gradients read planes only."""
+    B = 64
+    sb = lib.straps_conv_x3_stat_blocks
+    assert sb(B, 64, 64, 64, 64, 3, 3, 1, 1, 0) == B * 64 * 64 // 128
+    assert sb(B, 32, 32, 128, 128, 3, 3, 1, 1, 0) == B * 32 * 32 // 256
+    assert sb(B, 16, 16, 256, 256, 3, 3, 1, 1, 0) == B * 16 * 16 // 128
+    assert sb(B, 8, 8, 512, 512, 3, 3, 1, 1, 0) == B * 8 * 8 // 128
+    assert sb(B, 64, 64, 64, 128, 3, 3, 2, 1, 0) == B * 32 * 32 // 256                      # stride 2: im2col kernel, 256x128 tiles
+    assert sb(3, 10, 24, 128, 128, 3, 3, 1, 1, 0) == -(-3 * 10 * 24 // 128)                 # ragged M: 128x64 three-stage tiles
+    assert sb(3, 10, 24, 128, 128, 3, 3, 1, 1, 512) == -(-3 * 10 * 24 // 128)               # (no halo kernel: M % 128 != 0)
+    for cfg, bm in ((1, 128), (2, 128), (3, 64), (4, 256), (5, 128), (7, 128), (11, 128), (12, 256)):
+        assert sb(2, 10, 10, 128, 128, 3, 3, 1, 1, cfg) == -(-200 // bm), cfg
+    on = lib.straps_conv_wgrad_x3_on_planes
+    assert on(B, 64, 64, 64, 64, 3, 3, 1, 1) == 1 and on(B, 8, 8, 512, 512, 3, 3, 1, 1) == 1   # halo-patch kernel
+    assert on(B, 64, 64, 64, 128, 3, 3, 2, 1) == 1                                              # 3x3 / stride 2: per-tap kernel on planes
+    assert on(B, 64, 64, 64, 128, 1, 1, 2, 0) == 0                                              # 1x1 with a 64-channel side: fp32 kernel
+    assert on(B, 28, 28, 128, 512, 1, 1, 1, 0) == 1
+    assert on(2, 10, 24, 64, 64, 3, 3, 1, 1) == 1                                               # no halo plan (width 24): per-tap kernel on planes
