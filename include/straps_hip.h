@@ -313,6 +313,24 @@ int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const
 /* weight gradient on the bf16x3 route: straps_conv_wgrad's arguments plus the planes of x and dy; 3x3 / stride 1 /
  * pad 1 layers (power-of-two width >= 8) run on the planes (halo-patch kernel, ds_read_b64_tr_b16 operand gathers),
  * every other shape -- or NULL planes -- uses the fp32 kernels on (x, dy).  Workspace as for straps_conv_wgrad.      */
+/* The data gradient with the sums of the NEXT BatchNorm backward fused into its epilogue: dx (= the gradient dy entering the
+ * BatchNorm + ReLU that produced this convolution's input) is written as by straps_conv_dgrad_x3, and per M tile one partial
+ * bn_partials[block][cin][2] = (S1, invstd * S2) of  S1 = sum mask*dy,  S2 = sum mask*dy*(raw - mean)  (double; mask = bn_out > 0
+ * if bn_out, else fma(raw, bn_mask_scale, bn_mask_shift) > 0) -- the reduction pass of straps_bn_bwd_x3 over (dy, raw) is not
+ * needed: straps_bn_bwd_finish_x3 takes the partials (blocks from straps_conv_dgrad_x3_bn_blocks; workspace: 2 c doubles + c floats). */
+int straps_conv_dgrad_x3_bn_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride,
+                                   int pad, int tile_cfg);
+int straps_conv_dgrad_x3_bn(const unsigned short* dy3, long long dy_plane_stride,
+                            const unsigned short* w3_crsk, long long w_plane_stride, const float* addend,
+                            float* dx_nhwc, int batch, int h, int w, int cin, int cout, int kh, int kw,
+                            int stride, int pad, int tile_cfg, const float* bn_raw, const float* bn_out,
+                            const float* bn_mask_scale, const float* bn_mask_shift, const float* bn_mean,
+                            const float* bn_invstd, double* bn_partials, void* stream);
+int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const float* raw, const float* save_mean,
+                            const float* save_invstd, const float* gamma, const float* mask_scale,
+                            const float* mask_shift, float* dgamma, float* dbeta, float* draw, float* dz_out,
+                            unsigned short* draw_planes, long long plane_stride, const double* partials,
+                            int nblk, void* workspace, long long rows, int c, int accumulate, void* stream);
 /* 1 if straps_conv_wgrad_x3 handles this geometry on the planes alone (x_nhwc / dy_nhwc may then be NULL, and the producers
  * -- straps_bn_apply_x3's y, straps_bn_bwd_x3's draw -- need not write their fp32 copies), 0 if it needs the fp32 tensors.      */
 int straps_conv_wgrad_x3_on_planes(int batch, int h, int w, int cin, int cout, int kh, int kw,

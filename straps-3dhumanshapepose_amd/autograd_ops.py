@@ -3,6 +3,7 @@
 computed by the HIP kernels behind the C ABI.  Nothing here does arithmetic in torch.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -52,6 +53,9 @@ class _SideStream:
 
 
 # ------------------------------------------------------------------------------------------ encoder
+_FUSE_BN_SUMS = os.environ.get('STRAPS_NO_FUSED_BN_SUMS', '0') != '1'     # (A/B switch for tools)
+
+
 def _packed_dgrad_weight(net, conv):
     w = conv.weight
 
@@ -85,10 +89,18 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True
         ps = (raw.numel() + 7) // 8 * 8
         planes = torch.empty(3, ps, device=raw.device, dtype=torch.int16)
         planes_sink[id(draw)] = (draw, planes, ps)
-    hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked and not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
-                                    hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
-                                    hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw if keep_fp32 else None),
-                                    hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
+    fused = rec.pop('bwd_partials', None)         # (partials, blocks, dy they belong to): the sums came out of the data gradient's epilogue
+    if fused is not None and fused[2] is dy and masked:
+        hipabi.check(L.straps_bn_bwd_finish_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
+                                               hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
+                                               hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta),
+                                               hipabi.ptr(draw if keep_fp32 else None), hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(fused[0]),
+                                               fused[1], hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd_finish_x3')
+    else:
+        hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked and not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
+                                        hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
+                                        hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw if keep_fp32 else None),
+                                        hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
     grads[bn.weight] = dgamma
     grads[bn.bias] = dbeta
     return draw, dz
@@ -113,7 +125,10 @@ def _conv_wgrad(L, rec, draw, grads, planes_sink=None):
     grads[conv.weight] = dw
 
 
-def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None):
+def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None, bn_next=None):
+    """data gradient of one convolution.  bn_next (bf16x3 route): tape record of the BatchNorm (+ ReLU) whose output this convolution
+    read -- the returned gradient is that BatchNorm's dy, and the two sums of its backward are accumulated in this launch's epilogue
+    (straps_conv_dgrad_x3_bn) and left in bn_next['bwd_partials'] for _bn_bwd."""
     conv = rec['conv']
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     dx = torch.empty(B, H, W, Cin, device=draw.device, dtype=torch.float32)
@@ -127,6 +142,18 @@ def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None):
             from .encoder_exec import split3
             g3, gps = split3(L, draw)
         w3, wps = net._packed_weight_x3(conv, dgrad=True)
+        if bn_next is not None and _FUSE_BN_SUMS:
+            ssn = bn_next['stats']
+            from_raw = bn_next.get('residual') is None
+            nblk = L.straps_conv_dgrad_x3_bn_blocks(B, H, W, Cin, Cout, k, k, stride, pad, 0)
+            part = torch.empty(nblk, Cin, 2, device=dx.device, dtype=torch.float64)
+            hipabi.check(L.straps_conv_dgrad_x3_bn(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(dx), B, H, W, Cin, Cout,
+                                                   k, k, stride, pad, 0, hipabi.ptr(bn_next['raw']), hipabi.ptr(None if from_raw else bn_next['out']),
+                                                   hipabi.ptr(ssn[0] if from_raw else None), hipabi.ptr(ssn[1] if from_raw else None),
+                                                   hipabi.ptr(ssn[2]), hipabi.ptr(ssn[3]), hipabi.ptr(part), hipabi.stream_ptr()),
+                         'straps_conv_dgrad_x3_bn')
+            bn_next['bwd_partials'] = (part, nblk, dx)
+            return dx
         hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(dx), B, H, W, Cin, Cout,
                                             k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_dgrad_x3')
         return dx
@@ -154,9 +181,12 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
     B, HW, Cf = rec['geom']
     dy = _empty_like(rec['x'])
     hipabi.check(L.straps_gap_bwd(hipabi.ptr(dfeat.contiguous()), hipabi.ptr(dy), B, HW, Cf, hipabi.stream_ptr()), 'straps_gap_bwd')
+    units = [u for li in range(1, 5) for u in getattr(net, 'layer%d' % li)]
     for li in range(4, 0, -1):
         for unit in reversed(list(getattr(net, 'layer%d' % li))):
             pairs = unit.conv_bn_pairs()
+            ui = units.index(unit)
+            prev_last = tape[id(units[ui - 1].conv_bn_pairs()[-1][0])] if ui > 0 else None      # the BatchNorm this unit's input came out of
             rec = tape[id(pairs[-1][0])]
             draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink, keep(rec))    # ReLU(out) mask; dz feeds the skip connection
             side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
@@ -168,11 +198,13 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
             else:
                 dskip = dz
             for ci in range(len(pairs) - 1, 0, -1):
-                dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None, sink)
-                rec = tape[id(pairs[ci - 1][0])]
+                rec_prev = tape[id(pairs[ci - 1][0])]
+                dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None, sink, bn_next=rec_prev if sink is not None else None)
+                rec = rec_prev
                 draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink, keep(rec))
                 side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
-            dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink)   # + skip gradient fused in the epilogue
+            # (+ skip gradient fused in the epilogue; the result is dy of the PREVIOUS unit's last BatchNorm, whose sums ride along)
+            dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink, bn_next=prev_last if sink is not None else None)
         if li == 3 and after_layer3 is not None:
             side.join()
             after_layer3()

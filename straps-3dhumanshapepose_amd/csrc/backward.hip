@@ -1790,6 +1790,30 @@ extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float*
     return STRAPS_OK;
 }
 
+// straps_bn_bwd_x3 when the two sums already exist as per-tile partials [nblk][c][2] (S1, invstd * S2) -- written by
+// straps_conv_dgrad_x3_bn, the data-gradient launch that produced dy: finalize + apply only, no pass over (dy, raw) for the sums.
+// workspace: (2 c) doubles + c floats.
+extern "C" int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
+                                       const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta,
+                                       float* draw, float* dz_out, unsigned short* draw_planes, long long plane_stride, const double* partials,
+                                       int nblk, void* workspace, long long rows, int c, int accumulate, void* stream) {
+    STRAPS_REQUIRE(!draw_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "straps_bn_bwd_finish_x3: plane_stride must be >= rows*c and a multiple of 8");
+    STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && (draw || draw_planes) && workspace && partials && nblk > 0,
+                   "straps_bn_bwd_finish_x3: null pointer");
+    STRAPS_REQUIRE(rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd_finish_x3: bad shape rows=%lld c=%d", rows, c);
+    const int C4 = c >> 2;
+    STRAPS_REQUIRE(C4 <= 256 ? (256 % C4 == 0) : (C4 % 256 == 0), "straps_bn_bwd_finish_x3: channel count %d not supported", c);
+    hipStream_t st = (hipStream_t)stream;
+    double* coefd = (double*)workspace;              // [2][c]  m1, m2
+    float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partials, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
+    STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    const long long n4 = rows * C4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
+    STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
                              const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
                              float* dz_out, void* workspace, long long rows, int c, int accumulate, void* stream) {

@@ -20,6 +20,18 @@ struct ConvP {
     int OH, OW, omul;               // physical output pixel = (b, ho*omul + oah, wo*omul + oaw) in [B][OH][OW][Cout]
     int NT, wtaps;                  // N tiles; taps stored per output channel in w
     long long xps, wps;             // three-plane bf16 operands (conv_x3.hip): elements between the planes of x / of w
+    // BatchNorm-backward sums fused into a data gradient's epilogue (conv_x3.hip, straps_conv_dgrad_x3_bn): the tensor this launch
+    // writes is the gradient dy entering the BatchNorm (+ ReLU) that produced the convolution's input; its two backward sums
+    // S1 = sum mask*dy, S2 = invstd * sum mask*dy*(raw - mean) per channel are accumulated here (double) as one partial per M tile
+    // instead of by a pass of their own over (dy, raw).  mask = out > 0 if bnr_out, else fma(raw, bnr_sc, bnr_sh) > 0.
+    const float* bnr_raw;
+    const float* bnr_out;
+    const float* bnr_sc;
+    const float* bnr_sh;
+    const float* bnr_mean;
+    const float* bnr_invstd;
+    double* bnr_part;               // [blocks][Cout][2]
+    int bnr_base[4];                // first partial block of each class
     // Up to four independent sub-problems per launch (blockIdx.y): the output-parity classes of a stride-2 data gradient
     // are GEMMs over a quarter of the pixels each with their own tap subset -- launched together they fill the chip
     // instead of queueing as four small grids.  A forward conv / stride-1 gradient is the single class 0.
@@ -36,9 +48,11 @@ struct ConvP {
 // Epilogue of a BM x BN block tile held as 32x32 accumulator blocks by 2x2 waves (C layout: lane = output channel, reg = pixel
 // row): BN scale/shift, residual/addend, ReLU fused; returns the per-lane (sum, sum of squares) of the raw values for the
 // training-mode batch statistics.
-template <int BM, int BN, int WGM = 2, int WGN = 2>
-__device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0,
-                                                 float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32]) {
+// (BNR: also accumulate the BatchNorm-backward sums described at ConvP::bnr_raw into d1 / d2 -- register arrays of the caller)
+template <int BM, int BN, int WGM, int WGN, bool BNR>
+__device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0,
+                                                      int n0, float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32], double (&d1)[BN / WGN / 32],
+                                                      double (&d2)[BN / WGN / 32]) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -53,6 +67,21 @@ __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Cl
         sh[j] = p.shift ? p.shift[n] : 0.f;
         s1[j] = 0.f;
         s2[j] = 0.f;
+    }
+    [[maybe_unused]] float bsc[NI], bsh[NI], bmu[NI];
+    [[maybe_unused]] const bool bnr = BNR && p.bnr_raw != nullptr;
+    if constexpr (BNR) {
+        if (bnr) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+                bsc[j] = p.bnr_out ? 0.f : p.bnr_sc[n];
+                bsh[j] = p.bnr_out ? 0.f : p.bnr_sh[n];
+                bmu[j] = p.bnr_mean[n];
+                d1[j] = 0.0;
+                d2[j] = 0.0;
+            }
+        }
     }
     // (32-bit element offsets, see the launcher's size check; an M tile that lies inside the problem skips the per-row test)
     const bool full = m0 + BM <= cM;
@@ -95,6 +124,20 @@ __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Cl
                         rv[r][j] = (FULL || m < cM) ? p.res[pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31)] : 0.f;
                     }
             }
+            [[maybe_unused]] float xr[16][NI], yo[16][NI];
+            if constexpr (BNR) {
+                if (bnr) {      // raw (and, for a residual unit's last BatchNorm, the activation) of the 16 rows: fetched together like rv
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const int m = mb + (r & 3) + 8 * (r >> 2);
+                            const int o = pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
+                            xr[r][j] = (FULL || m < cM) ? p.bnr_raw[o] : 0.f;
+                            yo[r][j] = (p.bnr_out && (FULL || m < cM)) ? p.bnr_out[o] : 0.f;
+                        }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -109,12 +152,58 @@ __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Cl
                         if (p.res) v += rv[r][j];
                         if (p.relu) v = fmaxf(v, 0.f);
                         p.y[o] = v;
+                        if constexpr (BNR) {
+                            if (bnr) {
+                                const bool on = p.bnr_out ? yo[r][j] > 0.f : fmaf(xr[r][j], bsc[j], bsh[j]) > 0.f;
+                                const float g = on ? v : 0.f;
+                                d1[j] += (double)g;
+                                d2[j] += (double)g * ((double)xr[r][j] - (double)bmu[j]);
+                            }
+                        }
                     }
                 }
             }
         }
     };
     if (full) rows(std::true_type{}); else rows(std::false_type{});
+}
+
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+__device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0,
+                                                 float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32]) {
+    double d1[BN / WGN / 32], d2[BN / WGN / 32];          // (unused)
+    igemm_store_rows_impl<BM, BN, WGM, WGN, false>(p, c, acc, m0, n0, s1, s2, d1, d2);
+}
+
+// BatchNorm-backward partial of one M tile -> bnr_part[blk][Cout][2] = (S1, invstd * S2), summed in a fixed order
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+__device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&bd1)[BN / WGN / 32], const double (&bd2)[BN / WGN / 32], int blk, int n0,
+                                                float* smem) {
+    constexpr int WTN = BN / WGN, NI = WTN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    if (!p.bnr_raw) return;
+    __syncthreads();   // all fragment reads of the last chunk are done: LDS is free
+    double* red = reinterpret_cast<double*>(smem);   // [WGM (wm)][BN][2]
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const double u1 = bd1[j] + __shfl_xor(bd1[j], 32, 64);
+        const double u2 = bd2[j] + __shfl_xor(bd2[j], 32, 64);
+        if (lane < 32) {
+            const int c = wn * WTN + j * 32 + lane;
+            red[(wm * BN + c) * 2 + 0] = u1;
+            red[(wm * BN + c) * 2 + 1] = u2;
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        double t1 = red[tid * 2 + 0], t2 = red[tid * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < WGM; ++w) { t1 += red[(w * BN + tid) * 2 + 0]; t2 += red[(w * BN + tid) * 2 + 1]; }
+        double* o = p.bnr_part + ((long long)blk * p.Cout + n0 + tid) * 2;
+        o[0] = t1;
+        o[1] = t2 * (double)p.bnr_invstd[n0 + tid];
+    }
 }
 
 // per-channel (sum, sum of squares) partials of one M tile -> stats[mt][Cout][2]
@@ -153,6 +242,7 @@ __device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&
 inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, const float* residual, int relu, float* y, float* stats_partial,
                             int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad) {
     p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
+    p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
     ConvP::Class& c = p.cls[0];
     p.ncls = 1;
@@ -176,6 +266,7 @@ inline int conv_dgrad_problem(ConvP& p, const float* addend, float* dx, int batc
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (wdt + 2 * pad - kw) / stride + 1;
     const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
+    p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
     p.omul = stride;

@@ -286,8 +286,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     }
 
     float s1[NI], s2[NI];
-    igemm_store_rows<BM, BN, WGM, WGN>(p, c, acc, m0, n0, s1, s2);
+    double bd1[NI], bd2[NI];
+    igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
     igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
 }
 
 // ---- halo-patch variant for the 3x3 / stride-1 layers (forward, and the data gradient, which is the same convolution over dy) ----
@@ -476,8 +478,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{});
 
     float s1[NI], s2[NI];
-    igemm_store_rows<BM, BN, WGM, WGN>(p, c, acc, m0, n0, s1, s2);
+    double bd1[NI], bd2[NI];
+    igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
     igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
 }
 
 template <int BM, int BN, int WGM, int WGN, int NST, int PS>
@@ -485,6 +489,7 @@ int launch_x3h(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     p.NT = p.Cout / BN;
     p.cls[0].MT = p.cls[0].M / BM;
+    p.bnr_base[0] = 0;
     const size_t lds = ((size_t)2 * 3 * PS + (size_t)NST * 3 * BN) * 32 * sizeof(u16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -517,9 +522,12 @@ int launch_x3(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     p.NT = p.Cout / BN;
     int maxblk = 0;
+    int base = 0;
     for (int i = 0; i < p.ncls; ++i) {
         p.cls[i].MT = (p.cls[i].M + BM - 1) / BM;
         if (p.cls[i].MT * p.NT > maxblk) maxblk = p.cls[i].MT * p.NT;
+        p.bnr_base[i] = base;                   // (BatchNorm-backward partials: one block per M tile, classes one after the other)
+        base += p.cls[i].MT;
     }
     const size_t lds = (size_t)NST * 3 * (BM + BN) * 32 * sizeof(u16);
     static bool attr_set = false;
@@ -662,6 +670,50 @@ extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plan
 }
 
 // number of [cout][2] statistics partials straps_conv_fwd_x3 writes for this geometry (= its M tiles)
+// M tiles (= BatchNorm-backward partial blocks) of straps_conv_dgrad_x3[_bn] for this geometry, all parity classes
+static int dgrad_x3_blocks(const ConvP& p, int tile_cfg) {
+    if (halo_choice(p, tile_cfg)) return p.cls[0].M / 128;
+    int bm, bn, kdim = 0;
+    long long M = 0;
+    for (int i = 0; i < p.ncls; ++i) {
+        M += p.cls[i].M;
+        if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
+    }
+    pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn);
+    int blocks = 0;
+    for (int i = 0; i < p.ncls; ++i) blocks += (p.cls[i].M + bm - 1) / bm;
+    return blocks;
+}
+
+extern "C" int straps_conv_dgrad_x3_bn_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg) {
+    ConvP p;
+    p.x = nullptr; p.w = nullptr; p.xps = p.wps = 0;
+    if (!(stride == 1 || stride == 2) || kh * kw > 9 || kh - 1 - pad < 0 || kw - 1 - pad < 0) return -1;
+    if (conv_dgrad_problem(p, nullptr, nullptr, batch, h, w, cin, cout, kh, kw, stride, pad) != STRAPS_OK) return -1;
+    return dgrad_x3_blocks(p, tile_cfg);
+}
+
+extern "C" int straps_conv_dgrad_x3_bn(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                                       const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
+                                       int pad, int tile_cfg, const float* bn_raw, const float* bn_out, const float* bn_mask_scale,
+                                       const float* bn_mask_shift, const float* bn_mean, const float* bn_invstd, double* bn_partials, void* stream) {
+    STRAPS_REQUIRE(dy3 && w3_crsk && dx, "straps_conv_dgrad_x3_bn: null pointer");
+    STRAPS_REQUIRE(bn_raw && bn_mean && bn_invstd && bn_partials && (bn_out || (bn_mask_scale && bn_mask_shift)),
+                   "straps_conv_dgrad_x3_bn: the BatchNorm tensors (raw, mean, invstd, partials, and out or mask scale / shift) are required");
+    STRAPS_REQUIRE(cout % 32 == 0 && cin % 64 == 0, "straps_conv_dgrad_x3_bn: need cout%%32==0 and cin%%64==0 (cin=%d cout=%d)", cin, cout);
+    STRAPS_REQUIRE(stride == 1 || stride == 2, "straps_conv_dgrad_x3_bn: stride must be 1 or 2");
+    STRAPS_REQUIRE(kh * kw <= 9 && kh - 1 - pad >= 0 && kw - 1 - pad >= 0, "straps_conv_dgrad_x3_bn: unsupported filter geometry");
+    STRAPS_REQUIRE(dy_plane_stride % 8 == 0 && w_plane_stride % 8 == 0, "straps_conv_dgrad_x3_bn: plane strides must be multiples of 8 elements");
+    ConvP p;
+    p.x = reinterpret_cast<const float*>(dy3); p.w = reinterpret_cast<const float*>(w3_crsk);
+    p.xps = dy_plane_stride; p.wps = w_plane_stride;
+    const int rc = conv_dgrad_problem(p, addend, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad);
+    if (rc != STRAPS_OK) return rc;
+    p.bnr_raw = bn_raw; p.bnr_out = bn_out; p.bnr_sc = bn_mask_scale; p.bnr_sh = bn_mask_shift; p.bnr_mean = bn_mean; p.bnr_invstd = bn_invstd;
+    p.bnr_part = bn_partials;
+    return p.ncls ? dispatch_x3(p, tile_cfg, (hipStream_t)stream) : STRAPS_OK;
+}
+
 extern "C" int straps_conv_x3_stat_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg) {
     ConvP p;
     p.x = nullptr; p.w = nullptr; p.xps = p.wps = 0;

@@ -96,6 +96,9 @@ SIGNATURES = {
     'straps_bn_apply_x3': (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _P]),
     'straps_bn_relu_maxpool_fwd_x3': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'straps_conv_wgrad_x3_on_planes': (_I, [_I] * 9),
+    'straps_conv_dgrad_x3_bn_blocks': (_I, [_I] * 10),
+    'straps_conv_dgrad_x3_bn': (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'straps_bn_bwd_finish_x3': (_I, [_P] * 13 + [_L, _P, _I, _P, _L, _I, _I, _P]),
     'straps_conv_wgrad_x3': (_I, [_P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_bn_bwd_x3': (_I, [_P] * 13 + [_L, _P, _L, _I, _I, _P]),
     'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I, _I]),

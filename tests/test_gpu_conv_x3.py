@@ -202,6 +202,69 @@ def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg,from_out', [
+    (2, 64, 64, 16, 16, 3, 1, 0, False), (2, 64, 128, 16, 16, 3, 2, 0, True), (64, 256, 256, 16, 16, 3, 1, 0, False), (3, 128, 128, 8, 8, 3, 1, 5, True),
+    (2, 64, 128, 16, 16, 1, 2, 0, False), (5, 128, 128, 24, 24, 3, 1, 12, True), (2, 128, 256, 9, 14, 3, 2, 1, False), (4, 128, 64, 32, 32, 3, 1, 512, False)])
+def test_dgrad_x3_with_fused_batchnorm_sums(dev, B, Cin, Cout, H, W, k, stride, cfg, from_out):
+    """straps_conv_dgrad_x3_bn: dx as straps_conv_dgrad_x3 writes it (bit for bit), and the per-tile partials of the next BatchNorm
+    backward's sums S1 = sum mask*dy, S2 = invstd * sum mask*dy*(raw - mean) (double) -- every tile configuration in use, the four parity
+    classes of a stride-2 gradient, the halo-patch kernel, both mask sources -- against a float64 evaluation on the kernel's own dx; and
+    straps_bn_bwd_finish_x3 on those partials against straps_bn_bwd_x3 (which sums in its own pass)."""
+    L = hipabi.lib()
+    pad = 1 if k == 3 else 0
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 2, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
+    g = torch.from_numpy(det_uniform((B, Ho, Wo, Cout), 3, -1, 1)).to(dev) * 1e-3
+    g3, gps = _split(g)
+    w3, wps = _split(_pack(dev, w, dgrad=True))
+    add = torch.from_numpy(det_uniform((B, H, W, Cin), 4, -1, 1)).to(dev) * 1e-3
+    raw = torch.from_numpy(det_uniform((B, H, W, Cin), 5, -2, 2)).to(dev)
+    mean = raw.mean(dim=(0, 1, 2)).contiguous()
+    invstd = (raw.var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt().contiguous()
+    msc = torch.from_numpy(det_uniform((Cin,), 6, 0.5, 1.5)).to(dev)
+    msh = torch.from_numpy(det_uniform((Cin,), 7, -0.5, 0.5)).to(dev)
+    out = torch.relu(raw * msc + msh + torch.from_numpy(det_uniform((B, H, W, Cin), 8, -1, 1)).to(dev)).contiguous()      # (a residual unit's output)
+    dx0 = torch.full((B, H, W, Cin), float('nan'), device=dev)
+    dx1 = torch.full((B, H, W, Cin), float('nan'), device=dev)
+    geo = (B, H, W, Cin, Cout, k, k, stride, pad, cfg)
+    hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(add), hipabi.ptr(dx0), *geo, None), 'dgrad_x3')
+    nblk = L.straps_conv_dgrad_x3_bn_blocks(*geo)
+    assert nblk > 0
+    part = torch.full((nblk, Cin, 2), float('nan'), device=dev, dtype=torch.float64)
+    hipabi.check(L.straps_conv_dgrad_x3_bn(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(add), hipabi.ptr(dx1), *geo, hipabi.ptr(raw),
+                                           hipabi.ptr(out if from_out else None), hipabi.ptr(None if from_out else msc), hipabi.ptr(None if from_out else msh),
+                                           hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(part), None), 'dgrad_x3_bn')
+    assert torch.equal(dx0, dx1)
+    # mask = fma(raw, scale, shift) > 0 in the kernel; evaluated here in float64 and rounded once (= the fused fp32 operation except
+    # for values within half an ulp of a tie -- none with these inputs)
+    mask = (out > 0) if from_out else ((raw.double() * msc.double() + msh.double()).float() > 0)
+    gd = torch.where(mask, dx1, torch.zeros_like(dx1)).double()
+    s1 = gd.sum(dim=(0, 1, 2))
+    s2 = (gd * (raw.double() - mean.double())).sum(dim=(0, 1, 2)) * invstd.double()
+    got = part.sum(0)
+    scale1, scale2 = float(gd.abs().sum(dim=(0, 1, 2)).max()), float((gd * (raw.double() - mean.double())).abs().sum(dim=(0, 1, 2)).max() * invstd.max())
+    assert float((got[:, 0] - s1).abs().max()) <= 1e-9 * scale1 + 1e-30, 'S1'
+    assert float((got[:, 1] - s2).abs().max()) <= 1e-9 * scale2 + 1e-30, 'S2'
+    # finish = finalize + apply on the partials == the three-pass entry point on the same dy
+    rows = B * H * W
+    gamma = torch.from_numpy(det_uniform((Cin,), 9, 0.5, 1.5)).to(dev)
+    ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, Cin) // 4, device=dev)
+    outs = []
+    for fused in (False, True):
+        dg, db, draw, dz = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev), torch.empty_like(raw), torch.empty_like(raw)
+        common = (hipabi.ptr(dx1), hipabi.ptr(out if from_out else None), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma),
+                  hipabi.ptr(None if from_out else msc), hipabi.ptr(None if from_out else msh), hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(dz),
+                  None, 0)
+        if fused:
+            hipabi.check(L.straps_bn_bwd_finish_x3(*common, hipabi.ptr(part), nblk, hipabi.ptr(ws), rows, Cin, 0, None), 'bn_bwd_finish_x3')
+        else:
+            hipabi.check(L.straps_bn_bwd_x3(*common, hipabi.ptr(ws), rows, Cin, 0, None), 'bn_bwd_x3')
+        outs.append((dg, db, draw, dz))
+    for a, b, name in zip(outs[0], outs[1], ('dgamma', 'dbeta', 'draw', 'dz')):
+        err = float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+        assert err < 2e-6, (name, err)          # (the same double sums in another order, rounded once to fp32)
+
+
 def test_error_budget_of_the_six_products(dev):
     """long reductions (K = 4608, layer4) of same-sign terms -- where a systematic bias of the dropped low-order products would
     show -- stay at the exact-fp32 chain's error against float64, and so do operands spread over 12 orders of magnitude."""
