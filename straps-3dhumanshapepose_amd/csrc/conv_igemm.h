@@ -124,40 +124,47 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
                         rv[r][j] = (FULL || m < cM) ? p.res[pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31)] : 0.f;
                     }
             }
-            [[maybe_unused]] float xr[16][NI], yo[16][NI];
-            if constexpr (BNR) {
-                if (bnr) {      // raw (and, for a residual unit's last BatchNorm, the activation) of the 16 rows: fetched together like rv
+            // (BNR: raw -- and, for a residual unit's last BatchNorm, the activation -- of eight rows at a time: fetched together like rv;
+            //  two halves keep the 256x128 / 8-wave tile inside its 256 registers)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
+            for (int hb = 0; hb < 2; ++hb) {
+                [[maybe_unused]] float xr[8][NI], yo[8][NI];
+                if constexpr (BNR) {
+                    if (bnr) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j) {
+                                const int r = hb * 8 + q;
+                                const int m = mb + (r & 3) + 8 * (r >> 2);
+                                const int o = pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
+                                xr[q][j] = (FULL || m < cM) ? p.bnr_raw[o] : 0.f;
+                                yo[q][j] = (p.bnr_out && (FULL || m < cM)) ? p.bnr_out[o] : 0.f;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = hb * 8 + q;
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (FULL || m < cM) {
 #pragma unroll
                         for (int j = 0; j < NI; ++j) {
-                            const int m = mb + (r & 3) + 8 * (r >> 2);
                             const int o = pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
-                            xr[r][j] = (FULL || m < cM) ? p.bnr_raw[o] : 0.f;
-                            yo[r][j] = (p.bnr_out && (FULL || m < cM)) ? p.bnr_out[o] : 0.f;
-                        }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (FULL || m < cM) {
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int o = pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
-                        float v = acc[i][j][r];
-                        s1[j] += v;
-                        s2[j] = fmaf(v, v, s2[j]);
-                        if (p.scale) v = fmaf(v, sc[j], sh[j]);
-                        if (p.res) v += rv[r][j];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        p.y[o] = v;
-                        if constexpr (BNR) {
-                            if (bnr) {
-                                const bool on = p.bnr_out ? yo[r][j] > 0.f : fmaf(xr[r][j], bsc[j], bsh[j]) > 0.f;
-                                const float g = on ? v : 0.f;
-                                d1[j] += (double)g;
-                                d2[j] += (double)g * ((double)xr[r][j] - (double)bmu[j]);
+                            float v = acc[i][j][r];
+                            s1[j] += v;
+                            s2[j] = fmaf(v, v, s2[j]);
+                            if (p.scale) v = fmaf(v, sc[j], sh[j]);
+                            if (p.res) v += rv[r][j];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            p.y[o] = v;
+                            if constexpr (BNR) {
+                                if (bnr) {
+                                    const bool on = p.bnr_out ? yo[q][j] > 0.f : fmaf(xr[q][j], bsc[j], bsh[j]) > 0.f;
+                                    const float g = on ? v : 0.f;
+                                    d1[j] += (double)g;
+                                    d2[j] += (double)g * ((double)xr[q][j] - (double)bmu[j]);
+                                }
                             }
                         }
                     }
