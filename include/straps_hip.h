@@ -290,6 +290,12 @@ int straps_conv_fwd_x3(const unsigned short* x3, long long x_plane_stride,
                        const float* shift, const float* residual, int relu, float* y_nhwc,
                        float* stats_partial, int batch, int h, int w, int cin, int cout, int kh,
                        int kw, int stride, int pad, int tile_cfg, void* stream);
+/* straps_conv_fwd_x3 (no statistics) that also writes its result as planes -- y_nhwc may be NULL when only they are consumed   */
+int straps_conv_fwd_x3p(const unsigned short* x3, long long x_plane_stride,
+                        const unsigned short* w3_krsc, long long w_plane_stride, const float* scale,
+                        const float* shift, const float* residual, int relu, float* y_nhwc,
+                        unsigned short* y_planes, long long y_plane_stride, int batch, int h, int w,
+                        int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg, void* stream);
 int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plane_stride,
                          const unsigned short* w3_crsk, long long w_plane_stride,
                          const float* addend, float* dx_nhwc, int batch, int h, int w, int cin,

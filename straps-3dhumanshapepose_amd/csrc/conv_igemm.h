@@ -32,6 +32,10 @@ struct ConvP {
     const float* bnr_invstd;
     double* bnr_part;               // [blocks][Cout][2]
     int bnr_base[4];                // first partial block of each class
+    // eval-mode forward on the bf16x3 route: the epilogue's result also as three bf16 planes (the next convolution's operand),
+    // y itself may then be NULL when nothing reads the fp32 tensor
+    unsigned short* yplanes;
+    long long yps;
     // Up to four independent sub-problems per launch (blockIdx.y): the output-parity classes of a stride-2 data gradient
     // are GEMMs over a quarter of the pixels each with their own tap subset -- launched together they fill the chip
     // instead of queueing as four small grids.  A forward conv / stride-1 gradient is the single class 0.
@@ -157,8 +161,15 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
                             if (p.scale) v = fmaf(v, sc[j], sh[j]);
                             if (p.res) v += rv[r][j];
                             if (p.relu) v = fmaxf(v, 0.f);
-                            p.y[o] = v;
+                            if (!BNR || p.y) p.y[o] = v;
                             if constexpr (BNR) {
+                                if (p.yplanes) {
+                                    u16 b1, b2, b3;
+                                    split3(v, b1, b2, b3);
+                                    p.yplanes[o] = b1;
+                                    p.yplanes[p.yps + o] = b2;
+                                    p.yplanes[2 * p.yps + o] = b3;
+                                }
                                 if (bnr) {
                                     const bool on = p.bnr_out ? yo[q][j] > 0.f : fmaf(xr[q][j], bsc[j], bsh[j]) > 0.f;
                                     const float g = on ? v : 0.f;
@@ -250,6 +261,7 @@ inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, co
                             int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad) {
     p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
+    p.yplanes = nullptr; p.yps = 0;
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
     ConvP::Class& c = p.cls[0];
     p.ncls = 1;
@@ -274,6 +286,7 @@ inline int conv_dgrad_problem(ConvP& p, const float* addend, float* dx, int batc
     const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
+    p.yplanes = nullptr; p.yps = 0;
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
     p.omul = stride;

@@ -653,6 +653,28 @@ extern "C" int straps_conv_fwd_x3(const unsigned short* x3, long long x_plane_st
     return dispatch_x3(p, tile_cfg, (hipStream_t)stream);
 }
 
+// straps_conv_fwd_x3 whose epilogue also writes the result's three bf16 planes (eval-mode chains: the next convolution's operand without
+// a split pass); y may be NULL when only the planes are consumed.
+extern "C" int straps_conv_fwd_x3p(const unsigned short* x3, long long x_plane_stride, const unsigned short* w3, long long w_plane_stride,
+                                   const float* scale, const float* shift, const float* residual, int relu, float* y, unsigned short* y_planes,
+                                   long long y_plane_stride, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad,
+                                   int tile_cfg, void* stream) {
+    STRAPS_REQUIRE(x3 && w3 && y_planes, "straps_conv_fwd_x3p: null pointer");
+    STRAPS_REQUIRE(batch > 0 && h > 0 && wdt > 0, "straps_conv_fwd_x3p: empty input %dx%dx%d", batch, h, wdt);
+    STRAPS_REQUIRE(cin % 32 == 0 && cout % 64 == 0, "straps_conv_fwd_x3p: need cin%%32==0 and cout%%64==0 (cin=%d cout=%d)", cin, cout);
+    STRAPS_REQUIRE(kh >= 1 && kw >= 1 && kh * kw <= 9 && stride >= 1 && pad >= 0, "straps_conv_fwd_x3p: bad filter geometry");
+    STRAPS_REQUIRE((scale == nullptr) == (shift == nullptr), "straps_conv_fwd_x3p: scale and shift must be given together");
+    STRAPS_REQUIRE(x_plane_stride % 8 == 0 && w_plane_stride % 8 == 0 && y_plane_stride % 8 == 0, "straps_conv_fwd_x3p: plane strides must be multiples of 8 elements");
+    ConvP p;
+    p.x = reinterpret_cast<const float*>(x3); p.w = reinterpret_cast<const float*>(w3);
+    p.xps = x_plane_stride; p.wps = w_plane_stride;
+    const int rc = conv_fwd_problem(p, scale, shift, residual, relu, y, nullptr, batch, h, wdt, cin, cout, kh, kw, stride, pad);
+    if (rc != STRAPS_OK) return rc;
+    STRAPS_REQUIRE(y_plane_stride >= (long long)p.cls[0].M * cout, "straps_conv_fwd_x3p: y_plane_stride smaller than the output");
+    p.yplanes = y_planes; p.yps = y_plane_stride;
+    return dispatch_x3(p, tile_cfg, (hipStream_t)stream);
+}
+
 extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
                                     const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
                                     int pad, int tile_cfg, void* stream) {

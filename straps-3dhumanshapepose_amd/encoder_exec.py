@@ -130,6 +130,20 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, kee
         ctx.tape[id(conv)] = rec
     if not ctx.training:
         ss = net._folded_bn(bn)
+        if ctx.x3 and relu and rec is None:
+            # bf16x3 route, inference: every ReLU output feeds a convolution, so the epilogue writes its planes as well (no split pass);
+            # the fp32 tensor itself only where something reads it (keep_fp32: a unit's output -- the next identity / the pooling)
+            x3, xps = _planes_of(ctx, x)
+            w3, wps = net._packed_weight_x3(conv)
+            if not keep_fp32:
+                y = x.new_empty(0)
+            yps = (B * Ho * Wo * Cout + 7) // 8 * 8
+            yp = torch.empty(3, yps, device=x.device, dtype=torch.int16)
+            hipabi.check(L.straps_conv_fwd_x3p(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
+                                               hipabi.ptr(y if keep_fp32 else None), hipabi.ptr(yp), yps, B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg,
+                                               hipabi.stream_ptr()), 'straps_conv_fwd_x3p')
+            ctx.planes[id(y)] = (y, yp, yps)
+            return y, Ho, Wo
         _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, None, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
         return y, Ho, Wo
     nblk = conv_stat_blocks(L, net, (B, H, W, Cin, Cout, k, stride, pad), Ho, Wo, tile_cfg)
@@ -234,6 +248,8 @@ def _residual_stages(ctx, net, y, B, H, W, tape):
             for ci, (conv, bn) in enumerate(pairs):
                 last = ci == len(pairs) - 1
                 keep = True
+                if ctx.x3 and not ctx.training and tape is None:
+                    keep = last                     # inference: only a unit's output is read as fp32 (identity of the next unit, pooling)
                 if ctx.x3 and ctx.training and tape is not None and not last:
                     # the fp32 activation between two convolutions of a unit is dead when the next layer's weight gradient reads planes
                     nc = pairs[ci + 1][0]

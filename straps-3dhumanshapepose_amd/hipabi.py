@@ -91,6 +91,7 @@ SIGNATURES = {
     'straps_conv_trace_buffer': (_I, [_P]),
     'straps_split3_bf16': (_I, [_P, _P, _L, _L, _P]),
     'straps_conv_fwd_x3': (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'straps_conv_fwd_x3p': (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_conv_dgrad_x3': (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_conv_x3_stat_blocks': (_I, [_I] * 10),
     'straps_bn_apply_x3': (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _P]),

@@ -290,6 +290,34 @@ def test_error_budget_of_the_six_products(dev):
     print('same-sign K=4608: bf16x3 %.2e  fp32 chain %.2e | 12 decades: bf16x3 %.2e  fp32 chain %.2e' % (r3, r32, rs, rs32))
 
 
+@pytest.mark.parametrize('B,Cin,Cout,H,k,stride,cfg', [(2, 64, 64, 16, 3, 1, 0), (3, 128, 128, 8, 3, 1, 5), (2, 64, 128, 16, 3, 2, 12), (64, 256, 256, 16, 3, 1, 0), (5, 64, 64, 7, 3, 1, 2)])
+def test_conv_fwd_x3p_planes_equal_a_split_pass(dev, B, Cin, Cout, H, k, stride, cfg):
+    """straps_conv_fwd_x3p (inference chains): the fp32 result equals straps_conv_fwd_x3's bit for bit and the planes written by the epilogue
+    equal a straps_split3_bf16 pass over it; with y = NULL the planes alone."""
+    L = hipabi.lib()
+    pad = 1
+    Ho = (H + 2 * pad - k) // stride + 1
+    x = torch.from_numpy(det_uniform((B, H, H, Cin), 41, -1, 1)).to(dev)
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 42, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
+    sc = torch.from_numpy(det_uniform((Cout,), 43, 0.5, 1.5)).to(dev)
+    sh = torch.from_numpy(det_uniform((Cout,), 44, -0.5, 0.5)).to(dev)
+    res = torch.from_numpy(det_uniform((B, Ho, Ho, Cout), 45, -1, 1)).to(dev)
+    x3, xps = _split(x)
+    w3, wps = _split(_pack(dev, w))
+    y0 = torch.full((B, Ho, Ho, Cout), float('nan'), device=dev)
+    y1 = torch.full((B, Ho, Ho, Cout), float('nan'), device=dev)
+    hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, hipabi.ptr(y0), None,
+                                      B, H, H, Cin, Cout, k, k, stride, pad, cfg, None), 'fwd_x3')
+    want, ps = _split(y0)
+    for y in (y1, None):
+        pl = torch.zeros(3, ps, device=dev, dtype=torch.int16)
+        hipabi.check(L.straps_conv_fwd_x3p(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, hipabi.ptr(y),
+                                           hipabi.ptr(pl), ps, B, H, H, Cin, Cout, k, k, stride, pad, cfg, None), 'fwd_x3p')
+        assert torch.equal(pl, want)
+        if y is not None:
+            assert torch.equal(y, y0)
+
+
 def test_fused_plane_outputs_equal_a_split_pass(dev):
     """straps_bn_apply_x3 / straps_bn_relu_maxpool_fwd_x3 / straps_bn_bwd_x3 write the same fp32 outputs as their plain forms and the
     planes a straps_split3_bf16 pass over that output would (bit for bit)."""
