@@ -147,6 +147,12 @@ def instrument(timer):
         def straps_conv_fwd_x3(self, *a):      # (fp32-equivalent flops: the six bf16 products of a term count as one multiply-add)
             return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[10:19]), lambda: L.straps_conv_fwd_x3(*a), 1.5 * conv_bytes(*a[10:19]))
 
+        def straps_conv_fwd_x3p(self, *a):
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[11:20]), lambda: L.straps_conv_fwd_x3p(*a), 1.5 * conv_bytes(*a[11:20]))
+
+        def straps_conv_dgrad_x3_bn(self, *a):     # (the launch also carries the next BatchNorm backward's sums in its epilogue)
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3_bn(*a), 1.5 * conv_bytes(*a[6:15]))
+
         def straps_conv_dgrad_x3(self, *a):
             return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3(*a), 1.5 * conv_bytes(*a[6:15]))
 
