@@ -1552,12 +1552,7 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
             p3.x = x; p3.dy = dy; p3.part = (float*)workspace;
             constexpr int NG3 = 2;
             const size_t lds = (size_t)NG3 * 2 * W3PX * 64 * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_kernel<NG3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-                attr_set = true;
-            }
+            STRAPS_RAISE_LDS((conv_wgrad3x3_kernel<NG3>), lds, "conv_wgrad3x3_kernel");
             hipStream_t st3 = (hipStream_t)stream;
             hipLaunchKernelGGL(conv_wgrad3x3_kernel<NG3>, dim3((cout / 64) * (cin / 64), splits3), dim3(256 * NG3), lds, st3, p3);
             STRAPS_CHECK_LAUNCH("conv_wgrad3x3_kernel");
@@ -1583,12 +1578,7 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
     p.rows_per_split = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
     hipStream_t st = (hipStream_t)stream;
     if (big) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            if (e != hipSuccess) { straps_set_error("conv_wgrad_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-            attr_set = true;
-        }
+        STRAPS_RAISE_LDS((conv_wgrad_kernel<128, 128>), 64 * 1024, "conv_wgrad_kernel");
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3(tiles, splits), dim3(256), 64 * 1024, st, p);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3(tiles, splits), dim3(256), 32 * 1024, st, p);
@@ -1652,21 +1642,11 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
             q.chunks_per_split = p64.chunks_per_split;
             splits3 = splits64;
             const size_t lds = (size_t)2 * 3 * (64 + 136) * 64 * sizeof(u16);
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_x3_kernel<W3X_NG, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-                attr_set = true;
-            }
+            STRAPS_RAISE_LDS((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), lds, "conv_wgrad3x3_x3_kernel");
             hipLaunchKernelGGL((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), dim3((cout / 64) * (cin / 64), splits3), dim3(256 * W3X_NG), lds, st3, q);
         } else {
             const size_t lds = (size_t)2 * 3 * (32 + 128) * 64 * sizeof(u16);
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_x3_kernel<W3X_NG, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) { straps_set_error("conv_wgrad3x3_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-                attr_set = true;
-            }
+            STRAPS_RAISE_LDS((conv_wgrad3x3_x3_kernel<W3X_NG, 32>), lds, "conv_wgrad3x3_x3_kernel");
             hipLaunchKernelGGL((conv_wgrad3x3_x3_kernel<W3X_NG, 32>), dim3((cout / 64) * (cin / 64), splits3), dim3(256 * W3X_NG), lds, st3, q);
         }
         STRAPS_CHECK_LAUNCH("conv_wgrad3x3_x3_kernel");
@@ -1695,12 +1675,7 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         hipStream_t st = (hipStream_t)stream;
         if (big) {
             constexpr int LDSB = 2 * 3 * 32 * 256 * 2;
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-                if (e != hipSuccess) { straps_set_error("conv_wgrad_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-                attr_set = true;
-            }
+            STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<128, 128>), LDSB, "conv_wgrad_x3_kernel");
             hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128>), dim3(tiles, splits), dim3(256), LDSB, st, q);
         } else {
             hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 64>), dim3(tiles, splits), dim3(256), 2 * 3 * 32 * 128 * 2, st, q);

@@ -30,6 +30,28 @@ void straps_set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
+// Dynamic-LDS limit of a kernel above the 64 KiB default.  Function attributes are per device: `done` is the caller's static bit mask
+// of the devices this kernel has been raised on (a process that drives several GPUs sets each once).
+inline hipError_t straps_raise_dynamic_lds(const void* fn, size_t bytes, unsigned long long& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done |= bit;
+    return e;
+}
+#define STRAPS_RAISE_LDS(fn, bytes, name)                                                                  \
+    do {                                                                                                   \
+        static unsigned long long done__ = 0;                                                              \
+        hipError_t e__ = straps_raise_dynamic_lds((const void*)(fn), (size_t)(bytes), done__);             \
+        if (e__ != hipSuccess) {                                                                           \
+            straps_set_error("%s: cannot raise dynamic LDS to %zu: %s", name, (size_t)(bytes), hipGetErrorString(e__)); \
+            return STRAPS_EHIP;                                                                            \
+        }                                                                                                  \
+    } while (0)
+
 // fp32-input MFMA, 32x32 output tile, K=2 per instruction (exact fmaf chain, 64 cycles / SIMD).
 // A: lane l holds A[i = l&31][k = l>>5]; B: lane l holds B[k = l>>5][n = l&31];
 // C/D: lane l, reg r -> C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].

@@ -301,12 +301,7 @@ int launch(const ConvP& p0, hipStream_t st) {
         if (p.cls[i].MT * p.NT > maxblk) maxblk = p.cls[i].MT * p.NT;
     }
     const size_t lds = NS ? (size_t)NS * (BM + BN) * 32 * sizeof(float) : (size_t)2 * (BM + BN) * LS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, NS, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { straps_set_error("conv_igemm_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-        attr_set = true;
-    }
+    STRAPS_RAISE_LDS((conv_igemm_kernel<BM, BN, NS, TRACE>), lds, "conv_igemm_kernel");
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NS, TRACE>), dim3(maxblk, p.ncls), dim3(256), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_kernel");
     return STRAPS_OK;

@@ -2,7 +2,8 @@
 //
 //   Every fp32 operand value is carried as three bf16 planes  x = x1 + x2 + x3  (round-to-nearest splits: the sum is EXACT, 3 x 8
 //   significand bits cover fp32's 24; bf16 has fp32's exponent, so no scaling and no range analysis is needed; only below 2^-110 do
-//   the last bits fall under bf16's smallest subnormal: absolute error <= 2^-133 there), and a product
+//   the last bits fall under bf16's smallest subnormal: absolute error <= 2^-133 there; above bf16's largest finite value, 3.39e38,
+//   the leading plane rounds to infinity and the value is lost: an fp32 activation that close to overflow is already a failed run), and a product
 //   a*b is evaluated as the six bf16 products of weight >= 2^-16
 //        a1*b1 + a1*b2 + a2*b1 + a1*b3 + a3*b1 + a2*b2          (dropped: a2*b3 + a3*b2 + a3*b3 <= 2^-23 |a*b|)
 //   each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Six 32-cycle instructions do the work of eight 64-cycle
@@ -491,12 +492,7 @@ int launch_x3h(const ConvP& p0, hipStream_t st) {
     p.cls[0].MT = p.cls[0].M / BM;
     p.bnr_base[0] = 0;
     const size_t lds = ((size_t)2 * 3 * PS + (size_t)NST * 3 * BN) * 32 * sizeof(u16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { straps_set_error("conv_igemm_x3h_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-        attr_set = true;
-    }
+    STRAPS_RAISE_LDS((conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS>), lds, "conv_igemm_x3h_kernel");
     hipLaunchKernelGGL((conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS>), dim3(p.cls[0].MT * p.NT, 1), dim3(64 * WGM * WGN), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_x3h_kernel");
     return STRAPS_OK;
@@ -530,12 +526,7 @@ int launch_x3(const ConvP& p0, hipStream_t st) {
         base += p.cls[i].MT;
     }
     const size_t lds = (size_t)NST * 3 * (BM + BN) * 32 * sizeof(u16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { straps_set_error("conv_igemm_x3_kernel: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-        attr_set = true;
-    }
+    STRAPS_RAISE_LDS((conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL, PIPE>), lds, "conv_igemm_x3_kernel");
     hipLaunchKernelGGL((conv_igemm_x3_kernel<BM, BN, WGM, WGN, NST, ABL, PIPE>), dim3(maxblk, p.ncls), dim3(64 * WGM * WGN), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_x3_kernel");
     return STRAPS_OK;

@@ -861,12 +861,11 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                    : pf == 1 ? smpl_verts_hh_kernel<8, 1, 0> : smpl_verts_hh_kernel<8, 2, 0>;
     const size_t lds = split == 2 ? (size_t)(BT * FSH + 12 * BT * ASH) * sizeof(float)
                                   : (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
-    static bool attr_set[5] = {false, false, false, false, false};
-    if (!attr_set[split + pd16]) {
-        hipError_t e = hipFuncSetAttribute(split == 2 ? (const void*)hh_kernel : split ? (const void*)h_kernel : (const void*)smpl_verts_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static unsigned long long lds_raised[5] = {0, 0, 0, 0, 0};          // per kernel variant: bit mask of the devices done
+    {
+        hipError_t e = straps_raise_dynamic_lds(split == 2 ? (const void*)hh_kernel : split ? (const void*)h_kernel : (const void*)smpl_verts_kernel,
+                                                lds, lds_raised[split + pd16]);
         if (e != hipSuccess) { straps_set_error("smpl_verts_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
-        attr_set[split + pd16] = true;
     }
     const long long btiles = (batch + BT - 1) / BT;
     if (btiles * nch > 0x7fffffffLL || btiles > 0x3fffffLL) {

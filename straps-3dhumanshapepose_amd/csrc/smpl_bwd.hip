@@ -427,12 +427,7 @@ extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* be
     int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, nullptr, batch, st);
     if (rc != STRAPS_OK) return rc;
     const size_t lds = (size_t)(BT * AS + 4 * BT * SS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)smpl_verts_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { straps_set_error("smpl_verts_bwd_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
-        attr_set = true;
-    }
+    STRAPS_RAISE_LDS((smpl_verts_bwd_kernel), lds, "smpl_verts_bwd_kernel");
     const long long btiles = (batch + BT - 1) / BT;
     if (btiles > 65535) { straps_set_error("straps_smpl_bwd: batch %lld exceeds one launch; split it", batch); return STRAPS_EUNSUPPORTED; }
     hipLaunchKernelGGL(smpl_verts_bwd_kernel, dim3(nch, (unsigned)btiles), dim3(256), lds, st, *model, F, Amat, dverts, djoints, dFp, dAp, batch, rpc);

@@ -65,6 +65,21 @@ def test_split_is_exact(dev):
     assert np.abs(_planes_to_f64(planes, tiny.size) - tiny.astype(np.float64)).max() <= 2.0 ** -133
 
 
+def test_split_planes_equal_the_cpu_model_bit_for_bit(dev):
+    """integer work: the kernel's three planes are the bit patterns of oracle/bf16x3_emul.split3 (round to nearest even on the fp32 bit
+    pattern, exact residues) -- the bar is equality.  Values in the normal range of every residue (1e-20 .. 1e20, zeros, powers of two)."""
+    import bf16x3_emul as em
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.standard_normal(65536 + 5).astype(np.float32), (rng.standard_normal(4096) * 1e-20).astype(np.float32),
+                        (rng.standard_normal(4096) * 1e20).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -60, 2.0 ** 100, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0, 255.0, 257.0], np.float32)])
+    planes, ps = _split(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    got = planes[:, :x.size].cpu().numpy().view(np.uint16)
+    want, _ = em.split3(x)
+    assert np.array_equal(got, want)
+
+
 def _pack(dev, w, dgrad=False):
     L = hipabi.lib()
     Cout, Cin, k, _ = w.shape
