@@ -316,9 +316,6 @@ int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const
                      const float* mask_shift, float* dgamma, float* dbeta, float* draw, float* dz_out,
                      unsigned short* draw_planes, long long plane_stride, void* workspace,
                      long long rows, int c, int accumulate, void* stream);
-/* weight gradient on the bf16x3 route: straps_conv_wgrad's arguments plus the planes of x and dy; 3x3 / stride 1 /
- * pad 1 layers (power-of-two width >= 8) run on the planes (halo-patch kernel, ds_read_b64_tr_b16 operand gathers),
- * every other shape -- or NULL planes -- uses the fp32 kernels on (x, dy).  Workspace as for straps_conv_wgrad.      */
 /* The data gradient with the sums of the NEXT BatchNorm backward fused into its epilogue: dx (= the gradient dy entering the
  * BatchNorm + ReLU that produced this convolution's input) is written as by straps_conv_dgrad_x3, and per M tile one partial
  * bn_partials[block][cin][2] = (S1, invstd * S2) of  S1 = sum mask*dy,  S2 = sum mask*dy*(raw - mean)  (double; mask = bn_out > 0
@@ -337,6 +334,10 @@ int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const float* raw
                             const float* mask_shift, float* dgamma, float* dbeta, float* draw, float* dz_out,
                             unsigned short* draw_planes, long long plane_stride, const double* partials,
                             int nblk, void* workspace, long long rows, int c, int accumulate, void* stream);
+/* weight gradient on the bf16x3 route: straps_conv_wgrad's arguments plus the planes of x and dy.  3x3 / stride 1 / pad 1
+ * layers (power-of-two width >= 8) run the halo-patch kernel on the planes (ds_read_b64_tr_b16 operand gathers); the other
+ * 3x3 layers and the 1x1 layers whose channel counts are both >= 128 run the per-tap kernel on the planes; what is left
+ * (1x1 with a 64-channel side) -- or NULL planes -- uses the fp32 kernels on (x, dy).  Workspace as for straps_conv_wgrad.   */
 /* 1 if straps_conv_wgrad_x3 handles this geometry on the planes alone (x_nhwc / dy_nhwc may then be NULL, and the producers
  * -- straps_bn_apply_x3's y, straps_bn_bwd_x3's draw -- need not write their fp32 copies), 0 if it needs the fp32 tensors.      */
 int straps_conv_wgrad_x3_on_planes(int batch, int h, int w, int cin, int cout, int kh, int kw,

@@ -341,9 +341,7 @@ typedef short short8w __attribute__((ext_vector_type(8)));
 
 __device__ __attribute__((aligned(16))) float k_zero16x[4] = {0.f, 0.f, 0.f, 0.f};
 
-#ifndef W3X_TG
-#define W3X_TG 2          // taps whose MFMA chains are interleaved
-#endif
+constexpr int W3X_TG = 2;          // taps whose MFMA chains are interleaved
 
 // eight k values (pixels) of one channel: two transpose reads of four pixels each
 __device__ __forceinline__ bf16x8w tr_frag(const u16* lo, const u16* hi) {
@@ -1517,9 +1515,7 @@ static bool wgrad3_plan(int batch, int h, int w, int cin, int cout, int kh, int 
     p->nchunks = batch * p->chunk_rows_per_img * p->chunks_per_row;
     p->it = cin / 64;
     const int tiles = (cout / 64) * (cin / 64);
-#ifndef W3_TARGET
-#define W3_TARGET 256          // one 8-wave workgroup per CU (two 4-wave groups that share one partial)
-#endif
+    constexpr int W3_TARGET = 256;          // one 8-wave workgroup per CU (two 4-wave groups that share one partial)
     int s = (W3_TARGET + tiles - 1) / tiles;
     const int max_s = (p->nchunks + 3) / 4;                     // at least 4 chunks (576 MFMAs per wave) per workgroup
     if (s > max_s) s = max_s;
@@ -1629,9 +1625,7 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         q.H = p3.H; q.W = p3.W; q.Cin = p3.Cin; q.Cout = p3.Cout; q.cw = p3.cw; q.cw_log2 = p3.cw_log2; q.rpc = p3.rpc;
         q.chunks_per_row = p3.chunks_per_row; q.chunk_rows_per_img = p3.chunk_rows_per_img; q.nchunks = p3.nchunks;
         q.chunks_per_split = p3.chunks_per_split; q.it = p3.it;
-#ifndef W3X_NG
-#define W3X_NG 2
-#endif
+        constexpr int W3X_NG = 2;
         hipStream_t st3 = (hipStream_t)stream;
         // 64-pixel chunks where the rows allow it (fewer splits than the 32-pixel plan at most: the shared workspace size covers both)
         Wgrad3P p64;
