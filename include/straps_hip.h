@@ -62,6 +62,12 @@ typedef struct {
 } straps_pack_desc_t;
 int straps_pack_conv_weights_batched(const straps_pack_desc_t* descs, int n, long long total,
                                      void* stream);
+/* the same launch for the bf16x3 route: the three bf16 planes [3][plane_stride] of the packed layouts (element `first` +
+ * offset inside the layer; see straps_split3_bf16) are written in the same pass -- no split pass over the packed weights.
+ * Either plane buffer may be NULL; dst_krsc / dst_crsk of a descriptor may be NULL when only the planes are consumed.       */
+int straps_pack_conv_weights_batched_x3(const straps_pack_desc_t* descs, int n, long long total,
+                                        unsigned short* krsc_planes, unsigned short* crsk_planes,
+                                        long long plane_stride, void* stream);
 
 /* stem weights OIHW [64][cin][7][7] (models/resnet.py:145) -> MFMA fragment order
  * [ceil(cin*49/8)][2][64][4]; straps_stem_weight_floats gives the element count.              */

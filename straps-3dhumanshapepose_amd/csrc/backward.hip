@@ -954,14 +954,28 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
+// fixed-order sum of the per-block partials: 64 consecutive outputs per workgroup, the four waves take the blocks b = wave, wave + 4, ...
+// (independent loads, eight in flight per lane), their four sums are added in wave order -- the same order on every launch.
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblocks,
                                                                 int K, int Kp, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;   // over [64][K]
-    if (idx >= 64 * K) return;
-    const int co = idx / K, k = idx - co * K;
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;              // over [64][K]
+    const bool live = idx < 64 * K;
+    const int co = live ? idx / K : 0, k = live ? idx - co * K : 0;
+    const float* src = part + (long long)co * Kp + k;
+    const long long bstride = (long long)64 * Kp;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[((long long)b * 64 + co) * Kp + k];
-    dw[idx] = accumulate ? dw[idx] + s : s;      // OIHW row co is (c,r,s)-ordered == k
+    if (live) {
+#pragma unroll 8
+        for (int b = g; b < nblocks; b += 4) s += src[b * bstride];
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g == 0 && live) {
+        const float t = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+        dw[idx] = accumulate ? dw[idx] + t : t;       // OIHW row co is (c,r,s)-ordered == k
+    }
 }
 
 // =====================================================================================================
@@ -1720,7 +1734,7 @@ extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, floa
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk, groups), dim3(256), 0, st, x_nchw, dy_nhwc, part, tact, batch, cin, h, w, Ho, Wo,
                        tiles_x, tiles_y, Kp, ntiles);
     STRAPS_CHECK_LAUNCH("stem_wgrad_kernel");
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * K + 255) / 256), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk, K, Kp, accumulate);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * K + 63) / 64), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk, K, Kp, accumulate);
     STRAPS_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
     return STRAPS_OK;
 }

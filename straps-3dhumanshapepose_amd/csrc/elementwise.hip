@@ -34,8 +34,11 @@ __global__ __launch_bounds__(256) void pack_crsk_flip_kernel(const float* __rest
 // (32 runs of 32*RS contiguous floats) is read coalesced into an LDS tile, then written once as KRSC (128-byte runs over ci) and once
 // as flipped CRSK (128-byte runs over co) -- both sides of the transposes coalesced.  Blocks stride over the units; the layer of a
 // unit is found by walking the (few dozen) descriptors, wave-uniformly.
+// k3 / c3 (bf16x3 route): the three bf16 planes [3][ps] of the two packed layouts, element `first + offset inside the layer`, written
+// in the same pass (the fp32 destinations of a descriptor may then be NULL: nothing on that route reads them).
 constexpr int PK_T = 32, PK_RS = 9, PK_LD = PK_T * PK_RS + 1;
-__global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_desc_t* __restrict__ descs, int n) {
+__global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_desc_t* __restrict__ descs, int n, u16* __restrict__ k3,
+                                                           u16* __restrict__ c3, long long ps) {
     __shared__ float tile[PK_T * PK_LD];
     const int tid = threadIdx.x;
     int d = 0;
@@ -73,15 +76,33 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
             const int c = idx & (PK_T - 1);
             const int k = idx >> 5;
             const int j = k % nr, o = k / nr;
-            if (c < nc) D.dst_krsc[((long long)(o0 + o) * RS + rs0 + j) * D.c + c0 + c] = tile[o * PK_LD + c * PK_RS + j];
+            if (c < nc) {
+                const long long at = ((long long)(o0 + o) * RS + rs0 + j) * D.c + c0 + c;
+                const float v = tile[o * PK_LD + c * PK_RS + j];
+                if (D.dst_krsc) D.dst_krsc[at] = v;
+                if (k3) {
+                    u16 b1, b2, b3;
+                    split3(v, b1, b2, b3);
+                    k3[D.first + at] = b1; k3[ps + D.first + at] = b2; k3[2 * ps + D.first + at] = b3;
+                }
+            }
         }
         // flipped CRSK: dst[c][R-1-r][S-1-s][o] -- flipping (r, s) jointly is reversing the tap index rs
-        if (D.dst_crsk) {
+        if (D.dst_crsk || c3) {
             for (int idx = tid; idx < nc * nr * PK_T; idx += 256) {
                 const int o = idx & (PK_T - 1);
                 const int k = idx >> 5;
                 const int j = k % nr, c = k / nr;
-                if (o < no) D.dst_crsk[((long long)(c0 + c) * RS + (RS - 1 - (rs0 + j))) * D.o + o0 + o] = tile[o * PK_LD + c * PK_RS + j];
+                if (o < no) {
+                    const long long at = ((long long)(c0 + c) * RS + (RS - 1 - (rs0 + j))) * D.o + o0 + o;
+                    const float v = tile[o * PK_LD + c * PK_RS + j];
+                    if (D.dst_crsk) D.dst_crsk[at] = v;
+                    if (c3) {
+                        u16 b1, b2, b3;
+                        split3(v, b1, b2, b3);
+                        c3[D.first + at] = b1; c3[ps + D.first + at] = b2; c3[2 * ps + D.first + at] = b3;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -208,7 +229,19 @@ extern "C" int straps_pack_conv_weights_batched(const straps_pack_desc_t* descs,
     STRAPS_REQUIRE(descs && n > 0 && total > 0, "straps_pack_conv_weights_batched: bad arguments");
     long long blocks = (total + PK_T * PK_T * PK_RS - 1) / (PK_T * PK_T * PK_RS);       // ~ one unit per block for 3x3 layers, grid-stride beyond
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs, n);
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs, n, (u16*)nullptr, (u16*)nullptr, 0LL);
+    STRAPS_CHECK_LAUNCH("pack_batched_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_pack_conv_weights_batched_x3(const straps_pack_desc_t* descs, int n, long long total, unsigned short* krsc_planes,
+                                                   unsigned short* crsk_planes, long long plane_stride, void* stream) {
+    STRAPS_REQUIRE(descs && n > 0 && total > 0, "straps_pack_conv_weights_batched_x3: bad arguments");
+    STRAPS_REQUIRE(krsc_planes || crsk_planes, "straps_pack_conv_weights_batched_x3: no planes given (use straps_pack_conv_weights_batched)");
+    STRAPS_REQUIRE(plane_stride >= total && plane_stride % 8 == 0, "straps_pack_conv_weights_batched_x3: plane_stride must be >= total and a multiple of 8");
+    long long blocks = (total + PK_T * PK_T * PK_RS - 1) / (PK_T * PK_T * PK_RS);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs, n, krsc_planes, crsk_planes, plane_stride);
     STRAPS_CHECK_LAUNCH("pack_batched_kernel");
     return STRAPS_OK;
 }

@@ -121,7 +121,7 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, kee
     Cout, Cin, k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
     stride, pad = conv.stride[0], conv.padding[0]
     Ho, Wo = _conv_out(H, k, stride, pad), _conv_out(W, k, stride, pad)
-    wpk = net._packed_weight(conv)
+    wpk = None if ctx.x3 else net._packed_weight(conv)          # (the bf16x3 route reads the weights' planes: _conv_launch)
     y = ctx.empty(B, Ho, Wo, Cout)
     rec = None
     if ctx.tape is not None:

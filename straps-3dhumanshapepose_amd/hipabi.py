@@ -81,6 +81,7 @@ SIGNATURES = {
     'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weights_batched': (_I, [_P, _I, _L, _P]),
+    'straps_pack_conv_weights_batched_x3': (_I, [_P, _I, _L, _P, _P, _L, _P]),
     'straps_stem_weight_floats': (_Z, [_I]),
     'straps_pack_stem_weight': (_I, [_P, _P, _I, _P]),
     'straps_bn_fold': (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),

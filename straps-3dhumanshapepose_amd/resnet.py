@@ -128,7 +128,8 @@ class ResNet(nn.Module):
     def prepack(self, with_dgrad=True):
         """(re)pack the weights of every non-stem conv for the forward (KRSC) and data-gradient (flipped CRSK) kernels in
         ONE launch and seed the caches `_packed_weight` / autograd_ops._packed_dgrad_weight read.  The training step
-        calls this after each optimiser update instead of 2 x (19 | 52) tiny launches."""
+        calls this after each optimiser update instead of 2 x (19 | 52) tiny launches.  On the bf16x3 route the same launch
+        writes the three bf16 planes of both layouts and nothing else (no fp32 packed copies, no split pass)."""
         import ctypes as C
         import numpy as np
         convs = [m for m in self.modules() if isinstance(m, nn.Conv2d) and m is not self.conv1]
@@ -138,44 +139,45 @@ class ResNet(nn.Module):
             dev = convs[0].weight.device
             hipabi.require_gpu_tensor(convs[0].weight, 'conv weights (call .to(device) first)')
             total = sum(c.weight.numel() for c in convs)
-            krsc = torch.empty(total, device=dev, dtype=torch.float32)
-            crsk = torch.empty(total, device=dev, dtype=torch.float32) if with_dgrad else None
+            x3 = getattr(self, 'conv_precision', 'fp32') == 'bf16x3'
+            krsc = torch.empty(total, device=dev, dtype=torch.float32) if not x3 else None
+            crsk = torch.empty(total, device=dev, dtype=torch.float32) if with_dgrad and not x3 else None
             descs = (hipabi.PackDesc * len(convs))()
             off = 0
             for d, c in zip(descs, convs):
                 w = c.weight
                 if not w.is_contiguous():
                     raise RuntimeError('prepack: conv weights must be contiguous')
-                d.src, d.dst_krsc = w.data_ptr(), krsc.data_ptr() + 4 * off
-                d.dst_crsk = crsk.data_ptr() + 4 * off if with_dgrad else None
+                d.src = w.data_ptr()
+                d.dst_krsc = krsc.data_ptr() + 4 * off if krsc is not None else None
+                d.dst_crsk = crsk.data_ptr() + 4 * off if crsk is not None else None
                 d.o, d.c, d.r, d.s, d.first = w.shape[0], w.shape[1], w.shape[2], w.shape[3], off
                 off += w.numel()
             table = torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()).to(dev)
             st = dict(key=key, krsc=krsc, crsk=crsk, table=table, total=total, convs=convs)
-            if getattr(self, 'conv_precision', 'fp32') == 'bf16x3':
+            if x3:
                 ps = (total + 7) // 8 * 8
                 st['ps'] = ps
                 st['krsc3'] = torch.empty(3, ps, device=dev, dtype=torch.int16)
                 st['crsk3'] = torch.empty(3, ps, device=dev, dtype=torch.int16) if with_dgrad else None
             self._prepack_state = st
-        hipabi.check(hipabi.lib().straps_pack_conv_weights_batched(hipabi.ptr(st['table']), len(st['convs']), st['total'],
-                                                                   hipabi.stream_ptr()), 'straps_pack_conv_weights_batched')
         x3 = st.get('krsc3') is not None
-        if x3:      # one split launch per packed buffer: every conv's planes are slices with the common plane stride
-            L = hipabi.lib()
-            hipabi.check(L.straps_split3_bf16(hipabi.ptr(st['krsc']), hipabi.ptr(st['krsc3']), st['total'], st['ps'], hipabi.stream_ptr()),
-                         'straps_split3_bf16')
-            if with_dgrad:
-                hipabi.check(L.straps_split3_bf16(hipabi.ptr(st['crsk']), hipabi.ptr(st['crsk3']), st['total'], st['ps'], hipabi.stream_ptr()),
-                             'straps_split3_bf16')
+        if x3:      # every conv's planes are slices of the two plane buffers, with their common plane stride
+            hipabi.check(hipabi.lib().straps_pack_conv_weights_batched_x3(hipabi.ptr(st['table']), len(st['convs']), st['total'], hipabi.ptr(st['krsc3']),
+                                                                          hipabi.ptr(st['crsk3']), st['ps'], hipabi.stream_ptr()),
+                         'straps_pack_conv_weights_batched_x3')
+        else:
+            hipabi.check(hipabi.lib().straps_pack_conv_weights_batched(hipabi.ptr(st['table']), len(st['convs']), st['total'],
+                                                                       hipabi.stream_ptr()), 'straps_pack_conv_weights_batched')
         off = 0
         for c in st['convs']:
             w, n = c.weight, c.weight.numel()
             sig = ((w.data_ptr(), w._version),)
-            self._cache[('w', id(c))] = (sig, st['krsc'][off:off + n])
-            if with_dgrad:
-                self._cache[('wd', id(c))] = (sig, st['crsk'][off:off + n])
-            if x3:
+            if not x3:
+                self._cache[('w', id(c))] = (sig, st['krsc'][off:off + n])
+                if with_dgrad:
+                    self._cache[('wd', id(c))] = (sig, st['crsk'][off:off + n])
+            else:
                 self._cache[('w3', id(c))] = (sig, (st['krsc3'][0, off:], st['ps']))
                 if with_dgrad:
                     self._cache[('wd3', id(c))] = (sig, (st['crsk3'][0, off:], st['ps']))

@@ -80,6 +80,51 @@ def test_split_planes_equal_the_cpu_model_bit_for_bit(dev):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize('with_fp32', [False, True])
+def test_batched_weight_pack_writes_the_planes_of_both_layouts(dev, with_fp32):
+    """straps_pack_conv_weights_batched_x3 == straps_pack_conv_weights_batched followed by a split pass over each packed buffer, bit for
+    bit (1x1 / 3x3 / 5x5 taps, channel counts off the 32x32 tile); with NULL fp32 destinations only the planes are written."""
+    L = hipabi.lib()
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (96, 40, 3, 3), (33, 70, 5, 5), (256, 128, 3, 3), (8, 8, 1, 1)]
+    ws = [torch.from_numpy(det_uniform(sh, 140 + i, -1, 1)).to(dev) for i, sh in enumerate(shapes)]
+    total = sum(w.numel() for w in ws)
+    ps = (total + 7) // 8 * 8 + 8
+
+    def table(krsc, crsk):
+        descs = (hipabi.PackDesc * len(ws))()
+        off = 0
+        for d, w in zip(descs, ws):
+            d.src = w.data_ptr()
+            d.dst_krsc = krsc.data_ptr() + 4 * off if krsc is not None else None
+            d.dst_crsk = crsk.data_ptr() + 4 * off if crsk is not None else None
+            d.o, d.c, d.r, d.s, d.first = w.shape[0], w.shape[1], w.shape[2], w.shape[3], off
+            off += w.numel()
+        return torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()).to(dev)
+
+    krsc, crsk = torch.empty(total, device=dev), torch.empty(total, device=dev)
+    hipabi.check(L.straps_pack_conv_weights_batched(hipabi.ptr(table(krsc, crsk)), len(ws), total, None), 'batched pack')
+    want = []
+    for buf in (krsc, crsk):
+        planes = torch.zeros(3, ps, device=dev, dtype=torch.int16)
+        hipabi.check(L.straps_split3_bf16(hipabi.ptr(buf), hipabi.ptr(planes), total, ps, None), 'split3')
+        want.append(planes)
+    k2 = torch.full((total,), float('nan'), device=dev) if with_fp32 else None
+    c2 = torch.full((total,), float('nan'), device=dev) if with_fp32 else None
+    k3 = torch.zeros(3, ps, device=dev, dtype=torch.int16)
+    c3 = torch.zeros(3, ps, device=dev, dtype=torch.int16)
+    hipabi.check(L.straps_pack_conv_weights_batched_x3(hipabi.ptr(table(k2, c2)), len(ws), total, hipabi.ptr(k3), hipabi.ptr(c3), ps, None), 'batched pack x3')
+    torch.cuda.synchronize()
+    assert torch.equal(k3, want[0]) and torch.equal(c3, want[1])
+    if with_fp32:
+        assert torch.equal(k2, krsc) and torch.equal(c2, crsk)
+    # forward-only form: no data-gradient planes
+    k3b = torch.zeros(3, ps, device=dev, dtype=torch.int16)
+    hipabi.check(L.straps_pack_conv_weights_batched_x3(hipabi.ptr(table(None, None)), len(ws), total, hipabi.ptr(k3b), None, ps, None), 'batched pack x3 fwd')
+    torch.cuda.synchronize()
+    assert torch.equal(k3b, want[0])
+    assert L.straps_pack_conv_weights_batched_x3(hipabi.ptr(table(None, None)), len(ws), total, None, None, ps, None) != 0
+
+
 def _pack(dev, w, dgrad=False):
     L = hipabi.lib()
     Cout, Cin, k, _ = w.shape
