@@ -71,24 +71,40 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
             tile[o * PK_LD + c * PK_RS + j] = D.src[((long long)(o0 + o) * D.c + c0 + c) * RS + rs0 + j];
         }
         __syncthreads();
+        // planes of a layout go out four consecutive elements per lane (8-byte stores) when the layer allows it
+        const bool v4k = k3 && ((D.c | D.first) & 3) == 0, v4c = c3 && ((D.o | D.first) & 3) == 0;
         // KRSC: dst[o][rs][c]
-        for (int idx = tid; idx < no * nr * PK_T; idx += 256) {
-            const int c = idx & (PK_T - 1);
-            const int k = idx >> 5;
-            const int j = k % nr, o = k / nr;
-            if (c < nc) {
-                const long long at = ((long long)(o0 + o) * RS + rs0 + j) * D.c + c0 + c;
-                const float v = tile[o * PK_LD + c * PK_RS + j];
-                if (D.dst_krsc) D.dst_krsc[at] = v;
-                if (k3) {
-                    u16 b1, b2, b3;
-                    split3(v, b1, b2, b3);
-                    k3[D.first + at] = b1; k3[ps + D.first + at] = b2; k3[2 * ps + D.first + at] = b3;
+        if (D.dst_krsc || (k3 && !v4k)) {
+            for (int idx = tid; idx < no * nr * PK_T; idx += 256) {
+                const int c = idx & (PK_T - 1);
+                const int k = idx >> 5;
+                const int j = k % nr, o = k / nr;
+                if (c < nc) {
+                    const long long at = ((long long)(o0 + o) * RS + rs0 + j) * D.c + c0 + c;
+                    const float v = tile[o * PK_LD + c * PK_RS + j];
+                    if (D.dst_krsc) D.dst_krsc[at] = v;
+                    if (k3 && !v4k) {
+                        u16 b1, b2, b3;
+                        split3(v, b1, b2, b3);
+                        k3[D.first + at] = b1; k3[ps + D.first + at] = b2; k3[2 * ps + D.first + at] = b3;
+                    }
+                }
+            }
+        }
+        if (v4k) {
+            for (int idx = tid; idx < no * nr * (PK_T / 4); idx += 256) {
+                const int c = (idx & (PK_T / 4 - 1)) * 4;
+                const int k = idx >> 3;
+                const int j = k % nr, o = k / nr;
+                if (c < nc) {
+                    const float* t = tile + o * PK_LD + c * PK_RS + j;
+                    const f32x4 v = {t[0], t[PK_RS], t[2 * PK_RS], t[3 * PK_RS]};
+                    store_planes4(k3, ps, D.first + ((long long)(o0 + o) * RS + rs0 + j) * D.c + c0 + c, v);
                 }
             }
         }
         // flipped CRSK: dst[c][R-1-r][S-1-s][o] -- flipping (r, s) jointly is reversing the tap index rs
-        if (D.dst_crsk || c3) {
+        if (D.dst_crsk || (c3 && !v4c)) {
             for (int idx = tid; idx < nc * nr * PK_T; idx += 256) {
                 const int o = idx & (PK_T - 1);
                 const int k = idx >> 5;
@@ -97,11 +113,23 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
                     const long long at = ((long long)(c0 + c) * RS + (RS - 1 - (rs0 + j))) * D.o + o0 + o;
                     const float v = tile[o * PK_LD + c * PK_RS + j];
                     if (D.dst_crsk) D.dst_crsk[at] = v;
-                    if (c3) {
+                    if (c3 && !v4c) {
                         u16 b1, b2, b3;
                         split3(v, b1, b2, b3);
                         c3[D.first + at] = b1; c3[ps + D.first + at] = b2; c3[2 * ps + D.first + at] = b3;
                     }
+                }
+            }
+        }
+        if (v4c) {
+            for (int idx = tid; idx < nc * nr * (PK_T / 4); idx += 256) {
+                const int o = (idx & (PK_T / 4 - 1)) * 4;
+                const int k = idx >> 3;
+                const int j = k % nr, c = k / nr;
+                if (o < no) {
+                    const float* t = tile + o * PK_LD + c * PK_RS + j;
+                    const f32x4 v = {t[0], t[PK_LD], t[2 * PK_LD], t[3 * PK_LD]};
+                    store_planes4(c3, ps, D.first + ((long long)(c0 + c) * RS + (RS - 1 - (rs0 + j))) * D.o + o0 + o, v);
                 }
             }
         }
@@ -239,6 +267,8 @@ extern "C" int straps_pack_conv_weights_batched_x3(const straps_pack_desc_t* des
     STRAPS_REQUIRE(descs && n > 0 && total > 0, "straps_pack_conv_weights_batched_x3: bad arguments");
     STRAPS_REQUIRE(krsc_planes || crsk_planes, "straps_pack_conv_weights_batched_x3: no planes given (use straps_pack_conv_weights_batched)");
     STRAPS_REQUIRE(plane_stride >= total && plane_stride % 8 == 0, "straps_pack_conv_weights_batched_x3: plane_stride must be >= total and a multiple of 8");
+    STRAPS_REQUIRE((reinterpret_cast<uintptr_t>(krsc_planes) & 15) == 0 && (reinterpret_cast<uintptr_t>(crsk_planes) & 15) == 0,
+                   "straps_pack_conv_weights_batched_x3: plane buffers must be 16-byte aligned");
     long long blocks = (total + PK_T * PK_T * PK_RS - 1) / (PK_T * PK_T * PK_RS);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, descs, n, krsc_planes, crsk_planes, plane_stride);
