@@ -391,6 +391,19 @@ int straps_bn_bwd_pooled(const float* dy_pool_nhwc, const uint8_t* idx, const fl
                          const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta,
                          float* draw, void* workspace, int batch, int h, int w, int c, int accumulate,
                          void* stream);
+/* straps_bn_bwd_pooled that leaves unwritten what nobody reads: the only consumer of `draw` is straps_stem_wgrad, which visits a
+ * 2-row x 32-column tile of it only if some input channel has a non-zero under the tile (its 9 x 72 input patch).
+ * straps_stem_tile_activity derives that map (straps_stem_tiles(batch, in_h, in_w) bytes, 1 = read) from the input's non-zero
+ * bit map (straps_stem_nzmask); tile_active == NULL writes everything.  dgamma / dbeta are sums over the whole tensor either way;
+ * on the proxy representation ~40 % of the tiles are never read (tools/stem_tile_activity.py).                                  */
+size_t straps_stem_tiles(int batch, int in_h, int in_w);
+int straps_stem_tile_activity(const uint32_t* nzmask, uint8_t* tile_active, int batch, int cin, int in_h,
+                              int in_w, void* stream);
+int straps_bn_bwd_pooled_sparse(const float* dy_pool_nhwc, const uint8_t* idx, const float* raw,
+                                const float* save_mean, const float* save_invstd, const float* gamma,
+                                const float* mask_scale, const float* mask_shift, float* dgamma,
+                                float* dbeta, float* draw, void* workspace, int batch, int h, int w, int c,
+                                int accumulate, const uint8_t* tile_active, void* stream);
 /* max-pool forward that also records the arg-max tap (uint8 per element), and its backward.      */
 int straps_maxpool_fwd_idx(const float* x_nhwc, float* y_nhwc, uint8_t* idx, int batch, int h,
                            int w, int c, void* stream);

@@ -54,6 +54,7 @@ class _SideStream:
 
 # ------------------------------------------------------------------------------------------ encoder
 _FUSE_BN_SUMS = os.environ.get('STRAPS_NO_FUSED_BN_SUMS', '0') != '1'     # (A/B switch for tools)
+_SPARSE_STEM_TAIL = os.environ.get('STRAPS_DENSE_STEM_TAIL', '0') != '1'  # (A/B switch for tools)
 
 
 def _packed_dgrad_weight(net, conv):
@@ -218,9 +219,17 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
         ws = torch.empty(L.straps_bn_bwd_workspace_bytes(B * H * W, Cc) // 4, device=raw.device, dtype=torch.float32)
         dgamma, dbeta = grads.buf(bn.weight), grads.buf(bn.bias)
         draw = _empty_like(raw)
-        hipabi.check(L.straps_bn_bwd_pooled(hipabi.ptr(dy), hipabi.ptr(idx), hipabi.ptr(raw), hipabi.ptr(ss[2]), hipabi.ptr(ss[3]),
-                                            hipabi.ptr(bn.weight), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(dgamma), hipabi.ptr(dbeta),
-                                            hipabi.ptr(draw), hipabi.ptr(ws), B, H, W, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd_pooled')
+        # the stem weight gradient -- draw's only reader -- skips the tiles with no non-zero input under them: they stay unwritten
+        tact = None
+        if rec.get('nzmask') is not None and _SPARSE_STEM_TAIL:
+            _, Cin0, Hin, Win = rec['geom'][:4]
+            tact = torch.empty(L.straps_stem_tiles(B, Hin, Win), device=raw.device, dtype=torch.uint8)
+            hipabi.check(L.straps_stem_tile_activity(hipabi.ptr(rec['nzmask']), hipabi.ptr(tact), B, Cin0, Hin, Win, hipabi.stream_ptr()),
+                         'straps_stem_tile_activity')
+        hipabi.check(L.straps_bn_bwd_pooled_sparse(hipabi.ptr(dy), hipabi.ptr(idx), hipabi.ptr(raw), hipabi.ptr(ss[2]), hipabi.ptr(ss[3]),
+                                                   hipabi.ptr(bn.weight), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(dgamma), hipabi.ptr(dbeta),
+                                                   hipabi.ptr(draw), hipabi.ptr(ws), B, H, W, Cc, 0, hipabi.ptr(tact), hipabi.stream_ptr()),
+                     'straps_bn_bwd_pooled_sparse')
         grads[bn.weight] = dgamma
         grads[bn.bias] = dbeta
     else:

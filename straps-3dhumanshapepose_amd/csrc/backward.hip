@@ -780,6 +780,31 @@ __global__ __launch_bounds__(256) void stem_tileact_kernel(const unsigned* __res
     tact[idx] = (uint8_t)chact;
 }
 
+// per tile: does ANY input channel hold a non-zero inside the tile's input patch (= is the tile of dy read by stem_wgrad_kernel at all)
+__global__ __launch_bounds__(256) void stem_tileany_kernel(const unsigned* __restrict__ nzmask, uint8_t* __restrict__ tany, int C, int H, int W,
+                                                           int tiles_x, int tiles_y, int ntiles) {
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= ntiles) return;
+    int bid = tile;
+    const int b = bid / (tiles_x * tiles_y);
+    bid -= b * tiles_x * tiles_y;
+    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
+    const int hi0 = 2 * (ty * TY) - 3, wi0 = 2 * (tx * TX) - 3;
+    const int HC = (H + 3) >> 2, WW = (W + 255) >> 8;
+    const int rc0 = max(hi0, 0) >> 2, rc1 = min(hi0 + PH - 1, H - 1) >> 2;
+    const int wa = max(wi0 - 1, 0), wb = min(wi0 - 2 + PW, W - 1);
+    unsigned any = 0;
+    for (int c = 0; c < C; ++c)
+        for (int rcell = rc0; rcell <= rc1; ++rcell)
+            for (int word = wa >> 8; word <= (wb >> 8); ++word) {
+                const int lo = max(wa, word << 8), hi = min(wb, (word << 8) + 255);
+                const int b0 = (lo >> 3) & 31, b1 = (hi >> 3) & 31;
+                const unsigned bits = (b1 == 31 ? 0xffffffffu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+                any |= nzmask[(((long long)b * C + c) * HC + rcell) * WW + word] & bits;
+            }
+    tany[tile] = any ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ part, const uint8_t* __restrict__ tact, int B, int C, int H,
                                                          int W, int Ho, int Wo,
@@ -993,6 +1018,10 @@ struct PoolSrc {
     const float* dyp;       // [B][Ho][Wo][C] gradient of the pooled tensor
     const uint8_t* idx;     // [B][Ho][Wo][C] arg-max tap of every window
     int H, W, Ho, Wo;
+    // optional (the stem): tany[(b * tiles_y + h / 2) * tiles_x + w / 32] == 0 marks a 2-row x 32-column tile of the un-pooled grid whose
+    // gradient nobody reads (the stem weight gradient skips it: no non-zero input under it) -- the apply pass leaves it unwritten
+    const uint8_t* tany;
+    int tiles_x, tiles_y;
 };
 
 __device__ __forceinline__ f32x4 pool_grad(const PoolSrc& ps, long long row, int c4, int C) {
@@ -1188,6 +1217,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 
 // pass 2: draw = k1 * (dz - m1 - xhat*m2), evaluated in double and rounded once;  optionally also writes dz (the gradient the
 // skip connection receives)
+constexpr int POOL_CHUNK = 1024;        // float4 elements per workgroup of the pooled apply pass (64 pixels of a 64-channel tensor)
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                            const float* __restrict__ raw, const float* __restrict__ mean,
@@ -1196,11 +1226,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ msh, float* __restrict__ draw, float* dz_out,
                                                            u16* __restrict__ planes, long long pstride, long long n4, int C, PoolSrc ps) {
     const int C4 = C >> 2;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
+    // POOL: a workgroup owns POOL_CHUNK consecutive elements (with the tile map most workgroups of an empty region exit at once and the
+    // dispatcher hands out the rest: a grid-stride loop would pin every workgroup to one image position -- all work or none)
+    const long long first = POOL ? (long long)blockIdx.x * POOL_CHUNK + threadIdx.x : (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long last = POOL ? (n4 < ((long long)blockIdx.x + 1) * POOL_CHUNK ? n4 : ((long long)blockIdx.x + 1) * POOL_CHUNK) : n4;
+    const long long step = POOL ? 256 : (long long)gridDim.x * 256;
+    for (long long idx = first; idx < last; idx += step) {
         const int c4 = (int)(idx % C4);
         f32x4 g;
-        if constexpr (POOL) g = pool_grad(ps, idx / C4, c4, C);
-        else g = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+        if constexpr (POOL) {
+            const long long row = idx / C4;
+            if (ps.tany) {
+                const int wi = (int)(row % ps.W);
+                const long long t = row / ps.W;
+                const int hi = (int)(t % ps.H);
+                const long long b = t / ps.H;
+                if (!ps.tany[(b * ps.tiles_y + (hi >> 1)) * ps.tiles_x + (wi >> 5)]) continue;
+            }
+            g = pool_grad(ps, row, c4, C);
+        } else {
+            g = *reinterpret_cast<const f32x4*>(dy + idx * 4);
+        }
         const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + idx * 4);
         if (yact) {
             const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + idx * 4);
@@ -1804,9 +1850,34 @@ extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* ra
                             rows, c, accumulate, stream);
 }
 
+extern "C" size_t straps_stem_tiles(int batch, int h, int w) {
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    return (size_t)batch * ((Wo + TX - 1) / TX) * ((Ho + TY - 1) / TY);
+}
+
+extern "C" int straps_stem_tile_activity(const uint32_t* nzmask, uint8_t* tile_active, int batch, int cin, int h, int w, void* stream) {
+    STRAPS_REQUIRE(nzmask && tile_active, "straps_stem_tile_activity: null pointer");
+    STRAPS_REQUIRE(batch > 0 && cin > 0 && h >= 7 && w >= 7, "straps_stem_tile_activity: bad shape B=%d C=%d H=%d W=%d", batch, cin, h, w);
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+    const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;
+    const int ntiles = batch * tiles_x * tiles_y;
+    hipLaunchKernelGGL(stem_tileany_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, (hipStream_t)stream, nzmask, tile_active, cin, h, w, tiles_x, tiles_y,
+                       ntiles);
+    STRAPS_CHECK_LAUNCH("stem_tileany_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, const float* raw, const float* save_mean, const float* save_invstd,
                                     const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta,
                                     float* draw, void* workspace, int batch, int h, int w, int c, int accumulate, void* stream) {
+    return straps_bn_bwd_pooled_sparse(dy_pool, idx, raw, save_mean, save_invstd, gamma, mask_scale, mask_shift, dgamma, dbeta, draw, workspace, batch, h, w,
+                                       c, accumulate, nullptr, stream);
+}
+
+extern "C" int straps_bn_bwd_pooled_sparse(const float* dy_pool, const uint8_t* idx, const float* raw, const float* save_mean, const float* save_invstd,
+                                           const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta,
+                                           float* draw, void* workspace, int batch, int h, int w, int c, int accumulate,
+                                           const uint8_t* tile_active, void* stream) {
     STRAPS_REQUIRE(dy_pool && idx && raw && save_mean && save_invstd && gamma && mask_scale && mask_shift && dgamma && dbeta && draw && workspace,
                    "straps_bn_bwd_pooled: null pointer");
     STRAPS_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd_pooled: bad shape %dx%dx%dx%d", batch, h, w, c);
@@ -1819,7 +1890,7 @@ extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, co
     double* part = (double*)workspace;               // [nblk][c][2]  (straps_bn_bwd_workspace_bytes(rows, c))
     double* coefd = part + (size_t)nblk * c * 2;     // [2][c]  m1, m2
     float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
-    const PoolSrc ps{dy_pool, idx, h, w, (h - 1) / 2 + 1, (w - 1) / 2 + 1};
+    const PoolSrc ps{dy_pool, idx, h, w, (h - 1) / 2 + 1, (w - 1) / 2 + 1, tile_active, (w + TX - 1) / TX, (h + TY - 1) / TY};
     const long long prows = (long long)batch * ps.Ho * ps.Wo;
     const int prpb = (int)((prows + nblk - 1) / nblk);
     (void)rpb;
@@ -1828,7 +1899,7 @@ extern "C" int straps_bn_bwd_pooled(const float* dy_pool, const uint8_t* idx, co
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(capped_grid(n4)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)((n4 + POOL_CHUNK - 1) / POOL_CHUNK)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel<pool>");
     return STRAPS_OK;
 }

@@ -65,10 +65,21 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
         const int no = min(PK_T, D.o - o0), nc = min(PK_T, D.c - c0), nr = min(PK_RS, RS - rs0);
         // load: for each o a run of nc*RS floats (contiguous when the layer has <= 9 taps)
         const int run = nc * nr;
-        for (int idx = tid; idx < no * run; idx += 256) {
-            const int o = idx / run, k = idx - o * run;
-            const int c = k / nr, j = k - c * nr;
-            tile[o * PK_LD + c * PK_RS + j] = D.src[((long long)(o0 + o) * D.c + c0 + c) * RS + rs0 + j];
+        if (nr == PK_RS && RS == PK_RS && nc == PK_T && (D.c & 3) == 0 && (reinterpret_cast<uintptr_t>(D.src) & 15) == 0) {
+            // a full 3x3 unit: the run of an output channel IS its tile row (288 consecutive floats, 16-byte aligned): float4 loads
+            constexpr int RUN4 = PK_T * PK_RS / 4;
+            for (int idx = tid; idx < no * RUN4; idx += 256) {
+                const int o = idx / RUN4, q = idx - o * RUN4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(D.src + ((long long)(o0 + o) * D.c + c0) * PK_RS + q * 4);
+                float* t = tile + o * PK_LD + q * 4;
+                t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+            }
+        } else {
+            for (int idx = tid; idx < no * run; idx += 256) {
+                const int o = idx / run, k = idx - o * run;
+                const int c = k / nr, j = k - c * nr;
+                tile[o * PK_LD + c * PK_RS + j] = D.src[((long long)(o0 + o) * D.c + c0 + c) * RS + rs0 + j];
+            }
         }
         __syncthreads();
         // planes of a layout go out four consecutive elements per lane (8-byte stores) when the layer allows it
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
             for (int idx = tid; idx < no * nr * (PK_T / 4); idx += 256) {
                 const int c = (idx & (PK_T / 4 - 1)) * 4;
                 const int k = idx >> 3;
-                const int j = k % nr, o = k / nr;
+                const int o = nr == PK_RS ? k / PK_RS : k / nr, j = k - o * nr;        // (constant divisor for the 3x3 layers)
                 if (c < nc) {
                     const float* t = tile + o * PK_LD + c * PK_RS + j;
                     const f32x4 v = {t[0], t[PK_RS], t[2 * PK_RS], t[3 * PK_RS]};
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
             for (int idx = tid; idx < nc * nr * (PK_T / 4); idx += 256) {
                 const int o = (idx & (PK_T / 4 - 1)) * 4;
                 const int k = idx >> 3;
-                const int j = k % nr, c = k / nr;
+                const int c = nr == PK_RS ? k / PK_RS : k / nr, j = k - c * nr;
                 if (o < no) {
                     const float* t = tile + o * PK_LD + c * PK_RS + j;
                     const f32x4 v = {t[0], t[PK_LD], t[2 * PK_LD], t[3 * PK_LD]};

@@ -128,6 +128,9 @@ SIGNATURES = {
     'straps_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'straps_bn_relu_maxpool_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_bn_bwd_pooled': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'straps_bn_bwd_pooled_sparse': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    'straps_stem_tiles': (_Z, [_I, _I, _I]),
+    'straps_stem_tile_activity': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_maxpool_fwd_idx': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),

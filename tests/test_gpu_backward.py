@@ -311,6 +311,78 @@ def test_fused_stem_tail_equals_unfused(dev):
             assert torch.equal(ba[n], bb[n]), n
 
 
+def test_sparse_stem_tail_writes_only_what_the_weight_gradient_reads(dev):
+    """straps_bn_bwd_pooled_sparse on a proxy-like input (a silhouette box + a few heat-map blobs, whole channels empty): the tiles
+    straps_stem_tile_activity marks are written bit for bit as by the dense call, the others are left untouched, dgamma / dbeta are the
+    dense call's -- and through the module the stem's weight gradient equals the unfused route's (1e-5 of its maximum, the bar of
+    test_fused_stem_tail_equals_unfused), every other gradient bit for bit."""
+    L = hipabi.lib()
+    B, C, H, W = 3, 18, 256, 256
+    x = torch.zeros(B, C, H, W)
+    dense = torch.from_numpy(det_uniform((B, C, H, W), 91, 0.1, 1.0))
+    x[:, 0, 60:200, 90:170] = dense[:, 0, 60:200, 90:170]                     # silhouette
+    for j in range(1, 9):                                                     # heat-map blobs; channels 9..17 stay empty
+        x[:, j, 20 * j:20 * j + 16, 25 * j:25 * j + 16] = dense[:, j, 20 * j:20 * j + 16, 25 * j:25 * j + 16]
+    x = x.to(dev)
+    nz = torch.empty(L.straps_stem_nzmask_words(B, C, H, W), device=dev, dtype=torch.int32)
+    hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nz), B, C, H, W, None), 'nzmask')
+    nt = L.straps_stem_tiles(B, H, W)
+    assert nt == B * 64 * 4
+    act = torch.full((nt,), 7, device=dev, dtype=torch.uint8)
+    hipabi.check(L.straps_stem_tile_activity(hipabi.ptr(nz), hipabi.ptr(act), B, C, H, W, None), 'tile activity')
+    # the map against its definition: any non-zero in input rows 4ty-3 .. 4ty+5, columns 64tx-3 .. 64tx+68 (bit-map granularity: 4-row
+    # cells x 8-column bytes, so the kernel's patch is that rectangle widened to whole cells -- a superset, never a subset)
+    anynz = (x != 0).any(1).float()[:, None]
+    exact = torch.nn.functional.max_pool2d(torch.nn.functional.pad(anynz, (3, 5, 3, 5)), (9, 72), (4, 64)).reshape(-1) > 0
+    wide = torch.nn.functional.max_pool2d(torch.nn.functional.pad(anynz, (11, 13, 7, 9)), (17, 88), (4, 64)).reshape(-1) > 0
+    a = act.bool()
+    assert bool((a | ~exact).all()) and bool((~a | wide).all())
+    assert 0.2 < float(a.float().mean()) < 0.8
+    # kernel level: sparse call == dense call on the marked tiles, untouched elsewhere
+    Ho, Wo, Cc = 128, 128, 64
+    raw = torch.from_numpy(det_uniform((B, Ho, Wo, Cc), 92, -1, 1)).to(dev)
+    mean = torch.from_numpy(det_uniform((Cc,), 93, -0.1, 0.1)).to(dev)
+    invstd = torch.from_numpy(det_uniform((Cc,), 94, 0.5, 2.0)).to(dev)
+    gamma = torch.from_numpy(det_uniform((Cc,), 95, 0.5, 1.5)).to(dev)
+    msc, msh = (gamma * invstd).contiguous(), (-mean * gamma * invstd + 0.05).contiguous()
+    y = torch.relu(raw * msc + msh)
+    yp = torch.empty(B, 64, 64, Cc, device=dev)
+    idx = torch.empty(B, 64, 64, Cc, device=dev, dtype=torch.uint8)
+    hipabi.check(L.straps_maxpool_fwd_idx(hipabi.ptr(y), hipabi.ptr(yp), hipabi.ptr(idx), B, Ho, Wo, Cc, None), 'maxpool')
+    dyp = torch.from_numpy(det_uniform((B, 64, 64, Cc), 96, -1, 1)).to(dev)
+    ws = torch.empty(L.straps_bn_bwd_workspace_bytes(B * Ho * Wo, Cc) // 4, device=dev)
+    res = []
+    for tact in (None, act):
+        dg, db = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        draw = torch.full((B, Ho, Wo, Cc), float('nan'), device=dev)
+        hipabi.check(L.straps_bn_bwd_pooled_sparse(hipabi.ptr(dyp), hipabi.ptr(idx), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd),
+                                                   hipabi.ptr(gamma), hipabi.ptr(msc), hipabi.ptr(msh), hipabi.ptr(dg), hipabi.ptr(db),
+                                                   hipabi.ptr(draw), hipabi.ptr(ws), B, Ho, Wo, Cc, 0, hipabi.ptr(tact), None), 'bn_bwd_pooled_sparse')
+        torch.cuda.synchronize()
+        res.append((dg, db, draw))
+    (dg0, db0, d0), (dg1, db1, d1) = res
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and not bool(torch.isnan(d0).any())
+    m = act.view(B, 64, 1, 4, 1, 1).expand(B, 64, 2, 4, 32, Cc).reshape(B, Ho, Wo, Cc).bool()
+    assert torch.equal(d1[m], d0[m]) and bool(torch.isnan(d1[~m]).all())
+    # module level: the fused (sparse) tail against the unfused calls
+    outs = []
+    for unfused in (False, True):
+        reg, _ = _load_det(straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP), 18, dev)
+        reg.train()
+        reg.image_encoder.unfused_stem_tail = unfused
+        coef = torch.from_numpy(det_uniform((B, 157), 97)).to(dev)
+        cam, pose, shp = reg(x)
+        (torch.cat([cam, pose, shp], 1) * coef).sum().backward()
+        outs.append({n: p.grad.clone() for n, p in reg.named_parameters()})
+    ga, gb = outs
+    for n in ga:
+        if n in ('image_encoder.conv1.weight', 'image_encoder.bn1.weight', 'image_encoder.bn1.bias'):
+            err = float((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-30))
+            assert err < 1e-5, (n, err)
+        else:
+            assert torch.equal(ga[n], gb[n]), n
+
+
 def test_smpl_backward_vs_oracle_autograd(dev):
     model = straps_amd.synthetic_smpl_model(0)
     for B in (3, 37):
