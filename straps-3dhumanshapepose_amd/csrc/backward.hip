@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void stem_tileany_kernel(const unsigned* __res
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ part, const uint8_t* __restrict__ tact, int B, int C, int H,
                                                          int W, int Ho, int Wo,
-                                                         int tiles_x, int tiles_y, int Kp, int ntiles) {
+                                                         int tiles_x, int tiles_y, int Kp, int ntiles, int rot) {
     __shared__ __attribute__((aligned(16))) float patch[2 * CG * PH * PW]; // [buffer][cl][PH][PW]
     __shared__ __attribute__((aligned(16))) float dys[2 * TPIX * 68];      // [buffer][pixel][64 + 4]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
-    // Strided tile assignment (evens out body vs background tiles).  The activity bytes of 64 tiles are fetched with one
+    // Rotated strided tile assignment (evens out body vs background tiles, see the walk below).  The activity bytes of 64 tiles are fetched with one
     // load and only the active tiles are visited -- in ascending order, so the accumulation order is fixed.  The visit is
     // software-pipelined over a double-buffered LDS: while the MFMAs of tile t run, the global loads of the next active
     // tile are already in flight (registers), and one barrier per tile is enough (a buffer is rewritten two tiles later,
@@ -917,18 +917,25 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 
     const uint8_t* myact = tact + (long long)blockIdx.y * ntiles;
     int buf = 0;
-    for (int base = blockIdx.x; base < ntiles; base += 64 * gridDim.x) {
-        const int mine = base + lane * gridDim.x;
-        const unsigned act = mine < ntiles ? myact[mine] : 0u;
+    // tile walk: "row" m of the tile list holds tiles m*G .. m*G + G - 1 (G = gridDim.x); this workgroup takes element (bx + 97 m) mod G of
+    // every row.  With G = tiles per image (the B = 64, 256 x 256 case) a plain bx + m*G would pin a workgroup to ONE image position in all
+    // images -- the body sits in the middle of every proxy image, so a quarter of the workgroups would do all the work; the rotation walks
+    // each workgroup through the whole image instead.  Any G: a bijection per row, ascending tile order (fixed accumulation order).
+    const int G = gridDim.x;
+    for (int m0 = 0; (long long)m0 * G < ntiles; m0 += 64) {
+        const int m = m0 + lane;
+        const long long mine_l = (long long)m * G + (blockIdx.x + (long long)rot * m) % G;
+        const int mine = mine_l < ntiles ? (int)mine_l : -1;
+        const unsigned act = mine >= 0 ? myact[mine] : 0u;
         unsigned long long todo = __ballot(act != 0u);
         if (todo) {
             const int l0 = __ffsll((long long)todo) - 1;
-            issue_loads(base + l0 * gridDim.x, (unsigned)__shfl((int)act, l0, 64));
+            issue_loads(__shfl(mine, l0, 64), (unsigned)__shfl((int)act, l0, 64));
         }
         while (todo) {
             const int l = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const int tile = base + l * gridDim.x;
+            const int tile = __shfl(mine, l, 64);
             const unsigned chact = (unsigned)__shfl((int)act, l, 64);
             float* pb = patch + buf * (CG * PH * PW);
             float* db = dys + buf * (TPIX * 68);
@@ -936,7 +943,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
             __syncthreads();
             if (todo) {                                                    // next active tile of this chunk: loads fly during the MFMAs
                 const int ln = __ffsll((long long)todo) - 1;
-                issue_loads(base + ln * gridDim.x, (unsigned)__shfl((int)act, ln, 64));
+                issue_loads(__shfl(mine, ln, 64), (unsigned)__shfl((int)act, ln, 64));
             }
             // contraction over the tile's 64 pixels: A[co][pix] = dys[pix][co], B[pix][k] = patch[koff[k] + 2*py*PW + 2*px].
             // Unit-outer / pixel-inner and fully unrolled: every LDS operand is base + immediate offset (a unit is skipped
@@ -1777,8 +1784,9 @@ extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, floa
     hipLaunchKernelGGL(stem_tileact_kernel, dim3((ntiles * groups + 255) / 256), dim3(256), 0, st, nzmask, tact, cin, h, w, tiles_x, tiles_y, ntiles,
                        groups);
     STRAPS_CHECK_LAUNCH("stem_tileact_kernel");
+    static const int rot = getenv("STRAPS_STEM_WGRAD_ROT") ? atoi(getenv("STRAPS_STEM_WGRAD_ROT")) : 97;      // (A/B switch for tools: 0 = plain strided walk)
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk, groups), dim3(256), 0, st, x_nchw, dy_nhwc, part, tact, batch, cin, h, w, Ho, Wo,
-                       tiles_x, tiles_y, Kp, ntiles);
+                       tiles_x, tiles_y, Kp, ntiles, rot);
     STRAPS_CHECK_LAUNCH("stem_wgrad_kernel");
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * K + 63) / 64), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk, K, Kp, accumulate);
     STRAPS_CHECK_LAUNCH("stem_wgrad_reduce_kernel");

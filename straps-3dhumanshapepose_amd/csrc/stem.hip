@@ -371,11 +371,13 @@ extern "C" int straps_stem_fwd(const float* x, const float* w_frag, const float*
     STRAPS_REQUIRE(lds <= 160 * 1024, "straps_stem_fwd: %d input channels need %zu B of LDS (max 160 KiB)", cin, lds);
     const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
     const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
+    static size_t lds_set[64] = {};                 // per device: the limit grows with the channel count
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { straps_set_error("stem_kernel: hipGetDevice failed"); return STRAPS_EHIP; }
+    if (lds > lds_set[dev & 63]) {
         hipError_t e = hipFuncSetAttribute((const void*)stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { straps_set_error("stem_kernel: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return STRAPS_EHIP; }
-        lds_set = lds;
+        lds_set[dev & 63] = lds;
     }
     const long long nblk = (long long)batch * tiles_x * tiles_y;
     STRAPS_REQUIRE(nblk < (1LL << 31), "straps_stem_fwd: grid too large");
