@@ -1655,7 +1655,10 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
 
 // row blocks of tiles (grid.x): enough for 4-5 resident workgroups per CU across the channel groups, few enough that the
 // per-block partials stay small
-static int stem_wgrad_blocks(int ntiles) { return ntiles < 256 ? ntiles : 256; }
+static int stem_wgrad_blocks(int ntiles) {
+    static const int cap = getenv("STRAPS_STEM_WGRAD_BLOCKS") ? atoi(getenv("STRAPS_STEM_WGRAD_BLOCKS")) : 256;      // (A/B switch for tools)
+    return ntiles < cap ? ntiles : cap;
+}
 
 // weight gradient on the bf16x3 route: the 3x3 / stride 1 layers that fit the halo-patch plan run on the planes (x3, dy3: [3][plane
 // stride] bf16, see straps_split3_bf16); every other shape falls through to the fp32 kernels of straps_conv_wgrad on (x, dy).
