@@ -780,29 +780,34 @@ __global__ __launch_bounds__(256) void stem_tileact_kernel(const unsigned* __res
     tact[idx] = (uint8_t)chact;
 }
 
-// per tile: does ANY input channel hold a non-zero inside the tile's input patch (= is the tile of dy read by stem_wgrad_kernel at all)
+// per tile: does ANY input channel hold a non-zero inside the tile's input patch (= is the tile of dy read by stem_wgrad_kernel at all).
+// 32 lanes per tile, one channel each (a few independent word loads per lane), combined with a ballot.
 __global__ __launch_bounds__(256) void stem_tileany_kernel(const unsigned* __restrict__ nzmask, uint8_t* __restrict__ tany, int C, int H, int W,
                                                            int tiles_x, int tiles_y, int ntiles) {
-    const int tile = blockIdx.x * 256 + threadIdx.x;
-    if (tile >= ntiles) return;
-    int bid = tile;
-    const int b = bid / (tiles_x * tiles_y);
-    bid -= b * tiles_x * tiles_y;
-    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
-    const int hi0 = 2 * (ty * TY) - 3, wi0 = 2 * (tx * TX) - 3;
-    const int HC = (H + 3) >> 2, WW = (W + 255) >> 8;
-    const int rc0 = max(hi0, 0) >> 2, rc1 = min(hi0 + PH - 1, H - 1) >> 2;
-    const int wa = max(wi0 - 1, 0), wb = min(wi0 - 2 + PW, W - 1);
+    const int lane = threadIdx.x & 63, sub = lane & 31;
+    const int tile = (blockIdx.x * 256 + threadIdx.x) >> 5;
     unsigned any = 0;
-    for (int c = 0; c < C; ++c)
-        for (int rcell = rc0; rcell <= rc1; ++rcell)
-            for (int word = wa >> 8; word <= (wb >> 8); ++word) {
-                const int lo = max(wa, word << 8), hi = min(wb, (word << 8) + 255);
-                const int b0 = (lo >> 3) & 31, b1 = (hi >> 3) & 31;
-                const unsigned bits = (b1 == 31 ? 0xffffffffu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
-                any |= nzmask[(((long long)b * C + c) * HC + rcell) * WW + word] & bits;
-            }
-    tany[tile] = any ? 1 : 0;
+    if (tile < ntiles) {
+        int bid = tile;
+        const int b = bid / (tiles_x * tiles_y);
+        bid -= b * tiles_x * tiles_y;
+        const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
+        const int hi0 = 2 * (ty * TY) - 3, wi0 = 2 * (tx * TX) - 3;
+        const int HC = (H + 3) >> 2, WW = (W + 255) >> 8;
+        const int rc0 = max(hi0, 0) >> 2, rc1 = min(hi0 + PH - 1, H - 1) >> 2;
+        const int wa = max(wi0 - 1, 0), wb = min(wi0 - 2 + PW, W - 1);
+        for (int c = sub; c < C; c += 32)
+            for (int rcell = rc0; rcell <= rc1; ++rcell)
+                for (int word = wa >> 8; word <= (wb >> 8); ++word) {
+                    const int lo = max(wa, word << 8), hi = min(wb, (word << 8) + 255);
+                    const int b0 = (lo >> 3) & 31, b1 = (hi >> 3) & 31;
+                    const unsigned bits = (b1 == 31 ? 0xffffffffu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+                    any |= nzmask[(((long long)b * C + c) * HC + rcell) * WW + word] & bits;
+                }
+    }
+    const unsigned long long bal = __ballot(any != 0u);
+    const unsigned mine = (unsigned)(bal >> (lane & 32));            // the 32 lanes of this tile
+    if (sub == 0 && tile < ntiles) tany[tile] = mine ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -1872,7 +1877,7 @@ extern "C" int straps_stem_tile_activity(const uint32_t* nzmask, uint8_t* tile_a
     const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
     const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY;
     const int ntiles = batch * tiles_x * tiles_y;
-    hipLaunchKernelGGL(stem_tileany_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, (hipStream_t)stream, nzmask, tile_active, cin, h, w, tiles_x, tiles_y,
+    hipLaunchKernelGGL(stem_tileany_kernel, dim3((unsigned)(((long long)ntiles * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nzmask, tile_active, cin, h, w, tiles_x, tiles_y,
                        ntiles);
     STRAPS_CHECK_LAUNCH("stem_tileany_kernel");
     return STRAPS_OK;
