@@ -281,8 +281,9 @@ int straps_conv_dgrad(const float* dy_nhwc, const float* w_crsk, const float* ad
  * straps_conv_dgrad; x3 / dy3 are the planes of the NHWC tensor, w3 the planes of the packed
  * weights (straps_pack_conv_weight / straps_pack_conv_weight_dgrad output).
  * tile_cfg: 0 = auto (incl. the halo-patch kernel for 3x3 / stride-1 layers: the tile's input patch is
- * copied once per channel chunk and the nine taps are shifted LDS addresses), 1..12 = explicit tiles
- * of the im2col kernel (8..12: software-pipelined loop; csrc/conv_x3.hip), + 256 = auto without the
+ * copied once per channel chunk and the nine taps are shifted LDS addresses), 1..14 = explicit tiles
+ * of the im2col kernel (8..12: software-pipelined loop; 13 / 14: 128x64 / 256x64 tiles whose A operand goes straight from
+ * L2 into registers, 64-channel outputs; csrc/conv_x3.hip), + 256 = auto without the
  * halo-patch kernel, + 512 = the halo-patch kernel wherever it applies; bits 6 / 7 select
  * measurement builds with wrong results (no MFMAs / no operand copies; tools/pmc_x3.sh).
  * ------------------------------------------------------------------------------------------ */

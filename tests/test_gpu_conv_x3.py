@@ -174,7 +174,12 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
     (64, 256, 256, 16, 16, 3, 1, 0),
     # software-pipelined chunk loop (barrier between the two k steps, register double buffer): every such configuration
     (3, 128, 128, 8, 8, 3, 1, 8), (5, 128, 128, 24, 24, 3, 1, 9), (2, 64, 64, 16, 16, 3, 1, 10), (5, 64, 64, 7, 7, 3, 1, 11),
-    (5, 128, 128, 24, 24, 3, 1, 12), (2, 64, 128, 16, 16, 1, 2, 8), (1, 32, 64, 3, 3, 3, 1, 11), (2, 64, 128, 16, 16, 3, 2, 9)])
+    (5, 128, 128, 24, 24, 3, 1, 12), (2, 64, 128, 16, 16, 1, 2, 8), (1, 32, 64, 3, 3, 3, 1, 11), (2, 64, 128, 16, 16, 3, 2, 9),
+    # direct-A tiles (tile_cfg 13 / 14: the A operand goes straight from L2 into registers, LDS holds the weights alone; explicit only --
+    # the auto rule does not pick them: 147 vs 139 us on layer1): one- and many-chunk reductions, ragged M, 1x1, stride 2
+    (2, 64, 64, 16, 16, 3, 1, 13), (5, 64, 64, 7, 7, 3, 1, 13), (1, 32, 64, 3, 3, 3, 1, 13), (2, 256, 64, 16, 16, 1, 1, 13),
+    (3, 96, 128, 7, 13, 3, 2, 13), (2, 64, 64, 10, 24, 3, 1, 14), (5, 64, 64, 7, 7, 3, 1, 14), (2, 64, 128, 16, 16, 1, 2, 14),
+    (1, 32, 64, 8, 8, 1, 1, 13), (4, 64, 64, 32, 32, 3, 1, 14)])
 def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """all tile configurations (4- and 8-wave, 2- and 3-stage rings), ragged M, stride 1 / 2, 3x3 and 1x1, non-square maps, the
     fused epilogue and the training-mode statistics; the bar is the exact-fp32 kernel's (test_gpu_forward.py)."""
@@ -203,7 +208,8 @@ def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
 @pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
     (2, 64, 64, 16, 16, 3, 1, 0), (2, 64, 128, 16, 16, 3, 2, 0), (3, 128, 64, 9, 9, 3, 1, 0), (2, 64, 128, 16, 16, 1, 2, 0),
     (1, 256, 512, 8, 8, 3, 2, 0), (2, 256, 64, 8, 8, 1, 1, 0), (2, 128, 128, 15, 15, 3, 2, 1), (4, 128, 128, 20, 12, 3, 1, 4),
-    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3)])
+    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3),
+    (2, 64, 64, 16, 16, 3, 1, 13), (2, 64, 128, 16, 16, 3, 2, 13), (3, 128, 64, 9, 9, 3, 1, 14), (2, 64, 128, 16, 16, 1, 2, 14)])
 def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """data gradient on the bf16x3 route (stride-2 parity classes, odd sizes, the skip-gradient addend) vs float64 autograd."""
     L = hipabi.lib()
