@@ -284,7 +284,8 @@ int straps_conv_dgrad(const float* dy_nhwc, const float* w_crsk, const float* ad
  * copied once per channel chunk and the nine taps are shifted LDS addresses), 1..14 = explicit tiles
  * of the im2col kernel (8..12: software-pipelined loop; 13 / 14: 128x64 / 256x64 tiles whose A operand goes straight from
  * L2 into registers, 64-channel outputs; csrc/conv_x3.hip), + 256 = auto without the
- * halo-patch kernel, + 512 = the halo-patch kernel wherever it applies; bits 6 / 7 select
+ * halo-patch kernel, + 512 = the two-buffer halo-patch kernel wherever it applies, + 1024 = the single-buffer one (the rule for
+ * 64-channel outputs); bits 6 / 7 select
  * measurement builds with wrong results (no MFMAs / no operand copies; tools/pmc_x3.sh).
  * ------------------------------------------------------------------------------------------ */
 int straps_split3_bf16(const float* x, unsigned short* planes, long long n, long long plane_stride,

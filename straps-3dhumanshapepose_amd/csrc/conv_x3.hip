@@ -301,7 +301,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
 // L2 -> LDS bytes per step: (BM + BN) x 192  ->  (BN + patch / 9) x 192: 2.0x fewer for layer1 (128x64), 1.7-2.2x for the others.
 // PS = patch slot capacity.  Slot swizzle: 16-byte group g of slot s sits at g ^ ((s >> 2) & 3), conflict-free for the 16-lane
 // groups of ds_read_b128 over consecutive slots at any tap shift.
-template <int BM, int BN, int WGM, int WGN, int NST, int PS>
+// PBUF = 1 (the 64-channel outputs: layer1 and its data gradients): ONE patch buffer and a two-stage weight ring -- 76 KB of LDS, two
+// workgroups per CU.  The next chunk's patch is then copied at the chunk boundary itself (barrier: every wave is done with the old patch;
+// copy; wait; barrier) instead of a chunk ahead: the co-resident workgroup computes meanwhile.  123 us against 137 us for the im2col tile
+// on the layer1 shape (tools/x3d_probe.py): the 64-channel layers are bound by the L2 -> CU operand stream, and this form fetches every
+// input pixel once per channel chunk instead of once per tap without giving up the second workgroup.
+template <int BM, int BN, int WGM, int WGN, int NST, int PS, int PBUF = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p) {
     const ConvP::Class& c = p.cls[0];
     const int cntaps = c.ntaps;
@@ -314,8 +319,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     constexpr int NMFMA = 2 * 6 * MI * NI;
     constexpr int GAP = NMFMA / NPB > 0 ? NMFMA / NPB : 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    u16* As = reinterpret_cast<u16*>(smem);       // [2 patch buffers][3 planes][PS slots][32]
-    u16* Bs = As + 2 * 3 * PS * 32;               // [NST stages][3 planes][BN][32]
+    static_assert(PBUF == 1 || PBUF == 2, "one or two patch buffers");
+    u16* As = reinterpret_cast<u16*>(smem);       // [PBUF patch buffers][3 planes][PS slots][32]
+    u16* Bs = As + PBUF * 3 * PS * 32;            // [NST stages][3 planes][BN][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     const u16* zsrc = reinterpret_cast<const u16*>(k_zero16_x3);
     asm volatile("" : "+s"(zsrc));
     auto patch_dma = [&](int cc) {
-        u16* dst = As + (cc & 1) * (3 * PS * 32);
+        u16* dst = As + (PBUF == 2 ? (cc & 1) : 0) * (3 * PS * 32);
 #pragma unroll
         for (int pi = 0; pi < NPA; ++pi) {
             if (pi * (NTH / 4) + 16 * wave_u >= nslots) break;                 // wave-uniform: nothing of this round lies inside the patch
@@ -426,8 +432,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
         asm volatile("" ::: "memory");
         // first tap of a chunk: every wave is past the previous chunk, its patch buffer is free -> the next chunk's patch is copied
         // into it (issued before this step's weight copies: the in-order counter then retires it before any later weights)
-        if (c_tap == 0 && c_cc + 1 < cchunks) patch_dma(c_cc + 1);
-        const u16* Ap = As + (c_cc & 1) * (3 * PS * 32);
+        if constexpr (PBUF == 2) {
+            if (c_tap == 0 && c_cc + 1 < cchunks) patch_dma(c_cc + 1);
+        } else {
+            // one buffer: every wave is past the barrier above, i.e. done with the previous chunk's patch -- this chunk's is copied now and
+            // awaited (the weights of later steps that are in flight land with it: the in-order counter is at zero afterwards)
+            if (c_tap == 0 && c_cc > 0) {
+                patch_dma(c_cc);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        const u16* Ap = As + (PBUF == 2 ? (c_cc & 1) : 0) * (3 * PS * 32);
         const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
         const int tsh = __builtin_amdgcn_readlane(v_sh, c_tap);
         int ao[MI][2];
@@ -722,15 +739,15 @@ int launch_x3d(const ConvP& p0, hipStream_t st) {
     return STRAPS_OK;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int PS>
+template <int BM, int BN, int WGM, int WGN, int NST, int PS, int PBUF = 2>
 int launch_x3h(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     p.NT = p.Cout / BN;
     p.cls[0].MT = p.cls[0].M / BM;
     p.bnr_base[0] = 0;
-    const size_t lds = ((size_t)2 * 3 * PS + (size_t)NST * 3 * BN) * 32 * sizeof(u16);
-    STRAPS_RAISE_LDS((conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS>), lds, "conv_igemm_x3h_kernel");
-    hipLaunchKernelGGL((conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS>), dim3(p.cls[0].MT * p.NT, 1), dim3(64 * WGM * WGN), lds, st, p);
+    const size_t lds = ((size_t)PBUF * 3 * PS + (size_t)NST * 3 * BN) * 32 * sizeof(u16);
+    STRAPS_RAISE_LDS((conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS, PBUF>), lds, "conv_igemm_x3h_kernel");
+    hipLaunchKernelGGL((conv_igemm_x3h_kernel<BM, BN, WGM, WGN, NST, PS, PBUF>), dim3(p.cls[0].MT * p.NT, 1), dim3(64 * WGM * WGN), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_x3h_kernel");
     return STRAPS_OK;
 }
@@ -788,17 +805,19 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
     return cfg;
 }
 
-// auto tile choice only (tile_cfg & 15 == 0; bit 8 = im2col kernel only, bit 9 = halo kernel wherever it applies: A/B tools):
-// 1 = halo kernel 128x128, 2 = halo kernel 128x64, 0 = no.  Measured (tools/sweep_conv_x3.py, B = 64): halving the L2 -> LDS bytes
+// auto tile choice only (tile_cfg & 15 == 0; bit 8 = im2col kernel only, bit 9 = halo kernel wherever it applies: A/B tools; bit 10 = the
+// single-patch-buffer halo kernel for 64-channel outputs, explicit only):
+// 1 = halo kernel 128x128, 2 = halo kernel 128x64, 3 = halo kernel 128x64 with one patch buffer, 0 = no.  Measured (tools/sweep_conv_x3.py, B = 64): halving the L2 -> LDS bytes
 // buys only 4-5 % where the grid still fills the chip with 128x128 tiles (layer2: 104 vs 108 us -- 98 with the pipelined 256x128 tile,
-// which is what layer2 uses --, layer3: 96 vs 101) and loses
-// against the smaller / two-per-CU tiles of layer1 (154 vs 135) and layer4 (157 vs 111): operand bytes are not what limits
-// these kernels (the barrier-per-step skeleton is: DESIGN.md section 9).
+// which is what layer2 uses --, layer3: 96 vs 101) and loses against the smaller / two-per-CU tiles of layer4 (157 vs 111) and, in
+// its two-buffer form (140 KB of LDS, one workgroup per CU), of layer1 (154 vs 135).  With ONE patch buffer and a two-stage weight
+// ring (76 KB, two workgroups per CU) the 64-channel layers do gain: 123 vs 137 us -- that form is the rule for them.
 inline int halo_choice(const ConvP& p, int tile_cfg) {
     if ((tile_cfg & 15) != 0 || (tile_cfg & 256)) return 0;
     const int slots = halo_patch_slots(p);
     const bool all = (tile_cfg & 512) != 0;
     const long long t128 = (long long)(p.cls[0].M / 128) * (p.Cout / 128);
+    if (slots > 0 && p.Cout % 128 != 0 && slots <= 272 && (!all || (tile_cfg & 1024))) return 3;      // single patch buffer, two workgroups per CU: layer1 123 vs 137 us
     if (slots > 0 && p.Cout % 128 == 0 && slots <= 208 && (all || (t128 >= 256 && t128 < 512))) return 1;
     if (slots > 0 && p.Cout % 128 != 0 && slots <= 272 && all) return 2;
     return 0;
@@ -834,6 +853,7 @@ int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
     const int halo = halo_choice(p, tile_cfg);
     if (halo == 1) return launch_x3h<128, 128, 2, 2, 3, 208>(p, st);
     if (halo == 2) return launch_x3h<128, 64, 2, 2, 3, 272>(p, st);
+    if (halo == 3) return launch_x3h<128, 64, 2, 2, 2, 272, 1>(p, st);
     const int cfg = pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn);
     if ((tile_cfg & 192) == 192) return dispatch_x3_abl<3>(p, cfg, st);      // ablations (tools)
     if (tile_cfg & 64) return dispatch_x3_abl<1>(p, cfg, st);

@@ -172,6 +172,9 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
     (1, 64, 64, 64, 64, 3, 1, 512), (1, 128, 128, 32, 32, 3, 1, 512), (2, 256, 256, 16, 16, 3, 1, 512), (4, 512, 512, 8, 8, 3, 1, 512),
     (2, 64, 128, 8, 16, 3, 1, 512), (1, 64, 64, 8, 32, 3, 1, 512), (2, 64, 64, 16, 16, 3, 1, 256), (4, 512, 512, 8, 8, 3, 1, 256),
     (64, 256, 256, 16, 16, 3, 1, 0),
+    # the single-patch-buffer halo kernel (the auto rule for 64-channel outputs; cfg 1024 = explicitly): four channel chunks = three
+    # patch reloads at chunk boundaries, whole-image tiles
+    (2, 128, 64, 16, 16, 3, 1, 0), (4, 64, 64, 8, 8, 3, 1, 1024),
     # software-pipelined chunk loop (barrier between the two k steps, register double buffer): every such configuration
     (3, 128, 128, 8, 8, 3, 1, 8), (5, 128, 128, 24, 24, 3, 1, 9), (2, 64, 64, 16, 16, 3, 1, 10), (5, 64, 64, 7, 7, 3, 1, 11),
     (5, 128, 128, 24, 24, 3, 1, 12), (2, 64, 128, 16, 16, 1, 2, 8), (1, 32, 64, 3, 3, 3, 1, 11), (2, 64, 128, 16, 16, 3, 2, 9),

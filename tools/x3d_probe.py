@@ -60,6 +60,15 @@ def run(B, Cin, Cout, H, W, k, stride, cfgs, time_it=False):
             float((s - s0).abs().max() / s0.abs().max())), flush=True)
 
 
+if os.environ.get('PROBE', 'halo1') == 'halo1':
+    # single-patch-buffer halo kernel (tile_cfg bit 10) against the auto rule: 8 / 4 / 2 rows per tile, whole images, 4 channel chunks (three reloads)
+    run(2, 64, 64, 16, 16, 3, 1, (0, 1024))
+    run(1, 64, 64, 8, 32, 3, 1, (0, 1024))
+    run(4, 64, 64, 8, 8, 3, 1, (0, 1024))
+    run(2, 128, 64, 16, 16, 3, 1, (0, 1024))
+    run(1, 256, 64, 64, 64, 3, 1, (0, 1024))
+    run(64, 64, 64, 64, 64, 3, 1, (0, 2, 512, 1024, 11), time_it=True)
+    sys.exit(0)
 run(2, 64, 64, 16, 16, 3, 1, (0, 13, 14))
 run(5, 64, 64, 7, 7, 3, 1, (0, 13, 14))
 run(3, 96, 128, 7, 13, 3, 2, (0, 13))
