@@ -12,7 +12,8 @@
   update     Adam over the flat parameter buffer (66|165 regressor tensors + 5 log-variances)
 
 Random draws come from the device-resident Philox generator of `device_rng` (seed + rank, step counter on the device):
-no torch operator runs inside the step -- torch provides memory, streams, hipGraph capture and `torch.distributed`.
+no torch operator does arithmetic inside the step (a few `clone()` / `zeros` of small tensors remain) -- torch provides memory, streams,
+hipGraph capture and `torch.distributed`.
 """
 import ctypes as C
 
