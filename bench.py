@@ -44,7 +44,7 @@ def pmc_traffic(args, kernel):
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
     tag = '%s_r%d_b%d' % (args.workload, args.layers, args.batch or (65536 if args.workload == 'smpl' else 64))
-    if args.workload == 'smpl' and args.smpl_precision != 'fp16x3_lbs_p16':
+    if args.workload == 'smpl':
         tag += '_' + args.smpl_precision
     if args.workload != 'smpl' and args.conv_precision != 'bf16x3':
         tag += '_' + args.conv_precision + 'conv'
@@ -97,25 +97,61 @@ class KernelTimer:
         self.recs = []
         self.on = False
 
-    def wrap(self, name, flops, fn, nbytes=0.0):
+    def wrap(self, name, flops, fn, nbytes=0.0, cls=None):
         if not self.on:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = fn()
         e.record()
-        self.recs.append((name, flops, s, e, nbytes))
+        self.recs.append((name, flops, s, e, nbytes, cls))
         return out
 
     def summary(self):
         agg = {}
-        for name, flops, s, e, nbytes in self.recs:
+        for name, flops, s, e, nbytes, cls in self.recs:
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += s.elapsed_time(e) * 1e-3
             a[3] += nbytes
         return agg
+
+    def classes(self, name):
+        """launches of kernel family `name` by problem class (the geometry string the proxy attached): a box-to-box or commit-to-commit
+        difference of the family's average shows up here as the class that moved."""
+        agg = {}
+        for nm, flops, s, e, nbytes, cls in self.recs:
+            if nm != name or cls is None:
+                continue
+            a = agg.setdefault(cls, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += s.elapsed_time(e) * 1e-3
+        return {k: {'launches': v[0], 'avg_launch_us': round(v[2] / v[0] * 1e6, 2), 'fp32_equivalent_tflops': round(v[1] / v[2] / 1e12, 1)}
+                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+
+
+class ClockProbe:
+    """sustained shader clock over a region: straps_clock_probe (one spinning lane, csrc/abi.hip) on its own stream, started just before
+    the region with the region's expected duration.  MHz = shader ticks / wall ticks x wall-clock rate."""
+
+    def __init__(self, dev):
+        self.out = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.khz = hipabi.lib().straps_wall_clock_khz()
+
+    def start(self, seconds):
+        import ctypes
+        seconds = min(max(seconds, 0.002), 5.0)
+        self.out.zero_()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        hipabi.check(hipabi.lib().straps_clock_probe(hipabi.ptr(self.out), float(seconds), ctypes.c_void_p(self.stream.cuda_stream)), 'straps_clock_probe')
+
+    def mhz(self):
+        self.stream.synchronize()
+        c, w = (int(v) for v in self.out.tolist())
+        return round(c / w * self.khz / 1e3, 1) if w > 0 and self.khz > 0 else None
 
 
 def _out(h, k, s, p):
@@ -130,6 +166,9 @@ def instrument(timer):
     def conv_flops(B, H, W, Cin, Cout, kh, kw, stride, pad):
         return 2.0 * B * _out(H, kh, stride, pad) * _out(W, kw, stride, pad) * Cout * Cin * kh * kw
 
+    def geo(tag, B, H, W, Cin, Cout, kh, kw, stride, pad):
+        return '%s %dx%dx%d %d->%d k%d s%d' % (tag, B, H, W, Cin, Cout, kh, stride)
+
     def conv_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad):
         # algorithmic HBM bytes of one convolution launch: input + packed weights + output, each touched once (fp32)
         return 4.0 * (B * H * W * Cin + Cout * Cin * kh * kw + B * _out(H, kh, stride, pad) * _out(W, kw, stride, pad) * Cout)
@@ -139,28 +178,28 @@ def instrument(timer):
             return getattr(L, k)
 
         def straps_conv_fwd(self, *a):
-            return timer.wrap('conv_igemm_kernel', conv_flops(*a[8:17]), lambda: L.straps_conv_fwd(*a), conv_bytes(*a[8:17]))
+            return timer.wrap('conv_igemm_kernel', conv_flops(*a[8:17]), lambda: L.straps_conv_fwd(*a), conv_bytes(*a[8:17]), geo('fwd', *a[8:17]))
 
         def straps_conv_dgrad(self, *a):
-            return timer.wrap('conv_igemm_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_dgrad(*a), conv_bytes(*a[4:13]))
+            return timer.wrap('conv_igemm_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_dgrad(*a), conv_bytes(*a[4:13]), geo('dgrad', *a[4:13]))
 
         def straps_conv_fwd_x3(self, *a):      # (fp32-equivalent flops: the six bf16 products of a term count as one multiply-add)
-            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[10:19]), lambda: L.straps_conv_fwd_x3(*a), 1.5 * conv_bytes(*a[10:19]))
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[10:19]), lambda: L.straps_conv_fwd_x3(*a), 1.5 * conv_bytes(*a[10:19]), geo('fwd', *a[10:19]))
 
         def straps_conv_fwd_x3p(self, *a):
-            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[11:20]), lambda: L.straps_conv_fwd_x3p(*a), 1.5 * conv_bytes(*a[11:20]))
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[11:20]), lambda: L.straps_conv_fwd_x3p(*a), 1.5 * conv_bytes(*a[11:20]), geo('fwd', *a[11:20]))
 
         def straps_conv_dgrad_x3_bn(self, *a):     # (the launch also carries the next BatchNorm backward's sums in its epilogue)
-            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3_bn(*a), 1.5 * conv_bytes(*a[6:15]))
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3_bn(*a), 1.5 * conv_bytes(*a[6:15]), geo('dgrad+bn', *a[6:15]))
 
         def straps_conv_dgrad_x3(self, *a):
-            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3(*a), 1.5 * conv_bytes(*a[6:15]))
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3(*a), 1.5 * conv_bytes(*a[6:15]), geo('dgrad', *a[6:15]))
 
         def straps_conv_wgrad(self, *a):
-            return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a))
+            return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a), 0.0, geo('wgrad', *a[4:13]))
 
         def straps_conv_wgrad_x3(self, *a):
-            return timer.wrap('conv_wgrad_x3_kernel', conv_flops(*a[8:17]), lambda: L.straps_conv_wgrad_x3(*a))
+            return timer.wrap('conv_wgrad_x3_kernel', conv_flops(*a[8:17]), lambda: L.straps_conv_wgrad_x3(*a), 0.0, geo('wgrad', *a[8:17]))
 
         def straps_stem_fwd(self, *a):
             B, C, H, W = a[8:12]
@@ -191,8 +230,11 @@ def main():
     ap.add_argument('--config', type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help='BASELINE.json configs[N] alias: 1 = --workload fwd, 2 = --workload train, 3 = train --layers 50 --batch 32 (per GPU), 4 = --workload smpl')
     ap.add_argument('--smpl-exact', action='store_true', help='smpl workload: exact-fp32 MFMA blend contraction (= --smpl-precision fp32)')
-    ap.add_argument('--smpl-precision', default='fp16x3_lbs_p16', choices=['fp32', 'fp16x3', 'fp16x3_lbs', 'fp16x3_lbs_pd16', 'fp16x3_lbs_p16'],
-                    help='smpl workload: fp32 = exact, fp16x3 = blend contraction as a three-product fp16 split, fp16x3_lbs = skinning on the matrix pipe too')
+    ap.add_argument('--smpl-precision', default='fp16x3_lbs', choices=['fp32', 'fp16x3', 'fp16x3_lbs', 'fp16x3_lbs_pd16', 'fp16x3_lbs_p16'],
+                    help='smpl workload: fp32 = exact fp32 MFMA chain; fp16x3 = blend contraction as a three-product fp16 split; fp16x3_lbs (default: every '
+                         'product split three ways, fp32-class accuracy) = skinning on the matrix pipe too; _pd16 / _p16 = pose-corrective blend in plain '
+                         'fp16 (narrower than fp32: opt-in A/B only, reported beside the headline under "reduced_precision_modes")')
+    ap.add_argument('--no-reduced-ab', action='store_true', help='smpl workload: skip the extra timed pass of the reduced-precision p16 mode')
     ap.add_argument('--conv-precision', default='bf16x3', choices=['fp32', 'bf16x3'],
                     help="encoder convolutions (forward + data gradient): 'fp32' = exact-fp32 MFMA chain, 'bf16x3' = three bf16 planes per fp32 "
                          "operand, six products per term, fp32 accumulate (same accuracy class, bf16 matrix pipe)")
@@ -321,38 +363,56 @@ def main():
             graph_mode, run = False, step
     else:
         run = step
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
     run()
     torch.cuda.synchronize()
+    step_guess = time.perf_counter() - tw          # one step, host-timed: sizes the clock probe's spin
+    probe = ClockProbe(dev)
+    if args.workload == 'train':
+        ts.time_exchange, ts.exchange_events = True, []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     timer.on = not graph_mode          # a replayed graph makes no Python-side launches: kernels are timed in the pass below
+    probe.start(0.85 * step_guess * args.steps)    # (one lane on a side stream; ends inside the region)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.on = False
+    sclk_mhz = probe.mhz()
+    exposed_exchange_ms = None
+    if args.workload == 'train':
+        ts.time_exchange = False
+        if ts.exchange_events:
+            exposed_exchange_ms = sum(a.elapsed_time(b) for a, b in ts.exchange_events) / len(ts.exchange_events)
     graph_captured = args.workload != 'train' or ts.graph is not None
-    eager_ms = None
+    eager_ms, eager_sclk_mhz = None, None
     if graph_mode:
         # same K steps launched eagerly with HIP-event pairs around the MFMA kernels (roofline section)
         if args.workload == 'train':
             ts.use_graph = False
             ts.side_stream = None          # one stream: kernels run back to back, so each event pair times ONE kernel alone
             ts.pipeline = False            # (and no next-batch generation running beside the timed kernels)
+        tw = time.perf_counter()
         step()
         torch.cuda.synchronize()
+        eager_guess = time.perf_counter() - tw
         timer.on = True
+        probe.start(0.85 * eager_guess * args.steps)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
         timer.on = False
+        eager_sclk_mhz = probe.mhz()
     # A/B inside the same run: the stem kernels with their exact zero skipping defeated (every input cell marked non-zero = the
     # plain dense convolution), 3 eager steps on every rank (the step's all-reduce is collective)
     stem_ab = None
@@ -372,10 +432,42 @@ def main():
         timer.recs = saved
         reg.image_encoder.dense_stem = False
         stem_ab = {k: dense[k][2] / 3 * 1e3 for k in ('stem_kernel', 'stem_wgrad_kernel') if k in dense}
+    reduced = None
+    if args.workload == 'smpl' and smpl_precision == 'fp16x3_lbs' and not args.no_reduced_ab:
+        # the pose-corrective blend in plain fp16 (narrower than the reference's fp32; inside north_star's 1e-4 m): NOT the headline --
+        # the same K steps timed again and reported beside it
+        def step_p16():
+            return smpl.forward_arrays(betas, R, want_joints=True, precision='fp16x3_lbs_p16')[0]
+        for _ in range(3):
+            step_p16()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step_p16()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        reduced = {'fp16x3_lbs_p16': {'value': round(B * args.steps / dt2, 1), 'unit': 'bodies/s (this rank)', 'ms_per_step': round(dt2 / args.steps * 1e3, 4),
+                                      'launch_mode': 'eager', 'note': 'pose-corrective blend as ONE plain-fp16 product per term: reduced precision, opt-in'}}
+    rank_ms = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank view: each rank's own time to finish its K steps (before the closing barrier) and the part of the gradient
+        # exchange its backward did not hide
+        mine = torch.tensor([local_elapsed / args.steps * 1e3, -1.0 if exposed_exchange_ms is None else exposed_exchange_ms,
+                             -1.0 if sclk_mhz is None else sclk_mhz], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        tab = torch.stack(allr).cpu()
+        rank_ms = {'ms_per_step_min': round(float(tab[:, 0].min()), 4), 'ms_per_step_max': round(float(tab[:, 0].max()), 4),
+                   'per_rank_ms_per_step': [round(float(v), 4) for v in tab[:, 0]]}
+        if float(tab[:, 1].max()) >= 0:
+            rank_ms.update({'exposed_exchange_ms_mean': round(float(tab[:, 1].mean()), 4), 'exposed_exchange_ms_max': round(float(tab[:, 1].max()), 4),
+                            'exposed_exchange_note': 'HIP-event pair on the step stream around GradientExchange.finish(): wait for the tail bucket '
+                                                     '(started mid-backward) + the head bucket all-reduce = what backward did not hide'})
+        if float(tab[:, 2].max()) > 0:
+            rank_ms['per_rank_sclk_mhz'] = [round(float(v), 1) for v in tab[:, 2]]
 
     out = None
     if rank == 0:
@@ -416,6 +508,11 @@ def main():
                              'fp32_equivalent_tflops': round(ach, 2), 'fp32_pipe_peak': MFMA_F32_PEAK_TFLOPS,
                              'fp32_equivalent_over_fp32_peak': round(ach / MFMA_F32_PEAK_TFLOPS, 4)})
             roof.update(pmc_traffic(args, dominant))
+            cls = timer.classes(dominant)
+            if cls:
+                roof['classes'] = cls
+            if eager_sclk_mhz is not None or not graph_mode:
+                roof['sclk_mhz_during_measurement'] = eager_sclk_mhz if eager_sclk_mhz is not None else sclk_mhz
         others = {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'avg_launch_us': round(v[2] / v[0] * 1e6, 2),
                       'ms_per_step': round(v[2] / args.steps * 1e3, 3)} for k, v in agg.items()}
         for k in others:
@@ -435,7 +532,13 @@ def main():
                'config': {'workload': workload, 'bodies_per_gpu_per_step': B, 'global_batch': B * world,
                           'input': 'theta(24x3x3), beta(10)' if args.workload == 'smpl' else '18x256x256 fp32 NCHW proxy built on the device by the step itself (rendered part silhouette + 17 joint heat-maps, ~98 % exact zeros as in the reference pipeline)',
                           'parallelism': par},
-               'roofline': roof, 'kernels': others, 'cpu_baseline': cpu}
+               'roofline': roof, 'kernels': others, 'cpu_baseline': cpu,
+               'sclk_mhz': sclk_mhz, 'sclk_note': 'sustained shader clock over the timed region (s_memtime / s_memrealtime of one spinning lane on a side '
+                                                  'stream; spec 2400): the chip clocks to its power budget, boards differ by several per cent'}
+        if rank_ms is not None:
+            out['ranks'] = rank_ms
+        if reduced is not None:
+            out['reduced_precision_modes'] = reduced
         if args.workload == 'train':
             out['final_loss'] = round(float(ts.last['loss'][0]), 5)
             captured = graph_mode and graph_captured            # TrainStep falls back to eager launches if capture fails

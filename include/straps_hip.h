@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STRAPS_ABI_VERSION 4
+#define STRAPS_ABI_VERSION 5
 
 #define STRAPS_OK 0
 #define STRAPS_EINVAL 1       /* bad argument (shape, alignment, null pointer) */
@@ -37,6 +37,11 @@ int straps_selftest_mfma_peak(const float* seed512, float* out, int blocks, int 
 const char* straps_last_error(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int straps_device_count(void);
+/* measurement aid (bench.py `sclk_mhz`; no reference counterpart): one lane spins for `spin_seconds` of wall time (<= 5 s) on `stream`
+ * and writes out2[0] = shader-clock ticks, out2[1] = constant-rate wall ticks that passed; sustained shader clock in MHz =
+ * out2[0] / out2[1] * straps_wall_clock_khz() / 1000.  Launch it on a side stream across the region whose clock is wanted. */
+int straps_wall_clock_khz(void);
+int straps_clock_probe(unsigned long long* out2, double spin_seconds, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder -- replaces nn.Conv2d / nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d / AdaptiveAvgPool2d as

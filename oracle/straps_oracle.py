@@ -108,23 +108,31 @@ def ief_init_estimate(mean_pose6d, mean_shape):
     return torch.from_numpy(v.astype(np.float32))
 
 
-def ief_forward(feat, sd, init_estimate, iterations=3, prefix='ief_module.'):
+def ief_forward(feat, sd, init_estimate, iterations=3, prefix='ief_module.', relu_masks=None, taps=None):
     """IEFModule.forward (models/ief_module.py:48-64).  est += fc3(relu(fc2(relu(fc1([feat,est])))))
-    `iterations` times; returns (cam[B,3], pose[B,144], shape[B,10]) and the full [B,157]."""
+    `iterations` times; returns (cam[B,3], pose[B,144], shape[B,10]) and the full [B,157].
+    taps (optional list) receives per iteration the two pre-activations (z1, z2), detached.
+    relu_masks (optional, tests only): per iteration a pair of boolean masks [B,H] that REPLACE the ReLU decisions
+    (h = z * mask): the function another evaluation actually differentiated when one of its pre-activations sat a
+    rounding error away from zero on the other side (tests/test_gpu_train_step.py)."""
     p = prefix
     est = init_estimate.to(feat.dtype).repeat(feat.shape[0], 1)
-    for _ in range(iterations):
+    for it in range(iterations):
         s = torch.cat([feat, est], dim=1)
-        h = F.relu(F.linear(s, sd[p + 'fc1.weight'], sd[p + 'fc1.bias']))
-        h = F.relu(F.linear(h, sd[p + 'fc2.weight'], sd[p + 'fc2.bias']))
+        z1 = F.linear(s, sd[p + 'fc1.weight'], sd[p + 'fc1.bias'])
+        h = F.relu(z1) if relu_masks is None else z1 * relu_masks[it][0].to(z1.dtype)
+        z2 = F.linear(h, sd[p + 'fc2.weight'], sd[p + 'fc2.bias'])
+        h = F.relu(z2) if relu_masks is None else z2 * relu_masks[it][1].to(z2.dtype)
+        if taps is not None:
+            taps.append((z1.detach(), z2.detach()))
         est = est + F.linear(h, sd[p + 'fc3.weight'], sd[p + 'fc3.bias'])
     return est[:, :3], est[:, 3:147], est[:, 147:], est
 
 
-def regressor_forward(x, sd, init_estimate, layers=18, iterations=3, training=False):
+def regressor_forward(x, sd, init_estimate, layers=18, iterations=3, training=False, ief_masks=None, ief_taps=None):
     """SingleInputRegressor.forward (models/regressor.py:43-47)."""
     feat = resnet_forward(x, sd, layers, training)
-    return ief_forward(feat, sd, init_estimate, iterations)
+    return ief_forward(feat, sd, init_estimate, iterations, relu_masks=ief_masks, taps=ief_taps)
 
 
 # --------------------------------------------------------------------------------------------
@@ -331,11 +339,13 @@ def multi_task_loss(labels, outputs, log_vars, losses_on=LOSS_TASKS, img_wh=REGR
 # --------------------------------------------------------------------------------------------
 # forward + loss + backward of one training step (train loop :186-232) on a GIVEN batch
 # --------------------------------------------------------------------------------------------
-def train_step_loss_and_grads(batch, sd, init_estimate, smpl_model, layers=18, iterations=3, log_vars=None, dtype=torch.float32):
+def train_step_loss_and_grads(batch, sd, init_estimate, smpl_model, layers=18, iterations=3, log_vars=None, dtype=torch.float32,
+                              ief_masks=None, ief_taps=None):
     """regressor (training-mode BatchNorm) -> rot6d -> SMPL -> heads -> multi-task loss -> autograd.
     batch: dict with 'input' [B,18,256,256], 'verts', 'joints2d', 'joints3d', 'shape', 'rot' (targets, CPU tensors);
     sd: regressor state dict (cloned and cast to `dtype` here; the caller's tensors are not touched);
-    log_vars: {task: float}.  Returns (total, weighted task losses, {parameter name: grad}, {task: d total / d log_var})."""
+    log_vars: {task: float}.  Returns (total, weighted task losses, {parameter name: grad}, {task: d total / d log_var}).
+    ief_masks / ief_taps: see ief_forward (forced ReLU decisions of the IEF head / its pre-activations)."""
     sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
     names = [k for k in sd if not k.startswith('ief_module.ief_layers.') and k.split('.')[-1] in ('weight', 'bias') and sd[k].is_floating_point()]
     for n in names:
@@ -346,7 +356,8 @@ def train_step_loss_and_grads(batch, sd, init_estimate, smpl_model, layers=18, i
             sd[n] = sd['ief_module.fc%d.%s' % ({'0': 1, '2': 2, '4': 3}[idx], leaf)]
     lv = {k: torch.tensor(float(v), dtype=dtype, requires_grad=True) for k, v in (log_vars or init_log_vars()).items()}
     x = batch['input'].to(dtype)
-    cam, pose, shape, _ = regressor_forward(x, sd, torch.as_tensor(init_estimate).to(dtype), layers, iterations, training=True)
+    cam, pose, shape, _ = regressor_forward(x, sd, torch.as_tensor(init_estimate).to(dtype), layers, iterations, training=True,
+                                            ief_masks=ief_masks, ief_taps=ief_taps)
     R = rot6d_to_rotmat(pose.contiguous()).view(-1, 24, 3, 3)
     verts, joints = smpl_forward(smpl_model, shape, rotmats=R, dtype=dtype)
     pred = {'verts': verts, 'joints2D': orthographic_project(joints[:, ALL_JOINTS_TO_COCO_MAP], cam),

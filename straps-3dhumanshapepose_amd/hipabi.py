@@ -26,7 +26,11 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into csrc/libstraps_hip.so (in-tree, so the .so travels
     with the repo snapshot).  hipcc cross-compiles without a GPU."""
     srcs = _existing_sources()
-    deps = srcs + [os.path.join(CSRC, 'common.h'), HEADER]
+    # every header under csrc/ (common.h, conv_igemm.h, ...) and the public header: a change in any of them rebuilds every object --
+    # translation units that share a struct (ConvP) can never be linked from different versions of it
+    import glob
+    hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [HEADER]
+    deps = srcs + hdrs
     if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -34,7 +38,6 @@ def build(force=False, verbose=False):
     # one object per source (csrc/build/*.o, compiled in parallel, rebuilt only when the source or a header is newer), then one link
     objdir = os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, 'common.h'), HEADER]
     jobs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + '.o')
@@ -77,6 +80,8 @@ SIGNATURES = {
     'straps_abi_version': (_I, []),
     'straps_last_error': (C.c_char_p, []),
     'straps_device_count': (_I, []),
+    'straps_wall_clock_khz': (_I, []),
+    'straps_clock_probe': (_I, [_P, _D, _P]),
     'straps_selftest_mfma_peak': (_I, [_P, _P, _I, _I, _P]),
     'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -136,6 +136,7 @@ class TrainStep:
                 break
             off += p_.numel()
         self.exchange = GradientExchange(self.flat_g, split_off if self.comm_overlap else 0, world_size, group)
+        self.time_exchange, self.exchange_events = False, []
         self.logvar_params = [getattr(criterion, n + '_log_var') for n in TASKS]
         # the five loss log-variances are the last five floats of the flat buffers, in the criterion's registration order; the
         # loss kernel wants its own task order: two 5-element gathers (values in, gradients out) instead of torch stack / copies
@@ -371,7 +372,7 @@ class TrainStep:
                 if p.requires_grad:
                     self.gviews[p].copy_(dlv[k])
         encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews, self.side_stream, after_layer3)
-        self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed, rot=R)
+        self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed, rot=R, ief_tape=ief_tape)
         if self.metrics is not None:
             from .cam_utils import orthographic_project_torch
             pred = {'verts': verts, 'joints3D': joints.index_select(1, self._h36m14), 'shape_params': pred_shape,
@@ -390,7 +391,16 @@ class TrainStep:
         return self.metrics.summary()
 
     def optimise(self):
-        gscale = self.exchange.finish()
+        if self.time_exchange and self.world > 1:
+            # event pair on the step's stream around the wait for the tail bucket + the head bucket's all-reduce: the part of the exchange
+            # that backward did NOT hide (bench.py --gpus N reports it)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gscale = self.exchange.finish()
+            e1.record()
+            self.exchange_events.append((e0, e1))
+        else:
+            gscale = self.exchange.finish()
         self.steps += 1
         hipabi.check(hipabi.lib().straps_counter_add(hipabi.ptr(self.step_t), 1, 1, hipabi.stream_ptr()), 'straps_counter_add(adam step)')
         hipabi.check(hipabi.lib().straps_adam_step(hipabi.ptr(self.flat_p), hipabi.ptr(self.flat_g), hipabi.ptr(self.exp_avg),

@@ -334,6 +334,62 @@ def test_dgrad_x3_with_fused_batchnorm_sums(dev, B, Cin, Cout, H, W, k, stride, 
         assert err < 2e-6, (name, err)          # (the same double sums in another order, rounded once to fp32)
 
 
+@pytest.mark.parametrize('B,Cin,Cout', [(64, 64, 64), (16, 128, 64)])
+def test_single_patch_buffer_halo_kernel_at_layer1_size_forward_dgrad_and_repeats(dev, B, Cin, Cout):
+    """conv_igemm_x3h_kernel<PBUF = 1> (the auto rule of every 64-channel 3x3 / stride-1 layer: one patch buffer re-copied at the channel-chunk
+    boundary while the co-resident workgroup computes) at the REAL layer1 map size 64 x 64 -- 2 048 / 512 tiles, two workgroups per CU, one and
+    three patch reloads per tile: forward and data gradient against float64, and 50 repeated launches on one input bit-identical (a stale
+    patch read -- the failure of an earlier form of this kernel -- would show as a launch-to-launch difference or a column of wrong values)."""
+    L = hipabi.lib()
+    H = W = 64
+    k, pad = 3, 1
+    assert L.straps_conv_x3_stat_blocks(B, H, W, Cin, Cout, k, k, 1, pad, 0) == B * H * W // 128
+    x = torch.from_numpy(det_uniform((B, Cin, H, W), 51, -1, 1))
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 52, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
+    torch.set_num_threads(min(32, __import__('os').cpu_count() or 8))
+    ref = F.conv2d(x.double(), w.double(), None, 1, pad)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    x3, xps = _split(xd)
+    w3, wps = _split(_pack(dev, w))
+    first = None
+    for rep in range(50):
+        y = torch.full((B, H, W, Cout), float('nan'), device=dev)
+        hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(y), None, B, H, W, Cin, Cout, k, k, 1, pad,
+                                          0, None), 'conv_fwd_x3')
+        if first is None:
+            first = y
+        else:
+            assert torch.equal(first, y), 'forward launch %d differs from launch 0' % rep
+    err = (first.permute(0, 3, 1, 2).cpu().double() - ref).abs()
+    assert float((err - (2e-5 + 2e-5 * ref.abs())).max()) <= 0, 'forward: max abs err %.3e' % float(err.max())
+    # the im2col kernel on the same operands (tile_cfg bit 8) agrees to rounding: the two kernels sum the same products in another order
+    y_i = torch.empty_like(first)
+    hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(y_i), None, B, H, W, Cin, Cout, k, k, 1, pad,
+                                      256, None), 'conv_fwd_x3 im2col')
+    assert float((first - y_i).abs().max()) < 2e-5
+    del ref, err
+    # data gradient of a Cout -> Cin convolution whose input has `Cout` channels: the GEMM has Cout output columns again
+    # (dy [B,H,W,Cin_of_gemm = Cin] -> dx [B,H,W,Cout]), i.e. the same kernel instantiation with the flipped taps
+    wd_full = torch.from_numpy(det_uniform((Cin, Cout, k, k), 53, -1, 1)) * (2.0 / (Cout * k * k)) ** 0.5      # conv: Cout channels in, Cin out
+    dy = torch.from_numpy(det_uniform((B, Cin, H, W), 54, -1, 1)) * 1e-3
+    want = F.conv_transpose2d(dy.double(), wd_full.double(), None, 1, pad)                                        # [B,Cout,H,W]
+    g3, gps = _split(dy.permute(0, 2, 3, 1).contiguous().to(dev))
+    wd3, wdps = _split(_pack(dev, wd_full, dgrad=True))
+    add = torch.from_numpy(det_uniform((B, H, W, Cout), 55, -1, 1)).to(dev) * 1e-3
+    first = None
+    for rep in range(50):
+        dx = torch.full((B, H, W, Cout), float('nan'), device=dev)
+        hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(wd3), wdps, hipabi.ptr(add), hipabi.ptr(dx), B, H, W, Cout, Cin, k, k, 1, pad, 0,
+                                            None), 'dgrad_x3')
+        if first is None:
+            first = dx
+        else:
+            assert torch.equal(first, dx), 'data-gradient launch %d differs from launch 0' % rep
+    wantn = want.permute(0, 2, 3, 1) + add.cpu().double()
+    e = float((first.cpu().double() - wantn).abs().max() / wantn.abs().max())
+    assert e < 2e-5, 'dgrad relative-to-max error %.3e' % e
+
+
 def test_error_budget_of_the_six_products(dev):
     """long reductions (K = 4608, layer4) of same-sign terms -- where a systematic bias of the dropped low-order products would
     show -- stay at the exact-fp32 chain's error against float64, and so do operands spread over 12 orders of magnitude."""
