@@ -133,24 +133,23 @@ class KernelTimer:
 
 
 class ClockProbe:
-    """sustained shader clock over a region: straps_clock_probe (one spinning lane, csrc/abi.hip) on its own stream, started just before
-    the region with the region's expected duration.  MHz = shader ticks / wall ticks x wall-clock rate."""
+    """sustained shader clock of the convolution kernels over a region: straps_set_clock_accumulator (csrc/abi.hip) makes workgroup 0 of
+    every implicit-GEMM launch add its shader-clock and wall-clock ticks to a device pair; MHz = ratio x wall-clock rate.  Must be
+    created BEFORE the step is captured into a hipGraph (the pointer is a kernel argument)."""
 
     def __init__(self, dev):
-        self.out = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.stream = torch.cuda.Stream(device=dev)
+        self.acc = torch.zeros(2, dtype=torch.int64, device=dev)
         self.khz = hipabi.lib().straps_wall_clock_khz()
+        hipabi.check(hipabi.lib().straps_set_clock_accumulator(hipabi.ptr(self.acc)), 'straps_set_clock_accumulator')
+        self.base = (0, 0)
 
-    def start(self, seconds):
-        import ctypes
-        seconds = min(max(seconds, 0.002), 5.0)
-        self.out.zero_()
-        self.stream.wait_stream(torch.cuda.current_stream())
-        hipabi.check(hipabi.lib().straps_clock_probe(hipabi.ptr(self.out), float(seconds), ctypes.c_void_p(self.stream.cuda_stream)), 'straps_clock_probe')
+    def start(self):
+        torch.cuda.synchronize()
+        self.base = tuple(int(v) for v in self.acc.tolist())
 
     def mhz(self):
-        self.stream.synchronize()
-        c, w = (int(v) for v in self.out.tolist())
+        torch.cuda.synchronize()
+        c, w = (int(v) - b for v, b in zip(self.acc.tolist(), self.base))
         return round(c / w * self.khz / 1e3, 1) if w > 0 and self.khz > 0 else None
 
 
@@ -286,6 +285,7 @@ def main():
         ranks_seen = int(ones.item())
         assert ranks_seen == world, 'only %d of %d ranks joined the process group' % (ranks_seen, world)
     hipabi.load()
+    probe = ClockProbe(dev)        # (before anything is captured into a hipGraph: the accumulator is a kernel argument)
 
     B = args.batch or (65536 if args.workload == 'smpl' else 64)
     mp = straps_amd.synthetic_mean_params(0)
@@ -364,18 +364,13 @@ def main():
     else:
         run = step
     torch.cuda.synchronize()
-    tw = time.perf_counter()
-    run()
-    torch.cuda.synchronize()
-    step_guess = time.perf_counter() - tw          # one step, host-timed: sizes the clock probe's spin
-    probe = ClockProbe(dev)
     if args.workload == 'train':
         ts.time_exchange, ts.exchange_events = True, []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     timer.on = not graph_mode          # a replayed graph makes no Python-side launches: kernels are timed in the pass below
-    probe.start(0.85 * step_guess * args.steps)    # (one lane on a side stream; ends inside the region)
+    probe.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
@@ -400,12 +395,10 @@ def main():
             ts.use_graph = False
             ts.side_stream = None          # one stream: kernels run back to back, so each event pair times ONE kernel alone
             ts.pipeline = False            # (and no next-batch generation running beside the timed kernels)
-        tw = time.perf_counter()
         step()
         torch.cuda.synchronize()
-        eager_guess = time.perf_counter() - tw
         timer.on = True
-        probe.start(0.85 * eager_guess * args.steps)
+        probe.start()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -533,8 +526,9 @@ def main():
                           'input': 'theta(24x3x3), beta(10)' if args.workload == 'smpl' else '18x256x256 fp32 NCHW proxy built on the device by the step itself (rendered part silhouette + 17 joint heat-maps, ~98 % exact zeros as in the reference pipeline)',
                           'parallelism': par},
                'roofline': roof, 'kernels': others, 'cpu_baseline': cpu,
-               'sclk_mhz': sclk_mhz, 'sclk_note': 'sustained shader clock over the timed region (s_memtime / s_memrealtime of one spinning lane on a side '
-                                                  'stream; spec 2400): the chip clocks to its power budget, boards differ by several per cent'}
+               'sclk_mhz': sclk_mhz, 'sclk_note': 'shader clock the implicit-GEMM convolution kernels ran at over the timed region (s_memtime / s_memrealtime '
+                                                  'ticks of workgroup 0 of every launch; spec 2400; null for workloads without convolutions): the chip clocks '
+                                                  'to its power budget, boards differ by several per cent'}
         if rank_ms is not None:
             out['ranks'] = rank_ms
         if reduced is not None:

@@ -37,11 +37,12 @@ int straps_selftest_mfma_peak(const float* seed512, float* out, int blocks, int 
 const char* straps_last_error(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int straps_device_count(void);
-/* measurement aid (bench.py `sclk_mhz`; no reference counterpart): one lane spins for `spin_seconds` of wall time (<= 5 s) on `stream`
- * and writes out2[0] = shader-clock ticks, out2[1] = constant-rate wall ticks that passed; sustained shader clock in MHz =
- * out2[0] / out2[1] * straps_wall_clock_khz() / 1000.  Launch it on a side stream across the region whose clock is wanted. */
+/* measurement aid (bench.py `sclk_mhz`; no reference counterpart): with acc2 != NULL (a zeroed device pair of 64-bit counters),
+ * workgroup 0 of every implicit-GEMM convolution launched AFTERWARDS (incl. launches captured into a hipGraph afterwards) adds the
+ * shader-clock ticks and the constant-rate wall ticks of its lifetime to acc2[0] / acc2[1]; sustained shader clock in MHz =
+ * acc2[0] / acc2[1] * straps_wall_clock_khz() / 1000.  NULL switches it off (the default: library use pays nothing).              */
 int straps_wall_clock_khz(void);
-int straps_clock_probe(unsigned long long* out2, double spin_seconds, void* stream);
+int straps_set_clock_accumulator(unsigned long long* acc2);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder -- replaces nn.Conv2d / nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d / AdaptiveAvgPool2d as
@@ -67,8 +68,13 @@ typedef struct {
 } straps_pack_desc_t;
 int straps_pack_conv_weights_batched(const straps_pack_desc_t* descs, int n, long long total,
                                      void* stream);
-/* the same launch for the bf16x3 route: the three bf16 planes [3][plane_stride] of the packed layouts (element `first` +
- * offset inside the layer; see straps_split3_bf16) are written in the same pass -- no split pass over the packed weights.
+/* the same launch for the bf16x3 route: the three bf16 planes [3][plane_stride] of the two packed layouts are written in the same
+ * pass -- no split pass over the packed weights.  Planes are CHUNK-MAJOR (what straps_conv_fwd_x3 / straps_conv_dgrad_x3 read):
+ * inside a layer's slot (element `first` ..) the weight of GEMM row `row`, tap `tap`, reduction index k sits at
+ *     ((tap * (K / 32) + k / 32) * rows + row) * 32 + k % 32
+ * with (row, k, rows, K) = (cout, cin, Cout, Cin) for the forward planes and (cin, cout, Cin, Cout) with flipped taps for the
+ * data-gradient planes: the 64 bytes of one 32-wide K chunk of one row lie next to the neighbouring rows' (whole 128-byte lines
+ * per LDS-DMA fetch).  A layer's planes are written only if its K is a multiple of 32 (others cannot run on this route).
  * Either plane buffer may be NULL; dst_krsc / dst_crsk of a descriptor may be NULL when only the planes are consumed.       */
 int straps_pack_conv_weights_batched_x3(const straps_pack_desc_t* descs, int n, long long total,
                                         unsigned short* krsc_planes, unsigned short* crsk_planes,
@@ -83,6 +89,12 @@ int straps_pack_stem_weight(const float* w_oihw, float* w_frag, int cin, void* s
  * shift = beta - mean*scale.                                                                  */
 int straps_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                    float eps, float* scale, float* shift, int c, void* stream);
+/* the same fold plus the statistics as the training-mode kernels take them (save_mean = mean, save_invstd = 1/sqrt(var+eps)):
+ * an eval-mode BatchNorm that must back-propagate (nn.BatchNorm2d in .eval() with requires_grad parameters -- fine-tuning with
+ * frozen statistics) runs the training-mode kernels on these vectors, with bit 1 of the backward entry points' `accumulate`. */
+int straps_bn_fold_stats(const float* gamma, const float* beta, const float* mean, const float* var,
+                         float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                         int c, void* stream);
 
 /* diagnostics: with tile_cfg bit 5 set, straps_conv_fwd / straps_conv_dgrad run a build of the implicit-GEMM kernel whose
  * wave 0 of every workgroup writes 8 shader-clock sums (copy wait, barrier, copy issue, MFMA burst, chunks, total, prologue,
@@ -152,6 +164,28 @@ int straps_pad_copy(const float* src, int ld_src, int col0, int rows, int cols, 
                     int ld_dst, int rows_pad, void* stream);
 /* broadcast the initial estimate (models/ief_module.py:50-52): est[m][0..157) = init, pad = 0  */
 int straps_broadcast_rows(const float* row, int cols, float* dst, int ld_dst, int m, void* stream);
+/* the three repacked weight views the IEF kernels read, one launch (replaces three straps_pad_copy calls per parameter update):
+ * fc1.weight [h1][f + p] -> w1f [h1][f] (feature columns) and w1e [h1][ld_e] (estimate columns, zero padded to ld_e >= p);
+ * fc3.weight [p][h2] -> w3 [p rounded up to 32][h2] (zero rows).  models/ief_module.py:16-18,54.                             */
+int straps_ief_pack(const float* fc1_w, const float* fc3_w, float* w1f, float* w1e, float* w3, int f, int p,
+                    int h1, int h2, int ld_e, void* stream);
+/* up to STRAPS_GEMM_MULTI_MAX small strided fp32-MFMA GEMMs in ONE launch (backward of the IEF's nn.Linear layers,
+ * models/ief_module.py:55-58 differentiated): per problem
+ *     v[m][n] = sum_k a[m*sam + k*sak] * b[k*sbk + n*sbn]  (+ addend[m*ldadd + n])  (then 0 where mask[m*ldmask + n] <= 0)
+ *     c[m*ldc + n] (+)= v ;  c2[m*ldc2 + n] (+)= v   (c2 optional)
+ * The descriptors are HOST memory (copied into the kernel arguments).  With the three iterations' activations stacked
+ * row-wise, a weight gradient is ONE problem with k = 3 x batch, a bias gradient the same with a = a single 1.0f (sam = sak = 0). */
+#define STRAPS_GEMM_MULTI_MAX 8
+typedef struct {
+    const float* a; long long sam, sak;
+    const float* b; long long sbk, sbn;
+    float* c; int32_t ldc, accumulate;
+    const float* addend; int32_t ldadd, reserved0;
+    const float* mask; int32_t ldmask, reserved1;
+    float* c2; int32_t ldc2, accumulate2;
+    int32_t m, n, k, reserved2;
+} straps_gemm_desc_t;
+int straps_gemm_multi(const straps_gemm_desc_t* descs_host, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pose representation -- utils/rigid_transform_utils.py:27-41 and smplx.lbs.batch_rodrigues.
@@ -162,6 +196,18 @@ int straps_rot6d_fwd(const float* x6, long long ld, int per_row, float* rotmats,
                      void* stream);
 /* axis-angle [n][3] -> R [n][3][3] (angle = ||r + 1e-8||).                                      */
 int straps_rodrigues_fwd(const float* aa, float* rotmats, long long n, void* stream);
+/* utils/cam_utils.py:5-26 orthographic_project_torch: points [batch][n][3], cam rows [s, tx, ty] (row stride ld_cam)
+ * -> out [batch][n][2] = s * (x + tx, y + ty); and its gradient (dpoints [batch][n][3] and / or dcam [batch][3]; per-body
+ * sums in a fixed order).                                                                          */
+int straps_orthographic_project(const float* points, const float* cam, int ld_cam, float* out,
+                                long long batch, int n, void* stream);
+int straps_orthographic_project_bwd(const float* points, const float* cam, int ld_cam, const float* dout,
+                                    float* dpoints, float* dcam, long long batch, int n, void* stream);
+/* utils/cam_utils.py:40-71 perspective_project_torch: p = R x + t, p /= p_z, out = (K p)[:2]; rotation [batch][3][3],
+ * translation [batch][3], cam_k one [3][3] (k_per_body = 0) or [batch][3][3] (k_per_body = 1) -> out [batch][n][2].           */
+int straps_perspective_project(const float* points, const float* rotation, const float* translation,
+                               const float* cam_k, int k_per_body, float* out, long long batch, int n,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * SMPL forward -- models/smpl_official.py:27-41 -> smplx.SMPL.forward -> smplx.lbs.lbs.
@@ -283,18 +329,26 @@ int straps_conv_dgrad(const float* dy_nhwc, const float* w_crsk, const float* ad
  * relative error <= ~2^-23 per product, the accuracy class of the fp32 chain, at 2.67x its
  * matrix-pipe rate.  planes: [3][plane_stride] bf16 bit patterns (uint16), plane_stride >= n,
  * a multiple of 8.  Geometry / epilogue arguments exactly as straps_conv_fwd /
- * straps_conv_dgrad; x3 / dy3 are the planes of the NHWC tensor, w3 the planes of the packed
- * weights (straps_pack_conv_weight / straps_pack_conv_weight_dgrad output).
+ * straps_conv_dgrad; x3 / dy3 are the CHUNK-MAJOR planes of the NHWC tensor [rows = B*H*W][C]:
+ * element (row, c) at ((c / 32) * rows + row) * 32 + c % 32 -- 32-channel chunks outermost, so the 64 bytes
+ * one K chunk of a pixel contributes lie next to the neighbouring pixels' and an LDS-DMA fetch of a chunk
+ * for 16 rows reads 1 KiB of whole 128-byte lines (plain NHWC planes made the same fetch touch half of each
+ * of 16 lines: 16-18 vs 31-36 TB/s of useful L2 -> LDS bytes, tools/l2_line_probe.hip); written by
+ * straps_split3_bf16_cm and the fused producers below.  w3: the chunk-major weight planes of
+ * straps_pack_conv_weights_batched_x3.
  * tile_cfg: 0 = auto (incl. the halo-patch kernel for 3x3 / stride-1 layers: the tile's input patch is
- * copied once per channel chunk and the nine taps are shifted LDS addresses), 1..14 = explicit tiles
- * of the im2col kernel (8..12: software-pipelined loop; 13 / 14: 128x64 / 256x64 tiles whose A operand goes straight from
- * L2 into registers, 64-channel outputs; csrc/conv_x3.hip), + 256 = auto without the
+ * copied once per channel chunk and the nine taps are shifted LDS addresses), 1..12 = explicit tiles
+ * of the im2col kernel (8..12: software-pipelined loop; csrc/conv_x3.hip), + 256 = auto without the
  * halo-patch kernel, + 512 = the two-buffer halo-patch kernel wherever it applies, + 1024 = the single-buffer one (the rule for
  * 64-channel outputs); bits 6 / 7 select
  * measurement builds with wrong results (no MFMAs / no operand copies; tools/pmc_x3.sh).
  * ------------------------------------------------------------------------------------------ */
+/* plain split of n values, planes in the order of x (any fp32 array; the exactness tests)                  */
 int straps_split3_bf16(const float* x, unsigned short* planes, long long n, long long plane_stride,
                        void* stream);
+/* split of an NHWC tensor [rows][c] (c % 32 == 0) into the chunk-major planes the convolutions read       */
+int straps_split3_bf16_cm(const float* x, unsigned short* planes, long long rows, int c,
+                          long long plane_stride, void* stream);
 /* statistics partials of straps_conv_fwd_x3 for this geometry: [blocks][cout][2]                          */
 int straps_conv_x3_stat_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride,
                                int pad, int tile_cfg);
@@ -377,7 +431,10 @@ int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_oihw,
  * may alias dy) receives dz for the skip connection.  When the activation was exactly
  * relu(raw*scale + shift) (no residual), pass yact = NULL and the forward's scale/shift as
  * mask_scale/mask_shift: the mask is then recomputed from raw with the forward's fmaf (bit-identical,
- * one tensor read less); both NULL with yact NULL = no ReLU.                                        */
+ * one tensor read less); both NULL with yact NULL = no ReLU.
+ * `accumulate` (here and in straps_bn_bwd_x3 / _finish_x3 / _pooled[_sparse]) is a flag word: bit 0 = add to dgamma / dbeta,
+ * bit 1 = FROZEN statistics (eval-mode BatchNorm, models/resnet.py:47 under .eval(): save_mean / save_invstd are constants, the
+ * two mean terms vanish: draw = gamma*invstd*dz; dgamma = sum dz*xhat and dbeta = sum dz as before).                          */
 int straps_bn_bwd_blocks(long long rows, int c);
 size_t straps_bn_bwd_workspace_bytes(long long rows, int c);
 int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean,
@@ -440,6 +497,10 @@ int straps_rot6d_bwd(const float* x6, long long ld, int per_row, const float* dr
  * (int-truncated) joints2d [B,nj,2]; writes the NCHW network input [B,1+nj,wh,wh].                */
 int straps_build_proxy_input(const float* seg, const float* joints2d, float* out_nchw, int batch,
                              int nj, int wh, void* stream);
+/* the same with the heat-maps' standard deviation as an argument (utils/label_conversions.py:90: `std`, an integer; the patch is
+ * 4 std x 4 std samples of torch.linspace(-2 std, 2 std, 4 std)); straps_build_proxy_input is std = 4, the value of every call site. */
+int straps_build_proxy_input_std(const float* seg, const float* joints2d, float* out_nchw, int batch,
+                                 int nj, int wh, int std, void* stream);
 /* prediction heads + HomoscedasticUncertaintyWeightedMultiTaskLoss (losses/multi_task_loss.py:76-119,
  * reduction 'mean') fused with its own backward.  From pred joints [B,90,3], cam [B,3] (row
  * stride ld_est) it forms joints2D = orthographic projection of the 17 COCO joints

@@ -90,18 +90,19 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True
         ps = (raw.numel() + 7) // 8 * 8
         planes = torch.empty(3, ps, device=raw.device, dtype=torch.int16)
         planes_sink[id(draw)] = (draw, planes, ps)
+    flags = 2 if rec.get('frozen') else 0         # bit 1: eval-mode BatchNorm, statistics are constants (encoder_exec._bn_train_finish)
     fused = rec.pop('bwd_partials', None)         # (partials, blocks, dy they belong to): the sums came out of the data gradient's epilogue
     if fused is not None and fused[2] is dy and masked:
         hipabi.check(L.straps_bn_bwd_finish_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
                                                hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
                                                hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta),
                                                hipabi.ptr(draw if keep_fp32 else None), hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(fused[0]),
-                                               fused[1], hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd_finish_x3')
+                                               fused[1], hipabi.ptr(ws), rows, Cc, flags, hipabi.stream_ptr()), 'straps_bn_bwd_finish_x3')
     else:
         hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if masked and not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
                                         hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
                                         hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta), hipabi.ptr(draw if keep_fp32 else None),
-                                        hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(ws), rows, Cc, 0, hipabi.stream_ptr()), 'straps_bn_bwd')
+                                        hipabi.ptr(dz), hipabi.ptr(planes), ps, hipabi.ptr(ws), rows, Cc, flags, hipabi.stream_ptr()), 'straps_bn_bwd')
     grads[bn.weight] = dgamma
     grads[bn.bias] = dbeta
     return draw, dz
@@ -228,8 +229,8 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
                          'straps_stem_tile_activity')
         hipabi.check(L.straps_bn_bwd_pooled_sparse(hipabi.ptr(dy), hipabi.ptr(idx), hipabi.ptr(raw), hipabi.ptr(ss[2]), hipabi.ptr(ss[3]),
                                                    hipabi.ptr(bn.weight), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(dgamma), hipabi.ptr(dbeta),
-                                                   hipabi.ptr(draw), hipabi.ptr(ws), B, H, W, Cc, 0, hipabi.ptr(tact), hipabi.stream_ptr()),
-                     'straps_bn_bwd_pooled_sparse')
+                                                   hipabi.ptr(draw), hipabi.ptr(ws), B, H, W, Cc, 2 if rec.get('frozen') else 0, hipabi.ptr(tact),
+                                                   hipabi.stream_ptr()), 'straps_bn_bwd_pooled_sparse')
         grads[bn.weight] = dgamma
         grads[bn.bias] = dbeta
     else:
@@ -250,48 +251,49 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
 
 # ------------------------------------------------------------------------------------------ IEF
 def ief_backward(ief, feat, tape, dest, views=None):
-    """dest: gradient w.r.t. the final estimate [B,160].  Returns (dfeat, {param: grad})."""
+    """dest: gradient w.r.t. the final estimate [B,160].  Returns (dfeat, {param: grad}).
+    Launches: one copy of dest into its slot, three small GEMMs per iteration (the dependent chain: ReLU masks, the `est_out = est_in + ...`
+    addend and the running sum dc1 fused into their epilogues), then ONE launch with every weight / bias gradient and the feature
+    gradient -- a weight gradient is a single GEMM over the three iterations' stacked rows (K = 3 B), a bias gradient the same against
+    a constant one (straps_gemm_multi)."""
     sink = GradSink(views)
     L, st = hipabi.lib(), hipabi.stream_ptr()
     pk = ief._packed(feat.device)
     B, F = feat.shape
     H1, H2, P = ief.fc1.out_features, ief.fc2.out_features, ief.num_output_params
     dev = feat.device
-    z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+    T = len(tape)
     e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-    dW3, db3 = sink.buf(ief.fc3.weight, True), sink.buf(ief.fc3.bias, True)
-    dW2, db2 = sink.buf(ief.fc2.weight, True), sink.buf(ief.fc2.bias, True)
-    dW1 = sink.buf(ief.fc1.weight, True)
-    dc1 = z(B, H1)
-    dest = dest.contiguous().clone()
-    gemm, colsum = L.straps_gemm_strided, L.straps_colsum
-    for it in reversed(range(len(tape))):
-        rec = tape[it]
-        est_in, h1, h2 = rec['est_in'], rec['h1'], rec['h2']
-        # est_out = est_in + h2 @ W3^T + b3
-        dh2 = e(B, H2)
-        hipabi.check(gemm(hipabi.ptr(dest), EST_LD, 1, hipabi.ptr(ief.fc3.weight), H2, 1, hipabi.ptr(dh2), H2, hipabi.ptr(h2), H2, B, H2, P, 0, st),
-                     'ief d_h2')                                   # masked by relu(h2) > 0  -> d pre-activation of fc2
-        hipabi.check(gemm(hipabi.ptr(dest), 1, EST_LD, hipabi.ptr(h2), H2, 1, hipabi.ptr(dW3), H2, None, 0, P, H2, B, 1, st), 'ief dW3')
-        hipabi.check(colsum(hipabi.ptr(dest), EST_LD, None, 0, hipabi.ptr(db3), B, P, 1, st), 'ief db3')
-        # h2 = relu(h1 @ W2^T + b2): dh2 already masked
-        dh1 = e(B, H1)
-        hipabi.check(gemm(hipabi.ptr(dh2), H2, 1, hipabi.ptr(ief.fc2.weight), H1, 1, hipabi.ptr(dh1), H1, hipabi.ptr(h1), H1, B, H1, H2, 0, st),
-                     'ief d_h1')                                   # masked by relu(h1) > 0
-        hipabi.check(gemm(hipabi.ptr(dh2), 1, H2, hipabi.ptr(h1), H1, 1, hipabi.ptr(dW2), H1, None, 0, H2, H1, B, 1, st), 'ief dW2')
-        hipabi.check(colsum(hipabi.ptr(dh2), H2, None, 0, hipabi.ptr(db2), B, H2, 1, st), 'ief db2')
-        # h1 = relu(c1 + est_in @ W1e^T): dh1 is d pre-activation
-        hipabi.check(L.straps_masked_copy(hipabi.ptr(dh1), H1, None, 0, hipabi.ptr(dc1), H1, B, H1, 1, st), 'ief dc1')
-        hipabi.check(gemm(hipabi.ptr(dh1), H1, 1, hipabi.ptr(pk['w1e']), EST_LD, 1, hipabi.ptr(dest), EST_LD, None, 0, B, P, H1, 1, st),
-                     'ief d_est')                                  # dest += dh1 @ W1e  (est_out = est_in + ...)
-        hipabi.check(gemm(hipabi.ptr(dh1), 1, H1, hipabi.ptr(est_in), EST_LD, 1, C.c_void_p(dW1.data_ptr() + 4 * F), F + P, None, 0, H1, P, B,
-                          1, st), 'ief dW1e')
-    # c1 = feat @ W1f^T + b1
+    D = hipabi.gemm_desc
+    ests, h1s, h2s = tape[0]['stacks']
+    assert ests.shape == (T + 1, B, EST_LD) and h1s.shape == (T, B, H1) and h2s.shape == (T, B, H2)
+    dW3, db3 = sink.buf(ief.fc3.weight), sink.buf(ief.fc3.bias)
+    dW2, db2 = sink.buf(ief.fc2.weight), sink.buf(ief.fc2.bias)
+    dW1, db1 = sink.buf(ief.fc1.weight), sink.buf(ief.fc1.bias)
+    # dests[it + 1] = gradient w.r.t. the estimate iteration it wrote (slot T = the incoming gradient), dests[0] = w.r.t. the initial one
+    dests = e(T + 1, B, EST_LD)
+    dsrc = dest if dest.stride(-1) == 1 and dest.dim() == 2 else dest.contiguous()
+    hipabi.check(L.straps_masked_copy(hipabi.ptr(dsrc), dsrc.stride(0), None, 0, hipabi.ptr(dests[T]), EST_LD, B, EST_LD, 0, st), 'ief dest slot')
+    dh2s, dh1s, dc1 = e(T, B, H2), e(T, B, H1), e(B, H1)
+    w3, w2 = ief.fc3.weight, ief.fc2.weight
+    for it in reversed(range(T)):
+        # est_out = est_in + relu(h2pre) @ W3^T + b3;  h2 = relu(h1 @ W2^T + b2);  h1 = relu(c1 + est_in @ W1e^T)
+        hipabi.gemm_multi([D(dests[it + 1], EST_LD, 1, w3, H2, 1, dh2s[it], H2, B, H2, P, mask=h2s[it], ldmask=H2)])            # d pre-activation of fc2
+        hipabi.gemm_multi([D(dh2s[it], H2, 1, w2, H1, 1, dh1s[it], H1, B, H1, H2, mask=h1s[it], ldmask=H1,
+                             c2=dc1, ldc2=H1, accumulate2=int(it != T - 1))])                                                   # d pre-activation of fc1 (+ its sum over iterations)
+        hipabi.gemm_multi([D(dh1s[it], H1, 1, pk['w1e'], EST_LD, 1, dests[it], EST_LD, B, P, H1, addend=dests[it + 1], ldadd=EST_LD)])
+    one = pk['one']
     dfeat = e(B, F)
-    hipabi.check(gemm(hipabi.ptr(dc1), H1, 1, hipabi.ptr(pk['w1f']), F, 1, hipabi.ptr(dfeat), F, None, 0, B, F, H1, 0, st), 'ief d_feat')
-    hipabi.check(gemm(hipabi.ptr(dc1), 1, H1, hipabi.ptr(feat), F, 1, hipabi.ptr(dW1), F + P, None, 0, H1, F, B, 1, st), 'ief dW1f')
-    db1 = sink.buf(ief.fc1.bias, True)
-    hipabi.check(colsum(hipabi.ptr(dc1), H1, None, 0, hipabi.ptr(db1), B, H1, 1, st), 'ief db1')
+    KB = T * B
+    hipabi.gemm_multi([
+        D(dh2s, 1, H2, h1s, H1, 1, dW2, H1, H2, H1, KB),                                                  # dW2 = sum_it dh2^T h1
+        D(dc1, 1, H1, feat, F, 1, dW1, F + P, H1, F, B),                                                   # dW1[:, :F] = dc1^T feat
+        D(dh1s, 1, H1, ests, EST_LD, 1, dW1.data_ptr() + 4 * F, F + P, H1, P, KB),                          # dW1[:, F:] = sum_it dh1^T est_in (slots 0..T-1)
+        D(dests[1], 1, EST_LD, h2s, H2, 1, dW3, H2, P, H2, KB),                                            # dW3 = sum_it dest_out^T h2 (slots 1..T)
+        D(dc1, H1, 1, pk['w1f'], F, 1, dfeat, F, B, F, H1),                                                # dfeat = dc1 @ W1f
+        D(one, 0, 0, dh2s, H2, 1, db2, H2, 1, H2, KB),
+        D(one, 0, 0, dests[1], EST_LD, 1, db3, P, 1, P, KB),
+        D(one, 0, 0, dc1, H1, 1, db1, H1, 1, H1, B)])
     grads = {ief.fc1.weight: dW1, ief.fc1.bias: db1, ief.fc2.weight: dW2, ief.fc2.bias: db2, ief.fc3.weight: dW3, ief.fc3.bias: db3}
     return dfeat, grads
 
@@ -322,9 +324,7 @@ class _RegressorFn(torch.autograd.Function):
 
 def regressor_autograd(reg, x):
     hipabi.require_gpu_tensor(x, 'regressor input', torch.float32)
-    if not reg.training:
-        raise RuntimeError('gradients through the encoder are implemented for training-mode BatchNorm only; call .train() '
-                           '(or torch.no_grad() for inference)')
+    # (eval mode: BatchNorm back-propagates through its running statistics as constants, like nn.BatchNorm2d -- models/resnet.py:47,147)
     params = list(reg.parameters())
     est = _RegressorFn.apply(reg, x, *params)
     P = reg.ief_module.num_output_params

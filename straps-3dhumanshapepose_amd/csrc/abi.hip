@@ -40,22 +40,12 @@ extern "C" int straps_selftest_mfma_peak(const float* seed512, float* out, int b
     return STRAPS_OK;
 }
 
-// ---- sustained shader clock: ONE lane spins for a given wall time next to whatever else runs on the chip and reports how many
-// shader-clock ticks (s_memtime: one per shader cycle, it follows DVFS) passed per constant-rate wall tick (s_memrealtime).  bench.py
-// launches it on a side stream across its timed region: the chip clocks to its power budget, so the same binary reads 8 % apart on
-// two boards -- this number says which part of a difference is the board's clock.
-__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, unsigned long long spin_wall_ticks) {
-    if (threadIdx.x != 0) return;
-    const unsigned long long w0 = wall_clock64(), c0 = clock64();
-    unsigned long long w1 = w0;
-    while (w1 - w0 < spin_wall_ticks) {
-        __builtin_amdgcn_s_sleep(64);
-        w1 = wall_clock64();
-    }
-    const unsigned long long c1 = clock64();
-    out[0] = c1 - c0;
-    out[1] = w1 - w0;
-}
+// ---- sustained shader clock of the convolution kernels: with an accumulator set, workgroup 0 of every implicit-GEMM launch adds the
+// shader-clock ticks (s_memtime: one per shader cycle, it follows DVFS) and the constant-rate wall ticks (s_memrealtime) of its lifetime
+// to the pair; MHz = ticks ratio x wall-clock rate.  The chip clocks to its power budget, so the same binary reads several per cent
+// apart on two boards -- bench.py reports this number so that a difference can be attributed.  (A lane spinning on a side stream, the
+// first form of this probe, stalled whatever stream shared its hardware queue.)
+unsigned long long* g_straps_clk_acc = nullptr;
 
 extern "C" int straps_wall_clock_khz(void) {
     int dev = 0, khz = 0;
@@ -64,12 +54,8 @@ extern "C" int straps_wall_clock_khz(void) {
     return khz;
 }
 
-extern "C" int straps_clock_probe(unsigned long long* out2, double spin_seconds, void* stream) {
-    STRAPS_REQUIRE(out2 && spin_seconds > 0.0 && spin_seconds <= 5.0, "straps_clock_probe: need an output pair and 0 < spin_seconds <= 5");
-    const int khz = straps_wall_clock_khz();
-    STRAPS_REQUIRE(khz > 0, "straps_clock_probe: the device reports no wall-clock rate");
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, (unsigned long long)(spin_seconds * 1e3 * khz));
-    STRAPS_CHECK_LAUNCH("clock_probe_kernel");
+extern "C" int straps_set_clock_accumulator(unsigned long long* acc2) {
+    g_straps_clk_acc = acc2;          // (kernel arguments are fixed at launch / graph-capture time: set it before capturing)
     return STRAPS_OK;
 }
 

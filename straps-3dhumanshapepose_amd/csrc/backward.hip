@@ -333,6 +333,7 @@ struct Wgrad3XP {
     int H, W, Cin, Cout;
     int cw, cw_log2, rpc;
     int chunks_per_row, chunk_rows_per_img, nchunks, chunks_per_split, it;
+    long long rows;                  // B * H * W: pixels of x and of dy (stride 1), the chunk stride of their chunk-major planes
 };
 
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
@@ -396,20 +397,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
 
     // copy slots at step 0: round q of this wave copies pixels (q*4 + wave) * PW .. of the tile; a lane's 16-byte slot j = lane % LP
     // of pixel row px receives channel group ((j >> 2) ^ swz(px)) * 4 + (j & 3)
-    int md[RDD], gd[RDD];
-    int mx[RDX], gx[RDX], wo_[RDX], ho_[RDX], b_[RDX];
+    // (chunk-major planes, common.h: channel c of pixel row m sits at ((c >> 5) * rows + m) * 32 + (c & 31); gd / gx = the chunk's
+    //  base + the 16-byte piece inside it, fixed per lane)
+    int md[RDD];
+    long long gd[RDD], gx[RDX];
+    int mx[RDX], wo_[RDX], ho_[RDX], b_[RDX];
+    const long long xrows = (long long)p.B * p.H * p.W;
 #pragma unroll
     for (int q = 0; q < RDD; ++q) {
         const int px = (q * 4 + wave) * PWD + lane / LPD, j = lane % LPD;
         md[q] = mbeg + px;
-        gd[q] = ((((j >> 2) ^ seg_swz<BCO>(px)) << 2) | (j & 3)) * 8;
+        const int c = co0 + ((((j >> 2) ^ seg_swz<BCO>(px)) << 2) | (j & 3)) * 8;
+        gd[q] = (long long)(c >> 5) * p.M * 32 + (c & 31);
     }
 #pragma unroll
     for (int q = 0; q < RDX; ++q) {
         const int px = (q * 4 + wave) * PWX + lane / LPX, j = lane % LPX;
         const int m = mbeg + px;
         mx[q] = m;
-        gx[q] = ((((j >> 2) ^ seg_swz<BCI>(px)) << 2) | (j & 3)) * 8;
+        const int c = ci0 + ((((j >> 2) ^ seg_swz<BCI>(px)) << 2) | (j & 3)) * 8;
+        gx[q] = (long long)(c >> 5) * xrows * 32 + (c & 31);
         const int HoWo = p.Ho * p.Wo;
         b_[q] = m / HoWo;
         const int rem = m - b_[q] * HoWo;
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
 #pragma unroll
         for (int q = 0; q < RDD; ++q) {
             const bool in = md[q] < mend;
-            const u16* src = in ? p.dy3 + (long long)md[q] * p.Cout + co0 + gd[q] : zsrc;
+            const u16* src = in ? p.dy3 + (long long)md[q] * 32 + gd[q] : zsrc;
             const long long ps = in ? p.dps : 0;
             md[q] += 32;
 #pragma unroll
@@ -436,11 +443,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
             bool in = mx[q] < mend;
             const u16* src = zsrc;
             if (pointwise) {
-                if (in) src = p.x3 + (long long)mx[q] * p.Cin + ci0 + gx[q];
+                if (in) src = p.x3 + (long long)mx[q] * 32 + gx[q];
             } else {
                 const int hi = ho_[q] * p.stride - p.pad + r, wi = wo_[q] * p.stride - p.pad + s;
                 in = in && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                if (in) src = p.x3 + (((long long)b_[q] * p.H + hi) * p.W + wi) * p.Cin + ci0 + gx[q];
+                if (in) src = p.x3 + (((long long)b_[q] * p.H + hi) * p.W + wi) * 32 + gx[q];
                 wo_[q] += adv_w; ho_[q] += adv_h;
                 if (wo_[q] >= p.Wo) { wo_[q] -= p.Wo; ++ho_[q]; }
                 if (ho_[q] >= p.Ho) { const int k = ho_[q] / p.Ho; ho_[q] -= k * p.Ho; b_[q] += k; }
@@ -556,19 +563,22 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
     // The five rounds of a chunk (dy tile, four patch rounds) alternate between the groups when NG = 2.
     const int lp = (tid & 255) >> 3, ls = tid & 7;
     const int d_g = ls ^ (((lp >> 1) & 1) << 2);           // (bit 1 of lp + 32 q is bit 1 of lp)
-    int d_off[DR];
+    // (chunk-major planes, common.h: a 64-channel row is two 64-byte pieces, one in each of two 32-channel chunks)
+    long long d_off[DR];
 #pragma unroll
     for (int q = 0; q < DR; ++q) {
         const int px = lp + 32 * q;
-        d_off[q] = ((px >> p.cw_log2) * p.W + (px & (p.cw - 1))) * p.Cout + co0 + d_g * 8;
+        d_off[q] = ((long long)((co0 >> 5) + (d_g >> 2)) * p.rows + (px >> p.cw_log2) * p.W + (px & (p.cw - 1))) * 32 + (d_g & 3) * 8;
     }
-    int x_pr[XR], x_pc[XR], x_g[XR];
+    int x_pr[XR], x_pc[XR];
+    long long x_g[XR];
 #pragma unroll
     for (int q = 0; q < XR; ++q) {
         const int pp = lp + 32 * q;
         x_pr[q] = pp / pw - 1;
         x_pc[q] = pp - (x_pr[q] + 1) * pw - 1;
-        x_g[q] = ls ^ (((pp >> 1) & 1) << 2);
+        const int g = ls ^ (((pp >> 1) & 1) << 2);
+        x_g[q] = (long long)((ci0 >> 5) + (g >> 2)) * p.rows * 32 + (g & 3) * 8;
     }
     auto dma_chunk = [&](int c, int stage) {
         const int per_img = p.chunk_rows_per_img * p.chunks_per_row;
@@ -578,8 +588,8 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
         const int ho0 = cr * p.rpc, wo0 = cc * p.cw;
         u16* D = smem + stage * STAGE;
         u16* X = D + 3 * DPX * 64;
-        const u16* dbase = p.dy3 + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cout;
-        const u16* xsrc = p.x3 + ((long long)(b * p.H + ho0) * p.W + wo0) * p.Cin + ci0;
+        const u16* dbase = p.dy3 + ((long long)(b * p.H + ho0) * p.W + wo0) * 32;
+        const u16* xsrc = p.x3 + ((long long)(b * p.H + ho0) * p.W + wo0) * 32;
 #pragma unroll
         for (int q = 0; q < DR; ++q) {
             if (NG > 1 && (q & 1) != grp) continue;          // the copy rounds of a chunk (dy rounds, then patch rounds) alternate between the groups
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
             if (NG > 1 && ((q + DR) & 1) != grp) continue;
             const int hi = ho0 + x_pr[q], wi = wo0 + x_pc[q];
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;     // (slots past the patch read anything)
-            const u16* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * p.Cin + x_g[q] * 8 : zsrc;
+            const u16* src = ok ? xsrc + (x_pr[q] * p.W + x_pc[q]) * 32 + x_g[q] : zsrc;
             const long long ps = ok ? p.xps : 0;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
@@ -1282,7 +1292,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         }
         if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = g;
         if (draw) *reinterpret_cast<f32x4*>(draw + idx * 4) = o;      // (NULL: only the planes are consumed, see straps_bn_bwd_x3)
-        if (planes) store_planes4(planes, pstride, idx * 4, o);      // bf16x3 route: the data-gradient kernel's operand
+        if (planes) store_planes4_cm(planes, pstride, idx / C4, c4 * 4, n4 / C4, o);      // bf16x3 route: the data-gradient kernel's operand (chunk-major planes)
     }
 }
 
@@ -1361,7 +1371,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
         }
         *reinterpret_cast<f32x4*>(y + i * 4) = m;
         *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4((unsigned char)am[0], (unsigned char)am[1], (unsigned char)am[2], (unsigned char)am[3]);
-        if (planes) store_planes4(planes, pstride, i * 4, m);
+        if (planes) store_planes4_cm(planes, pstride, i / C4, c4 * 4, (long long)B * Ho * Wo, m);
     }
 }
 
@@ -1700,6 +1710,7 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         q.H = p3.H; q.W = p3.W; q.Cin = p3.Cin; q.Cout = p3.Cout; q.cw = p3.cw; q.cw_log2 = p3.cw_log2; q.rpc = p3.rpc;
         q.chunks_per_row = p3.chunks_per_row; q.chunk_rows_per_img = p3.chunk_rows_per_img; q.nchunks = p3.nchunks;
         q.chunks_per_split = p3.chunks_per_split; q.it = p3.it;
+        q.rows = (long long)batch * h * w;
         constexpr int W3X_NG = 2;
         hipStream_t st3 = (hipStream_t)stream;
         // 64-pixel chunks where the rows allow it (fewer splits than the 32-pixel plan at most: the shared workspace size covers both)
@@ -1801,6 +1812,12 @@ extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, floa
     return STRAPS_OK;
 }
 
+// `accumulate` of the BatchNorm-backward entry points is a flag word: bit 0 = add to dgamma / dbeta instead of overwriting them, bit 1 =
+// FROZEN statistics (eval-mode BatchNorm: mean / invstd are the running statistics, constants of the graph -- the two mean terms of
+// the training-mode formula vanish: draw = gamma * invstd * dz).  Implemented as an infinite element count: m1 = S1 / N = 0, m2 = S2 / N = 0,
+// dgamma = S2 and dbeta = S1 unchanged.
+static double bn_bwd_count(long long rows, int flags) { return (flags & 2) ? (double)INFINITY : (double)rows; }
+
 // row blocks of the reduction pass: ~2048 blocks in total over (row blocks x 64-channel column blocks), >= 64 rows each
 extern "C" int straps_bn_bwd_blocks(long long rows, int c) {
     const int colblocks = (c + 63) / 64;
@@ -1827,7 +1844,7 @@ extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float*
     float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
@@ -1851,7 +1868,7 @@ extern "C" int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const
     hipStream_t st = (hipStream_t)stream;
     double* coefd = (double*)workspace;              // [2][c]  m1, m2
     float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partials, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partials, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
@@ -1912,7 +1929,7 @@ extern "C" int straps_bn_bwd_pooled_sparse(const float* dy_pool, const uint8_t* 
     (void)rpb;
     hipLaunchKernelGGL(bn_bwd_reduce_pooled_kernel, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, raw, save_mean, save_invstd, mask_scale, mask_shift, part, prows, c, prpb, ps);
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_pooled_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, (double)rows, gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)((n4 + POOL_CHUNK - 1) / POOL_CHUNK)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps);

@@ -12,6 +12,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // error text shared by all translation units (defined in abi.hip)
 void straps_set_error(const char* fmt, ...);
+// device pair the convolution kernels add their (shader ticks, wall ticks) to; NULL unless straps_set_clock_accumulator set it (abi.hip)
+extern unsigned long long* g_straps_clk_acc;
 
 #define STRAPS_REQUIRE(cond, ...)             \
     do {                                      \
@@ -120,6 +122,18 @@ __device__ __forceinline__ void store_planes4(u16* __restrict__ planes, long lon
     *reinterpret_cast<u16x4*>(planes + i) = q1;
     *reinterpret_cast<u16x4*>(planes + ps + i) = q2;
     *reinterpret_cast<u16x4*>(planes + 2 * ps + i) = q3;
+}
+
+// ---- chunk-major plane layout (what every bf16x3 kernel reads): a [rows][C] tensor's plane stores its 32-channel chunks outermost,
+//   element (r, c) at ((c >> 5) * rows + r) * 32 + (c & 31),
+// so that the 64 bytes one K chunk of one pixel contributes sit next to the neighbouring pixels' -- an LDS-DMA instruction that fetches a
+// chunk for 16 consecutive rows reads 1 KiB of whole 128-byte lines.  (In the plain NHWC order of round 2 the same fetch touched HALF of
+// each of 16 lines: tools/l2_line_probe.hip measures 16-18 TB/s of useful L2 -> LDS bytes for that pattern against 31-36 TB/s for whole
+// lines -- the "13 TB/s copy ceiling" of the implicit GEMM was this.)  C % 32 == 0.
+__device__ __forceinline__ long long cm_index(long long r, int c, long long rows) { return ((long long)(c >> 5) * rows + r) * 32 + (c & 31); }
+// four consecutive channels c .. c+3 (c % 4 == 0) of row r -> the three planes
+__device__ __forceinline__ void store_planes4_cm(u16* __restrict__ planes, long long ps, long long r, int c, long long rows, const f32x4& v) {
+    store_planes4(planes, ps, cm_index(r, c, rows), v);
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const ConvP::Class& c = p.cls[blockIdx.y];
     const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, coah = c.oah, coaw = c.oaw, cntaps = c.ntaps;
     if ((int)blockIdx.x >= cMT * p.NT) return;                 // a smaller class of the same launch
+    ClkSample clks;
+    clk_begin(p, clks);
     constexpr int WTM = BM / 2, WTN = BN / 2, MI = WTM / 32, NI = WTN / 32;
     constexpr int AP = BM / 32, BP = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
     }
     igemm_store_stats<BM, BN>(p, s1, s2, mt, n0, smem);
+    clk_end(p, clks);
 }
 
 // tile choice from the per-layer sweeps (tools/sweep_conv.py, tools/sweep_igemm_staging.py, B=64): the larger the tile the fewer

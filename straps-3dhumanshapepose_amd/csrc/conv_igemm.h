@@ -20,6 +20,7 @@ struct ConvP {
     int OH, OW, omul;               // physical output pixel = (b, ho*omul + oah, wo*omul + oaw) in [B][OH][OW][Cout]
     int NT, wtaps;                  // N tiles; taps stored per output channel in w
     long long xps, wps;             // three-plane bf16 operands (conv_x3.hip): elements between the planes of x / of w
+    int xrows, yrows;               // pixels of the source / of the physical output tensor (chunk-major plane addressing, common.h)
     // BatchNorm-backward sums fused into a data gradient's epilogue (conv_x3.hip, straps_conv_dgrad_x3_bn): the tensor this launch
     // writes is the gradient dy entering the BatchNorm (+ ReLU) that produced the convolution's input; its two backward sums
     // S1 = sum mask*dy, S2 = invstd * sum mask*dy*(raw - mean) per channel are accumulated here (double) as one partial per M tile
@@ -36,6 +37,9 @@ struct ConvP {
     // y itself may then be NULL when nothing reads the fp32 tensor
     unsigned short* yplanes;
     long long yps;
+    // measurement aid (straps_set_clock_accumulator; NULL in library use): workgroup 0 of every launch adds the shader-clock and the
+    // constant-rate wall-clock ticks it lived for to clk[0] / clk[1] -- their ratio is the clock the kernel really ran at
+    unsigned long long* clk;
     // Up to four independent sub-problems per launch (blockIdx.y): the output-parity classes of a stride-2 data gradient
     // are GEMMs over a quarter of the pixels each with their own tap subset -- launched together they fill the chip
     // instead of queueing as four small grids.  A forward conv / stride-1 gradient is the single class 0.
@@ -48,6 +52,18 @@ struct ConvP {
     } cls[4];
     int ncls;
 };
+
+struct ClkSample { unsigned long long c0, w0; };
+__device__ __forceinline__ void clk_begin(const ConvP& p, ClkSample& s) {
+    s.c0 = 0; s.w0 = 0;
+    if (p.clk) { s.c0 = __builtin_amdgcn_s_memtime(); s.w0 = __builtin_amdgcn_s_memrealtime(); }
+}
+__device__ __forceinline__ void clk_end(const ConvP& p, const ClkSample& s) {
+    if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        atomicAdd(p.clk, (unsigned long long)__builtin_amdgcn_s_memtime() - s.c0);
+        atomicAdd(p.clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - s.w0);
+    }
+}
 
 // Epilogue of a BM x BN block tile held as 32x32 accumulator blocks by 2x2 waves (C layout: lane = output channel, reg = pixel
 // row): BN scale/shift, residual/addend, ReLU fused; returns the per-lane (sum, sum of squares) of the raw values for the
@@ -166,9 +182,10 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
                                 if (p.yplanes) {
                                     u16 b1, b2, b3;
                                     split3(v, b1, b2, b3);
-                                    p.yplanes[o] = b1;
-                                    p.yplanes[p.yps + o] = b2;
-                                    p.yplanes[2 * p.yps + o] = b3;
+                                    const long long oc = cm_index(pixr[r], n0 + wn * WTN + j * 32 + (lane & 31), p.yrows);
+                                    p.yplanes[oc] = b1;
+                                    p.yplanes[p.yps + oc] = b2;
+                                    p.yplanes[2 * p.yps + oc] = b3;
                                 }
                                 if (bnr) {
                                     const bool on = p.bnr_out ? yo[q][j] > 0.f : fmaf(xr[q][j], bsc[j], bsh[j]) > 0.f;
@@ -261,7 +278,7 @@ inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, co
                             int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad) {
     p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
-    p.yplanes = nullptr; p.yps = 0;
+    p.yplanes = nullptr; p.yps = 0; p.clk = g_straps_clk_acc;
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
     ConvP::Class& c = p.cls[0];
     p.ncls = 1;
@@ -275,6 +292,8 @@ inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, co
     STRAPS_REQUIRE(M < (1LL << 31) && (long long)batch * h * wdt * cin < (1LL << 31) && M * cout < (1LL << 31),
                    "straps_conv_fwd: tensors must stay below 2^31 elements (32-bit offsets)");
     c.M = (int)M;
+    p.xrows = batch * h * wdt;
+    p.yrows = (int)M;
     return STRAPS_OK;
 }
 
@@ -286,10 +305,12 @@ inline int conv_dgrad_problem(ConvP& p, const float* addend, float* dx, int batc
     const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
-    p.yplanes = nullptr; p.yps = 0;
+    p.yplanes = nullptr; p.yps = 0; p.clk = g_straps_clk_acc;
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
     p.omul = stride;
+    p.xrows = batch * ho * wo;
+    p.yrows = batch * h * wdt;
     p.ncls = 0;
     for (int ph = 0; ph < stride; ++ph) {
         for (int pw = 0; pw < stride; ++pw) {

@@ -41,6 +41,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     const ConvP::Class& c = p.cls[blockIdx.y];
     const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, cntaps = c.ntaps;
     if ((int)blockIdx.x >= cMT * p.NT) return;                 // a smaller class of the same launch
+    ClkSample clk;
+    clk_begin(p, clk);
     constexpr int NW = WGM * WGN, RPP = 16 * NW;               // waves; rows per copy pass (4 lanes x 16 bytes per 64-byte row)
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
     constexpr int AP = BM / RPP, BP = BN / RPP;                // copy passes
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
             const int ho = rem / cMw, wo = rem - ho * cMw;
             a_hi0[q] = ho * p.stride;
             a_wi0[q] = wo * p.stride;
-            a_base[q] = ((b * p.H + a_hi0[q]) * p.W + a_wi0[q]) * p.Cin + lc * 8;
+            a_base[q] = ((b * p.H + a_hi0[q]) * p.W + a_wi0[q]) * 32 + lc * 8;       // chunk-major planes: 64 bytes per (pixel, chunk)
         } else {
             a_hi0[q] = -(1 << 28);
             a_wi0[q] = 0;
@@ -82,11 +84,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     }
     const u16* wrow[BP];
 #pragma unroll
-    for (int q = 0; q < BP; ++q) wrow[q] = wg + (long long)(n0 + lr + RPP * q) * p.wtaps * p.Cin + lc * 8;
+    for (int q = 0; q < BP; ++q) wrow[q] = wg + (n0 + lr + RPP * q) * 32 + lc * 8;      // + ((tap * cchunks + chunk) * Cout) * 32
 
     const int cchunks = p.Cin >> 5;
     const int nchunks = cntaps * cchunks;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int a_cstep = p.xrows * 32, b_cstep = p.Cout * 32;      // one channel chunk on: elements
 
     const u16* a_src[AP];
     long long a_ps[AP];            // plane stride, 0 for a padding pixel (all three planes read the zero constant)
@@ -99,17 +102,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     asm volatile("" : "+s"(zsrc));
     auto setup_tap = [&](int tap) {
         const int dh = __builtin_amdgcn_readlane(v_dh, tap), dw = __builtin_amdgcn_readlane(v_dw, tap), tw = __builtin_amdgcn_readlane(v_tw, tap);
-        const int toff = (dh * p.W + dw) * p.Cin;
+        const int toff = (dh * p.W + dw) * 32;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             a_src[i] = ok ? xg + (a_base[i] + toff) : zsrc;
             a_ps[i] = ok ? p.xps : 0;
-            a_inc[i] = ok ? 32 : 0;
+            a_inc[i] = ok ? a_cstep : 0;
         }
 #pragma unroll
-        for (int i = 0; i < BP; ++i) b_src[i] = wrow[i] + tw * p.Cin;
+        for (int i = 0; i < BP; ++i) b_src[i] = wrow[i] + (long long)tw * cchunks * b_cstep;
     };
     // copy piece `idx` (compile-time after unrolling) of the next chunk: planes outermost, A passes then B passes
     auto piece = [&](int stage, int idx) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
 #pragma unroll
         for (int i = 0; i < AP; ++i) a_src[i] += a_inc[i];
 #pragma unroll
-        for (int i = 0; i < BP; ++i) b_src[i] += 32;
+        for (int i = 0; i < BP; ++i) b_src[i] += b_cstep;
         if (++n_cc == cchunks) {
             n_cc = 0;
             if (++n_tap < cntaps) setup_tap(n_tap);
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
     igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
     igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
+    clk_end(p, clk);
 }
 
 // ---- halo-patch variant for the 3x3 / stride-1 layers (forward, and the data gradient, which is the same convolution over dy) ----
@@ -310,6 +314,8 @@ template <int BM, int BN, int WGM, int WGN, int NST, int PS, int PBUF = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p) {
     const ConvP::Class& c = p.cls[0];
     const int cntaps = c.ntaps;
+    ClkSample clk;
+    clk_begin(p, clk);
     constexpr int NW = WGM * WGN, NTH = 64 * NW, RPP = 16 * NW;
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
     constexpr int BP = BN / RPP;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
         const int py = rem / PW, px = rem - py * PW;
         const int sr = row0 + py - 1, sc = px - 1;
         const bool ok = slot < nslots && (unsigned)sr < (unsigned)p.H && (unsigned)sc < (unsigned)p.W;
-        poff[pi] = ok ? (((b0 + im) * p.H + sr) * p.W + sc) * p.Cin + (((tid & 3) ^ ((slot >> 2) & 3)) << 3) : -1;
+        poff[pi] = ok ? (((b0 + im) * p.H + sr) * p.W + sc) * 32 + (((tid & 3) ^ ((slot >> 2) & 3)) << 3) : -1;     // chunk-major planes
     }
     const u16* zsrc = reinterpret_cast<const u16*>(k_zero16_x3);
     asm volatile("" : "+s"(zsrc));
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
             if (pi * (NTH / 4) + 16 * wave_u >= nslots) break;                 // wave-uniform: nothing of this round lies inside the patch
             if (pi * (NTH / 4) + 16 * wave_u >= PS) break;
             const bool ok = poff[pi] >= 0;
-            const u16* src = ok ? xg + (poff[pi] + cc * 32) : zsrc;
+            const u16* src = ok ? xg + (poff[pi] + (long long)cc * p.xrows * 32) : zsrc;
             const long long ps = ok ? p.xps : 0;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     const int lc = (tid & 3) ^ swz3(lr);
     const u16* wrow[BP];
 #pragma unroll
-    for (int q = 0; q < BP; ++q) wrow[q] = wg + (long long)(n0 + lr + RPP * q) * p.wtaps * p.Cin + lc * 8;
+    for (int q = 0; q < BP; ++q) wrow[q] = wg + (n0 + lr + RPP * q) * 32 + lc * 8;      // + ((tap * cchunks + chunk) * Cout) * 32
     const int cchunks = p.Cin >> 5;
     const int nsteps = cntaps * cchunks;
     const int tl = lane < 9 ? lane : 0;
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     auto piece = [&](int stage, int idx) {
         const int plane = idx / BP, r = idx % BP;
         const int tw = __builtin_amdgcn_readlane(v_tw, i_tap);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[r] + (tw * p.Cin + i_cc * 32) + plane * p.wps),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[r] + (long long)(tw * cchunks + i_cc) * p.Cout * 32 + plane * p.wps),
                                          (__attribute__((address_space(3))) void*)(Bs + ((stage * 3 + plane) * BN + RPP * r + 16 * wave_u) * 32), 16, 0, 0);
     };
     auto advance = [&]() {
@@ -500,243 +506,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
     igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
     igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
-}
-
-// ---- direct-A variant (tile_cfg 13 / 14, explicit only: parity-tested -- tests/test_gpu_conv_x3.py -- but not faster as first written:
-// 147 us (128x64) / 162 us (256x64) against 139 us of the 128x64 LDS tile on layer1, tools/x3d_probe.py; the auto rule does not pick it.
-// Kept as the base of round 3's work on the 64-channel layers) ----
-// With 64 output channels an A byte feeds 64 outputs only, and the 128x64 tile's LDS port (fragment reads + operand copies: 1.125 KB per
-// MFMA = 8.8 clocks of 128 B against the 8 clocks per MFMA of four SIMDs) is what bounds layer1.  But the A operand needs no LDS at all:
-// the MFMA's A layout is lane -> (pixel row, 8 consecutive k), i.e. 16 contiguous bytes of one pixel of one plane.  Here every lane
-// loads its rows' operand bytes straight from L2 into registers, NST - 1 chunks ahead; LDS holds the weights alone (12 KB per stage);
-// all four waves sit along M and span the 64 columns (32 x 64 or 64 x 64 per wave: 0.625 / 0.31 KB of LDS traffic per MFMA).
-// K order inside a 32-channel chunk: lane half h owns channels [16 h, 16 h + 16) = 32 contiguous bytes (two 16-byte loads); k step kk
-// uses its bytes [16 kk, 16 kk + 16): the weights' fragment reads pick 16-byte group 2 h + kk of the row to match.
-__device__ __attribute__((aligned(16))) float k_zero64_x3[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_x3d_kernel(ConvP p) {
-    const ConvP::Class& c = p.cls[blockIdx.y];
-    const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, cntaps = c.ntaps;
-    if ((int)blockIdx.x >= cMT * p.NT) return;
-    constexpr int NST = 3, WGM = 4, WGN = 1, RPP = 64;
-    constexpr int WTM = BM / WGM, MI = WTM / 32, NI = BN / 32, BP = BN / RPP;
-    static_assert(BM % 128 == 0 && BN % 64 == 0, "tile / wave grid mismatch");
-    constexpr int NPA = 3 * MI * 2, NPB = 3 * BP, NPIECE = NPA + NPB;      // vector-memory instructions per thread and chunk
-    constexpr int NMFMA = 2 * 6 * MI * NI;
-    constexpr int GAP = NMFMA / NPIECE > 0 ? NMFMA / NPIECE : 1;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    u16* Bs = reinterpret_cast<u16*>(smem);       // [NST stages][3 planes][BN][32]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = xcd_remap(blockIdx.x, cMT * p.NT);
-    const int nt = bid % p.NT, mt = bid / p.NT;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int h2 = lane >> 5;
-    const u16* xg = reinterpret_cast<const u16*>(p.x);
-    const u16* wg = reinterpret_cast<const u16*>(p.w);
-
-    int a_hi0[MI], a_wi0[MI], a_base[MI];
-    const int MhMw = cMh * cMw;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wave * WTM + i * 32 + (lane & 31);
-        if (m < cM) {
-            const int b = m / MhMw;
-            const int rem = m - b * MhMw;
-            const int ho = rem / cMw, wo = rem - ho * cMw;
-            a_hi0[i] = ho * p.stride;
-            a_wi0[i] = wo * p.stride;
-            a_base[i] = ((b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + h2 * 16;
-        } else {
-            a_hi0[i] = -(1 << 28);
-            a_wi0[i] = 0;
-            a_base[i] = 0;
-        }
-    }
-    const int lr = tid >> 2;
-    const int lc = (tid & 3) ^ swz3(lr);
-    const u16* wrow[BP];
-#pragma unroll
-    for (int q = 0; q < BP; ++q) wrow[q] = wg + (long long)(n0 + lr + RPP * q) * p.wtaps * p.Cin + lc * 8;
-
-    const int cchunks = p.Cin >> 5;
-    const int nchunks = cntaps * cchunks;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    const u16* a_src[MI];
-    long long a_ps[MI];
-    int a_inc[MI];
-    const u16* b_src[BP];
-    int n_tap = 0, n_cc = 0;
-    const int tl = lane < 9 ? lane : 0;
-    const int v_dh = c.tap_dh[tl], v_dw = c.tap_dw[tl], v_tw = c.tap_w[tl];
-    const u16* zsrc = reinterpret_cast<const u16*>(k_zero64_x3);
-    asm volatile("" : "+s"(zsrc));
-    auto setup_tap = [&](int tap) {
-        const int dh = __builtin_amdgcn_readlane(v_dh, tap), dw = __builtin_amdgcn_readlane(v_dw, tap), tw = __builtin_amdgcn_readlane(v_tw, tap);
-        const int toff = (dh * p.W + dw) * p.Cin;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            a_src[i] = ok ? xg + (a_base[i] + toff) : zsrc;
-            a_ps[i] = ok ? p.xps : 0;
-            a_inc[i] = ok ? 32 : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < BP; ++i) b_src[i] = wrow[i] + tw * p.Cin;
-    };
-    auto advance = [&]() {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a_src[i] += a_inc[i];
-#pragma unroll
-        for (int i = 0; i < BP; ++i) b_src[i] += 32;
-        if (++n_cc == cchunks) {
-            n_cc = 0;
-            if (++n_tap < cntaps) setup_tap(n_tap);
-        }
-    };
-
-    bf16x8 ra[NST][3][MI][2];                     // A operand of NST chunks: [set][plane][row block][k step]
-    // piece idx of the chunk the issue stream stands at: the weights' LDS-DMA copies first, then this lane's A loads
-    auto piece = [&](auto set_c, int idx) {
-        constexpr int S = decltype(set_c)::value;
-        if (idx < NPB) {
-            const int plane = idx / BP, r = idx % BP;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[r] + plane * p.wps),
-                                             (__attribute__((address_space(3))) void*)(Bs + ((S * 3 + plane) * BN + RPP * r + 16 * wave_u) * 32), 16, 0, 0);
-        } else {
-            const int a = idx - NPB;
-            const int plane = a / (MI * 2), i = (a / 2) % MI, kk = a & 1;
-            // (inline asm: the compiler's own wait-count pass would otherwise put vmcnt(0) in front of the first MFMA of two chunks in three --
-            //  it cannot count plain loads across the back edge next to the LDS-DMA copies -- and the prefetch distance would be gone;
-            //  the chunk's s_waitcnt below covers these loads, and the registers are pinned behind it there)
-            const u16* ap = a_src[i] + plane * a_ps[i] + kk * 8;
-            bf16x8 t;                                   // (asm operands cannot name a captured array element directly)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t) : "v"(ap) : "memory");
-            ra[S][plane][i][kk] = t;
-        }
-    };
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    if (nchunks > 0) {
-        setup_tap(0);
-#pragma unroll
-        for (int idx = 0; idx < NPIECE; ++idx) piece(I0{}, idx);
-        advance();
-    }
-    if (nchunks > 1) {
-#pragma unroll
-        for (int idx = 0; idx < NPIECE; ++idx) piece(I1{}, idx);
-        advance();
-    }
-    int fo[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 31) * 32 + (((h2 * 2 + kk) ^ swz3(lane & 31)) << 3);
-
-    constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
-    constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
-
-    // chunk in set / stage S; MORE: chunk + 2 exists and is issued between this chunk's MFMAs into set / stage (S + 2) % 3 (read last by the
-    // previous chunk: every wave is past it once it is through this chunk's barrier); INFLIGHT: vector-memory instructions of younger
-    // chunks that may stay outstanding while this chunk's weights are awaited (the counter retires in order; the A loads are plain
-    // loads the compiler tracks itself -- the memory clobbers below keep them inside the chunk they are issued in)
-    auto chunk = [&](auto set_c, auto more_c, auto inflight_c) {
-        constexpr int S = decltype(set_c)::value;
-        constexpr bool MORE = decltype(more_c)::value;
-        constexpr int INFLIGHT = decltype(inflight_c)::value;
-        using NS = std::integral_constant<int, (S + 2) % 3>;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {          // no MFMA may read them above the wait
-                    bf16x8 t = ra[S][pl][i][kk];
-                    asm volatile("" : "+v"(t));
-                    ra[S][pl][i][kk] = t;
-                }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const u16* Bb = Bs + (S * 3 * BN) * 32;
-        int cnt = 0;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 b[NI][3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) b[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + (pl * BN + j * 32) * 32 + fo[kk]);
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        acc[i][j] = mfma_bf16(ra[S][TA[t]][i][kk], b[j][TB[t]], acc[i][j]);
-                        if (MORE && cnt % GAP == GAP - 1 && cnt / GAP < NPIECE) piece(NS{}, cnt / GAP);
-                        ++cnt;
-                    }
-        }
-        if (MORE) {
-#pragma unroll
-            for (int idx = NMFMA / GAP; idx < NPIECE; ++idx) piece(NS{}, idx);
-            advance();
-        }
-        asm volatile("" ::: "memory");
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    using NP = std::integral_constant<int, NPIECE>;
-    using Z = std::integral_constant<int, 0>;
-    const int ns = nchunks - 2;                   // chunks that still have a chunk + 2 to issue
-    int q = 0;
-    for (; q + 3 <= ns; q += 3) { chunk(I0{}, T{}, NP{}); chunk(I1{}, T{}, NP{}); chunk(I2{}, T{}, NP{}); }
-    const int r = ns > q ? ns - q : 0;            // 0..2 of them left, in sets 0..r-1; then the last two chunks (one if nchunks == 1)
-    if (r >= 1) chunk(I0{}, T{}, NP{});
-    if (r >= 2) chunk(I1{}, T{}, NP{});
-    if (nchunks >= 2) {
-        if (r == 0) { chunk(I0{}, F{}, NP{}); chunk(I1{}, F{}, Z{}); }
-        else if (r == 1) { chunk(I1{}, F{}, NP{}); chunk(I2{}, F{}, Z{}); }
-        else { chunk(I2{}, F{}, NP{}); chunk(I0{}, F{}, Z{}); }
-    } else if (nchunks == 1) {
-        chunk(I0{}, F{}, Z{});
-    }
-
-    float s1[NI], s2[NI];
-    double bd1[NI], bd2[NI];
-    igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
-    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
-    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
-}
-
-template <int BM, int BN>
-int launch_x3d(const ConvP& p0, hipStream_t st) {
-    ConvP p = p0;
-    p.NT = p.Cout / BN;
-    int maxblk = 0, base = 0;
-    for (int i = 0; i < p.ncls; ++i) {
-        p.cls[i].MT = (p.cls[i].M + BM - 1) / BM;
-        if (p.cls[i].MT * p.NT > maxblk) maxblk = p.cls[i].MT * p.NT;
-        p.bnr_base[i] = base;
-        base += p.cls[i].MT;
-    }
-    const size_t lds = (size_t)3 * 3 * BN * 32 * sizeof(u16);            // (36 KiB for BN = 64: inside the default limit)
-    hipLaunchKernelGGL((conv_igemm_x3d_kernel<BM, BN>), dim3(maxblk, p.ncls), dim3(256), lds, st, p);
-    STRAPS_CHECK_LAUNCH("conv_igemm_x3d_kernel");
-    return STRAPS_OK;
+    clk_end(p, clk);
 }
 
 template <int BM, int BN, int WGM, int WGN, int NST, int PS, int PBUF = 2>
@@ -788,7 +558,7 @@ int launch_x3(const ConvP& p0, hipStream_t st) {
 
 // tile_cfg & 15: 0 = auto, 1 = 128x128 (8 waves, 3 stages), 2 = 128x64 (4 waves, 2 stages, two workgroups per CU), 3 = 64x64 (4 waves, 3 stages),
 // 4 = 256x128 (8 waves, 2 stages), 5 = 128x128 (4 waves, 3 stages), 6 = 256x128 (4 waves, 2 stages), 7 = 128x64 (4 waves, 3 stages);
-// software-pipelined loop (PIPE): 8 = as 5, 9 = as 1, 10 = as 7, 11 = as 2, 12 = as 4; 13 / 14 = direct-A tiles 128x64 / 256x64 (explicit only)
+// software-pipelined loop (PIPE): 8 = as 5, 9 = as 1, 10 = as 7, 11 = as 2, 12 = as 4
 // auto rule from tools/sweep_conv_x3.py (resnet18 shapes, B = 64): 64-channel outputs take 128x64 tiles, two workgroups per CU; otherwise
 // the largest tile that still gives every CU a workgroup: 256x128 from 512 128x128-tiles on (layer2: 63 vs 68 us), 128x128 from 256
 // (layer3: 97 vs 108), else 128x64 with the three-stage ring (layer4's 4096 pixels: 113 vs 150).
@@ -799,9 +569,9 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
         const long long t128 = ((M + 127) / 128) * (cout / 128);
         cfg = cout % 128 != 0 ? 11 : t128 >= 512 ? 12 : t128 >= 256 ? 5 : 7;       // (11 / 12: the pipelined loop pays with two-stage rings: -7 %)
     }
-    if (cout % 128 != 0 && cfg != 3 && cfg != 7 && cfg != 10 && cfg != 11 && cfg != 13 && cfg != 14) cfg = 2;
-    bm = (cfg == 4 || cfg == 6 || cfg == 12 || cfg == 14) ? 256 : cfg == 3 ? 64 : 128;
-    bn = (cfg == 2 || cfg == 3 || cfg == 7 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 14) ? 64 : 128;
+    if (cout % 128 != 0 && cfg != 3 && cfg != 7 && cfg != 10 && cfg != 11) cfg = 2;
+    bm = (cfg == 4 || cfg == 6 || cfg == 12) ? 256 : cfg == 3 ? 64 : 128;
+    bn = (cfg == 2 || cfg == 3 || cfg == 7 || cfg == 10 || cfg == 11) ? 64 : 128;
     return cfg;
 }
 
@@ -837,8 +607,6 @@ int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
         case 10: return launch_x3<128, 64, 2, 2, 3, 0, true>(p, st);
         case 11: return launch_x3<128, 64, 2, 2, 2, 0, true>(p, st);
         case 12: return launch_x3<256, 128, 4, 2, 2, 0, true>(p, st);
-        case 13: return launch_x3d<128, 64>(p, st);          // direct-A tiles (see conv_igemm_x3d_kernel)
-        case 14: return launch_x3d<256, 64>(p, st);
         default: return launch_x3<128, 64, 2, 2, 3, ABL>(p, st);
     }
 }
@@ -874,7 +642,30 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     }
 }
 
+// the same split into the chunk-major layout the convolution kernels read (common.h: cm_index): x is a [rows][C] fp32 tensor
+__global__ __launch_bounds__(256) void split3_cm_kernel(const float* __restrict__ x, u16* __restrict__ o, long long rows, int C, long long ps) {
+    const int C4 = C >> 2;
+    const long long n4 = rows * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const long long r = i / C4;
+        const int c4 = (int)(i - r * C4);
+        store_planes4_cm(o, ps, r, c4 * 4, rows, *reinterpret_cast<const f32x4*>(x + i * 4));
+    }
+}
+
 }  // namespace
+
+extern "C" int straps_split3_bf16_cm(const float* x, unsigned short* planes, long long rows, int c, long long plane_stride, void* stream) {
+    STRAPS_REQUIRE(x && planes, "straps_split3_bf16_cm: null pointer");
+    STRAPS_REQUIRE(rows > 0 && c > 0 && c % 32 == 0, "straps_split3_bf16_cm: need rows > 0 and c %% 32 == 0 (rows=%lld c=%d)", rows, c);
+    STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "straps_split3_bf16_cm: plane_stride must be >= rows*c and a multiple of 8");
+    STRAPS_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15) == 0, "straps_split3_bf16_cm: pointers must be 16-byte aligned");
+    const long long n4 = rows * (c >> 2);
+    const long long g = (n4 + 255) / 256;
+    hipLaunchKernelGGL(split3_cm_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, x, planes, rows, c, plane_stride);
+    STRAPS_CHECK_LAUNCH("split3_cm_kernel");
+    return STRAPS_OK;
+}
 
 extern "C" int straps_split3_bf16(const float* x, unsigned short* planes, long long n, long long plane_stride, void* stream) {
     STRAPS_REQUIRE(x && planes, "straps_split3_bf16: null pointer");

@@ -37,8 +37,15 @@ __global__ __launch_bounds__(256) void pack_crsk_flip_kernel(const float* __rest
 // k3 / c3 (bf16x3 route): the three bf16 planes [3][ps] of the two packed layouts, element `first + offset inside the layer`, written
 // in the same pass (the fp32 destinations of a descriptor may then be NULL: nothing on that route reads them).
 constexpr int PK_T = 32, PK_RS = 9, PK_LD = PK_T * PK_RS + 1;
-__global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_desc_t* __restrict__ descs, int n, u16* __restrict__ k3,
-                                                           u16* __restrict__ c3, long long ps) {
+// chunk-major weight planes (bf16x3 route): the GEMM's B rows are `row` (output channels for the forward layout, input channels for the
+// data-gradient one), its K index is (tap, k); the 32-wide K chunks are outermost, element (row, tap, k) at
+//   ((tap * (K / 32) + (k >> 5)) * rows + row) * 32 + (k & 31)
+// -- the 64 bytes of one (tap, chunk) of one row sit next to the neighbouring rows' (whole 128-byte lines per LDS-DMA fetch, common.h).
+__device__ __forceinline__ long long wk_index(int row, int tap, int k, int rows, int K) {
+    return (((long long)tap * (K >> 5) + (k >> 5)) * rows + row) * 32 + (k & 31);
+}
+__global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_desc_t* __restrict__ descs, int n, u16* __restrict__ k3_all,
+                                                           u16* __restrict__ c3_all, long long ps) {
     __shared__ float tile[PK_T * PK_LD];
     const int tid = threadIdx.x;
     int d = 0;
@@ -57,6 +64,9 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
         if (d >= n) return;
         const straps_pack_desc_t D = descs[d];
         const int RS = D.r * D.s;
+        // planes exist only where the layout's K extent is a whole number of 32-wide chunks (the bf16x3 kernels need that anyway)
+        u16* const k3 = (D.c & 31) ? nullptr : k3_all;
+        u16* const c3 = (D.o & 31) ? nullptr : c3_all;
         int v = (int)(u - base);
         const int ri = v % rt; v /= rt;
         const int ci = v % ct;
@@ -97,7 +107,8 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
                     if (k3 && !v4k) {
                         u16 b1, b2, b3;
                         split3(v, b1, b2, b3);
-                        k3[D.first + at] = b1; k3[ps + D.first + at] = b2; k3[2 * ps + D.first + at] = b3;
+                        const long long w = D.first + wk_index(o0 + o, rs0 + j, c0 + c, D.o, D.c);
+                        k3[w] = b1; k3[ps + w] = b2; k3[2 * ps + w] = b3;
                     }
                 }
             }
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
                 if (c < nc) {
                     const float* t = tile + o * PK_LD + c * PK_RS + j;
                     const f32x4 v = {t[0], t[PK_RS], t[2 * PK_RS], t[3 * PK_RS]};
-                    store_planes4(k3, ps, D.first + ((long long)(o0 + o) * RS + rs0 + j) * D.c + c0 + c, v);
+                    store_planes4(k3, ps, D.first + wk_index(o0 + o, rs0 + j, c0 + c, D.o, D.c), v);
                 }
             }
         }
@@ -127,7 +138,8 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
                     if (c3 && !v4c) {
                         u16 b1, b2, b3;
                         split3(v, b1, b2, b3);
-                        c3[D.first + at] = b1; c3[ps + D.first + at] = b2; c3[2 * ps + D.first + at] = b3;
+                        const long long w = D.first + wk_index(c0 + c, RS - 1 - (rs0 + j), o0 + o, D.c, D.o);
+                        c3[w] = b1; c3[ps + w] = b2; c3[2 * ps + w] = b3;
                     }
                 }
             }
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const straps_pack_des
                 if (o < no) {
                     const float* t = tile + o * PK_LD + c * PK_RS + j;
                     const f32x4 v = {t[0], t[PK_LD], t[2 * PK_LD], t[3 * PK_LD]};
-                    store_planes4(c3, ps, D.first + ((long long)(c0 + c) * RS + (RS - 1 - (rs0 + j))) * D.o + o0 + o, v);
+                    store_planes4(c3, ps, D.first + wk_index(c0 + c, RS - 1 - (rs0 + j), o0 + o, D.c, D.o), v);
                 }
             }
         }
@@ -237,8 +249,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         if (y) *reinterpret_cast<f32x4*>(y + i * 4) = v;        // (NULL: only the planes are consumed -- bf16x3 route, see straps_bn_apply_x3)
-        if (planes) store_planes4(planes, ps, i * 4, v);       // bf16x3 route: the next convolution's operand, written here instead of by a split pass
+        if (planes) store_planes4_cm(planes, ps, i / C4, c4 * 4, n4 / C4, v);      // bf16x3 route: the next convolution's operand (chunk-major planes), written here instead of by a split pass
     }
+}
+
+// eval-mode BatchNorm as the four vectors the training-mode kernels take: scale, shift (the fold) and the statistics themselves
+__global__ void bn_fold_stats_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
+                                     const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                     float* __restrict__ smean, float* __restrict__ sinv, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.0f / sqrtf(var[c] + eps);
+    const float sc = g[c] / sqrtf(var[c] + eps);          // (the same expression as bn_fold_kernel: identical scale / shift)
+    scale[c] = sc;
+    shift[c] = b[c] - mean[c] * sc;
+    smean[c] = mean[c];
+    sinv[c] = inv;
 }
 
 inline unsigned capped_grid(long long n) {
@@ -292,6 +318,15 @@ extern "C" int straps_bn_fold(const float* gamma, const float* beta, const float
     STRAPS_REQUIRE(gamma && beta && mean && var && scale && shift && c > 0, "straps_bn_fold: bad arguments");
     hipLaunchKernelGGL(bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, scale, shift, c);
     STRAPS_CHECK_LAUNCH("bn_fold_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_bn_fold_stats(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                                    float* shift, float* save_mean, float* save_invstd, int c, void* stream) {
+    STRAPS_REQUIRE(gamma && beta && mean && var && scale && shift && save_mean && save_invstd && c > 0, "straps_bn_fold_stats: bad arguments");
+    hipLaunchKernelGGL(bn_fold_stats_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, scale, shift, save_mean,
+                       save_invstd, c);
+    STRAPS_CHECK_LAUNCH("bn_fold_stats_kernel");
     return STRAPS_OK;
 }
 

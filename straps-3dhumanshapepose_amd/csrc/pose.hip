@@ -44,7 +44,90 @@ __global__ __launch_bounds__(256) void rodrigues_kernel(const float* __restrict_
     o[6] = s * k20 + c1 * q20;        o[7] = s * k21 + c1 * q21;        o[8] = 1.0f + c1 * q22;
 }
 
+// ---- camera projections of the module-level helpers (utils/cam_utils.py:5-26, 40-71) ----
+// scaled orthographic: (u, v) = s * (x + tx, y + ty); cam rows [s, tx, ty] with stride ld_cam
+__global__ __launch_bounds__(256) void ortho_project_kernel(const float* __restrict__ pts, const float* __restrict__ cam, int ld_cam,
+                                                            float* __restrict__ out, long long B, int N) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    const long long b = i / N;
+    const float s = cam[b * ld_cam], tx = cam[b * ld_cam + 1], ty = cam[b * ld_cam + 2];
+    out[i * 2 + 0] = s * (pts[i * 3 + 0] + tx);
+    out[i * 2 + 1] = s * (pts[i * 3 + 1] + ty);
+}
+
+// its gradient: dpts = (s du, s dv, 0); dcam[b] = (sum du (x + tx) + dv (y + ty), s sum du, s sum dv) -- one workgroup per body, fixed
+// summation order (lane-strided partial sums, wave shuffle tree, four waves through LDS)
+__global__ __launch_bounds__(256) void ortho_project_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ cam, int ld_cam,
+                                                                const float* __restrict__ dout, float* __restrict__ dpts,
+                                                                float* __restrict__ dcam, int N) {
+    __shared__ float red[4][3];
+    const long long b = blockIdx.x;
+    const float s = cam[b * ld_cam], tx = cam[b * ld_cam + 1], ty = cam[b * ld_cam + 2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const long long i = b * N + n;
+        const float du = dout[i * 2], dv = dout[i * 2 + 1];
+        if (dpts) { dpts[i * 3] = s * du; dpts[i * 3 + 1] = s * dv; dpts[i * 3 + 2] = 0.f; }
+        a0 += du * (pts[i * 3] + tx) + dv * (pts[i * 3 + 1] + ty);
+        a1 += du;
+        a2 += dv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a0; red[threadIdx.x >> 6][1] = a1; red[threadIdx.x >> 6][2] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0 && dcam) {
+        dcam[b * 3 + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        dcam[b * 3 + 1] = s * ((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
+        dcam[b * 3 + 2] = s * ((red[0][2] + red[1][2]) + (red[2][2] + red[3][2]));
+    }
+}
+
+// perspective: p = R x + t; p /= p_z; (u, v) = first two rows of K p.  K: one 3x3 (k_stride = 0) or one per body (k_stride = 9)
+__global__ __launch_bounds__(256) void persp_project_kernel(const float* __restrict__ pts, const float* __restrict__ rot, const float* __restrict__ tr,
+                                                            const float* __restrict__ K, int k_stride, float* __restrict__ out, long long B, int N) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    const long long b = i / N;
+    const float* R = rot + b * 9;
+    const float* Kb = K + b * k_stride;
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    float p0 = (R[0] * x + R[1] * y) + R[2] * z + tr[b * 3];
+    float p1 = (R[3] * x + R[4] * y) + R[5] * z + tr[b * 3 + 1];
+    const float p2 = (R[6] * x + R[7] * y) + R[8] * z + tr[b * 3 + 2];
+    p0 = p0 / p2;
+    p1 = p1 / p2;
+    const float one = p2 / p2;
+    out[i * 2 + 0] = (Kb[0] * p0 + Kb[1] * p1) + Kb[2] * one;
+    out[i * 2 + 1] = (Kb[3] * p0 + Kb[4] * p1) + Kb[5] * one;
+}
+
 }  // namespace
+
+extern "C" int straps_orthographic_project(const float* points, const float* cam, int ld_cam, float* out, long long batch, int n, void* stream) {
+    STRAPS_REQUIRE(points && cam && out && batch > 0 && n > 0 && ld_cam >= 3, "straps_orthographic_project: bad arguments");
+    hipLaunchKernelGGL(ortho_project_kernel, dim3((unsigned)((batch * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points, cam, ld_cam, out, batch, n);
+    STRAPS_CHECK_LAUNCH("ortho_project_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_orthographic_project_bwd(const float* points, const float* cam, int ld_cam, const float* dout, float* dpoints, float* dcam,
+                                               long long batch, int n, void* stream) {
+    STRAPS_REQUIRE(points && cam && dout && (dpoints || dcam) && batch > 0 && n > 0 && ld_cam >= 3, "straps_orthographic_project_bwd: bad arguments");
+    hipLaunchKernelGGL(ortho_project_bwd_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, points, cam, ld_cam, dout, dpoints, dcam, n);
+    STRAPS_CHECK_LAUNCH("ortho_project_bwd_kernel");
+    return STRAPS_OK;
+}
+
+extern "C" int straps_perspective_project(const float* points, const float* rotation, const float* translation, const float* cam_k, int k_per_body,
+                                          float* out, long long batch, int n, void* stream) {
+    STRAPS_REQUIRE(points && rotation && translation && cam_k && out && batch > 0 && n > 0, "straps_perspective_project: bad arguments");
+    hipLaunchKernelGGL(persp_project_kernel, dim3((unsigned)((batch * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points, rotation, translation,
+                       cam_k, k_per_body ? 9 : 0, out, batch, n);
+    STRAPS_CHECK_LAUNCH("persp_project_kernel");
+    return STRAPS_OK;
+}
 
 extern "C" int straps_rot6d_fwd(const float* x6, long long ld, int per_row, float* rotmats, long long rows, void* stream) {
     STRAPS_REQUIRE(x6 && rotmats, "straps_rot6d_fwd: null pointer");

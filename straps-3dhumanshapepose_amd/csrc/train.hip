@@ -15,23 +15,23 @@ __constant__ int c_h36m14[14] = {73 + 6, 73 + 5, 73 + 4, 73 + 1, 73 + 2, 73 + 3,
 // =====================================================================================================
 // one (body, channel) plane per blockIdx.y, 4 consecutive pixels of a row per thread (32-bit index math, float4
 // stores: the kernel is a 302 MB write at B = 64 and should cost no more than that)
-__device__ __forceinline__ float heat_value(int x, int y, int jx, int jy, int WH) {
-    constexpr int size = 8;
-    const float step = 16.0f / 15.0f;
+__device__ __forceinline__ float heat_value(int x, int y, int jx, int jy, int WH, int size, float step, float two_var) {
+    // size = 2 std (the Gaussian is truncated two standard deviations from the joint, utils/label_conversions.py:102)
     if (!(jx > -size && jy > -size && jx < WH - 1 + size && jy < WH - 1 + size)) return 0.f;
     const int hx0 = max(0, jx - size), hx1 = min(WH - 1, jx + size);
     const int hy0 = max(0, jy - size), hy1 = min(WH - 1, jy + size);
     if (!(x >= hx0 && x < hx1 && y >= hy0 && y < hy1)) return 0.f;
     const int gx = x - hx0 + max(0, size - jx), gy = y - hy0 + max(0, size - jy);
-    // torch.linspace(-8, 8, 16): start + i*step in the first half, end - (15-i)*step in the second
-    const float lx = gx < 8 ? -8.f + step * gx : 8.f - step * (15 - gx);
-    const float ly = gy < 8 ? -8.f + step * gy : 8.f - step * (15 - gy);
+    // torch.linspace(-size, size, 2 size): start + i*step in the first half, end - (2 size - 1 - i)*step in the second
+    const float fs = (float)size;
+    const float lx = gx < size ? -fs + step * gx : fs - step * (2 * size - 1 - gx);
+    const float ly = gy < size ? -fs + step * gy : fs - step * (2 * size - 1 - gy);
     const float d = sqrtf(lx * lx + ly * ly);
-    return expf(-(d * d / 32.f));
+    return expf(-(d * d / two_var));
 }
 
 __global__ __launch_bounds__(256) void build_proxy_kernel(const float* __restrict__ seg, const float* __restrict__ j2d,
-                                                          float* __restrict__ out, int B, int NJ, int WH) {
+                                                          float* __restrict__ out, int B, int NJ, int WH, int size, float step, float two_var) {
     const int plane = blockIdx.y;                       // b * (NJ + 1) + ch
     const int b = plane / (NJ + 1), ch = plane - b * (NJ + 1);
     const int npix = WH * WH;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void build_proxy_kernel(const float* __restric
                 if (ch == 0) v[e] = s[q] != 0.f ? 1.f : 0.f;
                 else {
                     const int y = q / WH, x = q - y * WH;
-                    v[e] = heat_value(x, y, jx, jy, WH);
+                    v[e] = heat_value(x, y, jx, jy, WH, size, step, two_var);
                 }
             }
         }
@@ -238,14 +238,24 @@ inline unsigned capped_grid(long long n, int cap = 4096) {
 
 }  // namespace
 
-extern "C" int straps_build_proxy_input(const float* seg, const float* joints2d, float* out_nchw, int batch, int nj, int wh,
-                                        void* stream) {
+extern "C" int straps_build_proxy_input_std(const float* seg, const float* joints2d, float* out_nchw, int batch, int nj, int wh, int std,
+                                            void* stream) {
     STRAPS_REQUIRE(seg && joints2d && out_nchw && batch > 0 && nj > 0 && wh > 16, "straps_build_proxy_input: bad arguments");
+    STRAPS_REQUIRE(std >= 1 && 4 * std <= wh, "straps_build_proxy_input: std must be an integer in [1, wh / 4] (got %d)", std);
     STRAPS_REQUIRE((long long)batch * (nj + 1) <= 65535 && wh <= 16384, "straps_build_proxy_input: batch*(nj+1) must be <= 65535 per call");
     const int gx = (wh * wh / 4 + 255) / 256;
-    hipLaunchKernelGGL(build_proxy_kernel, dim3(gx < 64 ? gx : 64, batch * (nj + 1)), dim3(256), 0, (hipStream_t)stream, seg, joints2d, out_nchw, batch, nj, wh);
+    const int size = 2 * std;
+    const float step = (float)(2 * size) / (float)(2 * size - 1);          // torch.linspace's fp32 step: (end - start) / (steps - 1)
+    const float two_var = (float)(2.0 * std * std);
+    hipLaunchKernelGGL(build_proxy_kernel, dim3(gx < 64 ? gx : 64, batch * (nj + 1)), dim3(256), 0, (hipStream_t)stream, seg, joints2d, out_nchw, batch, nj, wh,
+                       size, step, two_var);
     STRAPS_CHECK_LAUNCH("build_proxy_kernel");
     return STRAPS_OK;
+}
+
+extern "C" int straps_build_proxy_input(const float* seg, const float* joints2d, float* out_nchw, int batch, int nj, int wh,
+                                        void* stream) {
+    return straps_build_proxy_input_std(seg, joints2d, out_nchw, batch, nj, wh, 4, stream);
 }
 
 extern "C" size_t straps_loss_workspace_bytes(long long batch) { return (size_t)(NVB + batch * 8 + 16) * sizeof(float); }

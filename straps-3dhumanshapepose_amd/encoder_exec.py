@@ -25,6 +25,7 @@ class _Ctx:
         self.defer_nbt = False        # True: the caller bumps every BatchNorm's num_batches_tracked itself (one fused add)
         self.x3 = False               # bf16x3 convolution route (net.conv_precision)
         self.planes = {}              # bf16x3 route: id(tensor) -> (tensor, planes, plane stride) of the activations split so far
+        self.net = None
 
     def empty(self, *shape):
         return torch.empty(*shape, device=self.device, dtype=torch.float32)
@@ -38,15 +39,22 @@ def _new_planes(t):
 def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=True, keep_fp32=True):
     C = bn.weight.shape[0]
     L = ctx.L
-    ss = ctx.empty(4, C)          # scale, shift, save_mean, save_invstd
-    track = bn.track_running_stats and bn.running_mean is not None
-    mom = 0.1 if bn.momentum is None else bn.momentum
-    hipabi.check(L.straps_bn_stats_finalize(hipabi.ptr(part), nblk, C, rows, hipabi.ptr(bn.weight), hipabi.ptr(bn.bias), bn.eps,
-                                            mom, hipabi.ptr(bn.running_mean if track else None),
-                                            hipabi.ptr(bn.running_var if track else None), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]),
-                                            hipabi.ptr(ss[2]), hipabi.ptr(ss[3]), hipabi.stream_ptr()), 'straps_bn_stats_finalize')
-    if track and not ctx.defer_nbt:
-        bn.num_batches_tracked.add_(1)
+    if not ctx.training:
+        # eval mode with a tape (gradients through frozen BatchNorm statistics, models/resnet.py:47 under .eval()): the running
+        # statistics in the role of the batch statistics, nothing is updated; the backward runs with the FROZEN flag
+        ss = ctx.net._frozen_bn(bn)
+        if rec is not None:
+            rec['frozen'] = True
+    else:
+        ss = ctx.empty(4, C)          # scale, shift, save_mean, save_invstd
+        track = bn.track_running_stats and bn.running_mean is not None
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        hipabi.check(L.straps_bn_stats_finalize(hipabi.ptr(part), nblk, C, rows, hipabi.ptr(bn.weight), hipabi.ptr(bn.bias), bn.eps,
+                                                mom, hipabi.ptr(bn.running_mean if track else None),
+                                                hipabi.ptr(bn.running_var if track else None), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]),
+                                                hipabi.ptr(ss[2]), hipabi.ptr(ss[3]), hipabi.stream_ptr()), 'straps_bn_stats_finalize')
+        if track and not ctx.defer_nbt:
+            bn.num_batches_tracked.add_(1)
     if not apply:                 # the caller fuses the normalisation into its consumer (stem: straps_bn_relu_maxpool_fwd)
         if rec is not None:
             rec.update(raw=raw, stats=ss, out=None)
@@ -74,11 +82,32 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=
 
 
 def split3(L, t):
-    """fp32 tensor -> its three bf16 planes [3][ps] (t = p1 + p2 + p3 exactly; csrc/conv_x3.hip), ps = numel rounded up to 8."""
+    """fp32 activation / gradient tensor [..., C] (NHWC) -> its three bf16 planes [3][ps] (t = p1 + p2 + p3 exactly) in the chunk-major
+    order the bf16x3 convolution kernels read (csrc/common.h cm_index: 32-channel chunks outermost); ps = numel rounded up to 8."""
     n = t.numel()
+    C = t.shape[-1]
     ps = (n + 7) // 8 * 8
     planes = torch.empty(3, ps, device=t.device, dtype=torch.int16)
-    hipabi.check(L.straps_split3_bf16(hipabi.ptr(t), hipabi.ptr(planes), n, ps, hipabi.stream_ptr()), 'straps_split3_bf16')
+    hipabi.check(L.straps_split3_bf16_cm(hipabi.ptr(t), hipabi.ptr(planes), n // C, C, ps, hipabi.stream_ptr()), 'straps_split3_bf16_cm')
+    return planes, ps
+
+
+def weight_planes(L, w, dgrad=False):
+    """chunk-major bf16x3 planes [3][ps] of ONE convolution weight (OIHW fp32, cin % 32 == 0; dgrad: the flipped data-gradient layout,
+    cout % 32 == 0) through the batched pack with a single descriptor -- what ResNet.prepack does for all layers at once."""
+    import numpy as np
+    wd = w.detach().float().contiguous()
+    O, C = wd.shape[0], wd.shape[1]
+    if (O if dgrad else C) % 32:
+        raise RuntimeError('weight_planes: the reduction extent (%d) must be a multiple of 32' % (O if dgrad else C))
+    n = wd.numel()
+    ps = (n + 7) // 8 * 8
+    planes = torch.zeros(3, ps, device=wd.device, dtype=torch.int16)
+    d = hipabi.PackDesc(wd.data_ptr(), None, None, O, C, wd.shape[2], wd.shape[3], 0)
+    table = torch.from_numpy(np.frombuffer(bytes(d), dtype=np.uint8).copy()).to(wd.device)
+    hipabi.check(L.straps_pack_conv_weights_batched_x3(hipabi.ptr(table), 1, n, hipabi.ptr(None if dgrad else planes), hipabi.ptr(planes if dgrad else None),
+                                                       ps, hipabi.stream_ptr()), 'straps_pack_conv_weights_batched_x3')
+    torch.cuda.current_stream().synchronize()          # (the descriptor table and wd die with this frame)
     return planes, ps
 
 
@@ -128,9 +157,9 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, kee
         rec = dict(kind='conv', conv=conv, bn=bn, x=x, geom=(B, H, W, Cin, Cout, k, stride, pad, Ho, Wo), relu=relu,
                    residual=residual)
         ctx.tape[id(conv)] = rec
-    if not ctx.training:
+    if not ctx.training and rec is None:
         ss = net._folded_bn(bn)
-        if ctx.x3 and relu and rec is None:
+        if ctx.x3 and relu:
             # bf16x3 route, inference: every ReLU output feeds a convolution, so the epilogue writes its planes as well (no split pass);
             # the fp32 tensor itself only where something reads it (keep_fp32: a unit's output -- the next identity / the pooling)
             x3, xps = _planes_of(ctx, x)
@@ -146,8 +175,11 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, kee
             return y, Ho, Wo
         _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, None, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
         return y, Ho, Wo
-    nblk = conv_stat_blocks(L, net, (B, H, W, Cin, Cout, k, stride, pad), Ho, Wo, tile_cfg)
-    part = ctx.empty(nblk, Cout, 2)
+    # training mode, or eval mode with a tape (frozen statistics: no partials needed)
+    nblk, part = 0, None
+    if ctx.training:
+        nblk = conv_stat_blocks(L, net, (B, H, W, Cin, Cout, k, stride, pad), Ho, Wo, tile_cfg)
+        part = ctx.empty(nblk, Cout, 2)
     _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
     if rec is not None and ctx.x3:
         rec['x3'] = ctx.planes.get(id(x))          # (x, planes, plane stride): the weight gradient reads the same planes
@@ -166,6 +198,7 @@ def encoder_forward(net, x, tape=None, nzmask=None):
     x = x.contiguous()
     B, C, H, W = x.shape
     ctx = _Ctx(x.device, net.training, tape)
+    ctx.net = net
     ctx.x3 = getattr(net, 'conv_precision', 'fp32') == 'bf16x3'
     if net.training:
         net._bn_epoch = getattr(net, '_bn_epoch', 0) + 1      # running statistics are about to change: folded-BN cache entries expire
@@ -192,11 +225,12 @@ def encoder_forward(net, x, tape=None, nzmask=None):
         hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(nzmask), B, C, H, W, hipabi.stream_ptr()), 'straps_stem_nzmask')
     if rec is not None:
         rec['nzmask'] = nzmask
-    if not net.training:
+    if not net.training and tape is None:
         ss = net._folded_bn(net.bn1)
         hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), 1, hipabi.ptr(y),
                                        None, hipabi.ptr(nzmask), B, C, H, W, hipabi.stream_ptr()), 'straps_stem_fwd')
     else:
+        # training mode -- or eval mode with a tape: the same kernels with the running statistics as frozen constants (_bn_train_finish)
         nblk = L.straps_stem_stat_blocks(B, H, W)
         part = ctx.empty(nblk, 64, 2)
         hipabi.check(L.straps_stem_fwd(hipabi.ptr(x), hipabi.ptr(wfrag), None, None, 0, hipabi.ptr(y), hipabi.ptr(part), hipabi.ptr(nzmask),

@@ -73,6 +73,26 @@ class PackDesc(C.Structure):
                 ('r', C.c_int32), ('s', C.c_int32), ('first', C.c_longlong)]
 
 
+class GemmDesc(C.Structure):
+    """mirror of straps_gemm_desc_t"""
+    _fields_ = [('a', C.c_void_p), ('sam', C.c_longlong), ('sak', C.c_longlong), ('b', C.c_void_p), ('sbk', C.c_longlong), ('sbn', C.c_longlong),
+                ('c', C.c_void_p), ('ldc', C.c_int32), ('accumulate', C.c_int32), ('addend', C.c_void_p), ('ldadd', C.c_int32), ('reserved0', C.c_int32),
+                ('mask', C.c_void_p), ('ldmask', C.c_int32), ('reserved1', C.c_int32), ('c2', C.c_void_p), ('ldc2', C.c_int32), ('accumulate2', C.c_int32),
+                ('m', C.c_int32), ('n', C.c_int32), ('k', C.c_int32), ('reserved2', C.c_int32)]
+
+
+def gemm_desc(a, sam, sak, b, sbk, sbn, c, ldc, m, n, k, accumulate=0, addend=None, ldadd=0, mask=None, ldmask=0, c2=None, ldc2=0, accumulate2=0):
+    """one problem of straps_gemm_multi; a / b / c / addend / mask / c2: tensors or raw device addresses (int)."""
+    adr = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
+    return GemmDesc(adr(a), sam, sak, adr(b), sbk, sbn, adr(c), ldc, accumulate, adr(addend), ldadd, 0, adr(mask), ldmask, 0, adr(c2), ldc2, accumulate2,
+                    m, n, k, 0)
+
+
+def gemm_multi(descs):
+    arr = (GemmDesc * len(descs))(*descs)
+    check(lib().straps_gemm_multi(arr, len(descs), stream_ptr()), 'straps_gemm_multi')
+
+
 _P, _I, _L, _F, _Z, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
@@ -81,7 +101,7 @@ SIGNATURES = {
     'straps_last_error': (C.c_char_p, []),
     'straps_device_count': (_I, []),
     'straps_wall_clock_khz': (_I, []),
-    'straps_clock_probe': (_I, [_P, _D, _P]),
+    'straps_set_clock_accumulator': (_I, [_P]),
     'straps_selftest_mfma_peak': (_I, [_P, _P, _I, _I, _P]),
     'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -90,12 +110,14 @@ SIGNATURES = {
     'straps_stem_weight_floats': (_Z, [_I]),
     'straps_pack_stem_weight': (_I, [_P, _P, _I, _P]),
     'straps_bn_fold': (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    'straps_bn_fold_stats': (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P]),
     'straps_stem_stat_blocks': (_I, [_I, _I, _I]),
     'straps_stem_nzmask_words': (_Z, [_I, _I, _I, _I]),
     'straps_stem_nzmask': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_stem_fwd': (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_conv_trace_buffer': (_I, [_P]),
     'straps_split3_bf16': (_I, [_P, _P, _L, _L, _P]),
+    'straps_split3_bf16_cm': (_I, [_P, _P, _L, _I, _L, _P]),
     'straps_conv_fwd_x3': (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_conv_fwd_x3p': (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_conv_dgrad_x3': (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -117,8 +139,13 @@ SIGNATURES = {
     'straps_linear_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'straps_pad_copy': (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     'straps_broadcast_rows': (_I, [_P, _I, _P, _I, _I, _P]),
+    'straps_ief_pack': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'straps_gemm_multi': (_I, [C.POINTER(GemmDesc), _I, _P]),
     'straps_rot6d_fwd': (_I, [_P, _L, _I, _P, _L, _P]),
     'straps_rodrigues_fwd': (_I, [_P, _P, _L, _P]),
+    'straps_orthographic_project': (_I, [_P, _P, _I, _P, _L, _I, _P]),
+    'straps_orthographic_project_bwd': (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _P]),
+    'straps_perspective_project': (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _P]),
     'straps_smpl_workspace_bytes': (_Z, [C.POINTER(SmplModelStruct), _L]),
     'straps_smpl_fwd': (_I, [C.POINTER(SmplModelStruct), _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'straps_smpl_bwd_workspace_bytes': (_Z, [_L, _I]),
@@ -144,6 +171,7 @@ SIGNATURES = {
     'straps_masked_copy': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     'straps_rot6d_bwd': (_I, [_P, _L, _I, _P, _P, _L, _L, _P]),
     'straps_build_proxy_input': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'straps_build_proxy_input_std': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_loss_workspace_bytes': (_Z, [_L]),
     'straps_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'straps_adam_step': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P]),

@@ -59,21 +59,24 @@ class IEFModule(nn.Module):
             w1f = torch.empty(H1, F, device=device)
             w1e = torch.empty(H1, EST_LD, device=device)
             w3 = torch.empty((P + 31) // 32 * 32, H2, device=device)
-            st = hipabi.stream_ptr()
-            hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc1.weight), F + P, 0, H1, F, hipabi.ptr(w1f), F, H1, st), 'straps_pad_copy')
-            hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc1.weight), F + P, F, H1, P, hipabi.ptr(w1e), EST_LD, H1, st), 'straps_pad_copy')
-            hipabi.check(L.straps_pad_copy(hipabi.ptr(self.fc3.weight), H2, 0, P, H2, hipabi.ptr(w3), H2, w3.shape[0], st), 'straps_pad_copy')
+            # fc1's feature / estimate column blocks and the row-padded fc3, one launch (straps_ief_pack)
+            hipabi.check(L.straps_ief_pack(hipabi.ptr(self.fc1.weight), hipabi.ptr(self.fc3.weight), hipabi.ptr(w1f), hipabi.ptr(w1e), hipabi.ptr(w3),
+                                           F, P, H1, H2, EST_LD, hipabi.stream_ptr()), 'straps_ief_pack')
             self._cache = {'sig': sig, 'w1f': w1f, 'w1e': w1e, 'w3': w3}
-        # the initial estimate is not a parameter: its device copy outlives weight updates (and is never
-        # re-uploaded inside a captured hipGraph)
+        # the initial estimate (and the constant 1.0 the bias gradients are contracted with) are not parameters: their device copies
+        # outlive weight updates (and are never re-uploaded inside a captured hipGraph)
         key = str(device)
         if getattr(self, '_init_dev', (None, None))[0] != key:
-            self._init_dev = (key, self.initial_params_estimate.to(device).contiguous())
+            self._init_dev = (key, self.initial_params_estimate.to(device).contiguous(), torch.ones(4, device=device))
         self._cache['init'] = self._init_dev[1]
+        self._cache['one'] = self._init_dev[2]
         return self._cache
 
     def forward_estimate(self, img_features, tape=None):
-        """[B,F] GPU features -> the full estimate buffer [B,160] (columns >= 157 are zero)."""
+        """[B,F] GPU features -> the full estimate buffer [B,160] (columns >= 157 are zero).
+        The estimates of all iterations live in ONE [iterations + 1][B][160] buffer (slot 0 = the initial estimate, slot it + 1 = the
+        output of iteration it, written from slot it: no in-place update, no snapshot copies for the backward), the hidden activations in
+        [iterations][B][H] buffers: the backward contracts a weight gradient over the three iterations' rows in one GEMM."""
         hipabi.require_gpu_tensor(img_features, 'IEF input features', torch.float32)
         hipabi.require_gpu_tensor(self.fc1.weight, 'IEF parameters (call .to(device))')
         feat = img_features.detach().contiguous()
@@ -84,24 +87,26 @@ class IEFModule(nn.Module):
         L, st = hipabi.lib(), hipabi.stream_ptr()
         H1, H2, P = self.fc1.out_features, self.fc2.out_features, self.num_output_params
         dev = feat.device
+        T = self.iterations
         c1 = torch.empty(B, H1, device=dev)
-        est = torch.empty(B, EST_LD, device=dev)
-        hipabi.check(L.straps_broadcast_rows(hipabi.ptr(pk['init']), P, hipabi.ptr(est), EST_LD, B, st), 'straps_broadcast_rows')
+        ests = torch.empty(T + 1, B, EST_LD, device=dev)
+        h1s = torch.empty(T, B, H1, device=dev)
+        h2s = torch.empty(T, B, H2, device=dev)
+        # every slot starts as the initial estimate with zero padding (the padding columns meet zero weights, but must be finite)
+        hipabi.check(L.straps_broadcast_rows(hipabi.ptr(pk['init']), P, hipabi.ptr(ests), EST_LD, (T + 1) * B, st), 'straps_broadcast_rows')
         hipabi.check(L.straps_linear_fwd(hipabi.ptr(feat), F, hipabi.ptr(pk['w1f']), F, hipabi.ptr(self.fc1.bias), None,
                                          hipabi.ptr(c1), H1, B, H1, F, 0, st), 'straps_linear_fwd(fc1 features)')
-        for it in range(self.iterations):
-            h1 = torch.empty(B, H1, device=dev)
-            h2 = torch.empty(B, H2, device=dev)
-            est_in = est.clone() if tape is not None else est
+        for it in range(T):
+            est_in, est_out, h1, h2 = ests[it], ests[it + 1], h1s[it], h2s[it]
             hipabi.check(L.straps_linear_fwd(hipabi.ptr(est_in), EST_LD, hipabi.ptr(pk['w1e']), EST_LD, None, hipabi.ptr(c1),
                                              hipabi.ptr(h1), H1, B, H1, EST_LD, 1, st), 'straps_linear_fwd(fc1 estimate)')
             hipabi.check(L.straps_linear_fwd(hipabi.ptr(h1), H1, self.fc2.weight.data_ptr(), H1, hipabi.ptr(self.fc2.bias), None,
                                              hipabi.ptr(h2), H2, B, H2, H1, 1, st), 'straps_linear_fwd(fc2)')
-            hipabi.check(L.straps_linear_fwd(hipabi.ptr(h2), H2, hipabi.ptr(pk['w3']), H2, hipabi.ptr(self.fc3.bias), hipabi.ptr(est),
-                                             hipabi.ptr(est), EST_LD, B, P, H2, 0, st), 'straps_linear_fwd(fc3)')
+            hipabi.check(L.straps_linear_fwd(hipabi.ptr(h2), H2, hipabi.ptr(pk['w3']), H2, hipabi.ptr(self.fc3.bias), hipabi.ptr(est_in),
+                                             hipabi.ptr(est_out), EST_LD, B, P, H2, 0, st), 'straps_linear_fwd(fc3)')
             if tape is not None:
-                tape.append(dict(est_in=est_in, h1=h1, h2=h2))
-        return est
+                tape.append(dict(est_in=est_in, h1=h1, h2=h2, stacks=(ests, h1s, h2s)))
+        return ests[T]
 
     @hipabi.on_tensor_device
     def forward(self, img_features):

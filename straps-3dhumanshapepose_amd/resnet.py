@@ -112,18 +112,17 @@ class ResNet(nn.Module):
         return self._cached(('w', id(conv)), [w], make)
 
     def _packed_weight_x3(self, conv, dgrad=False):
-        """(planes, plane stride) of the packed forward (KRSC) / data-gradient (CRSK) weights for the bf16x3 convolution route."""
+        """(planes, plane stride) of the packed forward / data-gradient weights for the bf16x3 convolution route: chunk-major planes
+        (csrc/elementwise.hip wk_index) written by the batched pack.  A stale or missing entry re-packs EVERY layer in one launch
+        (`prepack`), which refreshes all entries of the cache."""
         w = conv.weight
-
-        def make():
-            from .encoder_exec import split3
-            if dgrad:
-                from .autograd_ops import _packed_dgrad_weight
-                pk = _packed_dgrad_weight(self, conv)
-            else:
-                pk = self._packed_weight(conv)
-            return split3(hipabi.lib(), pk)
-        return self._cached(('wd3' if dgrad else 'w3', id(conv)), [w], make)
+        key = ('wd3' if dgrad else 'w3', id(conv))
+        sig = ((w.data_ptr(), w._version),)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != sig:
+            self.prepack(with_dgrad=dgrad or getattr(self, '_prepack_state', {}).get('crsk3') is not None)
+            hit = self._cache[key]
+        return hit[1]
 
     def prepack(self, with_dgrad=True):
         """(re)pack the weights of every non-stem conv for the forward (KRSC) and data-gradient (flipped CRSK) kernels in
@@ -194,6 +193,18 @@ class ResNet(nn.Module):
         # running_mean / running_var are updated by straps_bn_stats_finalize through raw pointers (no _version bump): the
         # training-forward counter is part of the signature, so eval() after train-mode forwards never sees stale folds
         return self._cached(('bn', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make, extra=(self._bn_epoch,))
+
+    def _frozen_bn(self, bn):
+        """eval-mode BatchNorm as (scale, shift, mean, invstd) [4][C] -- what the training-mode kernels take -- for an eval-mode forward
+        that records a tape (gradients through frozen statistics)."""
+        def make():
+            C = bn.weight.shape[0]
+            ss = torch.empty(4, C, device=bn.weight.device, dtype=torch.float32)
+            hipabi.check(hipabi.lib().straps_bn_fold_stats(hipabi.ptr(bn.weight), hipabi.ptr(bn.bias), hipabi.ptr(bn.running_mean), hipabi.ptr(bn.running_var),
+                                                           bn.eps, hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(ss[2]), hipabi.ptr(ss[3]), C,
+                                                           hipabi.stream_ptr()), 'straps_bn_fold_stats')
+            return ss
+        return self._cached(('bnf', id(bn)), [bn.weight, bn.bias, bn.running_mean, bn.running_var], make, extra=(self._bn_epoch,))
 
     @hipabi.on_tensor_device
     def forward(self, x):

@@ -129,3 +129,65 @@ def test_crop_resize_vs_oracle_and_reference_boxes():
         assert np.array_equal(np.stack([bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], 1), shapes)
         assert np.array_equal(out.cpu().numpy(), want)
         np.testing.assert_allclose(jout.cpu().numpy(), wj, rtol=1e-5, atol=1e-3)
+
+
+def test_cam_utils_projections_vs_reference_golden_and_autograd():
+    """the module-level helpers of utils/cam_utils.py on their HIP kernels (csrc/pose.hip): forward against the reference's outputs
+    (tests/golden/small_golden.npz: ortho_out / persp_out, made by importing the reference), a general rotation + per-body and shared
+    intrinsics against the oracle, a strided camera view (est[:, :3] of the [B,160] estimate buffer), 6890 points (predict_3D.py:144), and
+    the orthographic projection's gradient against autograd of the same expression in float64."""
+    import os
+    dev = torch.device('cuda:0')
+    small = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'small_golden.npz'))
+    pts = torch.from_numpy(det_uniform((3, 17, 3), 33, -1.0, 1.0))
+    cam = torch.from_numpy(det_uniform((3, 3), 34, 0.5, 1.2))
+    got = straps_amd.cam_utils.orthographic_project_torch(pts.to(dev), cam.to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), small['ortho_out'], rtol=1e-6, atol=1e-7)
+    K = torch.from_numpy(O.intrinsics_matrix().astype(np.float32))[None].expand(3, -1, -1)
+    tr = torch.tensor([[0., 0.2, 42.0]]).expand(3, -1) + torch.from_numpy(det_uniform((3, 3), 35, -0.1, 0.1))
+    R = torch.eye(3)[None].expand(3, -1, -1)
+    got = straps_amd.cam_utils.perspective_project_torch(pts.to(dev), R.to(dev), tr.to(dev), cam_K=K.to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), small['persp_out'], rtol=2e-5, atol=2e-3)       # pixels (focal length 5000: fp32 division / fma order)
+    # general rotation, many points, intrinsics from (focal_length, img_wh)
+    B, N = 4, 6890
+    P = torch.from_numpy(det_uniform((B, N, 3), 91, -1.0, 1.0))
+    Rg = O.batch_rodrigues(torch.from_numpy(det_uniform((B, 3), 92, -1.0, 1.0)))
+    tg = torch.tensor([[0., 0.2, 12.0]]).expand(B, -1) + torch.from_numpy(det_uniform((B, 3), 93, -0.5, 0.5))
+    Kg = torch.from_numpy(O.intrinsics_matrix(256, 256, 5000.0).astype(np.float32))[None].expand(B, -1, -1)
+    want = O.perspective_project(P.double(), Rg.double(), tg.double(), Kg.double())
+    got = straps_amd.cam_utils.perspective_project_torch(P.to(dev), Rg.to(dev), tg.to(dev), focal_length=5000.0, img_wh=256)
+    assert float((got.cpu().double() - want).abs().max()) < 5e-3                                  # pixels, values up to ~700
+    got = straps_amd.cam_utils.perspective_project_torch(P.to(dev), Rg.to(dev), tg.to(dev), cam_K=Kg.contiguous().to(dev))
+    assert float((got.cpu().double() - want).abs().max()) < 5e-3
+    # strided camera rows + gradient
+    est = torch.from_numpy(det_uniform((B, 160), 94, 0.5, 1.2)).to(dev).requires_grad_()
+    Pg = P.to(dev).requires_grad_()
+    out = straps_amd.cam_utils.orthographic_project_torch(Pg, est[:, :3])
+    w = torch.from_numpy(det_uniform((B, N, 2), 95, -1.0, 1.0)).to(dev)
+    (out * w).sum().backward()
+    P64, c64 = P.double().requires_grad_(), est.detach().cpu().double()[:, :3].clone().requires_grad_()
+    (O.orthographic_project(P64, c64) * w.cpu().double()).sum().backward()
+    assert float((out.detach().cpu().double() - O.orthographic_project(P64, c64).detach()).abs().max()) < 1e-6
+    assert float((Pg.grad.cpu().double() - P64.grad).abs().max()) < 1e-6
+    g = est.grad.cpu().double()
+    assert float((g[:, :3] - c64.grad).abs().max() / c64.grad.abs().max()) < 2e-6 and float(g[:, 3:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        straps_amd.cam_utils.orthographic_project_torch(P, cam)                                    # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize('std', [2, 4, 6])
+def test_heatmaps_with_other_standard_deviations_vs_oracle(std):
+    """convert_2Djoints_to_gaussian_heatmaps_torch(..., std): the reference takes the standard deviation (utils/label_conversions.py:90);
+    patch = 4 std x 4 std samples, truncated 2 std from the joint, borders and skipped joints as in the std = 4 golden test."""
+    dev = torch.device('cuda:0')
+    j = torch.from_numpy(det_uniform((3, 17, 2), 96, -20.0, 276.0))
+    j[0, 0] = torch.tensor([0.0, 255.0])
+    j[0, 1] = torch.tensor([255.9, 0.2])
+    j[0, 2] = torch.tensor([-2.0 * std + 0.5, 100.0])
+    j[0, 3] = torch.tensor([255.0 + 2 * std - 1, 128.0])
+    want = O.joints2d_to_heatmaps(j, 256, std)
+    got = straps_amd.label_conversions.convert_2Djoints_to_gaussian_heatmaps_torch(j.to(dev), 256, std).cpu()
+    assert torch.equal(got != 0, want != 0)                        # the same support, pixel for pixel
+    assert float((got - want).abs().max()) < 1e-6
+    with pytest.raises(ValueError):
+        straps_amd.label_conversions.convert_2Djoints_to_gaussian_heatmaps_torch(j.to(dev), 256, 2.5)

@@ -222,6 +222,59 @@ def _load_det(reg, layers, dev):
     return reg.to(dev), sd
 
 
+def test_gemm_multi_vs_float64(dev):
+    """straps_gemm_multi: eight problems of different shapes and stride patterns in one launch (transposed A, stacked K, a constant-one A =
+    column sums, ragged M / N / K), every epilogue feature (addend, mask, accumulate, second accumulating output), against float64."""
+    L = hipabi.lib()
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g)
+    B, H, P, F_ = 37, 96, 157, 72
+    dh = r(3, B, H).to(dev)
+    h1 = r(3, B, H).to(dev)
+    est = r(4, B, 160).to(dev)
+    feat = r(B, F_).to(dev)
+    w = r(H, H).to(dev)
+    w3 = r(P, H).to(dev)
+    mask = r(B, H).to(dev)
+    add = r(B, 160).to(dev)
+    one = torch.ones(4, device=dev)
+    dW2, dW1, dW3, y1, y2, y2b, cs, cs2 = (torch.full(sh, float('nan'), device=dev) for sh in
+                                          ((H, H), (H, F_ + P), (P, H), (B, H), (B, 160), (B, H), (H,), (P,)))
+    y2b = r(B, H).to(dev)
+    y2b0 = y2b.clone()
+    acc0 = r(B, H).to(dev)
+    y1.copy_(acc0)
+    D = hipabi.gemm_desc
+    hipabi.gemm_multi([
+        D(dh, 1, H, h1, H, 1, dW2, H, H, H, 3 * B),                                        # dh^T h1 over the three stacked blocks
+        D(dh[0], 1, H, feat, F_, 1, dW1, F_ + P, H, F_, B),                                 # into a column block of a wider matrix
+        D(dh, 1, H, est, 160, 1, dW1.data_ptr() + 4 * F_, F_ + P, H, P, 3 * B),             # the other column block, ragged N = 157
+        D(est[1], 1, 160, h1, H, 1, dW3, H, P, H, 3 * B),                                   # ragged M = 157
+        D(dh[1], H, 1, w, H, 1, y1, H, B, H, H, accumulate=1, mask=mask, ldmask=H, c2=y2b, ldc2=H, accumulate2=1),
+        D(dh[2], H, 1, w3, 1, H, y2, 160, B, P, H, addend=add, ldadd=160),                  # B(k, n) = w3[n][k]
+        D(one, 0, 0, dh, H, 1, cs, H, 1, H, 3 * B),                                         # column sums
+        D(one, 0, 0, est[1], 160, 1, cs2, P, 1, P, 3 * B)])
+    torch.cuda.synchronize()
+    d64 = lambda t: t.double().cpu()
+    dhf, h1f, estf = d64(dh).reshape(3 * B, H), d64(h1).reshape(3 * B, H), d64(est)
+
+    def close(got, want, name):
+        err = float((d64(got) - want).abs().max() / want.abs().max())
+        assert err < 2e-6, '%s: %.3e' % (name, err)
+    close(dW2, dhf.T @ h1f, 'dW2')
+    close(dW1[:, :F_], d64(dh[0]).T @ d64(feat), 'dW1 feature block')
+    close(dW1[:, F_:], dhf.T @ estf[:3].reshape(3 * B, 160)[:, :P], 'dW1 estimate block')
+    close(dW3, estf[1:].reshape(3 * B, 160)[:, :P].T @ h1f, 'dW3')
+    v = (d64(dh[1]) @ d64(w)) * (d64(mask) > 0)
+    close(y1, d64(acc0) + v, 'masked accumulate')
+    close(y2b, d64(y2b0) + v, 'second output')
+    close(y2[:, :P], d64(dh[2]) @ d64(w3).T + d64(add)[:, :P], 'addend')
+    assert torch.isnan(y2[:, P:]).all()                                                    # columns beyond N stay untouched
+    close(cs, dhf.sum(0), 'column sums')
+    close(cs2, estf[1:].reshape(3 * B, 160)[:, :P].sum(0), 'column sums (ragged)')
+    assert L.straps_gemm_multi(None, 1, None) != 0
+
+
 @pytest.mark.parametrize('layers,F_', [(18, 512), (50, 2048)])
 def test_ief_backward_vs_oracle_autograd(dev, layers, F_):
     reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)

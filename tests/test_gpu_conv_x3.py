@@ -27,13 +27,32 @@ def dev():
     return torch.device('cuda:0')
 
 
-def _split(t):
+def _split_linear(t):
+    """planes in the order of t (straps_split3_bf16: the exactness tests)"""
     L = hipabi.lib()
     n = t.numel()
     ps = (n + 7) // 8 * 8
     planes = torch.zeros(3, ps, device=t.device, dtype=torch.int16)
     hipabi.check(L.straps_split3_bf16(hipabi.ptr(t), hipabi.ptr(planes), n, ps, None), 'split3')
     return planes, ps
+
+
+def _split(t):
+    """chunk-major planes of an NHWC activation / gradient tensor [..., C] (what the convolution kernels read)"""
+    from straps_amd.encoder_exec import split3
+    return split3(hipabi.lib(), t)
+
+
+def _wsplit(dev, w, dgrad=False):
+    """chunk-major planes of a convolution weight (OIHW), forward or data-gradient layout"""
+    from straps_amd.encoder_exec import weight_planes
+    return weight_planes(hipabi.lib(), w.float().contiguous().to(dev), dgrad)
+
+
+def _cm(t):
+    """torch restatement of the chunk-major order (csrc/common.h cm_index) of an NHWC tensor [..., C]: [C/32][rows][32] flattened"""
+    C = t.shape[-1]
+    return t.reshape(-1, C // 32, 32).permute(1, 0, 2).contiguous().reshape(-1)
 
 
 def _planes_to_f64(planes, n):
@@ -49,7 +68,7 @@ def test_split_is_exact(dev):
                         (rng.standard_normal(4096) * 1e-25).astype(np.float32), (rng.standard_normal(4096) * 1e30).astype(np.float32),
                         np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -126, 2.0 ** 100, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0, 255.0, 257.0], np.float32)])
     t = torch.from_numpy(x).to(dev)
-    planes, ps = _split(t)
+    planes, ps = _split_linear(t)
     torch.cuda.synchronize()
     got = _planes_to_f64(planes, x.size)
     assert np.array_equal(got, x.astype(np.float64)), 'three-plane split is not exact'
@@ -60,7 +79,7 @@ def test_split_is_exact(dev):
     assert np.all(np.abs(b[2][nz]) <= np.abs(b[0][nz]) * 2.0 ** -16 * 1.01)
     # below 2^-110 the last bits of an fp32 value lie under bf16's smallest subnormal (2^-133): the split is then within 2^-133
     tiny = (rng.standard_normal(4096) * 1e-36).astype(np.float32)
-    planes, ps = _split(torch.from_numpy(tiny).to(dev))
+    planes, ps = _split_linear(torch.from_numpy(tiny).to(dev))
     torch.cuda.synchronize()
     assert np.abs(_planes_to_f64(planes, tiny.size) - tiny.astype(np.float64)).max() <= 2.0 ** -133
 
@@ -73,19 +92,36 @@ def test_split_planes_equal_the_cpu_model_bit_for_bit(dev):
     x = np.concatenate([rng.standard_normal(65536 + 5).astype(np.float32), (rng.standard_normal(4096) * 1e-20).astype(np.float32),
                         (rng.standard_normal(4096) * 1e20).astype(np.float32),
                         np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -60, 2.0 ** 100, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0, 255.0, 257.0], np.float32)])
-    planes, ps = _split(torch.from_numpy(x).to(dev))
+    planes, ps = _split_linear(torch.from_numpy(x).to(dev))
     torch.cuda.synchronize()
     got = planes[:, :x.size].cpu().numpy().view(np.uint16)
     want, _ = em.split3(x)
     assert np.array_equal(got, want)
 
 
+def test_chunk_major_split_is_the_permuted_plain_split(dev):
+    """straps_split3_bf16_cm == straps_split3_bf16 followed by the chunk-major permutation (csrc/common.h cm_index: element (row, c) of a
+    [rows][C] tensor at ((c / 32) * rows + row) * 32 + c % 32), restated here with torch views; odd row counts, C = 32 .. 512."""
+    for rows, C in ((37, 32), (1000, 64), (129, 128), (77, 512), (4096, 256)):
+        x = torch.from_numpy(det_uniform((rows, C), 70 + C, -3, 3)).to(dev)
+        lin, ps = _split_linear(x)
+        cm, ps2 = _split(x)
+        torch.cuda.synchronize()
+        assert ps == ps2
+        for pl in range(3):
+            want = _cm(lin[pl, :rows * C].view(rows, C))
+            assert torch.equal(cm[pl, :rows * C], want), (rows, C, pl)
+
+
 @pytest.mark.parametrize('with_fp32', [False, True])
 def test_batched_weight_pack_writes_the_planes_of_both_layouts(dev, with_fp32):
-    """straps_pack_conv_weights_batched_x3 == straps_pack_conv_weights_batched followed by a split pass over each packed buffer, bit for
-    bit (1x1 / 3x3 / 5x5 taps, channel counts off the 32x32 tile); with NULL fp32 destinations only the planes are written."""
+    """straps_pack_conv_weights_batched_x3: the fp32 outputs equal straps_pack_conv_weights_batched's, and the planes are the split of
+    the packed weights in CHUNK-MAJOR order -- forward planes: element (cout, tap, cin) at ((tap * Cin/32 + cin/32) * Cout + cout) * 32 +
+    cin % 32; data-gradient planes: (cin, flipped tap, cout) at ((tap * Cout/32 + cout/32) * Cin + cin) * 32 + cout % 32 -- restated here
+    with torch views, bit for bit (1x1 / 3x3 taps).  Layers whose reduction extent is not a multiple of 32 (they cannot run on the bf16x3
+    route) get no planes: their slots stay untouched; with NULL fp32 destinations only the planes are written."""
     L = hipabi.lib()
-    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (96, 40, 3, 3), (33, 70, 5, 5), (256, 128, 3, 3), (8, 8, 1, 1)]
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (96, 160, 3, 3), (33, 70, 5, 5), (256, 128, 3, 3), (8, 8, 1, 1), (64, 96, 3, 3)]
     ws = [torch.from_numpy(det_uniform(sh, 140 + i, -1, 1)).to(dev) for i, sh in enumerate(shapes)]
     total = sum(w.numel() for w in ws)
     ps = (total + 7) // 8 * 8 + 8
@@ -103,25 +139,35 @@ def test_batched_weight_pack_writes_the_planes_of_both_layouts(dev, with_fp32):
 
     krsc, crsk = torch.empty(total, device=dev), torch.empty(total, device=dev)
     hipabi.check(L.straps_pack_conv_weights_batched(hipabi.ptr(table(krsc, crsk)), len(ws), total, None), 'batched pack')
-    want = []
-    for buf in (krsc, crsk):
-        planes = torch.zeros(3, ps, device=dev, dtype=torch.int16)
-        hipabi.check(L.straps_split3_bf16(hipabi.ptr(buf), hipabi.ptr(planes), total, ps, None), 'split3')
-        want.append(planes)
+    # expected planes: per layer the chunk-major permutation of the packed fp32 block, split; zero where no planes are written
+    want_k, want_c = torch.zeros(3, ps, device=dev, dtype=torch.int16), torch.zeros(3, ps, device=dev, dtype=torch.int16)
+    off = 0
+    for w in ws:
+        O, C, R, S = w.shape
+        n, RS = w.numel(), R * S
+        if C % 32 == 0:
+            blk = krsc[off:off + n].view(O, RS, C // 32, 32).permute(1, 2, 0, 3).contiguous().reshape(-1)
+            pl, _ = _split_linear(blk)
+            want_k[:, off:off + n] = pl[:, :n]
+        if O % 32 == 0:
+            blk = crsk[off:off + n].view(C, RS, O // 32, 32).permute(1, 2, 0, 3).contiguous().reshape(-1)
+            pl, _ = _split_linear(blk)
+            want_c[:, off:off + n] = pl[:, :n]
+        off += n
     k2 = torch.full((total,), float('nan'), device=dev) if with_fp32 else None
     c2 = torch.full((total,), float('nan'), device=dev) if with_fp32 else None
     k3 = torch.zeros(3, ps, device=dev, dtype=torch.int16)
     c3 = torch.zeros(3, ps, device=dev, dtype=torch.int16)
     hipabi.check(L.straps_pack_conv_weights_batched_x3(hipabi.ptr(table(k2, c2)), len(ws), total, hipabi.ptr(k3), hipabi.ptr(c3), ps, None), 'batched pack x3')
     torch.cuda.synchronize()
-    assert torch.equal(k3, want[0]) and torch.equal(c3, want[1])
+    assert torch.equal(k3, want_k) and torch.equal(c3, want_c)
     if with_fp32:
         assert torch.equal(k2, krsc) and torch.equal(c2, crsk)
     # forward-only form: no data-gradient planes
     k3b = torch.zeros(3, ps, device=dev, dtype=torch.int16)
     hipabi.check(L.straps_pack_conv_weights_batched_x3(hipabi.ptr(table(None, None)), len(ws), total, hipabi.ptr(k3b), None, ps, None), 'batched pack x3 fwd')
     torch.cuda.synchronize()
-    assert torch.equal(k3b, want[0])
+    assert torch.equal(k3b, want_k)
     assert L.straps_pack_conv_weights_batched_x3(hipabi.ptr(table(None, None)), len(ws), total, None, None, ps, None) != 0
 
 
@@ -151,7 +197,7 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
         if stats:
             part = torch.empty(L.straps_conv_x3_stat_blocks(B, H, W, Cin, Cout, k, k, stride, pad, cfg), Cout, 2, device=dev)
         xp, xps = _split(x)
-        wp3, wps = _split(wp)
+        wp3, wps = _wsplit(dev, w)
         hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(xp), xps, hipabi.ptr(wp3), wps, hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), int(relu),
                                           hipabi.ptr(y), hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, cfg, None), 'conv_fwd_x3')
     else:
@@ -178,11 +224,8 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
     # software-pipelined chunk loop (barrier between the two k steps, register double buffer): every such configuration
     (3, 128, 128, 8, 8, 3, 1, 8), (5, 128, 128, 24, 24, 3, 1, 9), (2, 64, 64, 16, 16, 3, 1, 10), (5, 64, 64, 7, 7, 3, 1, 11),
     (5, 128, 128, 24, 24, 3, 1, 12), (2, 64, 128, 16, 16, 1, 2, 8), (1, 32, 64, 3, 3, 3, 1, 11), (2, 64, 128, 16, 16, 3, 2, 9),
-    # direct-A tiles (tile_cfg 13 / 14: the A operand goes straight from L2 into registers, LDS holds the weights alone; explicit only --
-    # the auto rule does not pick them: 147 vs 139 us on layer1): one- and many-chunk reductions, ragged M, 1x1, stride 2
-    (2, 64, 64, 16, 16, 3, 1, 13), (5, 64, 64, 7, 7, 3, 1, 13), (1, 32, 64, 3, 3, 3, 1, 13), (2, 256, 64, 16, 16, 1, 1, 13),
-    (3, 96, 128, 7, 13, 3, 2, 13), (2, 64, 64, 10, 24, 3, 1, 14), (5, 64, 64, 7, 7, 3, 1, 14), (2, 64, 128, 16, 16, 1, 2, 14),
-    (1, 32, 64, 8, 8, 1, 1, 13), (4, 64, 64, 32, 32, 3, 1, 14)])
+    # odd-sized maps through the chunk-major addressing: rows that are not a multiple of anything, stride 2 (64-byte pieces at a 128-byte stride)
+    (3, 64, 64, 5, 9, 3, 1, 0), (1, 160, 64, 11, 7, 3, 2, 0)])
 def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """all tile configurations (4- and 8-wave, 2- and 3-stage rings), ragged M, stride 1 / 2, 3x3 and 1x1, non-square maps, the
     fused epilogue and the training-mode statistics; the bar is the exact-fp32 kernel's (test_gpu_forward.py)."""
@@ -211,8 +254,7 @@ def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
 @pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
     (2, 64, 64, 16, 16, 3, 1, 0), (2, 64, 128, 16, 16, 3, 2, 0), (3, 128, 64, 9, 9, 3, 1, 0), (2, 64, 128, 16, 16, 1, 2, 0),
     (1, 256, 512, 8, 8, 3, 2, 0), (2, 256, 64, 8, 8, 1, 1, 0), (2, 128, 128, 15, 15, 3, 2, 1), (4, 128, 128, 20, 12, 3, 1, 4),
-    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3),
-    (2, 64, 64, 16, 16, 3, 1, 13), (2, 64, 128, 16, 16, 3, 2, 13), (3, 128, 64, 9, 9, 3, 1, 14), (2, 64, 128, 16, 16, 1, 2, 14)])
+    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3)])
 def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """data gradient on the bf16x3 route (stride-2 parity classes, odd sizes, the skip-gradient addend) vs float64 autograd."""
     L = hipabi.lib()
@@ -224,8 +266,7 @@ def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     y.backward(dy)
     dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
     g3, gps = _split(dyd)
-    wd = _pack(dev, w, dgrad=True)
-    w3, wps = _split(wd)
+    w3, wps = _wsplit(dev, w, dgrad=True)
     add = torch.from_numpy(det_uniform((B, H, W, Cin), 4, -1, 1)).to(dev) * 1e-3
     dx = torch.full((B, H, W, Cin), float('nan'), device=dev)
     hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(add), hipabi.ptr(dx), B, H, W, Cin, Cout, k, k,
@@ -285,7 +326,7 @@ def test_dgrad_x3_with_fused_batchnorm_sums(dev, B, Cin, Cout, H, W, k, stride, 
     w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 2, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
     g = torch.from_numpy(det_uniform((B, Ho, Wo, Cout), 3, -1, 1)).to(dev) * 1e-3
     g3, gps = _split(g)
-    w3, wps = _split(_pack(dev, w, dgrad=True))
+    w3, wps = _wsplit(dev, w, dgrad=True)
     add = torch.from_numpy(det_uniform((B, H, W, Cin), 4, -1, 1)).to(dev) * 1e-3
     raw = torch.from_numpy(det_uniform((B, H, W, Cin), 5, -2, 2)).to(dev)
     mean = raw.mean(dim=(0, 1, 2)).contiguous()
@@ -350,7 +391,7 @@ def test_single_patch_buffer_halo_kernel_at_layer1_size_forward_dgrad_and_repeat
     ref = F.conv2d(x.double(), w.double(), None, 1, pad)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     x3, xps = _split(xd)
-    w3, wps = _split(_pack(dev, w))
+    w3, wps = _wsplit(dev, w)
     first = None
     for rep in range(50):
         y = torch.full((B, H, W, Cout), float('nan'), device=dev)
@@ -374,7 +415,7 @@ def test_single_patch_buffer_halo_kernel_at_layer1_size_forward_dgrad_and_repeat
     dy = torch.from_numpy(det_uniform((B, Cin, H, W), 54, -1, 1)) * 1e-3
     want = F.conv_transpose2d(dy.double(), wd_full.double(), None, 1, pad)                                        # [B,Cout,H,W]
     g3, gps = _split(dy.permute(0, 2, 3, 1).contiguous().to(dev))
-    wd3, wdps = _split(_pack(dev, wd_full, dgrad=True))
+    wd3, wdps = _wsplit(dev, wd_full, dgrad=True)
     add = torch.from_numpy(det_uniform((B, H, W, Cout), 55, -1, 1)).to(dev) * 1e-3
     first = None
     for rep in range(50):
@@ -428,7 +469,7 @@ def test_conv_fwd_x3p_planes_equal_a_split_pass(dev, B, Cin, Cout, H, k, stride,
     sh = torch.from_numpy(det_uniform((Cout,), 44, -0.5, 0.5)).to(dev)
     res = torch.from_numpy(det_uniform((B, Ho, Ho, Cout), 45, -1, 1)).to(dev)
     x3, xps = _split(x)
-    w3, wps = _split(_pack(dev, w))
+    w3, wps = _wsplit(dev, w)
     y0 = torch.full((B, Ho, Ho, Cout), float('nan'), device=dev)
     y1 = torch.full((B, Ho, Ho, Cout), float('nan'), device=dev)
     hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, hipabi.ptr(y0), None,

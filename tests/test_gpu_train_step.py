@@ -182,7 +182,10 @@ def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5):
         r = grads[n].reshape(-1)
         e_gpu = float((ts.gviews[p].detach().cpu().double().reshape(-1) - r).norm() / r.norm().clamp_min(1e-30))
         e_32 = float((g32[n].double().reshape(-1) - r).norm() / r.norm().clamp_min(1e-30))
-        bar = 1e-5 if n.startswith('ief_module.') else 5e-3 if n.startswith('image_encoder.layer4.') else 2 * e_32 + 1e-3
+        # (layer4: 5e-3 -- unless the float32 CPU oracle, i.e. the reference's own arithmetic, is itself further than that from float64
+        #  on this tensor: resnet50's layer4.0.conv1 sits behind three BatchNorm backwards of the pooled, almost constant gradient and
+        #  reads 0.8-1.4e-2 in fp32 on the CPU; then the rule of the ill-conditioned tensors applies)
+        bar = 1e-5 if n.startswith('ief_module.') else max(5e-3, 2 * e_32 + 1e-3) if n.startswith('image_encoder.layer4.') else 2 * e_32 + 1e-3
         table.append((n, e_gpu, e_32, bar))
         if not e_gpu < bar:
             bad.append('%-52s gpu %.2e  cpu32 %.2e  bar %.2e' % table[-1])
@@ -191,11 +194,16 @@ def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5):
         g = float(ts.gviews[getattr(crit, name + '_log_var')])
         assert g == pytest.approx(float(glv[name]), rel=1e-4, abs=1e-7), name
     l4 = sorted(t[1] for t in table if t[0].startswith('image_encoder.layer4.'))
-    print(tag, '%d tensors, relative gradient error vs fp64 oracle autograd: IEF worst %.2e | layer4 median %.2e worst %.2e | stem..layer3 worst %.2e (float32 CPU oracle: %.2e)'
-          % (len(table), max(t[1] for t in table if t[0].startswith('ief_module.')), l4[len(l4) // 2], l4[-1],
+    l4_32 = sorted(t[2] for t in table if t[0].startswith('image_encoder.layer4.'))
+    print(tag, '%d tensors, relative gradient error vs fp64 oracle autograd: IEF worst %.2e | layer4 median %.2e worst %.2e (float32 CPU oracle: median %.2e worst %.2e) | '
+          'stem..layer3 worst %.2e (float32 CPU oracle: %.2e)'
+          % (len(table), max(t[1] for t in table if t[0].startswith('ief_module.')), l4[len(l4) // 2], l4[-1], l4_32[len(l4_32) // 2], l4_32[-1],
              max(t[1] for t in table if not t[0].startswith(('ief_module.', 'image_encoder.layer4.'))),
              max(t[2] for t in table if not t[0].startswith(('ief_module.', 'image_encoder.layer4.')))))
-    assert l4[len(l4) // 2] < 2e-4
+    # layer4 in the median: 2e-4 (resnet18: typical errors are 1e-5..1e-4) -- or twice the float32 CPU oracle's own median where that is
+    # larger: in resnet50 the whole of layer4 (three Bottlenecks = nine BatchNorm backwards on the 8x8 grid behind the pooling) is in the
+    # regime the docstring describes for stem..layer3, the reference's fp32 arithmetic itself sits at 5e-3 there
+    assert l4[len(l4) // 2] < max(2e-4, 2 * l4_32[len(l4_32) // 2])
     return table
 
 

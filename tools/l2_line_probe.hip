@@ -54,12 +54,19 @@ __global__ __launch_bounds__(256) void probe(const char* __restrict__ src, unsig
     } else {
         for (int it = 0; it < iters; ++it) {
             if (MODE == 7) {
-                u32x4 v;
-                const char* a = src + pos + off;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(a) : "memory");
-                if ((it & 7) == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-                asm volatile("" : "+v"(v));
-                if ((it & 7) == 7) acc += v;
+                // plain loads, eight per lane in flight (the compiler places the waits)
+                if ((it & 7) == 0) {
+                    u32x4 v[8];
+                    unsigned q = pos;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = *reinterpret_cast<const u32x4*>(src + q + off);
+                        q += extent * 4;
+                        if (q >= footprint) q -= footprint;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += v[j];
+                }
             } else {
                 dma(src + pos + off, my + (it & (SLOTS - 1)) * 1024);
                 if (MODE == 4) { dma(src + pos + off + 64, my + ((it + 1) & (SLOTS - 1)) * 1024); ++it; }
@@ -88,6 +95,7 @@ void run(const char* src, unsigned fp, unsigned* sink, int blocks, int iters) {
         const int eff_iters = MODE == 5 ? (iters / 18) * 18 : iters;
         const double bytes = (double)blocks * 4 * eff_iters * 1024.0;
         if (rep == 2) printf("mode %d footprint %5.1f MB: %7.3f ms  %8.1f GB/s useful  (%s)\n", MODE, fp / 1048576.0, ms, bytes / ms * 1e-6, hipGetErrorString(hipGetLastError()));
+        fflush(stdout);
     }
 }
 

@@ -32,12 +32,11 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def split3(t):
-    n = t.numel()
-    ps = (n + 7) // 8 * 8
-    out = torch.empty(3, ps, dtype=torch.int16, device=dev)
-    hipabi.check(L.straps_split3_bf16(hipabi.ptr(t), hipabi.ptr(out), n, ps, None), 'split3')
-    return out, ps
+from straps_amd.encoder_exec import split3 as _split3, weight_planes  # noqa: E402
+
+
+def split3(t):          # chunk-major planes of an NHWC tensor
+    return _split3(L, t)
 
 
 def ck(rc, what):
@@ -54,8 +53,8 @@ for name, H, Cin, Cout, k, stride in SHAPES:
     L.straps_pack_conv_weight(hipabi.ptr(w), hipabi.ptr(wp), Cout, Cin, k, k, None)
     L.straps_pack_conv_weight_dgrad(hipabi.ptr(w), hipabi.ptr(wd), Cout, Cin, k, k, None)
     x3, xps = split3(x)
-    wp3, wps = split3(wp)
-    wd3, wdps = split3(wd)
+    wp3, wps = weight_planes(L, w)
+    wd3, wdps = weight_planes(L, w, dgrad=True)
     y = torch.empty(B, Ho, Ho, Cout, device=dev)
     y3 = torch.empty_like(y)
     flops = 2.0 * B * Ho * Ho * Cout * Cin * k * k
@@ -100,6 +99,6 @@ for name, H, Cin, Cout, k, stride in SHAPES:
         t = timeit(lambda: L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(wd3), wdps, None, hipabi.ptr(dx3), B, H, H, Cin, Cout, k, k, stride, pad, cfg, None))
         row += ' c%d %5.1f' % (cfg, t * 1e6)
     out = torch.empty(3, xps, dtype=torch.int16, device=dev)
-    ts = timeit(lambda: L.straps_split3_bf16(hipabi.ptr(x), hipabi.ptr(out), x.numel(), xps, None))
+    ts = timeit(lambda: L.straps_split3_bf16_cm(hipabi.ptr(x), hipabi.ptr(out), x.numel() // Cin, Cin, xps, None))
     row += ' us | split(x) %5.1f us' % (ts * 1e6)
     print(row, flush=True)

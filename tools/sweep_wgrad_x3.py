@@ -34,12 +34,11 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-def split3(t):
-    n = t.numel()
-    ps = (n + 7) // 8 * 8
-    out = torch.empty(3, ps, dtype=torch.int16, device=dev)
-    hipabi.check(L.straps_split3_bf16(hipabi.ptr(t), hipabi.ptr(out), n, ps, None), 'split3')
-    return out, ps
+from straps_amd.encoder_exec import split3 as _split3  # noqa: E402
+
+
+def split3(t):          # chunk-major planes of an NHWC tensor
+    return _split3(L, t)
 
 
 for name, H, Cin, Cout, k, stride in SHAPES:

@@ -19,19 +19,10 @@ L = hipabi.load()
 dev = torch.device('cuda:0')
 x = torch.randn(B, H, H, Cin, device=dev).relu_()
 w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
-wp = torch.empty_like(w)
-L.straps_pack_conv_weight(hipabi.ptr(w), hipabi.ptr(wp), Cout, Cin, k, k, None)
+from straps_amd.encoder_exec import split3, weight_planes  # noqa: E402
 
-
-def split3(t):
-    n = t.numel()
-    out = torch.empty(3, n, dtype=torch.int16, device=dev)
-    hipabi.check(L.straps_split3_bf16(hipabi.ptr(t), hipabi.ptr(out), n, n, None), 'split3')
-    return out, n
-
-
-x3, xps = split3(x)
-w3, wps = split3(wp)
+x3, xps = split3(L, x)                  # chunk-major planes
+w3, wps = weight_planes(L, w)
 y = torch.empty(B, H, H, Cout, device=dev)
 for _ in range(iters):
     hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(y), None, B, H, H, Cin, Cout, k, k,
