@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
     import glob
     hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [HEADER]
     deps = srcs + hdrs
-    if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) > os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
     jobs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + '.o')
-        if force or not os.path.isfile(o) or any(os.path.getmtime(o) < os.path.getmtime(d) for d in [s] + hdrs):
+        if force or not os.path.isfile(o) or any(os.path.getmtime(o) <= os.path.getmtime(d) for d in [s] + hdrs):
             cmd = [hipcc] + flags + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))

@@ -332,6 +332,45 @@ def test_regressor_param_grads_vs_reference_golden(dev, layers):
     print('r%d worst grad-norm rel err %.2e, worst cosine %.6f' % (layers, worst, worst_cos))
 
 
+@pytest.mark.parametrize('layers,prec', [(18, 'bf16x3'), (18, 'fp32'), (50, 'bf16x3')])
+def test_eval_mode_gradients_through_frozen_batchnorm_vs_float64_oracle(dev, layers, prec):
+    """reg.eval() + loss.backward(): nn.BatchNorm2d in eval mode back-propagates through its running statistics as constants
+    (models/resnet.py:47,147; fine-tuning with frozen statistics).  Eval mode is well conditioned (no batch statistics), so the bars are
+    tight: outputs 2e-5, every parameter gradient (incl. BatchNorm weight / bias) 2e-4 relative L2 against autograd of the float64 oracle
+    with training=False; running statistics and num_batches_tracked untouched; the no-grad eval output unchanged by the taped run."""
+    reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+    reg.image_encoder.conv_precision = prec
+    reg.eval()
+    B = 3
+    x = torch.from_numpy(det_uniform((B, 18, 256, 256), 4343, 0.0, 1.0)).to(dev)
+    x[:, 1:, ::2] = 0.0
+    coef = torch.from_numpy(det_uniform((B, 157), 556)).to(dev)
+    with torch.no_grad():
+        y0 = torch.cat(reg(x), 1).clone()
+    buf0 = {n: b.clone() for n, b in reg.named_buffers()}
+    cam, pose, shape = reg(x)
+    y1 = torch.cat([cam, pose, shape], 1)
+    (y1 * coef).sum().backward()
+    assert float((y1.detach() - y0).abs().max()) < 2e-5
+    for n, b in reg.named_buffers():
+        assert torch.equal(b, buf0[n]), n
+    sdo = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    names = [n for n, _ in reg.named_parameters()]
+    for n in names:
+        sdo[n].requires_grad_(True)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    _, _, _, est = O.regressor_forward(x.cpu().double(), sdo, O.ief_init_estimate(MP['pose'], MP['shape']).double(), layers, 3, training=False)
+    (est * coef.cpu().double()).sum().backward()
+    assert float((y1.detach().cpu().double() - est.detach()).abs().max()) < 2e-4
+    worst = 0.0
+    for n, p in reg.named_parameters():
+        assert p.grad is not None, n
+        err = _relerr(p.grad, sdo[n].grad)
+        worst = max(worst, err)
+        assert err < 2e-4, '%s: %.3e' % (n, err)
+    print('eval-mode r%d %s: worst relative gradient error vs float64 %.2e' % (layers, prec, worst))
+
+
 def test_fused_stem_tail_equals_unfused(dev):
     """bn1 + relu + maxpool fused (straps_bn_relu_maxpool_fwd / straps_bn_bwd_pooled: the stem activation and its gradient are
     never materialised) against the unfused calls (straps_bn_apply, straps_maxpool_fwd_idx, straps_maxpool_bwd, straps_bn_bwd):
