@@ -297,208 +297,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     clk_end(p, clk);
 }
 
-// ---- loader / compute split of the im2col kernel ----
-// Round 3 ablations on the chunk-major planes (tools/x3_ablate.py, layer3 128x128 tile, us): MFMA stream + barriers 57, + fragment reads
-// 76, + operand copies 93 while the copies alone take 38 -- the copies are no longer a bandwidth problem, they are an ISSUE problem: every
-// global_load_lds costs the issuing wave tens of cycles in which it issues nothing else, and a wave that owns a quarter of the tile's
-// MFMAs stalls its SIMD's matrix pipe with it.  Here the WGM x WGN waves that hold the accumulators issue no copy at all: four more waves
-// -- one per SIMD, beside a compute wave -- do nothing but the address arithmetic and the LDS-DMA issue of the NST-stage ring (their
-// stalls cost nothing: they have nothing else to do) and meet the compute waves at the one barrier per K chunk.  The compute waves'
-// registers no longer carry the copy state, so a 128 x 64 wave tile (256 x 128 per workgroup, 0.375 fragment reads per MFMA instead of
-// 0.5) fits next to a loader on every SIMD.
-template <int BM, int BN, int WGM, int WGN, int NST>
-__global__ __launch_bounds__(64 * (WGM * WGN + 4)) void conv_igemm_x3s_kernel(ConvP p) {
-    const ConvP::Class& c = p.cls[blockIdx.y];
-    const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, cntaps = c.ntaps;
-    if ((int)blockIdx.x >= cMT * p.NT) return;                 // a smaller class of the same launch
-    ClkSample clk;
-    clk_begin(p, clk);
-    constexpr int NWC = WGM * WGN, NWL = 4, RPP = 16 * NWL;    // compute waves; loader waves; rows per copy pass of the loaders
-    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
-    constexpr int AP = BM / RPP, BP = BN / RPP;
-    static_assert(BM % RPP == 0 && BN % RPP == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NWC == 4 && NST >= 2 && NST <= 4, "tile / wave grid mismatch");
-    constexpr int NPIECE = 3 * (AP + BP);                      // LDS-DMA instructions per loader lane and chunk
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    u16* As = reinterpret_cast<u16*>(smem);       // [NST stages][3 planes][BM][32]
-    u16* Bs = As + NST * 3 * BM * 32;             // [NST stages][3 planes][BN][32]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = xcd_remap(blockIdx.x, cMT * p.NT);
-    const int nt = bid % p.NT, mt = bid / p.NT;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int cchunks = p.Cin >> 5;
-    const int nchunks = cntaps * cchunks;
-
-    if (wave >= NWC) {
-        // ===================== loader waves =====================
-        const int lw = wave - NWC;                               // 0..3
-        const int ltid = tid - 64 * NWC;
-        const int lr = ltid >> 2;                                // row of the RPP-row pass this lane copies
-        const int lc = (ltid & 3) ^ swz3(lr);                    // 16-byte K group it fetches for its slot ltid & 3
-        const u16* xg = reinterpret_cast<const u16*>(p.x);
-        const u16* wg = reinterpret_cast<const u16*>(p.w);
-        int a_hi0[AP], a_wi0[AP], a_base[AP];
-        const int MhMw = cMh * cMw;
-#pragma unroll
-        for (int q = 0; q < AP; ++q) {
-            const int m = m0 + lr + RPP * q;
-            if (m < cM) {
-                const int b = m / MhMw;
-                const int rem = m - b * MhMw;
-                const int ho = rem / cMw, wo = rem - ho * cMw;
-                a_hi0[q] = ho * p.stride;
-                a_wi0[q] = wo * p.stride;
-                a_base[q] = ((b * p.H + a_hi0[q]) * p.W + a_wi0[q]) * 32 + lc * 8;
-            } else {
-                a_hi0[q] = -(1 << 28);
-                a_wi0[q] = 0;
-                a_base[q] = 0;
-            }
-        }
-        const u16* wrow[BP];
-#pragma unroll
-        for (int q = 0; q < BP; ++q) wrow[q] = wg + (n0 + lr + RPP * q) * 32 + lc * 8;
-        const int a_cstep = p.xrows * 32, b_cstep = p.Cout * 32;
-        const u16* a_src[AP];
-        long long a_ps[AP];
-        int a_inc[AP];
-        const u16* b_src[BP];
-        int n_tap = 0, n_cc = 0;
-        const int tl = lane < 9 ? lane : 0;
-        const int v_dh = c.tap_dh[tl], v_dw = c.tap_dw[tl], v_tw = c.tap_w[tl];
-        const u16* zsrc = reinterpret_cast<const u16*>(k_zero16_x3);
-        asm volatile("" : "+s"(zsrc));
-        auto setup_tap = [&](int tap) {
-            const int dh = __builtin_amdgcn_readlane(v_dh, tap), dw = __builtin_amdgcn_readlane(v_dw, tap), tw = __builtin_amdgcn_readlane(v_tw, tap);
-            const int toff = (dh * p.W + dw) * 32;
-#pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
-                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                a_src[i] = ok ? xg + (a_base[i] + toff) : zsrc;
-                a_ps[i] = ok ? p.xps : 0;
-                a_inc[i] = ok ? a_cstep : 0;
-            }
-#pragma unroll
-            for (int i = 0; i < BP; ++i) b_src[i] = wrow[i] + (long long)tw * cchunks * b_cstep;
-        };
-        auto issue = [&](int stage) {                            // all copies of the chunk the issue stream stands at, then step on
-#pragma unroll
-            for (int plane = 0; plane < 3; ++plane) {
-#pragma unroll
-                for (int r = 0; r < AP; ++r)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[r] + plane * a_ps[r]),
-                                                     (__attribute__((address_space(3))) void*)(As + ((stage * 3 + plane) * BM + RPP * r + 16 * lw) * 32), 16, 0, 0);
-#pragma unroll
-                for (int r = 0; r < BP; ++r)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[r] + plane * p.wps),
-                                                     (__attribute__((address_space(3))) void*)(Bs + ((stage * 3 + plane) * BN + RPP * r + 16 * lw) * 32), 16, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < AP; ++i) a_src[i] += a_inc[i];
-#pragma unroll
-            for (int i = 0; i < BP; ++i) b_src[i] += b_cstep;
-            if (++n_cc == cchunks) {
-                n_cc = 0;
-                if (++n_tap < cntaps) setup_tap(n_tap);
-            }
-        };
-        if (nchunks > 0) setup_tap(0);
-#pragma unroll
-        for (int s = 0; s < NST - 1; ++s)
-            if (s < nchunks) issue(s);
-        int nstage = NST - 1;
-        for (int q = 0; q < nchunks; ++q) {
-            // chunk q has landed: of the younger chunks already issued (at most NST - 2) everything may stay in flight
-            const int ahead = min(nchunks - 1, q + NST - 2) - q;
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIECE) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                        // publishes chunk q; every compute wave is done reading chunk q - 1
-            asm volatile("" ::: "memory");
-            if (q + NST - 1 < nchunks) issue(nstage);            // chunk q + NST - 1 into the stage chunk q - 1 was read from
-            nstage = nstage + 1 == NST ? 0 : nstage + 1;
-        }
-        // the epilogue's workgroup barriers (statistics / BatchNorm-backward partials through LDS)
-        if (p.stats) { __syncthreads(); __syncthreads(); }
-        if (p.bnr_raw) { __syncthreads(); __syncthreads(); }
-        return;
-    }
-
-    // ===================== compute waves =====================
-    const int wm = wave / WGN, wn = wave % WGN;
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    int fo[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ swz3(lane & 31)) << 3);
-    constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
-    constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
-    int stage = 0;
-    for (int q = 0; q < nchunks; ++q) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const u16* Ab = As + (stage * 3 * BM + wm * WTM) * 32;
-        const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[MI][3], b[NI][3];
-            // fragment reads in the order the products need them (plane pairs (1,1), (0,2), (2,0), ..): the first MFMAs start after a
-            // third of the reads (the LDS counter retires in order)
-            constexpr int LA[3] = {1, 0, 2}, LB[3] = {1, 2, 0};
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[i][LA[u]] = *reinterpret_cast<const bf16x8*>(Ab + (LA[u] * BM + i * 32) * 32 + fo[kk]);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) b[j][LB[u]] = *reinterpret_cast<const bf16x8*>(Bb + (LB[u] * BN + j * 32) * 32 + fo[kk]);
-            }
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j] = mfma_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j]);
-            // (the eight-block wave tile keeps ONE k step's fragments live: hoisting the second step's reads over the first step's
-            //  MFMAs would need 272 registers)
-            if constexpr (MI * NI >= 8) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        stage = stage + 1 == NST ? 0 : stage + 1;
-    }
-    float s1[NI], s2[NI];
-    double bd1[NI], bd2[NI];
-    igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
-    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
-    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
-    clk_end(p, clk);
-}
-
-template <int BM, int BN, int WGM, int WGN, int NST>
-int launch_x3s(const ConvP& p0, hipStream_t st) {
-    ConvP p = p0;
-    p.NT = p.Cout / BN;
-    int maxblk = 0, base = 0;
-    for (int i = 0; i < p.ncls; ++i) {
-        p.cls[i].MT = (p.cls[i].M + BM - 1) / BM;
-        if (p.cls[i].MT * p.NT > maxblk) maxblk = p.cls[i].MT * p.NT;
-        p.bnr_base[i] = base;
-        base += p.cls[i].MT;
-    }
-    const size_t lds = (size_t)NST * 3 * (BM + BN) * 32 * sizeof(u16);
-    STRAPS_RAISE_LDS((conv_igemm_x3s_kernel<BM, BN, WGM, WGN, NST>), lds, "conv_igemm_x3s_kernel");
-    hipLaunchKernelGGL((conv_igemm_x3s_kernel<BM, BN, WGM, WGN, NST>), dim3(maxblk, p.ncls), dim3(64 * (WGM * WGN + 4)), lds, st, p);
-    STRAPS_CHECK_LAUNCH("conv_igemm_x3s_kernel");
-    return STRAPS_OK;
-}
-
 // ---- halo-patch variant for the 3x3 / stride-1 layers (forward, and the data gradient, which is the same convolution over dy) ----
 // The im2col A operand above copies every input pixel nine times per channel chunk (once per tap) from L2; here a tile's input patch
 // -- its BM output pixels are whole image rows (or whole images), so the patch is (rows + 2) x (W + 2) pixels per image -- is copied
@@ -785,7 +583,7 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
 // its two-buffer form (140 KB of LDS, one workgroup per CU), of layer1 (154 vs 135).  With ONE patch buffer and a two-stage weight
 // ring (76 KB, two workgroups per CU) the 64-channel layers do gain: 123 vs 137 us -- that form is the rule for them.
 inline int halo_choice(const ConvP& p, int tile_cfg) {
-    if ((tile_cfg & 15) != 0 || (tile_cfg & 256) || ((tile_cfg >> 11) & 7)) return 0;
+    if ((tile_cfg & 15) != 0 || (tile_cfg & 256)) return 0;
     const int slots = halo_patch_slots(p);
     const bool all = (tile_cfg & 512) != 0;
     const long long t128 = (long long)(p.cls[0].M / 128) * (p.Cout / 128);
@@ -813,29 +611,7 @@ int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
     }
 }
 
-// loader / compute split kernels: (tile_cfg >> 11) & 7 = 1: 128x128 (3 stages), 2: 256x128 (128x64 wave tiles, 2 stages), 3: 256x64 (four
-// compute waves along M, 2 stages), 4: 128x64 (4 stages), 5: 128x128 (2 stages); 0 = the kernels above
-inline int split_tile(int tile_cfg, int cout, int& bm, int& bn) {
-    int k = (tile_cfg >> 11) & 7;
-    if (k == 0 || k > 5) return 0;
-    if (cout % 128 != 0 && (k == 1 || k == 2 || k == 5)) k = 3;          // 64-channel outputs: the 64-wide tiles
-    bm = (k == 2 || k == 3) ? 256 : 128;
-    bn = (k == 3 || k == 4) ? 64 : 128;
-    return k;
-}
-
 int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
-    {
-        int sbm, sbn;
-        switch (split_tile(tile_cfg, p.Cout, sbm, sbn)) {
-            case 1: return launch_x3s<128, 128, 2, 2, 3>(p, st);
-            case 2: return launch_x3s<256, 128, 2, 2, 2>(p, st);
-            case 3: return launch_x3s<256, 64, 4, 1, 2>(p, st);
-            case 4: return launch_x3s<128, 64, 2, 2, 4>(p, st);
-            case 5: return launch_x3s<128, 128, 2, 2, 2>(p, st);
-            default: break;
-        }
-    }
     int bm, bn, kdim = 0;
     long long M = 0;
     for (int i = 0; i < p.ncls; ++i) {
@@ -959,14 +735,6 @@ extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plan
 // number of [cout][2] statistics partials straps_conv_fwd_x3 writes for this geometry (= its M tiles)
 // M tiles (= BatchNorm-backward partial blocks) of straps_conv_dgrad_x3[_bn] for this geometry, all parity classes
 static int dgrad_x3_blocks(const ConvP& p, int tile_cfg) {
-    {
-        int sbm, sbn;
-        if (split_tile(tile_cfg, p.Cout, sbm, sbn)) {
-            int blocks = 0;
-            for (int i = 0; i < p.ncls; ++i) blocks += (p.cls[i].M + sbm - 1) / sbm;
-            return blocks;
-        }
-    }
     if (halo_choice(p, tile_cfg)) return p.cls[0].M / 128;
     int bm, bn, kdim = 0;
     long long M = 0;
@@ -1014,10 +782,6 @@ extern "C" int straps_conv_x3_stat_blocks(int batch, int h, int w, int cin, int 
     p.x = nullptr; p.w = nullptr; p.xps = p.wps = 0;
     if (conv_fwd_problem(p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, batch, h, w, cin, cout, kh, kw, stride, pad) != STRAPS_OK) return -1;
     const long long M = p.cls[0].M;
-    {
-        int sbm, sbn;
-        if (split_tile(tile_cfg, cout, sbm, sbn)) return (int)((M + sbm - 1) / sbm);
-    }
     if (halo_choice(p, tile_cfg)) return (int)(M / 128);
     int bm, bn;
     pick_tile_x3(tile_cfg, M, cout, kh * kw * cin, bm, bn);

@@ -225,14 +225,7 @@ def _fwd(dev, x_nchw, w, stride, pad, cfg, x3=True, scale=None, shift=None, res_
     (3, 128, 128, 8, 8, 3, 1, 8), (5, 128, 128, 24, 24, 3, 1, 9), (2, 64, 64, 16, 16, 3, 1, 10), (5, 64, 64, 7, 7, 3, 1, 11),
     (5, 128, 128, 24, 24, 3, 1, 12), (2, 64, 128, 16, 16, 1, 2, 8), (1, 32, 64, 3, 3, 3, 1, 11), (2, 64, 128, 16, 16, 3, 2, 9),
     # odd-sized maps through the chunk-major addressing: rows that are not a multiple of anything, stride 2 (64-byte pieces at a 128-byte stride)
-    (3, 64, 64, 5, 9, 3, 1, 0), (1, 160, 64, 11, 7, 3, 2, 0),
-    # loader / compute split kernels (tile_cfg bits 11..13 = 1..5: 128x128x3, 256x128x2, 256x64x2, 128x64x4, 128x128x2 stages): one- and
-    # many-chunk reductions, ragged M, fewer chunks than ring stages, 1x1, stride 2, 64- and 128-channel outputs
-    (2, 64, 128, 16, 16, 3, 1, 2048), (3, 128, 128, 8, 8, 3, 1, 2048), (1, 32, 128, 3, 3, 1, 1, 2048), (5, 128, 128, 24, 24, 3, 1, 4096),
-    (2, 64, 128, 16, 16, 3, 2, 4096), (1, 32, 128, 5, 5, 1, 1, 4096), (2, 64, 64, 16, 16, 3, 1, 6144), (5, 64, 64, 7, 7, 3, 1, 6144),
-    (2, 256, 64, 16, 16, 1, 1, 6144), (1, 32, 64, 3, 3, 3, 1, 6144), (2, 64, 64, 10, 24, 3, 1, 8192), (1, 512, 512, 8, 8, 3, 1, 8192),
-    (1, 32, 64, 8, 8, 1, 1, 8192), (3, 96, 128, 7, 13, 3, 2, 8192), (3, 128, 128, 8, 8, 3, 1, 10240), (1, 32, 128, 3, 3, 1, 1, 10240),
-    (2, 64, 64, 16, 16, 3, 1, 2048)])
+    (3, 64, 64, 5, 9, 3, 1, 0), (1, 160, 64, 11, 7, 3, 2, 0)])
 def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """all tile configurations (4- and 8-wave, 2- and 3-stage rings), ragged M, stride 1 / 2, 3x3 and 1x1, non-square maps, the
     fused epilogue and the training-mode statistics; the bar is the exact-fp32 kernel's (test_gpu_forward.py)."""
@@ -261,10 +254,7 @@ def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
 @pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
     (2, 64, 64, 16, 16, 3, 1, 0), (2, 64, 128, 16, 16, 3, 2, 0), (3, 128, 64, 9, 9, 3, 1, 0), (2, 64, 128, 16, 16, 1, 2, 0),
     (1, 256, 512, 8, 8, 3, 2, 0), (2, 256, 64, 8, 8, 1, 1, 0), (2, 128, 128, 15, 15, 3, 2, 1), (4, 128, 128, 20, 12, 3, 1, 4),
-    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3),
-    # loader / compute split kernels: stride-1 and the four parity classes of a stride-2 gradient in one launch
-    (2, 128, 128, 16, 16, 3, 1, 2048), (2, 128, 256, 15, 15, 3, 2, 4096), (2, 64, 128, 16, 16, 3, 2, 6144), (3, 128, 64, 9, 9, 3, 1, 8192),
-    (2, 128, 128, 9, 14, 1, 2, 10240)])
+    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3)])
 def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """data gradient on the bf16x3 route (stride-2 parity classes, odd sizes, the skip-gradient addend) vs float64 autograd."""
     L = hipabi.lib()
@@ -324,10 +314,7 @@ def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride):
 
 @pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg,from_out', [
     (2, 64, 64, 16, 16, 3, 1, 0, False), (2, 64, 128, 16, 16, 3, 2, 0, True), (64, 256, 256, 16, 16, 3, 1, 0, False), (3, 128, 128, 8, 8, 3, 1, 5, True),
-    (2, 64, 128, 16, 16, 1, 2, 0, False), (5, 128, 128, 24, 24, 3, 1, 12, True), (2, 128, 256, 9, 14, 3, 2, 1, False), (4, 128, 64, 32, 32, 3, 1, 512, False),
-    # loader / compute split kernels (the loader waves join the epilogue's barriers)
-    (3, 128, 128, 8, 8, 3, 1, 2048, True), (5, 128, 128, 24, 24, 3, 1, 4096, False), (2, 128, 256, 9, 14, 3, 2, 4096, True), (2, 64, 128, 16, 16, 3, 2, 6144, False),
-    (4, 128, 64, 32, 32, 3, 1, 8192, True)])
+    (2, 64, 128, 16, 16, 1, 2, 0, False), (5, 128, 128, 24, 24, 3, 1, 12, True), (2, 128, 256, 9, 14, 3, 2, 1, False), (4, 128, 64, 32, 32, 3, 1, 512, False)])
 def test_dgrad_x3_with_fused_batchnorm_sums(dev, B, Cin, Cout, H, W, k, stride, cfg, from_out):
     """straps_conv_dgrad_x3_bn: dx as straps_conv_dgrad_x3 writes it (bit for bit), and the per-tile partials of the next BatchNorm
     backward's sums S1 = sum mask*dy, S2 = invstd * sum mask*dy*(raw - mean) (double) -- every tile configuration in use, the four parity
@@ -469,8 +456,7 @@ def test_error_budget_of_the_six_products(dev):
     print('same-sign K=4608: bf16x3 %.2e  fp32 chain %.2e | 12 decades: bf16x3 %.2e  fp32 chain %.2e' % (r3, r32, rs, rs32))
 
 
-@pytest.mark.parametrize('B,Cin,Cout,H,k,stride,cfg', [(2, 64, 64, 16, 3, 1, 0), (3, 128, 128, 8, 3, 1, 5), (2, 64, 128, 16, 3, 2, 12), (64, 256, 256, 16, 3, 1, 0), (5, 64, 64, 7, 3, 1, 2),
-                                                        (3, 128, 128, 8, 3, 1, 2048), (5, 64, 128, 12, 3, 1, 4096), (5, 64, 64, 7, 3, 1, 6144)])
+@pytest.mark.parametrize('B,Cin,Cout,H,k,stride,cfg', [(2, 64, 64, 16, 3, 1, 0), (3, 128, 128, 8, 3, 1, 5), (2, 64, 128, 16, 3, 2, 12), (64, 256, 256, 16, 3, 1, 0), (5, 64, 64, 7, 3, 1, 2)])
 def test_conv_fwd_x3p_planes_equal_a_split_pass(dev, B, Cin, Cout, H, k, stride, cfg):
     """straps_conv_fwd_x3p (inference chains): the fp32 result equals straps_conv_fwd_x3's bit for bit and the planes written by the epilogue
     equal a straps_split3_bf16 pass over it; with y = NULL the planes alone."""

@@ -38,7 +38,7 @@ for name, H, Cin, Cout, cfg in SHAPES:
     x3, xps = split3(L, x)
     w3, wps = weight_planes(L, w)
     y = torch.empty(B, H, H, Cout, device=dev)
-    nblk = max(L.straps_conv_x3_stat_blocks(B, H, H, Cin, Cout, 3, 3, 1, 1, c) for c in (0, cfg, 512, 2048, 4096, 6144, 8192, 10240))
+    nblk = max(L.straps_conv_x3_stat_blocks(B, H, H, Cin, Cout, 3, 3, 1, 1, c) for c in (0, cfg, 512))
     part = torch.empty(nblk, Cout, 2, device=dev)
 
     def run(c, stats=False):
@@ -48,12 +48,4 @@ for name, H, Cin, Cout, cfg in SHAPES:
         name, cfg, run(cfg), run(cfg, True), run(cfg + 64), run(cfg + 128), run(cfg + 192), run(0))
     if Cout <= 256:
         row += ' | halo(512) %6.1f' % run(512)
-    # loader / compute split kernels (tile_cfg bits 11..13)
-    row += ' | split:'
-    for kcfg, tag in ((1, '128x128x3'), (2, '256x128x2'), (3, '256x64x2'), (4, '128x64x4'), (5, '128x128x2')):
-        if Cout % 128 and kcfg in (1, 2, 5):
-            continue
-        if Cout % 128 == 0 and kcfg == 3:
-            continue
-        row += ' %s %6.1f (+stats %6.1f)' % (tag, run(kcfg << 11), run(kcfg << 11, True))
     print(row + ' us', flush=True)
