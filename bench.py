@@ -239,6 +239,9 @@ def main():
                          "operand, six products per term, fp32 accumulate (same accuracy class, bf16 matrix pipe)")
     ap.add_argument('--smpl-in-step', default='fp16x3_lbs', choices=['fp32', 'fp16x3', 'fp16x3_lbs'],
                     help='train / fwd workloads: arithmetic of the SMPL forward calls inside the step')
+    ap.add_argument('--global-masked-mean', action='store_true',
+                    help='train workload, N > 1: the joints2D task as the masked mean over the GLOBAL batch (one extra 1-float all-reduce per step, '
+                         'issued a step ahead); default = the average of per-rank masked means')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
@@ -306,7 +309,8 @@ def main():
         crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(
             ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
             init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}).to(dev)
-        ts = TrainStep(reg, smpl, crit, B, lr=1e-4, rank=rank, world_size=world, seed=1234, mean_shape=mp['shape'], use_graph=not args.no_graph, overlap_wgrad=args.overlap_wgrad and not args.no_overlap)
+        ts = TrainStep(reg, smpl, crit, B, lr=1e-4, rank=rank, world_size=world, seed=1234, mean_shape=mp['shape'], use_graph=not args.no_graph, overlap_wgrad=args.overlap_wgrad and not args.no_overlap,
+                       global_masked_mean=args.global_masked_mean)
         step = ts.step
         workload = '%s: full synthetic OTF training step (augmentation + proxy construction + forward + multi-task loss ' \
                    '+ backward + Adam), %s, 18x256x256 proxy' % ('configs[3] per-GPU shape' if args.layers == 50 else 'configs[2]', net)

@@ -517,6 +517,19 @@ int straps_loss_fwd_bwd(const float* pred_verts, const float* pred_joints, const
                         const float* tgt_shape, const float* tgt_rot, const float* log_vars,
                         float* loss_out, float* dverts, float* djoints, float* dest, float* drot,
                         float* dlogvar, void* workspace, long long batch, int img_wh, void* stream);
+/* data parallel with the GLOBAL visibility-masked mean: the joints2D task's denominator becomes
+ * 2 * j2d_count_global[0] * count_scale (device scalar = the job's visible-joint count, count_scale = 1 / world size) instead of
+ * this rank's own count -- the average over ranks of loss_out and of every gradient (what the sum all-reduce + 1/world of the
+ * step computes) is then the masked mean over the global batch, whatever the split of visible joints between ranks.
+ * j2d_count_global = NULL: straps_loss_fwd_bwd.  straps_count_visible gives a rank's own count (as a float, to be sum all-reduced). */
+int straps_loss_fwd_bwd_gm(const float* pred_verts, const float* pred_joints, const float* est, int ld_est,
+                           const float* pred_rot, const float* tgt_verts, const float* tgt_joints2d,
+                           const float* tgt_joints3d, const float* tgt_shape, const float* tgt_rot,
+                           const float* log_vars, float* loss_out, float* dverts, float* djoints, float* dest,
+                           float* drot, float* dlogvar, void* workspace, long long batch, int img_wh,
+                           const float* j2d_count_global, float count_scale, void* stream);
+int straps_count_visible(const float* tgt_joints2d, float* out_count, long long batch, int nj, int img_wh,
+                         void* stream);
 /* row-masked mean-squared error used by the drop-in criterion module (losses/multi_task_loss.py:78-112):
  * out3 = {sum of squares, kept element count, mean}; the target is read as tgt*tgt_scale + tgt_shift
  * (the 2x/256-1 normalisation of :92); row_mask (uint8 per row, may be NULL) is labels['vis'].

@@ -305,7 +305,7 @@ def init_log_vars(init_loss_weights=None, eps=1e-6):
     return {k: float(-np.log(init_loss_weights[k] + eps)) for k in LOSS_TASKS}
 
 
-def multi_task_loss(labels, outputs, log_vars, losses_on=LOSS_TASKS, img_wh=REGRESSOR_IMG_WH):
+def multi_task_loss(labels, outputs, log_vars, losses_on=LOSS_TASKS, img_wh=REGRESSOR_IMG_WH, j2d_count=None):
     """HomoscedasticUncertaintyWeightedMultiTaskLoss.forward, reduction='mean'.
     total = sum_task mse_task * exp(-s_task) + s_task; joints2D rows masked by labels['vis'] and the
     label normalised 2x/256-1 (:87-93).  log_vars: {task: 0-dim tensor}.  Returns (total, dict)."""
@@ -325,7 +325,9 @@ def multi_task_loss(labels, outputs, log_vars, losses_on=LOSS_TASKS, img_wh=REGR
         if 'vis' in labels:
             lab, pred = lab[labels['vis'], :], pred[labels['vis'], :]
         lab = (2.0 * lab) / img_wh - 1.0
-        add('joints2D', F.mse_loss(pred, lab))
+        # j2d_count (tests of the data-parallel global masked mean only): the number of visible joints to divide by instead of this
+        # batch's own -- a rank's share of the job-wide masked mean is sum / (2 * global count / world size)
+        add('joints2D', F.mse_loss(pred, lab) if j2d_count is None else ((pred - lab) ** 2).sum() / (2.0 * j2d_count))
     if 'joints3D' in losses_on:
         add('joints3D', F.mse_loss(outputs['joints3D'], labels['joints3D']))
     if 'shape_params' in losses_on:

@@ -11,8 +11,30 @@ CHECKPOINT_KEYS = ('epoch', 'best_epoch', 'best_epoch_val_metrics', 'model_state
                    'criterion_state_dict')
 
 
-def save_checkpoint(path, epoch, regressor, optimiser, criterion, best_epoch=None, best_epoch_val_metrics=None, best_model_wts=None):
-    """`optimiser`: a torch optimiser or a train_step.TrainStep (both expose state_dict() in torch.optim.Adam's schema)."""
+def sync_batchnorm_buffers(model, src=0, group=None):
+    """data parallel: BatchNorm running statistics (and num_batches_tracked) are per rank (every rank normalises with the statistics of
+    ITS shard, the DDP convention); this broadcasts rank `src`'s into every replica.  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return False
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats and m.running_mean is not None:
+                for b in (m.running_mean, m.running_var, m.num_batches_tracked):
+                    if b is not None:
+                        dist.broadcast(b, src=src, group=group)
+    return True
+
+
+def save_checkpoint(path, epoch, regressor, optimiser, criterion, best_epoch=None, best_epoch_val_metrics=None, best_model_wts=None, group=None):
+    """`optimiser`: a torch optimiser or a train_step.TrainStep (both expose state_dict() in torch.optim.Adam's schema).
+    Under data parallel (an initialised process group with more than one rank) call it on EVERY rank: rank 0's BatchNorm running statistics
+    are broadcast first -- the checkpoint and every replica then hold the same buffers (parameters and optimiser state are replicated
+    anyway) -- and only the rank that is given a path (rank 0) writes; pass path = None on the others."""
+    if sync_batchnorm_buffers(regressor, 0, group):
+        enc = getattr(regressor, 'image_encoder', None)
+        if enc is not None and hasattr(enc, '_bn_epoch'):
+            enc._bn_epoch += 1                    # (folded-BatchNorm caches of the eval path must not outlive the new statistics)
     sd = {k: v.detach().cpu().clone() for k, v in regressor.state_dict().items()}
     save_dict = {'epoch': epoch,
                  'best_epoch': epoch if best_epoch is None else best_epoch,
@@ -21,7 +43,8 @@ def save_checkpoint(path, epoch, regressor, optimiser, criterion, best_epoch=Non
                  'best_model_state_dict': copy.deepcopy(sd) if best_model_wts is None else best_model_wts,
                  'optimiser_state_dict': optimiser.state_dict(),
                  'criterion_state_dict': {k: v.detach().cpu().clone() for k, v in criterion.state_dict().items()}}
-    torch.save(save_dict, path)
+    if path is not None:
+        torch.save(save_dict, path)
     return save_dict
 
 

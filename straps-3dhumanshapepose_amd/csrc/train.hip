@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void loss_heads_kernel(const float* __restrict
 // single block: fixed-order fp64 sums -> MSEs, weighted losses, d/dlogvar, gradient coefficients
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ vpart, const float* __restrict__ body_sums,
                                                             const float* __restrict__ log_vars, float* __restrict__ loss_out,
-                                                            float* __restrict__ dlogvar, float* __restrict__ coef, long long B) {
+                                                            float* __restrict__ dlogvar, float* __restrict__ coef, long long B,
+                                                            const float* __restrict__ j2d_count, float count_scale) {
     __shared__ double red[256][6];
     double a[6] = {0, 0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < NVB; i += 256) a[0] += (double)vpart[i];
@@ -137,8 +138,12 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
         for (int i = 0; i < 256; ++i)
             for (int q = 0; q < 6; ++q) t[q] += red[i][q];
         const double nvis = t[2];
-        // element counts of the 'mean' reductions: verts B*6890*3, joints2D nvis*2, joints3D B*14*3, shape B*10, pose B*216
-        const double cnt[5] = {(double)B * 20670.0, nvis * 2.0, (double)B * 42.0, (double)B * 10.0, (double)B * 216.0};
+        // element counts of the 'mean' reductions: verts B*6890*3, joints2D nvis*2, joints3D B*14*3, shape B*10, pose B*216.
+        // Data parallel with the GLOBAL masked mean (straps_loss_fwd_bwd_gm): the joints2D denominator is the job's visible-joint count
+        // over the world size, so that the average over ranks of this rank's value -- and of its gradients -- is the masked mean over
+        // the global batch.
+        const double n2 = j2d_count ? (double)j2d_count[0] * (double)count_scale : nvis;
+        const double cnt[5] = {(double)B * 20670.0, n2 * 2.0, (double)B * 42.0, (double)B * 10.0, (double)B * 216.0};
         const double sq[5] = {t[0], t[1], t[3], t[4], t[5]};
         double total = 0.0;
         for (int k = 0; k < 5; ++k) {
@@ -260,10 +265,39 @@ extern "C" int straps_build_proxy_input(const float* seg, const float* joints2d,
 
 extern "C" size_t straps_loss_workspace_bytes(long long batch) { return (size_t)(NVB + batch * 8 + 16) * sizeof(float); }
 
+// visible target joints of a batch (utils/joints2d_utils.py:23-32 semantics), as a float: what every rank contributes to the job-wide
+// count of the global masked mean
+__global__ __launch_bounds__(256) void count_visible_kernel(const float* __restrict__ tj2d, float* __restrict__ out, long long n, float wh) {
+    __shared__ int red[4];
+    int c = 0;
+    for (long long i = threadIdx.x; i < n; i += 256) c += joint_visible(tj2d[i * 2], tj2d[i * 2 + 1], wh) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int straps_count_visible(const float* tgt_joints2d, float* out_count, long long batch, int nj, int img_wh, void* stream) {
+    STRAPS_REQUIRE(tgt_joints2d && out_count && batch > 0 && nj > 0, "straps_count_visible: bad arguments");
+    hipLaunchKernelGGL(count_visible_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tgt_joints2d, out_count, batch * nj, (float)img_wh);
+    STRAPS_CHECK_LAUNCH("count_visible_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_loss_fwd_bwd(const float* pred_verts, const float* pred_joints, const float* est, int ld_est, const float* pred_rot,
                                    const float* tgt_verts, const float* tgt_joints2d, const float* tgt_joints3d, const float* tgt_shape,
                                    const float* tgt_rot, const float* log_vars, float* loss_out, float* dverts, float* djoints,
                                    float* dest, float* drot, float* dlogvar, void* workspace, long long batch, int img_wh, void* stream) {
+    return straps_loss_fwd_bwd_gm(pred_verts, pred_joints, est, ld_est, pred_rot, tgt_verts, tgt_joints2d, tgt_joints3d, tgt_shape, tgt_rot, log_vars, loss_out,
+                                  dverts, djoints, dest, drot, dlogvar, workspace, batch, img_wh, nullptr, 1.0f, stream);
+}
+
+extern "C" int straps_loss_fwd_bwd_gm(const float* pred_verts, const float* pred_joints, const float* est, int ld_est, const float* pred_rot,
+                                      const float* tgt_verts, const float* tgt_joints2d, const float* tgt_joints3d, const float* tgt_shape,
+                                      const float* tgt_rot, const float* log_vars, float* loss_out, float* dverts, float* djoints,
+                                      float* dest, float* drot, float* dlogvar, void* workspace, long long batch, int img_wh,
+                                      const float* j2d_count_global, float count_scale, void* stream) {
     STRAPS_REQUIRE(pred_verts && pred_joints && est && pred_rot && tgt_verts && tgt_joints2d && tgt_joints3d && tgt_shape && tgt_rot &&
                        log_vars && loss_out && workspace,
                    "straps_loss_fwd_bwd: null pointer");
@@ -281,7 +315,7 @@ extern "C" int straps_loss_fwd_bwd(const float* pred_verts, const float* pred_jo
     hipLaunchKernelGGL(loss_heads_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, pred_joints, est, ld_est, pred_rot,
                        tgt_joints2d, tgt_joints3d, tgt_shape, tgt_rot, body, batch, (float)img_wh);
     STRAPS_CHECK_LAUNCH("loss_heads_kernel");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, vpart, body, log_vars, loss_out, dlv, coef, batch);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, vpart, body, log_vars, loss_out, dlv, coef, batch, j2d_count_global, count_scale);
     STRAPS_CHECK_LAUNCH("loss_finalize_kernel");
     if (want_grad) {
         hipLaunchKernelGGL(loss_grad_verts_kernel, dim3(capped_grid(nv)), dim3(256), 0, st, pred_verts, tgt_verts, coef, dverts, nv);

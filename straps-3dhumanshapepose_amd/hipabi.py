@@ -174,6 +174,8 @@ SIGNATURES = {
     'straps_build_proxy_input_std': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_loss_workspace_bytes': (_Z, [_L]),
     'straps_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    'straps_loss_fwd_bwd_gm': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _F, _P]),
+    'straps_count_visible': (_I, [_P, _P, _L, _I, _I, _P]),
     'straps_adam_step': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P, _P]),
     'straps_mse_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),
     'straps_mse_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P, _P, _P]),

@@ -64,6 +64,16 @@ def allreduce_gradients(flat_g, world_size, group=None):
     return 1.0 / world_size
 
 
+def allreduce_visible_count(count, world_size, group=None, async_op=False):
+    """global masked mean of the joints2D task under data parallel: every rank contributes the number of visible target
+    joints of ITS batch (a 1-element float tensor, straps_count_visible); after this sum all-reduce the tensor holds the job's count,
+    which straps_loss_fwd_bwd_gm divides by (x 1 / world size).  Returns the work handle when async_op, else None."""
+    if world_size > 1:
+        import torch.distributed as dist
+        return dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return None
+
+
 class GradientExchange:
     """The step's gradient exchange: a sum all-reduce of the flat fp32 gradient buffer (RCCL over xGMI on GPUs, gloo in the
     CPU tests), in two buckets so that it overlaps the backward pass.  `start_tail()` is called as soon as the tail of
@@ -95,8 +105,11 @@ class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
                  mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=False,
                  renderer=None, track_metrics=False, comm_overlap=None, pipeline_data=True, smpl_augment_params=None,
-                 cam_augment_params=None, bbox_augment_params=None, proxy_rep_augment_params=None):
-        """use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
+                 cam_augment_params=None, bbox_augment_params=None, proxy_rep_augment_params=None, global_masked_mean=False):
+        """global_masked_mean (data parallel only; default off = the average of per-rank masked means): the joints2D task
+        becomes the masked mean over the GLOBAL batch -- one extra 1-float sum all-reduce per step (each rank's visible-joint count,
+        issued a step ahead next to the data pipeline, off the critical path).
+        use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
         launches) in one hipGraph and replay it each step; the gradient all-reduce and Adam stay eager launches.
         *_augment_params: the dictionaries of run_train.py:133-190 (defaults = the values that script sets)."""
         p0 = next(regressor.parameters())
@@ -108,6 +121,10 @@ class TrainStep:
             self._init(regressor, smpl, criterion, batch_size, lr, rank, world_size, seed, group, mean_shape, mean_cam_t, pose_pool, use_graph,
                        overlap_wgrad, renderer, track_metrics, comm_overlap, pipeline_data, smpl_augment_params, cam_augment_params,
                        bbox_augment_params, proxy_rep_augment_params)
+            self.global_masked_mean = bool(global_masked_mean) and world_size > 1
+            self._vis_work = {}
+            if self.global_masked_mean and use_graph and not pipeline_data:
+                raise NotImplementedError('global_masked_mean with hipGraph capture needs the data pipeline (the count exchange cannot sit inside a captured graph)')
 
     def _init(self, regressor, smpl, criterion, batch_size, lr, rank, world_size, seed, group, mean_shape, mean_cam_t, pose_pool, use_graph,
               overlap_wgrad, renderer, track_metrics, comm_overlap, pipeline_data, smpl_augment_params, cam_augment_params, bbox_augment_params,
@@ -222,7 +239,7 @@ class TrainStep:
         return dict(input=torch.empty(B, 18, 256, 256, device=d), verts=torch.empty(B, 6890, 3, device=d),
                     joints2d=torch.empty(B, 17, 2, device=d), joints3d=torch.empty(B, 14, 3, device=d),
                     shape=torch.empty(B, 10, device=d), rot=torch.empty(B, 24, 3, 3, device=d),
-                    reposed=torch.empty(B, 6890, 3, device=d), cam_t=torch.empty(B, 3, device=d),
+                    reposed=torch.empty(B, 6890, 3, device=d), cam_t=torch.empty(B, 3, device=d), vis_count=torch.zeros(1, device=d),
                     nzmask=torch.empty(hipabi.lib().straps_stem_nzmask_words(B, 18, 256, 256), device=d, dtype=torch.int32))
 
     def draw_layout(self):
@@ -310,6 +327,8 @@ class TrainStep:
         hipabi.check(L.straps_build_proxy_input(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), B, 17, 256, st), 'straps_build_proxy_input')
         # non-zero map of the input for the stem's zero skipping: made here, next to the input, off the step's critical path
         hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(out['nzmask']), B, 18, 256, 256, st), 'straps_stem_nzmask')
+        # this rank's visible target joints (global masked mean under data parallel: summed over the ranks before the loss runs)
+        hipabi.check(L.straps_count_visible(hipabi.ptr(tgt_j2d), hipabi.ptr(out['vis_count']), B, 17, config.REGRESSOR_IMG_WH, st), 'straps_count_visible')
         if keep is not None:
             keep.update(uniforms=U, normals=N, joints=tgt_joints, joints2d_uncropped=j2d_full, seg=seg, seg_cropped=seg_c, boxes=boxes,
                         seg_aug=seg_aug, joints2d_input=j2d_in)
@@ -347,10 +366,12 @@ class TrainStep:
         dest, drot = torch.empty(B, EST_LD, device=d), torch.empty(B, 24, 3, 3, device=d)
         dlv = torch.empty(5, device=d)
         ws = torch.empty(L.straps_loss_workspace_bytes(B) // 4, device=d)
-        hipabi.check(L.straps_loss_fwd_bwd(hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(est), EST_LD, hipabi.ptr(R), hipabi.ptr(batch['verts']),
-                                           hipabi.ptr(batch['joints2d']), hipabi.ptr(batch['joints3d']), hipabi.ptr(batch['shape']),
-                                           hipabi.ptr(batch['rot']), hipabi.ptr(lv), hipabi.ptr(loss), hipabi.ptr(dverts), hipabi.ptr(djoints),
-                                           hipabi.ptr(dest), hipabi.ptr(drot), hipabi.ptr(dlv), hipabi.ptr(ws), B, config.REGRESSOR_IMG_WH, st),
+        gm = getattr(self, 'global_masked_mean', False)
+        hipabi.check(L.straps_loss_fwd_bwd_gm(hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(est), EST_LD, hipabi.ptr(R), hipabi.ptr(batch['verts']),
+                                              hipabi.ptr(batch['joints2d']), hipabi.ptr(batch['joints3d']), hipabi.ptr(batch['shape']),
+                                              hipabi.ptr(batch['rot']), hipabi.ptr(lv), hipabi.ptr(loss), hipabi.ptr(dverts), hipabi.ptr(djoints),
+                                              hipabi.ptr(dest), hipabi.ptr(drot), hipabi.ptr(dlv), hipabi.ptr(ws), B, config.REGRESSOR_IMG_WH,
+                                              hipabi.ptr(batch['vis_count'] if gm else None), 1.0 / self.world, st),
                      'straps_loss_fwd_bwd')
         # SMPL backward -> (dbetas, drot2)
         dbetas, drot2 = torch.empty(B, 10, device=d), torch.empty(B, 24, 3, 3, device=d)
@@ -415,7 +436,10 @@ class TrainStep:
         meanwhile on the data stream (joined before `after_layer3` -- where a split capture ends its first graph -- and at the
         end).  Used for eager launches and, unchanged, under hipGraph capture."""
         if not self.pipeline:
-            return self.forward_backward(self.make_batch(), after_layer3)
+            b = self.make_batch()
+            if self.global_masked_mean:                        # (no pipeline: the count exchange sits between the batch and the forward)
+                allreduce_visible_count(b['vis_count'], self.world, self.group)
+            return self.forward_backward(b, after_layer3)
         if not self._primed:                                   # very first step: there is no batch in flight yet
             self.make_batch(out=self._bufs[self._cur])
             self._primed = True
@@ -444,10 +468,28 @@ class TrainStep:
         device whatever the caller's current device is."""
         with torch.cuda.device(self.dev), torch.no_grad():
             start_tail = self.exchange.start_tail if self.comm_overlap else None
+            gm = self.global_masked_mean and self.pipeline
+            if gm:
+                # the job-wide visible-joint count of the batch this step trains on: its all-reduce was started a step ago (below);
+                # the very first batch is generated here and its count exchanged before anything runs
+                if not self._primed:
+                    self.make_batch(out=self._bufs[self._cur])
+                    self._primed = True
+                w = self._vis_work.pop(self._cur, None)
+                if w is None:
+                    allreduce_visible_count(self._bufs[self._cur]['vis_count'], self.world, self.group)
+                else:
+                    w.wait()
+
+            def count_next():
+                # the batch of the NEXT step has just been generated (data stream, joined): its count exchange runs under Adam
+                if gm:
+                    self._vis_work[self._cur] = allreduce_visible_count(self._bufs[self._cur]['vis_count'], self.world, self.group, async_op=True)
             if not self.use_graph or self._warm < 2:
                 self._warm += 1
                 loss = self._run(start_tail)
                 self._cur ^= 1
+                count_next()
                 self.optimise()
                 return loss
             if self.graph is None:
@@ -462,6 +504,7 @@ class TrainStep:
                 self.exchange.start_tail()       # layer3.. gradients are final: their all-reduce runs under the rest of backward
                 g2.replay()
             self._cur ^= 1
+            count_next()
             self.optimise()
             return loss
 
@@ -549,6 +592,9 @@ class TrainStep:
             torch.cuda.synchronize()
             self.draws.set_step(step)
             self._primed = False
+            for w in getattr(self, '_vis_work', {}).values():
+                w.wait()
+            self._vis_work = {}
             if self.graph is not None:             # captured graphs consume the batch that was in flight: re-prime eagerly, capture again
                 self.graph, self.graph_tail, self._warm, self._last_by_parity = None, None, 0, {}
 

@@ -136,3 +136,107 @@ def test_visibility_masked_mean_under_data_parallel_world4(uneven):
             assert len(set(counts)) == world and not same_as_global   # rank-dependent counts: NOT the global masked mean (documented)
         else:
             assert len(set(counts)) == 1 and same_as_global           # equal counts: identical to the single-process loss
+
+
+def _worker_gm(rank, world, port, q):
+    """the global masked mean option (TrainStep(global_masked_mean=True)): every rank sums the visible-joint counts
+    (train_step.allreduce_visible_count) and divides its joints2D sum by global count / world -- after the gradient exchange
+    (sum, x 1 / world) the update is the single-process one for ANY split of visible joints between the ranks."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import straps_oracle as O
+    from straps_amd.train_step import GradientExchange, allreduce_visible_count
+    Bl = 3
+    g = torch.Generator().manual_seed(7)
+    lab_all = torch.rand(world * Bl, 17, 2, generator=g) * 200 + 20
+    for r in range(world):                                                     # rank r hides 4 r joints of each of its bodies
+        lab_all[r * Bl:(r + 1) * Bl, :4 * r] = 300.0
+    pred_all = torch.rand(world * Bl, 17, 2, generator=g) * 2 - 1
+    w = torch.tensor([0.7, -0.2], requires_grad=True)
+    lv = {k: torch.tensor(0.0) for k in O.LOSS_TASKS}
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    vis = O.check_joints2d_visibility(lab_all[sl])
+    count = torch.tensor([float(vis.sum())])
+    work = allreduce_visible_count(count, world, async_op=True)                 # (issued a step ahead in the GPU step)
+    work.wait()
+    total, _ = O.multi_task_loss({'joints2D': lab_all[sl], 'vis': vis}, {'joints2D': w[0] * pred_all[sl] + w[1]}, lv, losses_on=('joints2D',),
+                                 j2d_count=float(count) / world)
+    (grad_r,) = torch.autograd.grad(total, w)
+    flat = grad_r.clone()
+    scale = GradientExchange(flat, 0, world).finish()
+    dp_grad = flat * scale
+    loss_sum = torch.tensor([float(total)])
+    dist.all_reduce(loss_sum)
+    vis_g = O.check_joints2d_visibility(lab_all)
+    total_g, _ = O.multi_task_loss({'joints2D': lab_all, 'vis': vis_g}, {'joints2D': w[0] * pred_all + w[1]}, lv, losses_on=('joints2D',))
+    (grad_g,) = torch.autograd.grad(total_g, w)
+    q.put((rank, float(count), int(vis_g.sum()), bool(torch.allclose(dp_grad, grad_g, rtol=1e-5, atol=1e-7)),
+           abs(float(loss_sum) / world - float(total_g)) < 1e-6 * abs(float(total_g))))
+    dist.destroy_process_group()
+
+
+def test_global_masked_mean_option_equals_the_single_process_loss_world4():
+    world = 4
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_gm, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for rank, count, nvis_g, grad_ok, loss_ok in [q.get(timeout=10) for _ in range(world)]:
+        assert count == nvis_g                                   # every rank holds the job-wide count after the exchange
+        assert grad_ok and loss_ok                               # uneven counts (51 / 39 / 27 / 15 visible joints): still the global masked mean
+
+
+def _worker_bn(rank, world, port, q, tmp):
+    """checkpoint_utils.save_checkpoint under data parallel: BatchNorm running statistics are per rank; the file holds
+    rank 0's, and every rank CONTINUES with rank 0's (broadcast at save time), so that a resumed job equals the job that kept running."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import straps_amd
+    from straps_amd import checkpoint_utils
+    torch.manual_seed(1234)
+    reg = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=straps_amd.synthetic_mean_params(0))
+    crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'])
+    with torch.no_grad():                                        # per-rank statistics, as after some data-parallel steps
+        for n, b in reg.named_buffers():
+            if b.is_floating_point():
+                b.add_(0.01 * (rank + 1))
+            else:
+                b.add_(5)
+    opt = torch.optim.Adam(list(reg.parameters()) + list(crit.parameters()), lr=1e-4)
+    before = float(reg.image_encoder.bn1.running_mean[0])
+    path = os.path.join(tmp, 'ck_rank%d.tar' % rank)
+    sd = checkpoint_utils.save_checkpoint(path if rank == 0 else None, 3, reg, opt, crit)
+    after = float(reg.image_encoder.bn1.running_mean[0])
+    digest = torch.stack([b.double().sum() for _, b in reg.named_buffers()]).sum().reshape(1)
+    allr = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(allr, digest)
+    same = all(torch.equal(allr[0], a) for a in allr)
+    in_file = float(sd['model_state_dict']['image_encoder.bn1.running_mean'][0]) if sd is not None else None
+    q.put((rank, before, after, same, in_file, os.path.isfile(path)))
+    dist.destroy_process_group()
+
+
+def test_checkpoint_broadcasts_rank0_batchnorm_statistics_world2(tmp_path):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_bn, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    (r0, b0, a0, same0, file0, wrote0), (r1, b1, a1, same1, file1, wrote1) = res
+    assert b0 != b1 and a0 == b0 and a1 == b0                   # rank 1 took rank 0's statistics, rank 0 kept its own
+    assert same0 and same1
+    assert file0 == b0 and wrote0 and not wrote1                 # the file (written by rank 0 only) holds what every rank continues with

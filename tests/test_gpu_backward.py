@@ -614,6 +614,72 @@ def test_fused_loss_vs_oracle(dev):
     assert _relerr(de, E.grad) < 1e-5
 
 
+def test_global_masked_mean_loss_two_virtual_ranks_equal_the_global_batch(dev):
+    """straps_loss_fwd_bwd_gm + straps_count_visible (data parallel with the GLOBAL visibility-masked mean): a batch of 6 bodies split over
+    two "ranks" of 3 with very different numbers of visible joints.  Each half evaluated with the job-wide count (scaled by 1 / world):
+    the AVERAGE of the two ranks' losses, log-variance gradients and head gradients -- what the step's sum all-reduce + 1 / world
+    computes -- equals the single-process result on the 6-body batch (float64 oracle), which the per-rank masked means do not."""
+    L = hipabi.lib()
+    B, Bh = 6, 3
+    joints = torch.from_numpy(det_uniform((B, 90, 3), 60, -1, 1))
+    est = torch.zeros(B, 160)
+    est[:, :157] = torch.from_numpy(det_uniform((B, 157), 61, -1, 1))
+    est[:, 0] = est[:, 0].abs() + 0.5
+    prot = torch.from_numpy(det_uniform((B, 24, 3, 3), 62))
+    pverts = torch.from_numpy(det_uniform((B, 6890, 3), 63))
+    tverts = torch.from_numpy(det_uniform((B, 6890, 3), 64))
+    tj2d = torch.from_numpy(det_uniform((B, 17, 2), 65, 20.0, 230.0))
+    tj2d[Bh:, :13] = 300.0                                    # the second rank sees 4 joints per body, the first all 17
+    tj3d = torch.from_numpy(det_uniform((B, 14, 3), 66))
+    tshape = torch.from_numpy(det_uniform((B, 10), 67, -2, 2))
+    trot = torch.from_numpy(det_uniform((B, 24, 3, 3), 68))
+    lv0 = O.init_log_vars({'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0})
+    order = ('verts', 'joints2D', 'joints3D', 'shape_params', 'pose_params')
+    J, E = joints.double().requires_grad_(), est.double().requires_grad_()
+    lv = {k: torch.tensor(lv0[k], dtype=torch.float64, requires_grad=True) for k in order}
+    outp = {'verts': pverts.double(), 'joints2D': O.orthographic_project(J[:, O.ALL_JOINTS_TO_COCO_MAP], E[:, :3]),
+            'joints3D': J[:, O.ALL_JOINTS_TO_H36M_MAP][:, O.H36M_TO_J14], 'shape_params': E[:, 147:157], 'pose_params_rot_matrices': prot.double()}
+    lab = {'verts': tverts.double(), 'joints2D': tj2d.double(), 'joints3D': tj3d.double(), 'shape_params': tshape.double(),
+           'pose_params_rot_matrices': trot.double(), 'vis': O.check_joints2d_visibility(tj2d)}
+    total, parts = O.multi_task_loss(lab, outp, lv)
+    total.backward()
+    d = lambda t: t.to(dev).contiguous()
+    lvd = torch.tensor([lv0[k] for k in order], dtype=torch.float32, device=dev)
+
+    def rank(sl, count_dev, scale):
+        n = sl.stop - sl.start
+        t = [d(pverts[sl]), d(joints[sl]), d(est[sl]), d(prot[sl]), d(tverts[sl]), d(tj2d[sl]), d(tj3d[sl]), d(tshape[sl]), d(trot[sl])]
+        loss = torch.empty(12, device=dev)
+        dv, dj, de, dr, dl = (torch.empty(n, 6890, 3, device=dev), torch.empty(n, 90, 3, device=dev), torch.empty(n, 160, device=dev),
+                              torch.empty(n, 24, 3, 3, device=dev), torch.empty(5, device=dev))
+        ws = torch.empty(L.straps_loss_workspace_bytes(n) // 4, device=dev)
+        hipabi.check(L.straps_loss_fwd_bwd_gm(hipabi.ptr(t[0]), hipabi.ptr(t[1]), hipabi.ptr(t[2]), 160, hipabi.ptr(t[3]), hipabi.ptr(t[4]), hipabi.ptr(t[5]),
+                                              hipabi.ptr(t[6]), hipabi.ptr(t[7]), hipabi.ptr(t[8]), hipabi.ptr(lvd), hipabi.ptr(loss), hipabi.ptr(dv), hipabi.ptr(dj),
+                                              hipabi.ptr(de), hipabi.ptr(dr), hipabi.ptr(dl), hipabi.ptr(ws), n, 256, hipabi.ptr(count_dev), scale, None), 'loss_gm')
+        return loss.cpu().double(), dl.cpu().double(), dj.cpu().double(), de.cpu().double()
+    # every rank counts its own visible joints; the sum is what the all-reduce delivers
+    counts = []
+    for sl in (slice(0, Bh), slice(Bh, B)):
+        c = torch.zeros(1, device=dev)
+        hipabi.check(L.straps_count_visible(hipabi.ptr(d(tj2d[sl])), hipabi.ptr(c), Bh, 17, 256, None), 'count')
+        counts.append(float(c))
+    assert counts == [51.0, 12.0] and sum(counts) == float(lab['vis'].sum())
+    glob = torch.tensor([sum(counts)], device=dev)
+    r0, r1 = rank(slice(0, Bh), glob, 0.5), rank(slice(Bh, B), glob, 0.5)
+    mean = [(a + b) / 2 for a, b in zip(r0, r1)]
+    # joints2D: weighted task loss (slot 2), its log-variance gradient, the head gradients of the camera / the COCO joints
+    assert float(mean[0][2]) == pytest.approx(float(parts['joints2D']), rel=2e-5)
+    assert float(mean[1][1]) == pytest.approx(float(lv['joints2D'].grad), rel=2e-5)
+    got_dj = torch.cat([r0[2], r1[2]]) / 2                      # each body's gradient lives on one rank; the exchange averages over ranks
+    got_de = torch.cat([r0[3], r1[3]]) / 2
+    # (the other tasks are plain per-rank means of equal-sized halves: their rank average is the global mean as well)
+    assert _relerr(got_dj, J.grad) < 1e-5 and _relerr(got_de, E.grad) < 1e-5
+    assert float(mean[0][0]) == pytest.approx(float(total), rel=2e-5)
+    # without the global count the same average is NOT the global masked mean (rank 1's few joints weigh as much as rank 0's many)
+    p0, p1 = rank(slice(0, Bh), None, 1.0), rank(slice(Bh, B), None, 1.0)
+    assert abs(float((p0[0][2] + p1[0][2]) / 2) - float(parts['joints2D'])) > 1e-3 * float(parts['joints2D'])
+
+
 def test_build_proxy_input_vs_reference_golden(dev):
     small = np.load(os.path.join(GOLD, 'small_golden.npz'))
     jh = torch.from_numpy(small['heat_in']).to(dev)

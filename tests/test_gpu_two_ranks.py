@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, overlap, use_graph, q):
+def _worker(rank, world, port, overlap, use_graph, q, gm=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -28,7 +28,7 @@ def _worker(rank, world, port, overlap, use_graph, q):
     smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=8).to(dev)
     crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D']).to(dev)
     ts = TrainStep(reg, smpl, crit, 8, lr=1e-3, rank=rank, world_size=world, seed=77, mean_shape=mp_['shape'], use_graph=use_graph,
-                   comm_overlap=overlap)
+                   comm_overlap=overlap, global_masked_mean=gm)
     losses = [float(ts.step()[0]) for _ in range(6)]
     torch.cuda.synchronize()
     digest = torch.stack([ts.flat_p.double().sum(), ts.flat_p.double().abs().sum(), ts.exp_avg.double().abs().sum()]).cpu()
@@ -39,11 +39,11 @@ def _worker(rank, world, port, overlap, use_graph, q):
     dist.destroy_process_group()
 
 
-def _run(overlap, use_graph):
+def _run(overlap, use_graph, gm=False):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + (2 if overlap else 0) + (1 if use_graph else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, use_graph, q)) for r in range(2)]
+    port = 29700 + (os.getpid() % 1000) + (2 if overlap else 0) + (1 if use_graph else 0) + (4 if gm else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, use_graph, q, gm)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -61,3 +61,16 @@ def test_two_ranks_stay_in_sync_and_overlap_changes_nothing():
     assert all(r[6] and r[7] for r in got), 'the split hipGraph capture fell back to eager launches'
     assert got[0][4] == ref[0][4]                                # two-bucket overlapped exchange + graphs == plain eager step, bit for bit
     assert [r[5] for r in got] == [r[5] for r in ref]
+
+
+def test_two_ranks_with_the_global_masked_mean_option():
+    """TrainStep(global_masked_mean=True): the 1-float count exchange a step ahead of its batch (async, next to the data pipeline) under
+    eager launches and under the split hipGraph replay -- replicas stay in sync, graphs == eager bit for bit, and the trajectory differs
+    from the default (average of per-rank masked means) because the ranks see different numbers of visible joints."""
+    ref = _run(overlap=False, use_graph=False, gm=True)
+    assert all(r[3] for r in ref)
+    got = _run(overlap=True, use_graph=True, gm=True)
+    assert all(r[3] for r in got) and all(r[6] and r[7] for r in got)
+    assert got[0][4] == ref[0][4] and [r[5] for r in got] == [r[5] for r in ref]
+    plain = _run(overlap=False, use_graph=False)
+    assert plain[0][4] != ref[0][4]
