@@ -34,7 +34,8 @@ def split3(x):
     """fp32 array -> (bits [3, ...] uint16, values [3, ...] float32)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     b1 = bf16_rn_bits(x)
-    r1 = x - bf16_bits_to_f32(b1)
+    with np.errstate(invalid='ignore'):
+        r1 = np.where(np.isinf(x), np.float32(0), x - bf16_bits_to_f32(b1)).astype(np.float32)      # an infinite value keeps zero residues (csrc/common.h)
     b2 = bf16_rn_bits(r1)
     r2 = r1 - bf16_bits_to_f32(b2)
     b3 = bf16_rn_bits(r2)

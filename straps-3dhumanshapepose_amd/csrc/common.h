@@ -105,7 +105,9 @@ __device__ __forceinline__ u16 bf16_rn(float x) {
 }
 __device__ __forceinline__ void split3(float x, u16& b1, u16& b2, u16& b3) {
     b1 = bf16_rn(x);
-    const float r1 = x - __uint_as_float((unsigned)b1 << 16);       // exact
+    // (an infinite x keeps its leading plane and zero residues -- inf - inf would put a NaN into the low planes, and a NaN times a zero
+    //  weight poisons outputs the fp32 chain would leave finite; a NaN stays a NaN)
+    const float r1 = (__float_as_uint(x) & 0x7fffffffu) == 0x7f800000u ? 0.f : x - __uint_as_float((unsigned)b1 << 16);       // exact
     b2 = bf16_rn(r1);
     const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);      // exact; at most 8 significant bits are left
     b3 = bf16_rn(r2);

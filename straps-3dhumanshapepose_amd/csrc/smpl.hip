@@ -299,6 +299,10 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_kernel(straps_smpl_model_t
 // D[k = 16*kstep + 8*(l>>5) + j][vertex = 32*tile + (l&31)][coord], j = 0..7 (the A operand of the 32x32x16 MFMA; the
 // B operand -- features, n = body -- uses the same k map, so the contraction is independent of the hardware's k order).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// out-of-range operands of the split kernels SATURATE (largest finite fp16) instead of overflowing to inf, whose low half x - inf would be
+// NaN and poison the whole body: |feature| >= 1023 (e.g. a diverging regressor's betas) or |joint transform| >= 63 m then give finite,
+// clipped meshes; inside the range nothing changes.  (NaN inputs stay NaN.)
+__device__ __forceinline__ float sat_h(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 constexpr int KS = KP / 16;               // 14 k-steps of 16
 constexpr int FSH = 232;                  // halves per LDS feature row: 464 bytes = 4 * 29 dwords -> conflict-free b128 reads
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model
         half4 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float x = v[e] * F_SCALE;
+            const float x = sat_h(v[e] * F_SCALE);
             hi[e] = (_Float16)x;
             lo[e] = (_Float16)(x - (float)hi[e]);
         }
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
                 half4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x = fv[t][e] * F_SCALE;
+                    const float x = sat_h(fv[t][e] * F_SCALE);
                     hi[e] = (_Float16)x;
                     lo[e] = (_Float16)(x - (float)hi[e]);
                 }
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
             if (i < AITEMS) {
 #pragma unroll
                 for (int e = 0; e < 12; ++e) {
-                    const float x = av[t][e >> 2][e & 3] * A_SCALE;
+                    const float x = sat_h(av[t][e >> 2][e & 3] * A_SCALE);
                     const _Float16 hi = (_Float16)x;
                     Ah[(e * BT + b) * ASH + j] = hi;
                     Al[(e * BT + b) * ASH + j] = (_Float16)(x - (float)hi);

@@ -47,23 +47,45 @@ class DeviceDraws:
 
 
 _default = {}
+_seed = None          # set by manual_seed(); None: derived from torch's seed and the rank on first use
+
+
+def _base_seed():
+    """seed of the module-level generators: what manual_seed() set, else torch.initial_seed() + the process's rank -- like the reference's
+    unseeded torch / numpy generators, every process and every run draws its own stream unless the caller seeds (torch.manual_seed or
+    device_rng.manual_seed)."""
+    if _seed is not None:
+        return _seed
+    rank = 0
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank = dist.get_rank()
+    except Exception:      # noqa: BLE001
+        rank = 0
+    return (int(torch.initial_seed()) + rank) & 0xFFFFFFFFFFFFFFFF
 
 
 def default_draws(device):
-    """module-level generator of the function-style augmentation entry points (one per device, seed 0 until `manual_seed`)."""
+    """module-level generator of the function-style augmentation entry points (one per device, created on first use from
+    `_base_seed()`; distinct devices get distinct streams)."""
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, idx)
     if key not in _default:
-        _default[key] = DeviceDraws(0, device)
+        _default[key] = DeviceDraws(_base_seed() + 0x9E3779B97F4A7C15 * idx, torch.device(device.type, idx))
     return _default[key]
 
 
 def manual_seed(seed, device=None):
-    """reseed the module-level generator(s) used by augmentation.augment_* when no `draws=` is passed."""
+    """reseed the module-level generator(s) used by augmentation.augment_* / image_utils when no draws are passed.  device = None: every
+    device -- existing generators are dropped and generators created later use the same seed; a device: that device's generator only."""
+    global _seed
     if device is None:
+        _seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         _default.clear()
-        device = torch.device('cuda', torch.cuda.current_device())
+        return default_draws(torch.device('cuda', torch.cuda.current_device()))
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    _default[key] = DeviceDraws(seed, device)
-    return _default[key]
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    _default[(device.type, idx)] = DeviceDraws(int(seed) + 0x9E3779B97F4A7C15 * idx, torch.device(device.type, idx))
+    return _default[(device.type, idx)]

@@ -36,7 +36,7 @@ def _new_planes(t):
     return torch.empty(3, ps, device=t.device, dtype=torch.int16), ps
 
 
-def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=True, keep_fp32=True):
+def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=True, keep_fp32=True, planes=True):
     C = bn.weight.shape[0]
     L = ctx.L
     if not ctx.training:
@@ -59,7 +59,7 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=
         if rec is not None:
             rec.update(raw=raw, stats=ss, out=None)
         return ss
-    if ctx.x3 and relu:
+    if ctx.x3 and relu and planes:
         # bf16x3 route: every ReLU output of the residual stages feeds a convolution -- its planes are written here, not by a split pass.
         # keep_fp32 = False: nothing reads the fp32 activation (its only consumers, the next convolution and that layer's weight
         # gradient, run on the planes; the ReLU mask of the backward is re-derived from raw): it is not written -- y is then an
@@ -254,7 +254,7 @@ def encoder_forward(net, x, tape=None, nzmask=None):
                                                           B, H, W, 64, hipabi.stream_ptr()), 'straps_bn_relu_maxpool_fwd')
             tape['maxpool'] = dict(kind='maxpool_fused', out=p, idx=idx, geom=(B, H, W, 64, Hp, Wp))
             return _residual_stages(ctx, net, p, B, Hp, Wp, tape)
-        y = _bn_train_finish(ctx, net.bn1, y, part, nblk, B * Ho * Wo, None, True, rec)
+        y = _bn_train_finish(ctx, net.bn1, y, part, nblk, B * Ho * Wo, None, True, rec, planes=False)      # (its consumer is the pooling: no planes)
     # ---- maxpool 3x3/s2/p1 (:149) ----
     H, W = Ho, Wo
     Hp, Wp = _conv_out(H, 3, 2, 1), _conv_out(W, 3, 2, 1)

@@ -10,13 +10,16 @@ def batch_crop_and_resize(seg, joints2D, img_wh, orig_scale_factor=1.2, delta_sc
                           uniforms=None, out=None, jout=None):
     """seg [B,wh,wh] part ids, joints2D [B,J,2] (GPU fp32) -> (resized seg [B,img_wh,img_wh], resized joints, boxes).
     Random scale / centre jitter is applied when both ranges are given; `uniforms` [B,3] in [0,1) may be supplied
-    (otherwise drawn from torch's device generator)."""
+    (otherwise drawn from the module-level device generator, `device_rng.manual_seed`)."""
     hipabi.require_gpu_tensor(seg, 'segmentation', torch.float32)
     hipabi.require_gpu_tensor(joints2D, 'joints2D', torch.float32)
     B, wh, nj = seg.shape[0], seg.shape[-1], joints2D.shape[1]
     jitter = delta_scale_range is not None and delta_centre_range is not None
     if jitter and uniforms is None:
-        uniforms = torch.rand(B, 3, device=seg.device)
+        from . import device_rng
+        g = device_rng.default_draws(seg.device)
+        uniforms = g.uniform(B, 3)
+        g.advance()
     ds, dc = (delta_scale_range or (0.0, 0.0)), (delta_centre_range or (0.0, 0.0))
     out = torch.empty(B, img_wh, img_wh, device=seg.device, dtype=torch.float32) if out is None else out
     jout = torch.empty(B, nj, 2, device=seg.device, dtype=torch.float32) if jout is None else jout

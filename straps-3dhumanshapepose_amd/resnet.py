@@ -50,8 +50,13 @@ class ResidualUnit(nn.Module):
 
 
 class ResNet(nn.Module):
-    def __init__(self, kind, counts, in_channels, zero_init_residual=False):
+    def __init__(self, kind, counts, in_channels, zero_init_residual=False, conv_precision='bf16x3'):
+        """conv_precision (extension, also an attribute that may be set at any time; NOT part of the state dict): arithmetic of the
+        3x3 / 1x1 convolutions -- 'bf16x3' (default): fp32 operands as exact bf16 triples on the bf16 matrix pipe, six products per
+        term, fp32 accumulate (the fp32 chain's accuracy class: tests/test_gpu_conv_x3.py), 'fp32': the exact fp32-input MFMA chain."""
         super().__init__()
+        if conv_precision not in ('fp32', 'bf16x3'):
+            raise ValueError("conv_precision must be 'fp32' or 'bf16x3'")
         self.kind, self.in_channels = kind, in_channels
         self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -82,7 +87,7 @@ class ResNet(nn.Module):
         # products per term, fp32 accumulate on the bf16 matrix pipe (csrc/conv_x3.hip; same error class against float64 as the fp32
         # chain: tests/test_gpu_conv_x3.py), 'fp32' = the exact-fp32 MFMA chain (csrc/conv.hip).  The weight gradients and the stem
         # are fp32 MFMA on both routes.
-        self.conv_precision = 'bf16x3'
+        self.conv_precision = conv_precision
         self._bn_epoch = 0          # bumped by every training-mode forward (running statistics change behind torch's back)
 
     # ---- packed-weight / folded-BN caches, refreshed when a parameter's version changes ----

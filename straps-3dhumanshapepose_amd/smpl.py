@@ -220,7 +220,11 @@ class SMPL(nn.Module):
         out_verts / out_joints: optional resident output buffers ([B,6890,3] / [B,90,3], contiguous fp32).
         precision: 'fp32' (exact fp32 everywhere), 'fp16x3' (blend contraction as a three-product fp16 split with fp32
         accumulate: same accuracy class, 16x the matrix rate) or 'fp16x3_lbs' (the skinning transforms on the matrix pipe as
-        well); None = the module's setting."""
+        well); None = the module's setting.
+        Range of the split modes: |beta| and the pose features below 1023, joint transforms (rotations and joint positions in metres)
+        below 63, skinning weights below 3.9 -- far outside anything a body model produces; operands beyond it SATURATE at the
+        largest fp16 value (finite, clipped meshes; csrc/smpl.hip sat_h) rather than turning the body into NaNs.  'fp32' has
+        no such range."""
         hipabi.require_gpu_tensor(betas, 'betas', torch.float32)
         hipabi.require_gpu_tensor(rotmats, 'rotmats', torch.float32)
         hipabi.require_gpu_tensor(self._k_blend_frag, 'SMPL model buffers (call .to(device))')

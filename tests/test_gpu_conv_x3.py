@@ -91,7 +91,7 @@ def test_split_planes_equal_the_cpu_model_bit_for_bit(dev):
     rng = np.random.default_rng(21)
     x = np.concatenate([rng.standard_normal(65536 + 5).astype(np.float32), (rng.standard_normal(4096) * 1e-20).astype(np.float32),
                         (rng.standard_normal(4096) * 1e20).astype(np.float32),
-                        np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -60, 2.0 ** 100, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0, 255.0, 257.0], np.float32)])
+                        np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -60, 2.0 ** 100, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0, 255.0, 257.0, np.inf, -np.inf], np.float32)])
     planes, ps = _split_linear(torch.from_numpy(x).to(dev))
     torch.cuda.synchronize()
     got = planes[:, :x.size].cpu().numpy().view(np.uint16)

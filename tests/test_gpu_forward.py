@@ -127,6 +127,28 @@ def test_smpl_pd16_mode_vs_oracle(dev, smpl_model, B, mode):
         assert torch.equal(vs, v[30:37]) and torch.equal(js, j[30:37])
 
 
+@pytest.mark.parametrize('mode', ['fp16x3', 'fp16x3_lbs', 'fp16x3_lbs_p16'])
+def test_smpl_split_modes_saturate_out_of_range_operands(dev, smpl_model, mode):
+    """a diverging regressor can predict betas in the thousands: the split kernels' fp16 operands then SATURATE (finite output for that
+    body, clipped) instead of overflowing to inf / NaN -- and the other bodies of the batch are bit-identical to a run without the outlier
+    (bodies are independent).  The exact-fp32 kernel has no such range."""
+    B = 40
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    betas = torch.from_numpy(det_uniform((B, 10), 300, -2.5, 2.5))
+    aa = torch.from_numpy(det_uniform((B, 72), 301, -0.9, 0.9))
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3).to(dev)
+    v0, j0 = smpl.forward_arrays(betas.to(dev), R, precision=mode)
+    wild = betas.clone()
+    wild[5] = 5000.0
+    wild[17, 3] = -2.0e6
+    v1, j1 = smpl.forward_arrays(wild.to(dev), R, precision=mode)
+    assert torch.isfinite(v1).all() and torch.isfinite(j1).all()
+    keep = [b for b in range(B) if b not in (5, 17)]
+    assert torch.equal(v1[keep], v0[keep]) and torch.equal(j1[keep], j0[keep])
+    vf, _ = smpl.forward_arrays(wild.to(dev), R, precision='fp32')
+    assert torch.isfinite(vf).all() and float(vf[5].abs().max()) > float(v1[5].abs().max())      # fp32 follows the huge betas, the split modes clip
+
+
 def test_smpl_module_call_forms(dev, smpl_model):
     """the three call forms of the reference (train loop :132, :144, :258)."""
     B = 4

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""tools/find_torch_copies.py -- which Python lines of the training step still make torch launch a kernel of its own (copy / fill /
-elementwise)?  Runs eager steps under torch.profiler with stacks and prints, per aten operator that launched a device kernel or
-memcpy, the innermost frames inside this package.  Run on the GPU box."""
+"""tools/find_torch_copies.py -- which Python lines of the training step still make torch launch a kernel of its own (device-to-device
+copies, fills)?  Wraps the tensor methods that can do so, runs one eager step and prints every call site that really copied / filled a
+GPU tensor (a `.contiguous()` of a contiguous tensor is free and is not listed).  Run on the GPU box."""
 import os
 import sys
+import traceback
 from collections import Counter
 
 import torch
-from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import straps_amd  # noqa: E402
@@ -26,17 +26,51 @@ ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=mp['shape'], use_graph=Fa
 for _ in range(3):
     ts.step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    ts.step()
-    torch.cuda.synchronize()
+
 hits = Counter()
-for ev in prof.events():
-    if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith('aten::'):
-        continue
-    if not ev.kernels:
-        continue
-    frames = [f for f in (ev.stack or []) if 'straps' in f or 'bench.py' in f]
-    where = frames[0] if frames else '(no package frame)'
-    hits[(ev.name, ','.join(sorted({k.name[:40] for k in ev.kernels})), where)] += 1
-for (name, kern, where), n in sorted(hits.items(), key=lambda kv: -kv[1]):
-    print('%3d x %-22s -> %-42s @ %s' % (n, name, kern, where))
+ON = [False]
+
+
+def site():
+    for f in reversed(traceback.extract_stack()[:-2]):
+        if 'straps' in f.filename and 'find_torch_copies' not in f.filename:
+            return '%s:%d %s' % (os.path.basename(f.filename), f.lineno, f.line)
+    return '(outside the package)'
+
+
+def wrap(name, copies):
+    orig = getattr(torch.Tensor, name)
+
+    def w(self, *a, **k):
+        out = orig(self, *a, **k)
+        if ON[0] and isinstance(self, torch.Tensor) and self.is_cuda and copies(self, out, a, k):
+            hits[(name, site())] += 1
+        return out
+    setattr(torch.Tensor, name, w)
+
+
+wrap('contiguous', lambda s, o, a, k: o.data_ptr() != s.data_ptr())
+wrap('clone', lambda s, o, a, k: True)
+wrap('copy_', lambda s, o, a, k: True)
+wrap('fill_', lambda s, o, a, k: True)
+wrap('zero_', lambda s, o, a, k: True)
+wrap('float', lambda s, o, a, k: o.data_ptr() != s.data_ptr())
+wrap('to', lambda s, o, a, k: o.data_ptr() != s.data_ptr())
+wrap('index_select', lambda s, o, a, k: True)
+for fn in ('zeros', 'zeros_like', 'ones', 'full', 'cat', 'stack', 'tensor'):
+    orig = getattr(torch, fn)
+
+    def w(*a, _orig=orig, _fn=fn, **k):
+        out = _orig(*a, **k)
+        if ON[0] and isinstance(out, torch.Tensor) and out.is_cuda:
+            hits[('torch.' + _fn, site())] += 1
+        return out
+    setattr(torch, fn, w)
+
+ON[0] = True
+ts.step()
+torch.cuda.synchronize()
+ON[0] = False
+for (name, where), n in sorted(hits.items(), key=lambda kv: -kv[1]):
+    print('%3d x %-18s @ %s' % (n, name, where))
+print('total', sum(hits.values()))

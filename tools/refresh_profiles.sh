@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-create everything under profiles/ for round RND (run on the GPU box through gpurun; results land in gpurun_out/refresh, copy the
 # summaries into profiles/ afterwards).  Counter passes are separate rocprofv3 runs with --kernel-trace only (never with sys/hip traces).
-RND=${RND:-r02}
+RND=${RND:-r03}
 R=$PWD; export TMPDIR=/tmp; O=$R/gpurun_out/refresh; mkdir -p $O
 cd /tmp
 prof() {  # tag, bench args...
@@ -12,8 +12,8 @@ prof() {  # tag, bench args...
 pmc() {  # json tag, summary name, source text, bench args...
   tag=$1; name=$2; src=$3; shift 3
   fs=""
-  for C in "MfmaUtil" "FETCH_SIZE" "WRITE_SIZE"; do
-    d=$O/pmc_${name}_$C
+  for C in "MfmaUtil GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+    d=$O/pmc_${name}_$(echo $C | cut -d' ' -f1)
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $d -- python $R/bench.py "$@" > $d.log 2>&1
     fs="$fs $(find $d -name '*counter_collection.csv' | head -1)"
   done
@@ -21,28 +21,20 @@ pmc() {  # json tag, summary name, source text, bench args...
 }
 cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 prof train_b64 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
-prof train_b64_fp32conv --conv-precision fp32 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
 prof fwd_b64 --workload fwd --steps 10 --warmup 3 --no-cpu-baseline --no-graph
-prof smpl_65536 --workload smpl --steps 5 --warmup 2 --no-cpu-baseline --no-graph
-prof smpl_65536_fp32 --workload smpl --smpl-precision fp32 --steps 5 --warmup 2 --no-cpu-baseline --no-graph
+prof smpl_65536 --workload smpl --steps 5 --warmup 2 --no-cpu-baseline --no-graph --no-reduced-ab
 prof train_r50_b32 --config 3 --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
-S='rocprofv3 --kernel-trace --pmc MfmaUtil | FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py'
+S='rocprofv3 --kernel-trace --pmc MfmaUtil GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py'
 pmc train_r18_b64 train_b64 "$S --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
-pmc train_r18_b64_fp32conv train_b64_fp32conv "$S --conv-precision fp32 --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --conv-precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
-pmc fwd_r18_b64 fwd_b64 "$S --workload fwd --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload fwd --steps 2 --warmup 1 --no-cpu-baseline --no-graph
-pmc smpl_r18_b65536 smpl_65536 "$S --workload smpl --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload smpl --steps 2 --warmup 1 --no-cpu-baseline --no-graph
-pmc smpl_r18_b65536_fp32 smpl_65536_fp32 "$S --workload smpl --smpl-precision fp32 --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload smpl --smpl-precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --no-graph
+pmc smpl_r18_b65536_fp16x3_lbs smpl_65536 "$S --workload smpl --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload smpl --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-reduced-ab
+pmc smpl_r18_b65536_fp16x3_lbs_p16 smpl_65536_p16 "$S --workload smpl --smpl-precision fp16x3_lbs_p16 --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --workload smpl --smpl-precision fp16x3_lbs_p16 --steps 2 --warmup 1 --no-cpu-baseline --no-graph
 pmc train_r50_b32 train_r50_b32 "$S --config 3 --steps 2 --warmup 1 --no-graph; tools/refresh_profiles.sh" --config 3 --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-overlap --no-stem-ab
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json      # bench.py reports roofline.traffic from this file
 cd $R
 python bench.py 2>/dev/null | tail -1 > $O/${RND}_bench_train_b64.json
 python bench.py --conv-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_train_b64_fp32conv.json
 python bench.py --config 1 2>/dev/null | tail -1 > $O/${RND}_bench_fwd_b64.json
-python bench.py --config 1 --conv-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_fwd_b64_fp32conv.json
 python bench.py --config 4 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M.json
-python bench.py --config 4 --smpl-precision fp16x3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp16x3.json
-python bench.py --config 4 --smpl-precision fp16x3_lbs --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp16x3_lbs.json
-python bench.py --config 4 --smpl-precision fp16x3_lbs_pd16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp16x3_lbs_pd16.json
 python bench.py --config 4 --smpl-precision fp32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_smpl_1M_fp32.json
 python bench.py --config 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${RND}_bench_train_r50_b32.json
 rm -rf $O/prof_*/ $O/pmc_*/
