@@ -153,6 +153,27 @@ class ClockProbe:
         return round(c / w * self.khz / 1e3, 1) if w > 0 and self.khz > 0 else None
 
 
+def sustained_bf16_mfma(dev):
+    """what the bf16 matrix pipe sustains on THIS board under its power budget: straps_selftest_mfma_bf16 (every SIMD issuing
+    register-resident 32x32x16 bf16 MFMAs on operand-like data, no memory traffic), timed with HIP events; also the shader clock it ran at."""
+    L = hipabi.lib()
+    blocks, iters = 1024, 1500
+    out = torch.empty(blocks * 256, device=dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    for _ in range(2):
+        hipabi.check(L.straps_selftest_mfma_bf16(hipabi.ptr(out), hipabi.ptr(clk), blocks, iters, hipabi.stream_ptr()), 'straps_selftest_mfma_bf16')
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    hipabi.check(L.straps_selftest_mfma_bf16(hipabi.ptr(out), hipabi.ptr(clk), blocks, iters, hipabi.stream_ptr()), 'straps_selftest_mfma_bf16')
+    e.record()
+    torch.cuda.synchronize()
+    secs = s.elapsed_time(e) * 1e-3
+    flops = blocks * 4 * iters * 48 * 32768.0
+    c, w = (int(v) for v in clk.tolist())
+    khz = L.straps_wall_clock_khz()
+    return round(flops / secs / 1e12, 1), (round(c / w * khz / 1e3, 1) if w > 0 and khz > 0 else None)
+
+
 def _out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
@@ -505,6 +526,15 @@ def main():
                              'fp32_equivalent_tflops': round(ach, 2), 'fp32_pipe_peak': MFMA_F32_PEAK_TFLOPS,
                              'fp32_equivalent_over_fp32_peak': round(ach / MFMA_F32_PEAK_TFLOPS, 4)})
             roof.update(pmc_traffic(args, dominant))
+            if dominant == 'conv_igemm_x3_kernel' or (args.workload == 'smpl' and not args.smpl_exact):
+                # the spec peak assumes 2.4 GHz; under its power budget the board runs a pure bf16 / fp16 MFMA stream on real data at ~1.5 GHz
+                # (tools/mfma_lds_probe.hip).  Measured here, in this process, on this board:
+                sus, sus_mhz = sustained_bf16_mfma(dev)
+                issued = roof['achieved'] if roof.get('bound') == 'mfma' else roof['mfma_side']['issued']
+                roof['sustained_mfma'] = {'tflops': sus, 'sclk_mhz': sus_mhz, 'frac_of_spec_peak': round(sus / MFMA_BF16_PEAK_TFLOPS, 4),
+                                          'kernel_frac_of_sustained': round(issued / sus, 4),
+                                          'note': 'register-resident v_mfma_f32_32x32x16_bf16 stream on operand-like data, every SIMD, no memory traffic '
+                                                  '(straps_selftest_mfma_bf16): the power-limited ceiling of the matrix pipe on this board'}
             cls = timer.classes(dominant)
             if cls:
                 roof['classes'] = cls

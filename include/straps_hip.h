@@ -34,11 +34,15 @@ int straps_abi_version(void);
 /* calibration: `blocks` x 4 waves each issue 4*iters register-resident fp32 MFMAs (32x32x2);
  * seed512 = 512 floats, out = blocks*256 floats.  Time it to get the board's sustained MFMA rate. */
 int straps_selftest_mfma_peak(const float* seed512, float* out, int blocks, int iters, void* stream);
+/* calibration of the bf16 matrix pipe: `blocks` x 4 waves each issue iters x 48 register-resident v_mfma_f32_32x32x16_bf16 on
+ * operand-like data (out = blocks*256 floats; clk2 optional: shader / wall ticks of workgroup 0).  Timed, it gives the rate the pipe
+ * SUSTAINS under the board's power budget -- the ceiling of the bf16x3 convolution kernels (bench.py: roofline.sustained_*). */
+int straps_selftest_mfma_bf16(float* out, unsigned long long* clk2, int blocks, int iters, void* stream);
 const char* straps_last_error(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int straps_device_count(void);
 /* measurement aid (bench.py `sclk_mhz`; no reference counterpart): with acc2 != NULL (a zeroed device pair of 64-bit counters),
- * workgroup 0 of every implicit-GEMM convolution launched AFTERWARDS (incl. launches captured into a hipGraph afterwards) adds the
+ * workgroup 0 of every implicit-GEMM convolution (and matrix-pipe SMPL vertex kernel) launched AFTERWARDS (incl. launches captured into a hipGraph afterwards) adds the
  * shader-clock ticks and the constant-rate wall ticks of its lifetime to acc2[0] / acc2[1]; sustained shader clock in MHz =
  * acc2[0] / acc2[1] * straps_wall_clock_khz() / 1000.  NULL switches it off (the default: library use pays nothing).              */
 int straps_wall_clock_khz(void);

@@ -33,6 +33,58 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(const float* __restrict_
     out[blockIdx.x * 256 + threadIdx.x] = t;
 }
 
+// ---- what the bf16 matrix pipe SUSTAINS on this board with operand-like data: every SIMD of the chip issues `iters` x 48 independent-
+// accumulator v_mfma_f32_32x32x16_bf16 from registers (no memory traffic at all) -- the inner loop of the bf16x3 convolution without
+// its operand movement.  The chip clocks to its power budget: with non-trivial operands this stream runs ~1.5 GHz, not 2.4
+// (tools/mfma_lds_probe.hip), so the time per MFMA it reports -- not the 2.5 PFLOP/s of the data sheet -- is the ceiling the
+// convolution kernels can be held against.  clk2: (shader ticks, wall ticks) of workgroup 0.
+typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void mfma_bf16_sustained_kernel(float* __restrict__ out, unsigned long long* __restrict__ clk2, int iters) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    st_bf16x8 a[6], b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        u16x8 ua, ub;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {       // bf16 bit patterns with exponents 0x3c..0x3f and pseudo-random mantissas / signs
+            const unsigned h = (threadIdx.x * 2654435761u) ^ ((blockIdx.x * 8 + i) * 40503u + e * 0x9E3779B9u);
+            ua[e] = (unsigned short)(0x3c00u | (h & 0x83ffu));
+            ub[e] = (unsigned short)(0x3c00u | ((h >> 16) & 0x83ffu));
+        }
+        a[i] = __builtin_bit_cast(st_bf16x8, ua);
+        b[i] = __builtin_bit_cast(st_bf16x8, ub);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(t + i) % 6], b[(t * 5 + i) % 6], acc[i], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = t;
+    if (clk2 && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk2[0] = __builtin_amdgcn_s_memtime() - c0;
+        clk2[1] = __builtin_amdgcn_s_memrealtime() - w0;
+    }
+}
+
+extern "C" int straps_selftest_mfma_bf16(float* out, unsigned long long* clk2, int blocks, int iters, void* stream) {
+    STRAPS_REQUIRE(out && blocks > 0 && iters > 0, "straps_selftest_mfma_bf16: bad arguments");
+    hipLaunchKernelGGL(mfma_bf16_sustained_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, clk2, iters);
+    STRAPS_CHECK_LAUNCH("mfma_bf16_sustained_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_selftest_mfma_peak(const float* seed512, float* out, int blocks, int iters, void* stream) {
     STRAPS_REQUIRE(seed512 && out && blocks > 0 && iters > 0, "straps_selftest_mfma_peak: bad arguments");
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, seed512, out, iters);

@@ -509,7 +509,11 @@ template <int NWV, int PF, int ABL, int PD16 = 0>
 __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_model_t m, const float* __restrict__ F,
                                                                  const float* __restrict__ Amat, float* __restrict__ verts,
                                                                  float* __restrict__ vout, long long B, int btiles,
-                                                                 int ntiles, int rounds, int rounds_per_chunk) {
+                                                                 int ntiles, int rounds, int rounds_per_chunk, unsigned long long* clk) {
+    // (clk: measurement aid, NULL in library use -- straps_set_clock_accumulator: workgroup 0 adds the shader-clock and wall-clock ticks of
+    //  its lifetime, bench.py's sclk_mhz of the SMPL-only workload)
+    unsigned long long clk_c0 = 0, clk_w0 = 0;
+    if (clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = __builtin_amdgcn_s_memrealtime(); }
     // (ABL: compile-time measurement switches, 0 in production -- 1 = no output stores, 2 = no fragment loads after the first
     //  k-step, 4 = no skinning MFMAs, 8 = no blend MFMAs; tools/smpl_ablate.sh)
     constexpr int ablate = ABL;
@@ -752,6 +756,10 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
         ptile = tile;
     }
     if (ptile >= 0) store_tile(ptile, outp);
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(clk, (unsigned long long)__builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_w0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -883,7 +891,7 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
         const int rpc2 = rpc_env > 0 ? (rpc_env > rounds2 ? rounds2 : rpc_env) : resolve_rpc(rounds2, batch, chunks);
         const int nch2 = (rounds2 + rpc2 - 1) / rpc2;
         hipLaunchKernelGGL(hh_kernel, dim3((unsigned)(btiles * nch2)), dim3(nwv * 64), lds, st, *model, F, Amat, verts, joints ? vout : nullptr,
-                           batch, (int)btiles, ntiles, rounds2, rpc2);
+                           batch, (int)btiles, ntiles, rounds2, rpc2, g_straps_clk_acc);
     } else if (split)
         hipLaunchKernelGGL(h_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
                            joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);

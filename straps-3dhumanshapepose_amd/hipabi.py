@@ -103,6 +103,7 @@ SIGNATURES = {
     'straps_wall_clock_khz': (_I, []),
     'straps_set_clock_accumulator': (_I, [_P]),
     'straps_selftest_mfma_peak': (_I, [_P, _P, _I, _I, _P]),
+    'straps_selftest_mfma_bf16': (_I, [_P, _P, _I, _I, _P]),
     'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weights_batched': (_I, [_P, _I, _L, _P]),
