@@ -53,21 +53,51 @@ def _bn(x, sd, name, training):
                         sd[name + '.weight'], sd[name + '.bias'], training, BN_MOMENTUM, BN_EPS)
 
 
-def resnet_forward(x, sd, layers=18, training=False, prefix='image_encoder.', taps=None):
+def _relu_dec(z, dec):
+    """F.relu, or (tests only) z * the next recorded decision mask of `dec`; dec = {'record': True}: plain ReLU, the
+    pre-activations are appended to dec['z']"""
+    if dec is None:
+        return F.relu(z)
+    if dec.get('record'):
+        dec.setdefault('z', []).append(z.detach())
+        return F.relu(z)
+    m = dec['relu'][dec['next']]
+    dec['next'] += 1
+    return z * m.to(z.dtype)
+
+
+def resnet_forward(x, sd, layers=18, training=False, prefix='image_encoder.', taps=None, decisions=None):
     """ResNet.forward (models/resnet.py:201-216) without the FC head.
 
     x: float32 [B,C,256,256] NCHW.  sd: state dict (reference key names).  Returns [B,512|2048].
     `taps` (optional dict) receives named intermediate activations for layer-wise checks.
     Stem: conv7x7/s2/p3 -> BN -> ReLU -> maxpool3x3/s2/p1 (:145-149); stages (:150-156) of
     BasicBlock (:61-77) or Bottleneck (:101-121); GAP + flatten (:213-214).
+    `decisions` (optional, tests only): {'relu': [bool masks NCHW in evaluation order: stem, then per block bn1 (, bn2), block output],
+    'pool': long [B,64,Hp,Wp] arg-max tap (row * 3 + column of the 3x3 window)} REPLACE the ReLU / max-pool decisions, like
+    ief_forward's relu_masks: the piecewise-linear function another evaluation actually differentiated.  {'record': True} instead
+    leaves the forward alone and stores the pre-activations (decisions['z'], same order) and the pooling windows
+    (decisions['pool_windows'] [B,64,Hp,Wp,9], -inf outside the image) for comparing decisions.
     """
     kind, counts = _RESNET_SPECS[layers]
     p = prefix
+    dec = decisions
+    if dec is not None:
+        dec['next'] = 0
     y = F.conv2d(x, sd[p + 'conv1.weight'], None, 2, 3)
-    y = F.relu(_bn(y, sd, p + 'bn1', training))
+    y = _relu_dec(_bn(y, sd, p + 'bn1', training), dec)
     if taps is not None:
         taps['stem'] = y
-    y = F.max_pool2d(y, 3, 2, 1)
+    if dec is None:
+        y = F.max_pool2d(y, 3, 2, 1)
+    else:
+        win = F.pad(y, (1, 1, 1, 1), value=float('-inf')).unfold(2, 3, 2).unfold(3, 3, 2)        # [B,C,Hp,Wp,3,3]
+        win = win.reshape(win.shape[:4] + (9,))
+        if dec.get('record'):
+            dec['pool_windows'] = win.detach()
+            y = F.max_pool2d(y, 3, 2, 1)
+        else:
+            y = win.gather(4, dec['pool'][..., None]).squeeze(4)
     if taps is not None:
         taps['pool'] = y
     for li, nblk in enumerate(counts):
@@ -77,20 +107,20 @@ def resnet_forward(x, sd, layers=18, training=False, prefix='image_encoder.', ta
             idt = y
             if kind == 'basic':
                 o = F.conv2d(y, sd[q + 'conv1.weight'], None, stride, 1)
-                o = F.relu(_bn(o, sd, q + 'bn1', training))
+                o = _relu_dec(_bn(o, sd, q + 'bn1', training), dec)
                 o = F.conv2d(o, sd[q + 'conv2.weight'], None, 1, 1)
                 o = _bn(o, sd, q + 'bn2', training)
             else:
                 o = F.conv2d(y, sd[q + 'conv1.weight'], None, 1, 0)
-                o = F.relu(_bn(o, sd, q + 'bn1', training))
+                o = _relu_dec(_bn(o, sd, q + 'bn1', training), dec)
                 o = F.conv2d(o, sd[q + 'conv2.weight'], None, stride, 1)
-                o = F.relu(_bn(o, sd, q + 'bn2', training))
+                o = _relu_dec(_bn(o, sd, q + 'bn2', training), dec)
                 o = F.conv2d(o, sd[q + 'conv3.weight'], None, 1, 0)
                 o = _bn(o, sd, q + 'bn3', training)
             if (q + 'downsample.0.weight') in sd:
                 idt = F.conv2d(y, sd[q + 'downsample.0.weight'], None, stride, 0)
                 idt = _bn(idt, sd, q + 'downsample.1', training)
-            y = F.relu(o + idt)
+            y = _relu_dec(o + idt, dec)
         if taps is not None:
             taps['layer%d' % (li + 1)] = y
     return y.mean(dim=(2, 3))
@@ -129,9 +159,10 @@ def ief_forward(feat, sd, init_estimate, iterations=3, prefix='ief_module.', rel
     return est[:, :3], est[:, 3:147], est[:, 147:], est
 
 
-def regressor_forward(x, sd, init_estimate, layers=18, iterations=3, training=False, ief_masks=None, ief_taps=None):
+def regressor_forward(x, sd, init_estimate, layers=18, iterations=3, training=False, ief_masks=None, ief_taps=None, enc_decisions=None,
+                      enc_taps=None):
     """SingleInputRegressor.forward (models/regressor.py:43-47)."""
-    feat = resnet_forward(x, sd, layers, training)
+    feat = resnet_forward(x, sd, layers, training, taps=enc_taps, decisions=enc_decisions)
     return ief_forward(feat, sd, init_estimate, iterations, relu_masks=ief_masks, taps=ief_taps)
 
 
@@ -342,12 +373,13 @@ def multi_task_loss(labels, outputs, log_vars, losses_on=LOSS_TASKS, img_wh=REGR
 # forward + loss + backward of one training step (train loop :186-232) on a GIVEN batch
 # --------------------------------------------------------------------------------------------
 def train_step_loss_and_grads(batch, sd, init_estimate, smpl_model, layers=18, iterations=3, log_vars=None, dtype=torch.float32,
-                              ief_masks=None, ief_taps=None):
+                              ief_masks=None, ief_taps=None, enc_decisions=None):
     """regressor (training-mode BatchNorm) -> rot6d -> SMPL -> heads -> multi-task loss -> autograd.
     batch: dict with 'input' [B,18,256,256], 'verts', 'joints2d', 'joints3d', 'shape', 'rot' (targets, CPU tensors);
     sd: regressor state dict (cloned and cast to `dtype` here; the caller's tensors are not touched);
     log_vars: {task: float}.  Returns (total, weighted task losses, {parameter name: grad}, {task: d total / d log_var}).
-    ief_masks / ief_taps: see ief_forward (forced ReLU decisions of the IEF head / its pre-activations)."""
+    ief_masks / ief_taps: see ief_forward (forced ReLU decisions of the IEF head / its pre-activations); enc_decisions: see
+    resnet_forward (forced or recorded ReLU / max-pool decisions of the encoder)."""
     sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
     names = [k for k in sd if not k.startswith('ief_module.ief_layers.') and k.split('.')[-1] in ('weight', 'bias') and sd[k].is_floating_point()]
     for n in names:
@@ -359,7 +391,7 @@ def train_step_loss_and_grads(batch, sd, init_estimate, smpl_model, layers=18, i
     lv = {k: torch.tensor(float(v), dtype=dtype, requires_grad=True) for k, v in (log_vars or init_log_vars()).items()}
     x = batch['input'].to(dtype)
     cam, pose, shape, _ = regressor_forward(x, sd, torch.as_tensor(init_estimate).to(dtype), layers, iterations, training=True,
-                                            ief_masks=ief_masks, ief_taps=ief_taps)
+                                            ief_masks=ief_masks, ief_taps=ief_taps, enc_decisions=enc_decisions)
     R = rot6d_to_rotmat(pose.contiguous()).view(-1, 24, 3, 3)
     verts, joints = smpl_forward(smpl_model, shape, rotmats=R, dtype=dtype)
     pred = {'verts': verts, 'joints2D': orthographic_project(joints[:, ALL_JOINTS_TO_COCO_MAP], cam),

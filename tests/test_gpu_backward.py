@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 import straps_amd
 import straps_oracle as O
+import decisions
 from detgen import det_uniform, det_state_dict
 from straps_amd import hipabi
 
@@ -330,14 +331,40 @@ def test_regressor_param_grads_vs_reference_golden(dev, layers):
         assert err < 1e-2, '%s: grad norm %.6e vs reference %.6e' % (n, float(g.norm()), ref_norm)
         assert cos > 0.995, '%s: cosine vs oracle autograd %.6f' % (n, cos)
     print('r%d worst grad-norm rel err %.2e, worst cosine %.6f' % (layers, worst, worst_cos))
+    # ... and what those loose bars hide is decisions, not arithmetic: the float64 oracle evaluated on the ReLU / max-pool decisions the
+    # GPU took (tests/decisions.py; every differing decision a tie) agrees with the GPU's gradients to 2e-4 (resnet50: 1e-3) relative L2 in every tensor
+    reg.zero_grad()
+    dec, feat = decisions.gpu_encoder_decisions(reg.image_encoder, x)          # (a second training-mode forward: same batch statistics)
+    masks = decisions.gpu_ief_masks(reg.ief_module, feat)
+    cam, pose, shape = reg(x)
+    (torch.cat([cam, pose, shape], 1) * coef).sum().backward()
+    rec64 = {'record': True}
+    sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    O.regressor_forward(x.cpu().double(), sd64, O.ief_init_estimate(MP['pose'], MP['shape']).double(), layers, 3, training=True, enc_decisions=rec64)
+    n_relu, n_pool, tie_relu, tie_pool = decisions.compare_encoder_decisions(dec, rec64)
+    assert tie_relu <= 4.0 and tie_pool <= 4.0
+    sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for n in names:
+        sd64[n].requires_grad_(True)
+    _, _, _, est = O.regressor_forward(x.cpu().double(), sd64, O.ief_init_estimate(MP['pose'], MP['shape']).double(), layers, 3, training=True,
+                                       ief_masks=masks, enc_decisions={'relu': dec['relu'], 'pool': dec['pool']})
+    (est * coef.cpu().double()).sum().backward()
+    worst = 0.0
+    for n, p in reg.named_parameters():
+        r = sd64[n].grad.reshape(-1)
+        e = float((p.grad.cpu().double().reshape(-1) - r).norm() / r.norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < (2e-4 if layers == 18 else 1e-3), '%s: %.3e vs the float64 oracle on the GPU decisions' % (n, e)      # (measured: 2.0e-5 / 2.0e-4 worst; two samples per batch statistic)
+    print('r%d: %d ReLU / %d pooling decisions differ from float64 (ties); worst relative gradient error on the GPU decisions %.2e' % (layers, n_relu, n_pool, worst))
 
 
 @pytest.mark.parametrize('layers,prec', [(18, 'bf16x3'), (18, 'fp32'), (50, 'bf16x3')])
 def test_eval_mode_gradients_through_frozen_batchnorm_vs_float64_oracle(dev, layers, prec):
     """reg.eval() + loss.backward(): nn.BatchNorm2d in eval mode back-propagates through its running statistics as constants
     (models/resnet.py:47,147; fine-tuning with frozen statistics).  Eval mode is well conditioned (no batch statistics), so the bars are
-    tight: outputs 2e-5, every parameter gradient (incl. BatchNorm weight / bias) 2e-4 relative L2 against autograd of the float64 oracle
-    with training=False; running statistics and num_batches_tracked untouched; the no-grad eval output unchanged by the taped run."""
+    tight: outputs 2e-5, every parameter gradient (incl. BatchNorm weight / bias) 2e-4 (resnet50: 5e-4) of the tensor's maximum against autograd of the
+    float64 oracle with training=False -- evaluated on the GPU's ReLU / max-pool decisions where a rounding-level tie was decided the other
+    way (tests/decisions.py); running statistics and num_batches_tracked untouched; the no-grad eval output unchanged by the taped run."""
     reg, sd = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
     reg.image_encoder.conv_precision = prec
     reg.eval()
@@ -354,44 +381,47 @@ def test_eval_mode_gradients_through_frozen_batchnorm_vs_float64_oracle(dev, lay
     assert float((y1.detach() - y0).abs().max()) < 2e-5
     for n, b in reg.named_buffers():
         assert torch.equal(b, buf0[n]), n
-    sdo = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     names = [n for n, _ in reg.named_parameters()]
-    for n in names:
-        sdo[n].requires_grad_(True)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    _, _, _, est = O.regressor_forward(x.cpu().double(), sdo, O.ief_init_estimate(MP['pose'], MP['shape']).double(), layers, 3, training=False)
-    (est * coef.cpu().double()).sum().backward()
-    assert float((y1.detach().cpu().double() - est.detach()).abs().max()) < 2e-4
-    # the float32 CPU oracle (= the reference's own arithmetic) on the same problem: its distance from float64 is the yardstick
-    sd32 = {k: v.clone() for k, v in sd.items()}
-    for n in names:
-        sd32[n].requires_grad_(True)
-    _, _, _, est32 = O.regressor_forward(x.cpu(), sd32, O.ief_init_estimate(MP['pose'], MP['shape']), layers, 3, training=False)
-    (est32 * coef.cpu()).sum().backward()
-    # Bar per tensor: max |error| / max |gradient| < max(2e-4, 3 x the float32 CPU oracle's).  A handful of tensors may carry a DECISION TIE:
-    # a max-pool window (or ReLU) whose two candidates agree to within fp32 resolution takes the other branch than float64 and one
-    # gradient term moves by a pixel -- measured on this very input (tools/debug_eval_stem2.py): ONE of the stem's 786 432 pooling
-    # windows, top two values 1.323754461 / 1.323754109, relative gap 2.7e-7; conv1.weight then differs in the 882 taps of that output
-    # channel by up to 2.4e-3 of the maximum while every other tensor sits at 1e-5.  Such tensors: < 5 % of their elements outside the
-    # bar, none beyond 2e-2, and few: at most three, or a tenth of the tensors in the 53-layer resnet50 (where one flipped unit early in
-    # the network reaches every gradient upstream of it).
-    worst, ties, bad = 0.0, [], []
+    init = O.ief_init_estimate(MP['pose'], MP['shape'])
+
+    def oracle(dtype, **kw):
+        sdo = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for n in names:
+            sdo[n].requires_grad_(True)
+        _, _, _, est = O.regressor_forward(x.cpu().to(dtype), sdo, init.to(dtype), layers, 3, training=False, **kw)
+        (est * coef.cpu().to(dtype)).sum().backward()
+        return est.detach(), {n: sdo[n].grad for n in names}
+    rec64, taps64 = {'record': True}, []
+    est, g64 = oracle(torch.float64, enc_decisions=rec64, ief_taps=taps64)
+    assert float((y1.detach().cpu().double() - est).abs().max()) < 2e-4
+    # the decisions the GPU took (taped forward = the forward of the backward above), unit by unit against float64's
+    dec, feat = decisions.gpu_encoder_decisions(reg.image_encoder, x)
+    masks = decisions.gpu_ief_masks(reg.ief_module, feat)
+    n_relu, n_pool, tie_relu, tie_pool = decisions.compare_encoder_decisions(dec, rec64)
+    n_ief = sum(int((m != (z > 0)).sum()) for pair, zs in zip(masks, taps64) for m, z in zip(pair, zs))
+    total_units = sum(m.numel() for m in dec['relu'])
+    print('eval-mode r%d %s: %d of %d encoder ReLU decisions, %d of %d pooling windows and %d IEF ReLU decisions differ from float64 '
+          '(|z64| / float64 gap of the differing ones: <= %.2f x / %.2f x the activation error observed on the same layer)'
+          % (layers, prec, n_relu, total_units, n_pool, dec['pool'].numel(), n_ief, tie_relu, tie_pool))
+    # every differing decision is a TIE: the float64 pre-activation (gap between the window's two candidates) lies within a few times the
+    # evaluation error measured on the units of the same layer that both sides agree on.  One such unit moves a whole term of every
+    # gradient upstream of it (measured on this input with tools/debug_eval_stem2.py: ONE of the stem's 786 432 pooling windows,
+    # candidates 1.323754461 / 1.323754109, moves conv1.weight by 2.4e-3 of its maximum while every other tensor sits at 1e-5), so the
+    # gradients are compared with the float64 oracle evaluating the function the GPU did differentiate: the GPU's decisions forced.
+    assert tie_relu <= 4.0 and tie_pool <= 4.0
+    assert n_relu <= 1e-5 * total_units + 3
+    if n_relu or n_pool or n_ief:
+        _, g64 = oracle(torch.float64, enc_decisions={'relu': dec['relu'], 'pool': dec['pool']}, ief_masks=masks)
+    worst, bad = 0.0, []
     for n, p in reg.named_parameters():
         assert p.grad is not None, n
-        ref = sdo[n].grad
-        scale = float(ref.abs().max().clamp_min(1e-30))
-        d = (p.grad.cpu().double() - ref).abs() / scale
-        err, e32 = float(d.max()), _relerr(sd32[n].grad, ref)
-        bar = max(2e-4, 3 * e32)
-        if err < bar:
-            worst = max(worst, err)
-        elif err < 2e-2 and float((d > bar).double().mean()) < 0.05:
-            ties.append('%s: %.3e (%.2f %% of the elements over %.1e)' % (n, err, 100 * float((d > bar).double().mean()), bar))
-        else:
-            bad.append('%s: gpu %.3e  cpu32 %.3e' % (n, err, e32))
-    print('eval-mode r%d %s: worst relative gradient error vs float64 %.2e; decision ties: %s' % (layers, prec, worst, ties or 'none'))
+        err = _relerr(p.grad, g64[n])
+        worst = max(worst, err)
+        if not err < (2e-4 if layers == 18 else 5e-4):          # (measured: 2.1e-5 / 1.3e-6 resnet18 bf16x3 / fp32, 2.5e-4 resnet50 bf16x3)
+            bad.append('%s: %.3e' % (n, err))
+    print('eval-mode r%d %s: worst max-norm relative gradient error vs float64 (GPU decisions): %.2e over %d tensors' % (layers, prec, worst, len(names)))
     assert not bad, '\n'.join(bad)
-    assert len(ties) <= max(3, len(names) // 10), ties
 
 
 def test_fused_stem_tail_equals_unfused(dev):

@@ -39,3 +39,57 @@ def test_forced_masks_reproduce_relu_and_flip_one_unit_by_its_rank_one_term():
     bound = float(z2[r, u].abs() * sd['ief_module.fc3.weight'][:, u].abs().max())
     assert 0 < float((est_f - est).abs().max()) <= bound * (1 + 1e-12)
     assert torch.equal(est_f[torch.arange(B) != r], est[torch.arange(B) != r])
+
+
+def _encoder_decisions_of(x, sd, layers, training=False):
+    """the oracle's own ReLU / max-pool decisions, recorded by running its plain forward with hooks on the two functionals"""
+    import torch.nn.functional as F
+    rec = {'relu': [], 'pool': None}
+    relu0, pool0 = F.relu, F.max_pool2d
+
+    def relu(z, *a, **k):
+        rec['relu'].append(z > 0)
+        return relu0(z, *a, **k)
+
+    def pool(y, *a, **k):
+        out, idx = F.max_pool2d_with_indices(y, 3, 2, 1)
+        W = y.shape[3]
+        hi, wi = idx // W, idx % W
+        ho = torch.arange(out.shape[2]).view(1, 1, -1, 1)
+        wo = torch.arange(out.shape[3]).view(1, 1, 1, -1)
+        rec['pool'] = (hi - (2 * ho - 1)) * 3 + (wi - (2 * wo - 1))
+        return out
+    F.relu, F.max_pool2d = relu, pool
+    try:
+        sdc = {k: v.clone() for k, v in sd.items()}
+        with torch.no_grad():
+            O.resnet_forward(x, sdc, layers, training)
+    finally:
+        F.relu, F.max_pool2d = relu0, pool0
+    return rec
+
+
+def test_forced_encoder_decisions_reproduce_the_plain_forward_and_its_gradients():
+    import straps_amd
+    torch.manual_seed(3)
+    for layers in (18, 50):
+        net = straps_amd.SingleInputRegressor(18, layers, 3, mean_params=straps_amd.synthetic_mean_params(0))
+        sd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in net.state_dict().items()}
+        x = torch.rand(2, 18, 64, 64, dtype=torch.float64)
+        for training in (False, True):
+            dec = _encoder_decisions_of(x, sd, layers, training)
+            n_relu = {18: 1 + 8 * 2, 50: 1 + 16 * 3}[layers]
+            assert len(dec['relu']) == n_relu and dec['pool'].shape == (2, 64, 16, 16)
+            assert int(dec['pool'].min()) >= 0 and int(dec['pool'].max()) <= 8
+            w = 'image_encoder.layer1.0.conv1.weight'
+            outs = []
+            for d in (None, dec):
+                sdc = {k: v.clone() for k, v in sd.items()}
+                sdc[w].requires_grad_(True)
+                sdc['image_encoder.conv1.weight'].requires_grad_(True)
+                f = O.resnet_forward(x, sdc, layers, training, decisions=d)
+                g = torch.autograd.grad(f.square().sum(), [sdc[w], sdc['image_encoder.conv1.weight']])
+                outs.append((f.detach(), g))
+            assert torch.equal(outs[0][0], outs[1][0])
+            for a, b in zip(outs[0][1], outs[1][1]):
+                assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max())
