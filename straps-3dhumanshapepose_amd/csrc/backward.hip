@@ -369,7 +369,11 @@ struct WgradXP {
 template <int BC>
 __device__ __forceinline__ int seg_swz(int px) { return BC == 64 ? ((px >> 1) & 1) : (px & 3); }
 
-template <int BCO, int BCI>
+// NST stages: two in production.  Round 3 tried three and four (copies of NST - 1 steps in flight, s_waitcnt vmcnt(DPS * (NST - 2))), on
+// the reasoning that a 32-pixel step is only 0.1-0.4 us of matrix work: no gain on any resnet18 / resnet50 shape and 10-60 % slower on
+// the 3x3 / stride-2 layers (tools/sweep_wgrad_x3.py with STRAPS_WGRAD_TAP_NST=3|4: the LDS the extra stages take costs a resident
+// workgroup) -- the kernel is bound by the operand bytes it streams from L2, not by their latency.
+template <int BCO, int BCI, int NST = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
     constexpr int PLD = 32 * BCO, PLX = 32 * BCI;                 // u16 elements per plane of a stage: [32 px][BCO], [32 px][BCI]
     constexpr int STG = 3 * (PLD + PLX);
@@ -467,7 +471,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
         for (int c = 0; c < NI; ++c)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][c][q] = 0.f;
-    if (nsteps > 0) dma_step(0);
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < nsteps) dma_step(s0);
     // fragment addresses: lane t = lane & 15 names row t >> 2 of a 4-pixel group and channel quad t & 3 of its 16-channel half
     const int tt = lane & 15, ch16 = (lane >> 4) & 1, kh = lane >> 5;
     int fd[2][2][MI], fx[2][2][NI];                               // [k step][read][32-channel block]
@@ -489,14 +495,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
         }
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
     constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+    constexpr int DPS = 3 * (RDD + RDX);                      // LDS-DMA instructions per step and wave
+    static_assert(DPS * (NST - 2) <= 63, "vmcnt range");
+    int stage = 0;
     for (int st = 0; st < nsteps; ++st) {
-        const int stage = st & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies of step st have landed ...
-        __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
+        // my copies of step st have landed (the younger steps' may still be in flight) ...
+        const int ahead = nsteps - 1 - st;
+        if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NST >= 4 ? 2 : 0)) : "memory");
+        else if (NST >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (NST >= 3 ? 1 : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the stage about to be refilled is no longer being read
         asm volatile("" ::: "memory");
-        if (st + 1 < nsteps) dma_step(stage ^ 1);
+        if (st + NST - 1 < nsteps) dma_step(stage == 0 ? NST - 1 : stage - 1);
         const u16* D = smem + stage * STG;
         const u16* X = D + 3 * PLD;
+        stage = stage + 1 == NST ? 0 : stage + 1;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1573,8 +1586,13 @@ inline bool wgrad_big_tile(long long M, int cin, int cout, int taps) {
     return cin % 128 == 0 && cout % 128 == 0 && taps == 1 && M >= 8192;
 }
 
-inline int wgrad_splits(long long M, int tiles, bool big = false) {
-    int s = ((big ? 512 : 1536) + tiles - 1) / tiles;
+// x3: the per-tap kernel on the planes (its 128x128 tile takes 96 KB of LDS: one workgroup per CU is resident, so 256 workgroups = one
+// round; 512 cost 10-18 % on resnet50's 1x1 layers -- tools/sweep_wgrad_x3.py, round 3).  The fp32 kernel (64 KB, two resident) keeps 512;
+// the shared workspace size is the fp32 plan's, which is the larger.
+inline int wgrad_splits(long long M, int tiles, bool big = false, bool x3 = false) {
+    static const int t_big = getenv("STRAPS_WGRAD_WGS_BIG") ? atoi(getenv("STRAPS_WGRAD_WGS_BIG")) : 0;          // (A/B switches for tools)
+    static const int t_small = getenv("STRAPS_WGRAD_WGS_SMALL") ? atoi(getenv("STRAPS_WGRAD_WGS_SMALL")) : 1536;
+    int s = ((big ? (t_big > 0 && x3 ? t_big : x3 ? 256 : 512) : t_small) + tiles - 1) / tiles;
     const long long max_s = (M + 127) / 128;      // at least 4 K-steps of 32 pixels per split
     if (s > max_s) s = (int)max_s;
     return s < 1 ? 1 : s;
@@ -1750,15 +1768,27 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         const int tile = big ? 128 : 64;
         q.ct = cout / tile; q.it = cin / tile;
         const int tiles = kh * kw * q.ct * q.it;
-        const int splits = wgrad_splits(M, tiles, big);
+        const int splits = wgrad_splits(M, tiles, big, true);
         q.rows_per_split = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
         hipStream_t st = (hipStream_t)stream;
+        static const int nst_env = getenv("STRAPS_WGRAD_TAP_NST") ? atoi(getenv("STRAPS_WGRAD_TAP_NST")) : 2;      // (A/B switch for tools: 3, 4 -- measured slower)
+        constexpr int SB = 3 * 32 * 256 * 2, SS = 3 * 32 * 128 * 2;      // bytes per stage: 128x128 / 64x64 channel block
         if (big) {
-            constexpr int LDSB = 2 * 3 * 32 * 256 * 2;
-            STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<128, 128>), LDSB, "conv_wgrad_x3_kernel");
-            hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128>), dim3(tiles, splits), dim3(256), LDSB, st, q);
+            if (nst_env == 3) {
+                STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<128, 128, 3>), 3 * SB, "conv_wgrad_x3_kernel");
+                hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128, 3>), dim3(tiles, splits), dim3(256), 3 * SB, st, q);
+            } else {
+                STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<128, 128, 2>), 2 * SB, "conv_wgrad_x3_kernel");
+                hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128, 2>), dim3(tiles, splits), dim3(256), 2 * SB, st, q);
+            }
+        } else if (nst_env == 3) {
+            STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<64, 64, 3>), 3 * SS, "conv_wgrad_x3_kernel");
+            hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 64, 3>), dim3(tiles, splits), dim3(256), 3 * SS, st, q);
+        } else if (nst_env == 4) {
+            STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<64, 64, 4>), 4 * SS, "conv_wgrad_x3_kernel");
+            hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 64, 4>), dim3(tiles, splits), dim3(256), 4 * SS, st, q);
         } else {
-            hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 64>), dim3(tiles, splits), dim3(256), 2 * 3 * 32 * 128 * 2, st, q);
+            hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 64, 2>), dim3(tiles, splits), dim3(256), 2 * SS, st, q);
         }
         STRAPS_CHECK_LAUNCH("conv_wgrad_x3_kernel");
         const long long n = (long long)cout * kh * kw * cin;

@@ -562,12 +562,18 @@ int launch_x3(const ConvP& p0, hipStream_t st) {
 // auto rule from tools/sweep_conv_x3.py (resnet18 shapes, B = 64): 64-channel outputs take 128x64 tiles, two workgroups per CU; otherwise
 // the largest tile that still gives every CU a workgroup: 256x128 from 512 128x128-tiles on (layer2: 63 vs 68 us), 128x128 from 256
 // (layer3: 97 vs 108), else 128x64 with the three-stage ring (layer4's 4096 pixels: 113 vs 150).
-inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& bn) {
+// Stride-2 data gradients (ncls = 4 output-parity classes, each a quarter of the pixels with 1-4 of the taps -- a 1x1 filter has ONE live
+// class) are sized by the tiles of a class, not of the launch (round 3, tools/sweep_conv_x3.py on the resnet18 and resnet50 shapes):
+// resnet50's 1024 -> 2048 shortcut 124 -> 54 us, 256 -> 256 3x3 77 -> 59, 512 -> 1024 shortcut 71 -> 59; resnet18's 128 -> 256 74 -> 58,
+// 256 -> 512 75 -> 64.
+inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& bn, int ncls = 1, bool one_tap = false) {
     (void)kdim;
     cfg &= 15;
     if (cfg == 0) {
         const long long t128 = ((M + 127) / 128) * (cout / 128);
-        cfg = cout % 128 != 0 ? 11 : t128 >= 512 ? 12 : t128 >= 256 ? 5 : 7;       // (11 / 12: the pipelined loop pays with two-stage rings: -7 %)
+        if (cout % 128 != 0) cfg = 11;
+        else if (ncls > 1) cfg = t128 / ncls >= 512 ? 12 : t128 / ncls >= 256 ? (one_tap ? 9 : 12) : 11;
+        else cfg = t128 >= 512 ? 12 : t128 >= 256 ? 5 : 7;       // (11 / 12: the pipelined loop pays with two-stage rings: -7 %)
     }
     if (cout % 128 != 0 && cfg != 3 && cfg != 7 && cfg != 10 && cfg != 11) cfg = 2;
     bm = (cfg == 4 || cfg == 6 || cfg == 12) ? 256 : cfg == 3 ? 64 : 128;
@@ -622,7 +628,7 @@ int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
     if (halo == 1) return launch_x3h<128, 128, 2, 2, 3, 208>(p, st);
     if (halo == 2) return launch_x3h<128, 64, 2, 2, 3, 272>(p, st);
     if (halo == 3) return launch_x3h<128, 64, 2, 2, 2, 272, 1>(p, st);
-    const int cfg = pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn);
+    const int cfg = pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn, p.ncls, kdim == p.Cin);
     if ((tile_cfg & 192) == 192) return dispatch_x3_abl<3>(p, cfg, st);      // ablations (tools)
     if (tile_cfg & 64) return dispatch_x3_abl<1>(p, cfg, st);
     if (tile_cfg & 128) return dispatch_x3_abl<2>(p, cfg, st);
@@ -742,7 +748,7 @@ static int dgrad_x3_blocks(const ConvP& p, int tile_cfg) {
         M += p.cls[i].M;
         if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
     }
-    pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn);
+    pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn, p.ncls, kdim == p.Cin);
     int blocks = 0;
     for (int i = 0; i < p.ncls; ++i) blocks += (p.cls[i].M + bm - 1) / bm;
     return blocks;

@@ -17,6 +17,14 @@ dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 SHAPES = [('l1 3x3 s1', 64, 64, 64, 3, 1), ('l2.0 3x3 s2', 64, 64, 128, 3, 2), ('l2 3x3 s1', 32, 128, 128, 3, 1), ('l2 ds 1x1 s2', 64, 64, 128, 1, 2),
           ('l3.0 3x3 s2', 32, 128, 256, 3, 2), ('l3 3x3 s1', 16, 256, 256, 3, 1), ('l4.0 3x3 s2', 16, 256, 512, 3, 2), ('l4 3x3 s1', 8, 512, 512, 3, 1)]
+if len(sys.argv) > 2 and sys.argv[2] == 'r50':          # the Bottleneck encoder's distinct shapes (models/resnet.py:80-121), use with B = 32
+    SHAPES = [('l1 1x1 64-64', 64, 64, 64, 1, 1), ('l1 3x3', 64, 64, 64, 3, 1), ('l1 1x1 64-256', 64, 64, 256, 1, 1), ('l1 1x1 256-64', 64, 256, 64, 1, 1),
+              ('l2.0 1x1 256-128', 64, 256, 128, 1, 1), ('l2.0 3x3 s2', 64, 128, 128, 3, 2), ('l2 1x1 128-512', 32, 128, 512, 1, 1), ('l2 ds 256-512 s2', 64, 256, 512, 1, 2),
+              ('l2 1x1 512-128', 32, 512, 128, 1, 1), ('l2 3x3', 32, 128, 128, 3, 1),
+              ('l3.0 1x1 512-256', 32, 512, 256, 1, 1), ('l3.0 3x3 s2', 32, 256, 256, 3, 2), ('l3 1x1 256-1024', 16, 256, 1024, 1, 1), ('l3 ds 512-1024 s2', 32, 512, 1024, 1, 2),
+              ('l3 1x1 1024-256', 16, 1024, 256, 1, 1), ('l3 3x3', 16, 256, 256, 3, 1),
+              ('l4.0 1x1 1024-512', 16, 1024, 512, 1, 1), ('l4.0 3x3 s2', 16, 512, 512, 3, 2), ('l4 1x1 512-2048', 8, 512, 2048, 1, 1), ('l4 ds 1024-2048 s2', 16, 1024, 2048, 1, 2),
+              ('l4 1x1 2048-512', 8, 2048, 512, 1, 1), ('l4 3x3', 8, 512, 512, 3, 1)]
 
 
 def timeit(fn, iters=20):

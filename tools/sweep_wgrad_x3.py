@@ -16,9 +16,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 SHAPES = [('l1 3x3 s1', 64, 64, 64, 3, 1), ('l2 3x3 s1', 32, 128, 128, 3, 1), ('l3 3x3 s1', 16, 256, 256, 3, 1), ('l4 3x3 s1', 8, 512, 512, 3, 1),
           ('l2.0 3x3 s2', 64, 64, 128, 3, 2), ('l2 ds 1x1 s2', 64, 64, 128, 1, 2), ('l3.0 3x3 s2', 32, 128, 256, 3, 2), ('l3 ds 1x1 s2', 32, 128, 256, 1, 2),
           ('l4.0 3x3 s2', 16, 256, 512, 3, 2), ('l4 ds 1x1 s2', 16, 256, 512, 1, 2),
-          ('r50 l1 64>256', 56, 64, 256, 1, 1), ('r50 l1 256>64', 56, 256, 64, 1, 1), ('r50 l2 256>128', 56, 256, 128, 1, 1), ('r50 l2 128>512', 28, 128, 512, 1, 1),
-          ('r50 l2 512>128', 28, 512, 128, 1, 1), ('r50 l3 256>1024', 14, 256, 1024, 1, 1), ('r50 l3 1024>256', 14, 1024, 256, 1, 1),
-          ('r50 l4 512>2048', 7, 512, 2048, 1, 1), ('r50 l4 2048>512', 7, 2048, 512, 1, 1), ('r50 l3 3x3 s2', 28, 256, 256, 3, 2)]
+          ('r50 l1 64>256', 64, 64, 256, 1, 1), ('r50 l1 256>64', 64, 256, 64, 1, 1), ('r50 l2 256>128', 64, 256, 128, 1, 1), ('r50 l2 128>512', 32, 128, 512, 1, 1),
+          ('r50 l2 512>128', 32, 512, 128, 1, 1), ('r50 l2 ds 256>512 s2', 64, 256, 512, 1, 2), ('r50 l3 512>256', 32, 512, 256, 1, 1), ('r50 l3 256>1024', 16, 256, 1024, 1, 1),
+          ('r50 l3 1024>256', 16, 1024, 256, 1, 1), ('r50 l3 ds 512>1024 s2', 32, 512, 1024, 1, 2), ('r50 l4 1024>512', 16, 1024, 512, 1, 1),
+          ('r50 l4 512>2048', 8, 512, 2048, 1, 1), ('r50 l4 2048>512', 8, 2048, 512, 1, 1), ('r50 l4 ds 1024>2048 s2', 16, 1024, 2048, 1, 2),
+          ('r50 l2 3x3 s2', 64, 128, 128, 3, 2), ('r50 l3 3x3 s2', 32, 256, 256, 3, 2), ('r50 l4 3x3 s2', 16, 512, 512, 3, 2)]
 
 
 def timeit(fn, iters=20):
