@@ -550,7 +550,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradXP p) {
 // sets are added through LDS at the end (fixed order) -- two waves per SIMD cover each other's LDS latency and barrier waits.
 // CP = pixels per chunk (32 or 64; the plan's cw x rpc): 64 halves the barriers per MFMA and the halo overhead of the patch
 // ((rpc + 2) x (cw + 2) slots per chunk: 3.2 -> 2.1 per pixel at cw = 32); a group then runs two k steps per chunk.
-template <int NG, int CP>
+// ABL: compile-time measurement switches (tools, STRAPS_WGRAD3_ABL; 0 in production): 1 = no operand copies after the first chunk,
+// 2 = no MFMAs (the fragments are folded into one accumulator on the VALU), 4 = a tenth of the fragment reads (every tap uses tap 0's)
+template <int NG, int CP, int ABL = 0>
 __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) {
     constexpr int DPX = CP, XPX = CP == 32 ? 128 : 136;          // pixel rows per stage and plane: dy tile, input patch slots
     constexpr int STAGE = 3 * (DPX + XPX) * 64;                   // u16 elements per stage
@@ -657,8 +659,8 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my copies of chunk c have landed ...
         __builtin_amdgcn_s_barrier();                         // ... everybody's have, and the other stage is no longer being read
         asm volatile("" ::: "memory");
-        if (c + 1 < cend) dma_chunk(c + 1, stage ^ 1);
-        const u16* D = smem + stage * STAGE;
+        if (c + 1 < cend && !(ABL & 1)) dma_chunk(c + 1, stage ^ 1);
+        const u16* D = smem + ((ABL & 1) ? 0 : stage) * STAGE;
         const u16* X = D + 3 * DPX * 64;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -675,10 +677,18 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad3x3_x3_kernel(Wgrad3XP p) 
                 for (int u = 0; u < W3X_TG; ++u) {
                     const int tp = tp0 + u;
                     if (tp >= 9) break;
-                    const int sh = (tp / 3) * pw + (tp % 3);
+                    const int sh = (ABL & 4) ? 0 : (tp / 3) * pw + (tp % 3);      // (ablation 4: every tap reads tap 0's fragments -- the compiler merges the reads)
                     const int o0 = row_off(x_fo[ks][0] + sh, x_c4), o1 = row_off(x_fo[ks][1] + sh, x_c4);
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) b[u][pl] = tr_frag(X + pl * XPX * 64 + o0, X + pl * XPX * 64 + o1);
+                }
+                if (ABL & 2) {
+#pragma unroll
+                    for (int u = 0; u < W3X_TG; ++u)
+                        if (tp0 + u < 9)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) acc[0][pl] += (float)b[u][pl][0] + (float)a[pl][1];
+                    continue;
                 }
 #pragma unroll
                 for (int e = 0; e < 6; ++e)
@@ -1740,8 +1750,18 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
             q.chunks_per_split = p64.chunks_per_split;
             splits3 = splits64;
             const size_t lds = (size_t)2 * 3 * (64 + 136) * 64 * sizeof(u16);
+            static const int abl = getenv("STRAPS_WGRAD3_ABL") ? atoi(getenv("STRAPS_WGRAD3_ABL")) : 0;      // (tools: tools/wgrad3_ablate.py)
+            const dim3 grid3((cout / 64) * (cin / 64), splits3);
+            if (abl) {
+                auto kern = abl == 1 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 1> : abl == 2 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 2>
+                          : abl == 3 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 3> : abl == 4 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 4> : conv_wgrad3x3_x3_kernel<W3X_NG, 64, 5>;
+                hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, grid3, dim3(256 * W3X_NG), lds, st3, q);
+                STRAPS_CHECK_LAUNCH("conv_wgrad3x3_x3_kernel (ablation)");
+                return STRAPS_OK;
+            }
             STRAPS_RAISE_LDS((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), lds, "conv_wgrad3x3_x3_kernel");
-            hipLaunchKernelGGL((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), dim3((cout / 64) * (cin / 64), splits3), dim3(256 * W3X_NG), lds, st3, q);
+            hipLaunchKernelGGL((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), grid3, dim3(256 * W3X_NG), lds, st3, q);
         } else {
             const size_t lds = (size_t)2 * 3 * (32 + 128) * 64 * sizeof(u16);
             STRAPS_RAISE_LDS((conv_wgrad3x3_x3_kernel<W3X_NG, 32>), lds, "conv_wgrad3x3_x3_kernel");
