@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STRAPS_ABI_VERSION 5
+#define STRAPS_ABI_VERSION 6
 
 #define STRAPS_OK 0
 #define STRAPS_EINVAL 1       /* bad argument (shape, alignment, null pointer) */
@@ -162,13 +162,9 @@ int straps_bn_apply(const float* x, const float* scale, const float* shift, cons
 int straps_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias,
                       const float* addend, float* out, int ldo, int m, int n, int kdim, int relu,
                       void* stream);
-/* copy a [rows][cols] slice of a row-major matrix into a zero-padded [rows_pad][ld_dst] one
- * (splits fc1.weight [H][F+157] into its feature and estimate parts, pads 157 -> 160).          */
-int straps_pad_copy(const float* src, int ld_src, int col0, int rows, int cols, float* dst,
-                    int ld_dst, int rows_pad, void* stream);
 /* broadcast the initial estimate (models/ief_module.py:50-52): est[m][0..157) = init, pad = 0  */
 int straps_broadcast_rows(const float* row, int cols, float* dst, int ld_dst, int m, void* stream);
-/* the three repacked weight views the IEF kernels read, one launch (replaces three straps_pad_copy calls per parameter update):
+/* the three repacked weight views the IEF kernels read, one launch per parameter update:
  * fc1.weight [h1][f + p] -> w1f [h1][f] (feature columns) and w1e [h1][ld_e] (estimate columns, zero padded to ld_e >= p);
  * fc3.weight [p][h2] -> w3 [p rounded up to 32][h2] (zero rows).  models/ief_module.py:16-18,54.                             */
 int straps_ief_pack(const float* fc1_w, const float* fc3_w, float* w1f, float* w1e, float* w3, int f, int p,
@@ -478,14 +474,6 @@ int straps_maxpool_fwd_idx(const float* x_nhwc, float* y_nhwc, uint8_t* idx, int
 int straps_maxpool_bwd(const float* dy_nhwc, const uint8_t* idx, float* dx_nhwc, int batch, int h,
                        int w, int c, void* stream);
 int straps_gap_bwd(const float* dfeat, float* dx_nhwc, int batch, int hw, int c, void* stream);
-/* small strided GEMM on the fp32 MFMA: c[m][n] (+)= mask?(sum_k a[m*sam + k*sak] * b[k*sbk + n*sbn])
- * (linear-layer data / weight gradients of the IEF, models/ief_module.py:16-18).                 */
-int straps_gemm_strided(const float* a, long long sam, long long sak, const float* b,
-                        long long sbk, long long sbn, float* c, int ldc, const float* mask,
-                        int ldmask, int m, int n, int k, int accumulate, void* stream);
-/* out[n] (+)= sum_m x[m][n] * (mask[m][n] > 0)   (bias gradients)                                 */
-int straps_colsum(const float* x, int ldx, const float* mask, int ldmask, float* out, int m, int n,
-                  int accumulate, void* stream);
 /* y[m][n] (+)= x[m][n] * (mask[m][n] > 0)        (ReLU backward on small matrices)                */
 int straps_masked_copy(const float* x, int ldx, const float* mask, int ldmask, float* y, int ldy,
                        int m, int n, int accumulate, void* stream);

@@ -7,7 +7,6 @@
 //   stem_wgrad_kernel      same for the 7x7/s2 stem straight from the NCHW input (LDS halo patch, like stem.hip)
 //   bn_bwd_*               training-mode BatchNorm backward with the ReLU mask fused (two passes: reduce, apply)
 //   maxpool / gap backward
-//   gemm_strided_kernel    small generic C[M,N] (+)= A.B with arbitrary strides (IEF linear dgrad / wgrad)
 //   rot6d_bwd_kernel       Gram-Schmidt backward
 #include "common.h"
 #include <stdlib.h>
@@ -1442,76 +1441,6 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// =====================================================================================================
-// small strided GEMM on the fp32 MFMA:  C[m][n] = (mask? ...)(sum_k A(m,k) * B(k,n)) (+ C)
-// =====================================================================================================
-// A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn].  One 32x32 tile per wave, 4 tiles (along n) per block.
-constexpr int GW = 8;      // waves per workgroup (K groups dealt round-robin)
-__global__ __launch_bounds__(64 * GW) void gemm_strided_kernel(const float* __restrict__ a, long long sam, long long sak,
-                                                           const float* __restrict__ b, long long sbk, long long sbn, float* c,
-                                                           int ldc, const float* __restrict__ mask, int ldmask, int M, int N, int K,
-                                                           int accumulate) {
-    // one 32x32 output tile per workgroup; the K groups of 8 are dealt round-robin to the 8 waves (these GEMMs are
-    // tiny and latency-bound: 8x shorter dependent load chains, two groups of loads in flight per wave), partial
-    // tiles combined through LDS in a fixed order.
-    __shared__ float red[GW][32][33];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const int mr = min(m0 + i, M - 1), nr = min(n0 + i, N - 1);
-    const float* ap = a + (long long)mr * sam;
-    const float* bp = b + (long long)nr * sbn;
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    const int G = (K + 7) >> 3;
-    for (int g = wave; g < G; g += 2 * GW) {
-        float av[8], bv[8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = (g + GW * u) * 8 + 4 * h + e;
-                const bool ok = k < K;
-                av[u * 4 + e] = ok ? ap[(long long)k * sak] : 0.f;
-                bv[u * 4 + e] = ok ? bp[(long long)k * sbk] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = mfma32(av[e], bv[e], acc);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) red[wave][mfma_row(q, lane)][i] = acc[q];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 1024 / (64 * GW); ++q) {
-        const int idx = threadIdx.x + 64 * GW * q;
-        const int row = idx >> 5, col = idx & 31;
-        const int m = m0 + row, n = n0 + col;
-        if (m < M && n < N) {
-            float v = ((red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col])) +
-                      ((red[4][row][col] + red[5][row][col]) + (red[6][row][col] + red[7][row][col]));
-            if (mask) v = mask[(long long)m * ldmask + n] > 0.f ? v : 0.f;
-            float* o = c + (long long)m * ldc + n;
-            *o = accumulate ? *o + v : v;
-        }
-    }
-}
-
-// column sums: out[n] (+)= sum_m x[m][n] * (mask[m][n] > 0)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mask, int ldmask,
-                                                     float* __restrict__ out, int M, int N, int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) {
-        float v = x[(long long)m * ldx + n];
-        if (mask) v = mask[(long long)m * ldmask + n] > 0.f ? v : 0.f;
-        s += v;
-    }
-    out[n] = accumulate ? out[n] + s : s;
-}
-
 // elementwise: y = x * (mask > 0) (+ y)
 __global__ __launch_bounds__(256) void masked_copy_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mask, int ldm,
                                                           float* y, int ldy, int M, int N, int accumulate) {
@@ -2030,22 +1959,6 @@ extern "C" int straps_gap_bwd(const float* dfeat, float* dx, int batch, int hw, 
     const long long n = (long long)batch * hw * c;
     hipLaunchKernelGGL(gap_bwd_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, dfeat, dx, batch, hw, c);
     STRAPS_CHECK_LAUNCH("gap_bwd_kernel");
-    return STRAPS_OK;
-}
-
-extern "C" int straps_gemm_strided(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn, float* c,
-                                   int ldc, const float* mask, int ldmask, int m, int n, int k, int accumulate, void* stream) {
-    STRAPS_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0, "straps_gemm_strided: bad arguments");
-    dim3 grid((n + 31) / 32, (m + 31) / 32);
-    hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(64 * GW), 0, (hipStream_t)stream, a, sam, sak, b, sbk, sbn, c, ldc, mask, ldmask, m, n, k, accumulate);
-    STRAPS_CHECK_LAUNCH("gemm_strided_kernel");
-    return STRAPS_OK;
-}
-
-extern "C" int straps_colsum(const float* x, int ldx, const float* mask, int ldmask, float* out, int m, int n, int accumulate, void* stream) {
-    STRAPS_REQUIRE(x && out && m > 0 && n > 0, "straps_colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, mask, ldmask, out, m, n, accumulate);
-    STRAPS_CHECK_LAUNCH("colsum_kernel");
     return STRAPS_OK;
 }
 

@@ -53,14 +53,6 @@ __global__ __launch_bounds__(64 * LW) void linear_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, int ld_src, int col0, int rows, int cols,
-                                                       float* __restrict__ dst, int ld_dst, int rows_pad) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)rows_pad * ld_dst) return;
-    const int r = (int)(i / ld_dst), c = (int)(i - (long long)r * ld_dst);
-    dst[i] = (r < rows && c < cols) ? src[(long long)r * ld_src + col0 + c] : 0.f;
-}
-
 __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ row, int cols, float* __restrict__ dst,
                                                              int ld_dst, int m) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -72,7 +64,7 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __rest
 // ---- several small strided GEMMs in ONE launch (blockIdx.z = problem): the IEF backward's weight / bias gradients of all three
 // iterations (K = the three iterations' rows stacked: one reduction instead of three accumulating launches), the feature gradient, and --
 // with one problem -- each link of its dependent chain with the elementwise work around it fused into the epilogue (ReLU mask, the
-// addend of est_out = est_in + ..., the running sum dc1 += dh1).  Same tile as gemm_strided_kernel: one 32x32 output tile per
+// addend of est_out = est_in + ..., the running sum dc1 += dh1).  One 32x32 output tile per
 // workgroup, the K groups of 8 dealt round-robin to 8 waves, partial tiles combined through LDS in a fixed order.
 struct GemmBatch {
     straps_gemm_desc_t d[STRAPS_GEMM_MULTI_MAX];
@@ -194,16 +186,6 @@ extern "C" int straps_linear_fwd(const float* x, int ldx, const float* w, int ld
     dim3 grid((n + 31) / 32, (m + 31) / 32);
     hipLaunchKernelGGL(linear_kernel, grid, dim3(64 * LW), 0, (hipStream_t)stream, x, ldx, w, ldw, bias, addend, out, ldo, m, n, kdim, relu);
     STRAPS_CHECK_LAUNCH("linear_kernel");
-    return STRAPS_OK;
-}
-
-extern "C" int straps_pad_copy(const float* src, int ld_src, int col0, int rows, int cols, float* dst, int ld_dst, int rows_pad,
-                               void* stream) {
-    STRAPS_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_dst >= cols && rows_pad >= rows, "straps_pad_copy: bad arguments");
-    const long long n = (long long)rows_pad * ld_dst;
-    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, col0, rows, cols,
-                       dst, ld_dst, rows_pad);
-    STRAPS_CHECK_LAUNCH("pad_copy_kernel");
     return STRAPS_OK;
 }
 

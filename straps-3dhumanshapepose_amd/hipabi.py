@@ -138,7 +138,6 @@ SIGNATURES = {
     'straps_bn_stats_finalize': (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     'straps_bn_apply': (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _P]),
     'straps_linear_fwd': (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    'straps_pad_copy': (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     'straps_broadcast_rows': (_I, [_P, _I, _P, _I, _I, _P]),
     'straps_ief_pack': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'straps_gemm_multi': (_I, [C.POINTER(GemmDesc), _I, _P]),
@@ -167,8 +166,6 @@ SIGNATURES = {
     'straps_maxpool_fwd_idx': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_gap_bwd': (_I, [_P, _P, _I, _I, _I, _P]),
-    'straps_gemm_strided': (_I, [_P, _L, _L, _P, _L, _L, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    'straps_colsum': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     'straps_masked_copy': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     'straps_rot6d_bwd': (_I, [_P, _L, _I, _P, _P, _L, _L, _P]),
     'straps_build_proxy_input': (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -45,7 +45,7 @@ def test_version_and_error_channel(lib):
     ms = hipabi.SmplModelStruct()
     ms.n_tiles = 224
     assert lib.straps_smpl_workspace_bytes(C.byref(ms), 64) == 64 * (224 + 288 + 8 * 96) * 4
-    assert lib.straps_abi_version() == 5
+    assert lib.straps_abi_version() == 6
 
 
 def test_tile_choice_of_the_implicit_gemm(lib):

@@ -555,3 +555,49 @@ def test_eval_after_train_mode_forward_sees_fresh_running_statistics():
         y3 = torch.cat(fresh(x), 1)
     assert not torch.equal(y1, y2)
     assert torch.equal(y2, y3)
+
+
+def test_calibration_and_utility_entry_points(dev):
+    """straps_device_count, straps_wall_clock_khz, the two matrix-pipe calibration kernels (bench.py's roofline.sustained_mfma /
+    tools/mfma_peak.py) and the clock accumulator: they run, write every output and report plausible rates (the bf16 stream between
+    a fifth of the 2.5 PFLOP/s spec and the spec; the accumulated shader clock between 0.5 and 3 GHz)."""
+    L = hipabi.lib()
+    assert L.straps_device_count() >= 1
+    khz = L.straps_wall_clock_khz()
+    assert 1e4 < khz < 1e6                                   # (100 MHz on gfx950)
+    blocks, iters = 512, 400
+    out = torch.full((blocks * 256,), float('nan'), device=dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def timed(fn):
+        fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e-3
+    t = timed(lambda: hipabi.check(L.straps_selftest_mfma_bf16(hipabi.ptr(out), hipabi.ptr(clk), blocks, iters, hipabi.stream_ptr()), 'selftest bf16'))
+    assert torch.isfinite(out).all()
+    rate = blocks * 4 * iters * 48 * 32768.0 / t
+    assert 0.5e15 < rate < 2.6e15, rate
+    c, w = (int(v) for v in clk.tolist())
+    assert w > 0 and 500 < c / w * khz / 1e3 < 3000
+    seed = torch.rand(512, device=dev)
+    out.fill_(float('nan'))
+    t = timed(lambda: hipabi.check(L.straps_selftest_mfma_peak(hipabi.ptr(seed), hipabi.ptr(out), blocks, iters, hipabi.stream_ptr()), 'selftest fp32'))
+    assert torch.isfinite(out).all()
+    rate32 = blocks * 4 * iters * 4 * 2.0 * 32 * 32 * 2 / t
+    assert 0.2e14 < rate32 < 1.6e14, rate32
+    # clock accumulator: a convolution launched while it is set adds its ticks; unset afterwards
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    assert L.straps_set_clock_accumulator(hipabi.ptr(acc)) == 0
+    try:
+        reg = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MP).to(dev).eval()
+        with torch.no_grad():
+            reg(torch.rand(2, 18, 256, 256, device=dev))
+        torch.cuda.synchronize()
+    finally:
+        L.straps_set_clock_accumulator(None)
+    c, w = (int(v) for v in acc.tolist())
+    assert c > 0 and w > 0 and 500 < c / w * khz / 1e3 < 3000
