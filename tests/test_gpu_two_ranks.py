@@ -72,3 +72,32 @@ def test_two_ranks_with_the_global_masked_mean_option():
     got = _run(overlap=True, use_graph=True, gm=True)
     assert all(r[3] for r in got) and all(r[6] and r[7] for r in got)
     assert got[0][4] == ref[0][4] and [r[5] for r in got] == [r[5] for r in ref]
+
+
+def test_bench_launched_the_way_the_driver_launches_it_two_ranks():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` -- the
+    driver's multi-GPU command line -- with the two validation hooks that let it run on a one-GPU box (STRAPS_FORCE_DEVICE=0: both ranks
+    on device 0; STRAPS_DIST_BACKEND=gloo: RCCL cannot span two ranks of one device).  Exactly one JSON line, from rank 0, with the
+    contract's fields: whole-job bodies/s over both ranks, weak scaling, both ranks seen, per-rank step times and the exposed exchange time."""
+    import json
+    import subprocess
+    env = dict(os.environ, STRAPS_FORCE_DEVICE='0', STRAPS_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2']
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['metric'] == 'bodies/sec' and d['unit'] == 'bodies/s' and d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 2
+    assert d['scaling'] == 'weak' and d['higher_is_better'] is True and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert d['config']['global_batch'] == 2 * d['config']['bodies_per_gpu_per_step'] == 128
+    assert d['ranks_seen'] == 2
+    assert d['value'] == pytest.approx(128 / (d['ms_per_step'] * 1e-3), rel=1e-3)          # whole-job aggregate over the max-over-ranks time
+    assert d['cpu_baseline'] is None                                                      # (rank 0 at N = 1 only)
+    r = d['ranks']
+    assert len(r['per_rank_ms_per_step']) == 2 and r['ms_per_step_min'] <= r['ms_per_step_max'] <= d['ms_per_step'] * 1.02
+    assert len(r['per_rank_sclk_mhz']) == 2
+    assert 0 <= r['exposed_exchange_ms_mean'] <= r['exposed_exchange_ms_max'] < d['ms_per_step']
+    assert d['roofline']['kernel'].startswith('conv_igemm') and 0 < d['roofline']['frac'] < 1
