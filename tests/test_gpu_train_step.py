@@ -148,7 +148,7 @@ def _ief_relu_flips(ts, taps64):
     return masks, flips, err
 
 
-def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5, enc_bar=5e-5):
+def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5, enc_bar=5e-5, with_fp32=True):
     """forward + loss + backward of `ts` on a fresh batch against autograd of the float64 oracle on the SAME batch: loss, the five loss
     weights and EVERY parameter tensor, relative L2 error per tensor < 1e-5 (IEF head) / enc_bar (encoder).
 
@@ -168,8 +168,11 @@ def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5, enc_bar=5e
         batch = ts.make_batch()
     taps, rec64 = [], {'record': True}
     total, parts, grads, glv = _oracle_step(ts, reg, batch, layers, torch.float64, ief_taps=taps, enc_decisions=rec64)   # before the step touches the running statistics
-    _, _, g32, _ = _oracle_step(ts, reg, batch, layers, torch.float32)
-    e32 = max(float((g32[n].double().reshape(-1) - grads[n].reshape(-1)).norm() / grads[n].norm().clamp_min(1e-30)) for n in grads)
+    e32 = float('nan')
+    if with_fp32:          # (informative only: the reference's own arithmetic against the same plain float64 run)
+        _, _, g32, _ = _oracle_step(ts, reg, batch, layers, torch.float32)
+        e32 = max(float((g32[n].double().reshape(-1) - grads[n].reshape(-1)).norm() / grads[n].norm().clamp_min(1e-30)) for n in grads)
+        del g32
     ts.keep_enc_tape = True
     with torch.no_grad():
         loss = ts.forward_backward(batch)
@@ -185,7 +188,7 @@ def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5, enc_bar=5e
         for it, li, r, u, z in flips:
             assert abs(z) <= tol, 'IEF unit (iteration %d, fc%d, row %d, unit %d) flipped its ReLU with |z64| = %.3e > %.3e: not a tie' % (it, li + 1, r, u, abs(z), tol)
     assert tie_relu <= 4.0 and tie_pool <= 4.0, 'a differing encoder decision is not a tie: |z64| %.2f x / gap %.2f x the activation error' % (tie_relu, tie_pool)
-    assert n_relu <= 3 + 5e-6 * n_units and n_pool <= 3
+    assert n_relu <= 3 + 5e-6 * n_units and n_pool <= 3 + 2e-6 * ts.B * 64 * 64 * 64
     plain_worst = None
     if flips or n_relu or n_pool:
         plain_worst = max(float((ts.gviews[p].detach().cpu().double().reshape(-1) - grads[n].reshape(-1)).norm() / grads[n].norm().clamp_min(1e-30))
@@ -231,6 +234,18 @@ def test_whole_step_loss_and_all_71_gradients_vs_oracle_autograd(conv_precision)
     dev, reg, smpl, crit = _setup(B, seed=5, conv_precision=conv_precision)
     ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'])
     table = _whole_step_vs_float64(ts, reg, crit, 18, conv_precision + ' r18 B=8')
+    assert len(table) == 66
+
+
+def test_whole_step_at_the_bench_size_b64_vs_float64_oracle():
+    """configs[2] itself -- resnet18, 64 bodies, the default bf16x3 route -- not a scaled-down stand-in: loss + all 71 gradients of one
+    step against the float64 oracle on the GPU's decisions (two float64 passes over a 64-body batch: about a minute of CPU time on the
+    GPU box's host).  Measured: 30 of 192 937 984 ReLU decisions and 3 of 16 777 216 pooling windows tied; IEF worst 1.6e-7, encoder worst
+    3.4e-5 (bar 1e-4); 3.5e-3 against the plain float64 run."""
+    B = 64
+    dev, reg, smpl, crit = _setup(B, seed=11, conv_precision='bf16x3')
+    ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], seed=5)
+    table = _whole_step_vs_float64(ts, reg, crit, 18, 'bf16x3 r18 B=64 (configs[2])', loss_rel=2e-5, enc_bar=1e-4, with_fp32=False)
     assert len(table) == 66
 
 
