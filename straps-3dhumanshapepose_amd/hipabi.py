@@ -96,6 +96,7 @@ def gemm_multi(descs):
 _P, _I, _L, _F, _Z, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
+ABI_VERSION = 6      # == STRAPS_ABI_VERSION of include/straps_hip.h (tests/test_abi.py compares the two); load() refuses a library of another version
 SIGNATURES = {
     'straps_abi_version': (_I, []),
     'straps_last_error': (C.c_char_p, []),
@@ -204,6 +205,12 @@ def load(path=None):
         raise RuntimeError('libstraps_hip.so is not built (%s missing): run `python -c "import __graft_entry__ as g; '
                            'g.build()"` -- this package has no CPU fallback' % p)
     lib = C.CDLL(p)
+    if hasattr(lib, 'straps_abi_version'):
+        lib.straps_abi_version.restype = C.c_int
+        got = lib.straps_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError('%s is ABI version %d, this package binds version %d: rebuild it (`python -c "import __graft_entry__ as g; g.build()"`)'
+                               % (p, got, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         if not hasattr(lib, name):
             continue                      # symbols of later sources may be absent in partial builds

@@ -45,7 +45,9 @@ def test_version_and_error_channel(lib):
     ms = hipabi.SmplModelStruct()
     ms.n_tiles = 224
     assert lib.straps_smpl_workspace_bytes(C.byref(ms), 64) == 64 * (224 + 288 + 8 * 96) * 4
-    assert lib.straps_abi_version() == 6
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'straps_hip.h')).read()
+    declared = int(re.search(r'#define STRAPS_ABI_VERSION (\d+)', header).group(1))
+    assert lib.straps_abi_version() == declared == hipabi.ABI_VERSION
 
 
 def test_tile_choice_of_the_implicit_gemm(lib):
