@@ -870,7 +870,7 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                    : ablate == 7 ? smpl_verts_hh_kernel<8, 1, 7> : ablate == 15 ? smpl_verts_hh_kernel<8, 1, 15>
                    : pd16 == 1 ? (pf == 1 ? smpl_verts_hh_kernel<8, 1, 0, 1> : smpl_verts_hh_kernel<8, 2, 0, 1>)
                    : pd16 == 2 ? (pf == 1 ? smpl_verts_hh_kernel<8, 1, 0, 2> : smpl_verts_hh_kernel<8, 2, 0, 2>)
-                   : pf == 1 ? smpl_verts_hh_kernel<8, 1, 0> : pf == 3 ? smpl_verts_hh_kernel<8, 3, 0> : pf == 4 ? smpl_verts_hh_kernel<8, 4, 0> : smpl_verts_hh_kernel<8, 2, 0>;
+                   : pf == 1 ? smpl_verts_hh_kernel<8, 1, 0> : smpl_verts_hh_kernel<8, 2, 0>;      // (a deeper ring does not fit: PF = 2 uses 255 of the 256 registers two waves per SIMD leave a wave)
     const size_t lds = split == 2 ? (size_t)(BT * FSH + 12 * BT * ASH) * sizeof(float)
                                   : (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
     static unsigned long long lds_raised[5] = {0, 0, 0, 0, 0};          // per kernel variant: bit mask of the devices done
