@@ -254,7 +254,9 @@ def test_conv_fwd_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
 @pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
     (2, 64, 64, 16, 16, 3, 1, 0), (2, 64, 128, 16, 16, 3, 2, 0), (3, 128, 64, 9, 9, 3, 1, 0), (2, 64, 128, 16, 16, 1, 2, 0),
     (1, 256, 512, 8, 8, 3, 2, 0), (2, 256, 64, 8, 8, 1, 1, 0), (2, 128, 128, 15, 15, 3, 2, 1), (4, 128, 128, 20, 12, 3, 1, 4),
-    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3)])
+    (2, 128, 256, 9, 14, 3, 2, 5), (2, 64, 64, 10, 24, 3, 1, 3),
+    # the stride-2 rule of round 3 (tiles per parity class): >= 512 -> 256x128; 256..511 -> 128x128 8-wave (1x1) / 256x128 (3x3); the 8x8 case above -> 128x64
+    (2, 256, 64, 256, 256, 3, 2, 0), (2, 512, 64, 128, 128, 1, 2, 0), (2, 512, 64, 128, 128, 3, 2, 0)])
 def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """data gradient on the bf16x3 route (stride-2 parity classes, odd sizes, the skip-gradient addend) vs float64 autograd."""
     L = hipabi.lib()
