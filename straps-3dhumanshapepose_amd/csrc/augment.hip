@@ -255,10 +255,36 @@ extern "C" int straps_deviate_verts2d(const float* verts, const float* uniforms,
     return STRAPS_OK;
 }
 
+// a fill KERNEL, not hipMemsetAsync: inside a captured hipGraph a memset node is not an ordinary member of the stream's kernel chain
+// (round 3: with the batch generation and the step captured on ONE stream and sharing a memory pool, the runtime's memset nodes clobbered
+// neighbouring pool memory -- tools/graph_bisect.py; as kernels the same graphs replay correctly)
+__global__ __launch_bounds__(256) void fill_bytes_kernel(unsigned char* __restrict__ p, unsigned long long bytes, unsigned int word) {
+    const unsigned long long head = (16 - (reinterpret_cast<unsigned long long>(p) & 15)) & 15;      // bytes in front of the first 16-byte boundary
+    const unsigned long long h = head < bytes ? head : bytes;
+    const unsigned long long n16 = (bytes - h) >> 4;
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    const uint4 v = make_uint4(word, word, word, word);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256) q[i] = v;
+    if (blockIdx.x == 0) {
+        const unsigned char b = (unsigned char)(word & 0xff);
+        for (unsigned long long i = threadIdx.x; i < h; i += 256) p[i] = b;
+        const unsigned long long tail0 = h + (n16 << 4);
+        for (unsigned long long i = tail0 + threadIdx.x; i < bytes; i += 256) p[i] = b;
+    }
+}
+
+int straps_fill_bytes(void* ptr, size_t bytes, unsigned char value, hipStream_t st) {
+    if (bytes == 0) return STRAPS_OK;
+    const unsigned int word = 0x01010101u * value;
+    unsigned long long blocks = ((bytes >> 4) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char*)ptr, (unsigned long long)bytes, word);
+    STRAPS_CHECK_LAUNCH("fill_bytes_kernel");
+    return STRAPS_OK;
+}
+
 extern "C" int straps_memset_zero(void* ptr, size_t bytes, void* stream) {
     STRAPS_REQUIRE(ptr || bytes == 0, "straps_memset_zero: null pointer");
-    if (bytes == 0) return STRAPS_OK;
-    hipError_t e = hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream);
-    if (e != hipSuccess) { straps_set_error("straps_memset_zero: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-    return STRAPS_OK;
+    return straps_fill_bytes(ptr, bytes, 0, (hipStream_t)stream);
 }

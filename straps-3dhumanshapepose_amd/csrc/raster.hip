@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const unsigned long
 
 }  // namespace
 
+int straps_fill_bytes(void* ptr, size_t bytes, unsigned char value, hipStream_t st);      // csrc/augment.hip
+
 extern "C" size_t straps_rasterize_workspace_bytes(long long batch, int nverts, int wh) {
     if (batch <= 0 || nverts <= 0 || wh <= 0) return 0;
     return (size_t)batch * ((size_t)wh * wh * sizeof(unsigned long long) + (size_t)nverts * 3 * sizeof(float));
@@ -154,8 +156,10 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* zbuf = (unsigned long long*)workspace;
     float* ndc = (float*)(zbuf + batch * (long long)wh * wh);
-    hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)batch * wh * wh * sizeof(unsigned long long), st);
-    if (e != hipSuccess) { straps_set_error("straps_rasterize_parts: z-buffer clear failed: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+    {   // z-buffer = all ones (a fill kernel: see straps_memset_zero on memset nodes in captured graphs)
+        const int rc = straps_fill_bytes(zbuf, (size_t)batch * wh * wh * sizeof(unsigned long long), 0xff, st);
+        if (rc != STRAPS_OK) return rc;
+    }
     const long long nv = batch * nverts, nf = batch * nfaces, np = batch * (long long)wh * wh;
     STRAPS_REQUIRE((nv + 255) / 256 < (1LL << 31) && (nf * 16 + 255) / 256 < (1LL << 31) && (np + 255) / 256 < (1LL << 31), "straps_rasterize_parts: batch too large for one launch");
     hipLaunchKernelGGL(raster_project_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam_K, cam_R, cam_t, ndc, nv, nverts,

@@ -226,9 +226,23 @@ def lib():
     return load()
 
 
+_TRACE = os.environ.get('STRAPS_TRACE_CALLS')      # debugging aid: a file that receives the name of every entry point just launched, followed by a
+_trace_fh = None                                    # device synchronisation -- after a GPU memory fault its last line names the kernel (tools/README)
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError('%s failed (code %d): %s' % (what, rc, lib().straps_last_error().decode()))
+    if _TRACE:
+        import torch
+        global _trace_fh
+        if _trace_fh is None:
+            _trace_fh = open(_TRACE, 'a', buffering=1)
+        if not torch.cuda.is_current_stream_capturing():
+            _trace_fh.write(what + '\n')
+            _trace_fh.flush()
+            os.fsync(_trace_fh.fileno())
+            torch.cuda.synchronize()
 
 
 def stream_ptr():

@@ -379,3 +379,41 @@ def test_set_data_state_with_captured_graphs_recaptures():
     la, pa = run(False)
     lb, pb = run(True)
     assert torch.equal(la, lb) and torch.equal(pa, pb)
+
+
+def _nine_losses(use_graph, pipeline, alias_capture_stream=False, B=4):
+    dev, reg, smpl, crit = _setup(B, seed=6)
+    keep = []
+    if alias_capture_stream:
+        # torch.cuda.Stream() hands out 32 pooled streams round-robin and torch.cuda.graph captures on ONE class-level stream from the same
+        # pool: arrange that the TrainStep's data stream IS that capture stream (in a long process -- the full GPU suite -- this happens by itself)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            torch.zeros(4, device=dev) + 1
+        cap = torch.cuda.graph.default_capture_stream.cuda_stream
+        for _ in range(64):
+            keep.append(torch.cuda.Stream(device=dev))
+            if keep[-1].cuda_stream == cap:
+                break
+        assert keep[-1].cuda_stream == cap
+        keep += [torch.cuda.Stream(device=dev) for _ in range(31)]
+    ts = TrainStep(reg, smpl, crit, B, lr=1e-4, mean_shape=MP['shape'], use_graph=use_graph, pipeline_data=pipeline)
+    if alias_capture_stream:
+        assert ts.data_stream.cuda_stream == cap
+    out = torch.stack([ts.step().clone() for _ in range(9)]).cpu()
+    torch.cuda.synchronize()
+    assert ts.graph is not None or not use_graph
+    return out, ts.flat_p.clone().cpu()
+
+
+def test_graph_replay_on_one_stream_and_with_an_aliased_data_stream_equals_eager_over_nine_steps():
+    """Round 3 regression.  With the batch generation and the step captured on ONE stream (no data pipeline -- or a data stream that happens to
+    be torch's graph-capture stream, which the 32-entry stream pool makes inevitable in a long process) the two share pool memory, and the
+    runtime's memset nodes (hipMemsetAsync of the z-buffer and of the flat gradient buffer) clobbered it: wrong losses from the fourth replay on,
+    or a memory fault.  The clears are fill kernels now (csrc/augment.hip straps_fill_bytes).  Nine steps: eager == every graph form, bit for bit."""
+    ref, p_ref = _nine_losses(False, False)
+    for kw in (dict(use_graph=True, pipeline=False), dict(use_graph=True, pipeline=True), dict(use_graph=True, pipeline=True, alias_capture_stream=True),
+               dict(use_graph=False, pipeline=True)):
+        got, p = _nine_losses(**kw)
+        assert torch.equal(got, ref), kw
+        assert torch.equal(p, p_ref), kw
