@@ -49,6 +49,7 @@ def compare_encoder_decisions(gpu, rec64):
     -> (number of differing ReLU decisions, number of differing pooling decisions, worst |z64| of a differing ReLU relative to the
     activation error observed on its layer, worst float64 gap of a differing window relative to the stem's activation error).
     A ratio <= ~4 is a tie: the other side of the decision lies within the evaluation error."""
+    assert len(gpu['relu']) == len(gpu['act']) == len(rec64['z']), 'the two evaluations list different numbers of ReLUs'
     n_relu, worst_relu = 0, 0.0
     errs = []
     for m, a, z in zip(gpu['relu'], gpu['act'], rec64['z']):
