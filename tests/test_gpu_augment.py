@@ -191,3 +191,18 @@ def test_heatmaps_with_other_standard_deviations_vs_oracle(std):
     assert float((got - want).abs().max()) < 1e-6
     with pytest.raises(ValueError):
         straps_amd.label_conversions.convert_2Djoints_to_gaussian_heatmaps_torch(j.to(dev), 256, 2.5)
+
+
+def test_memset_zero_is_exact_for_any_alignment_and_size():
+    """straps_memset_zero (a fill kernel since round 3: memset nodes misbehave inside captured hipGraphs) clears exactly the requested bytes:
+    unaligned starts, sizes below / at / above the 16-byte vector width, zero bytes, and a size with a partial last block."""
+    import ctypes as C
+    import torch
+    from straps_amd import hipabi
+    L = hipabi.lib()
+    dev = torch.device('cuda:0')
+    for off, n in ((0, 0), (0, 1), (3, 15), (5, 16), (1, 17), (3, 777), (16, 4096), (7, 1 << 20), (0, (1 << 22) + 12)):
+        buf = torch.full((off + n + 40,), 7, dtype=torch.uint8, device=dev)
+        hipabi.check(L.straps_memset_zero(C.c_void_p(buf.data_ptr() + off), n, hipabi.stream_ptr()), 'straps_memset_zero')
+        torch.cuda.synchronize()
+        assert bool((buf[:off] == 7).all()) and bool((buf[off:off + n] == 0).all()) and bool((buf[off + n:] == 7).all()), (off, n)
