@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STRAPS_ABI_VERSION 6
+#define STRAPS_ABI_VERSION 7
 
 #define STRAPS_OK 0
 #define STRAPS_EINVAL 1       /* bad argument (shape, alignment, null pointer) */
@@ -44,7 +44,8 @@ int straps_device_count(void);
 /* measurement aid (bench.py `sclk_mhz`; no reference counterpart): with acc2 != NULL (a zeroed device pair of 64-bit counters),
  * workgroup 0 of every implicit-GEMM convolution (and matrix-pipe SMPL vertex kernel) launched AFTERWARDS (incl. launches captured into a hipGraph afterwards) adds the
  * shader-clock ticks and the constant-rate wall ticks of its lifetime to acc2[0] / acc2[1]; sustained shader clock in MHz =
- * acc2[0] / acc2[1] * straps_wall_clock_khz() / 1000.  NULL switches it off (the default: library use pays nothing).              */
+ * acc2[0] / acc2[1] * straps_wall_clock_khz() / 1000.  NULL switches it off (the default: library use pays nothing).  The setting is
+ * PER DEVICE (the current one); clear it before freeing the buffer, and do not replay hipGraphs captured with it afterwards.           */
 int straps_wall_clock_khz(void);
 int straps_set_clock_accumulator(unsigned long long* acc2);
 
@@ -625,6 +626,27 @@ int straps_point_metrics(const float* pred, const float* target, float* out3, lo
 int straps_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                      long long n, int step, float lr, float beta1, float beta2, float eps,
                      float grad_scale, const long long* step_dev, void* stream);
+
+/* ---- gradient exchange of data-parallel training -----------------------------------------------
+ * The reference trains on one GPU (run_train.py:23-26) and so has no counterpart; north_star asks for "a single RCCL all-reduce of
+ * grads over xGMI per step".  These entry points give a host WITHOUT torch that exchange: the flat fp32 gradient buffer every
+ * backward kernel of this library writes into (one buffer, straps_adam_step's `grads`) is summed over the ranks in place.
+ * RCCL is resolved at run time: the copy already loaded in the process (a torch host's) is preferred so that communicator handles
+ * created by the host are valid here; otherwise librccl.so.1 is loaded.  STRAPS_EUNSUPPORTED when no RCCL can be found.
+ *   straps_comm_unique_id : rank 0 generates the 128-byte rendezvous id (ncclGetUniqueId); the host ships it to the other ranks.
+ *   straps_comm_init_rank : every rank joins (ncclCommInitRank; collective, blocks until all `nranks` have called it).  One
+ *                           communicator per process per GPU; the current HIP device is the one it binds to.
+ *   straps_allreduce_grads: in-place sum all-reduce of n floats, enqueued on `stream` (asynchronous like every kernel launch here;
+ *                           calls on one communicator must be issued in the same order on every rank).  `comm` may equally be
+ *                           an ncclComm_t the host created itself with the same RCCL library.
+ *   straps_comm_size      : number of ranks of the communicator (0 on error);  straps_comm_library: which librccl is in use.  */
+#define STRAPS_COMM_ID_BYTES 128
+int straps_comm_unique_id(void* id128);
+int straps_comm_init_rank(const void* id128, int nranks, int rank, void** comm);
+int straps_comm_destroy(void* comm);
+int straps_comm_size(void* comm);
+const char* straps_comm_library(void);
+int straps_allreduce_grads(float* flat_g, long long n, void* comm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,6 @@
 computed by the HIP kernels behind the C ABI.  Nothing here does arithmetic in torch.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -53,8 +52,8 @@ class _SideStream:
 
 
 # ------------------------------------------------------------------------------------------ encoder
-_FUSE_BN_SUMS = os.environ.get('STRAPS_NO_FUSED_BN_SUMS', '0') != '1'     # (A/B switch for tools)
-_SPARSE_STEM_TAIL = os.environ.get('STRAPS_DENSE_STEM_TAIL', '0') != '1'  # (A/B switch for tools)
+_FUSE_BN_SUMS = True         # (A/B switch: tools set autograd_ops._FUSE_BN_SUMS = False; the product never reads the environment)
+_SPARSE_STEM_TAIL = True     # (A/B switch: tools set autograd_ops._SPARSE_STEM_TAIL = False)
 
 
 def _packed_dgrad_weight(net, conv):

@@ -26,15 +26,20 @@ def sync_batchnorm_buffers(model, src=0, group=None):
     return True
 
 
-def save_checkpoint(path, epoch, regressor, optimiser, criterion, best_epoch=None, best_epoch_val_metrics=None, best_model_wts=None, group=None):
+def save_checkpoint(path, epoch, regressor, optimiser, criterion, best_epoch=None, best_epoch_val_metrics=None, best_model_wts=None, group=None,
+                    sync_bn=False):
     """`optimiser`: a torch optimiser or a train_step.TrainStep (both expose state_dict() in torch.optim.Adam's schema).
-    Under data parallel (an initialised process group with more than one rank) call it on EVERY rank: rank 0's BatchNorm running statistics
-    are broadcast first -- the checkpoint and every replica then hold the same buffers (parameters and optimiser state are replicated
-    anyway) -- and only the rank that is given a path (rank 0) writes; pass path = None on the others."""
-    if sync_batchnorm_buffers(regressor, 0, group):
+    NOT a collective by default: the usual data-parallel idiom `if rank == 0: save_checkpoint(path, ...)` works as it does with the
+    reference's single-process writer (train loop :365-377).  BatchNorm running statistics are per rank under data parallel (DESIGN
+    section 6); to make the file and every replica agree either call `sync_batchnorm_buffers(regressor)` on EVERY rank first, or pass
+    sync_bn=True and call this function on every rank (path = None on the ranks that do not write: they only take part in the broadcast
+    and build nothing)."""
+    if sync_bn and sync_batchnorm_buffers(regressor, 0, group):
         enc = getattr(regressor, 'image_encoder', None)
         if enc is not None and hasattr(enc, '_bn_epoch'):
             enc._bn_epoch += 1                    # (folded-BatchNorm caches of the eval path must not outlive the new statistics)
+    if path is None and sync_bn:
+        return None                               # a non-writing rank of a synchronised save: no device-to-host copies, no deepcopy
     sd = {k: v.detach().cpu().clone() for k, v in regressor.state_dict().items()}
     save_dict = {'epoch': epoch,
                  'best_epoch': epoch if best_epoch is None else best_epoch,

@@ -97,7 +97,16 @@ extern "C" int straps_selftest_mfma_peak(const float* seed512, float* out, int b
 // to the pair; MHz = ticks ratio x wall-clock rate.  The chip clocks to its power budget, so the same binary reads several per cent
 // apart on two boards -- bench.py reports this number so that a difference can be attributed.  (A lane spinning on a side stream, the
 // first form of this probe, stalled whatever stream shared its hardware queue.)
-unsigned long long* g_straps_clk_acc = nullptr;
+// One accumulator PER DEVICE (the pointer is device memory of the device that was current when it was set; ADVICE round 3: a process-global
+// pointer would have been handed to launches on other GPUs).  The owner clears it -- straps_set_clock_accumulator(NULL) -- before freeing the
+// buffer; launches captured into a hipGraph keep the pointer they were captured with, so a graph must not outlive the buffer either.
+static unsigned long long* g_straps_clk_acc[64] = {nullptr};
+
+unsigned long long* straps_clk_acc_current() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    return g_straps_clk_acc[dev & 63];
+}
 
 extern "C" int straps_wall_clock_khz(void) {
     int dev = 0, khz = 0;
@@ -107,7 +116,9 @@ extern "C" int straps_wall_clock_khz(void) {
 }
 
 extern "C" int straps_set_clock_accumulator(unsigned long long* acc2) {
-    g_straps_clk_acc = acc2;          // (kernel arguments are fixed at launch / graph-capture time: set it before capturing)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { straps_set_error("straps_set_clock_accumulator: no current device"); return STRAPS_EHIP; }
+    g_straps_clk_acc[dev & 63] = acc2;          // (kernel arguments are fixed at launch / graph-capture time: set it before capturing)
     return STRAPS_OK;
 }
 

@@ -1529,8 +1529,8 @@ inline bool wgrad_big_tile(long long M, int cin, int cout, int taps) {
 // round; 512 cost 10-18 % on resnet50's 1x1 layers -- tools/sweep_wgrad_x3.py, round 3).  The fp32 kernel (64 KB, two resident) keeps 512;
 // the shared workspace size is the fp32 plan's, which is the larger.
 inline int wgrad_splits(long long M, int tiles, bool big = false, bool x3 = false) {
-    static const int t_big = getenv("STRAPS_WGRAD_WGS_BIG") ? atoi(getenv("STRAPS_WGRAD_WGS_BIG")) : 0;          // (A/B switches for tools)
-    static const int t_small = getenv("STRAPS_WGRAD_WGS_SMALL") ? atoi(getenv("STRAPS_WGRAD_WGS_SMALL")) : 1536;
+    static const int t_big = STRAPS_TOOL_ENV_INT("STRAPS_WGRAD_WGS_BIG", 0);          // (A/B switches for tools)
+    static const int t_small = STRAPS_TOOL_ENV_INT("STRAPS_WGRAD_WGS_SMALL", 1536);
     int s = ((big ? (t_big > 0 && x3 ? t_big : x3 ? 256 : 512) : t_small) + tiles - 1) / tiles;
     const long long max_s = (M + 127) / 128;      // at least 4 K-steps of 32 pixels per split
     if (s > max_s) s = (int)max_s;
@@ -1628,7 +1628,7 @@ extern "C" int straps_conv_wgrad(const float* x, const float* dy, float* dw_oihw
 // row blocks of tiles (grid.x): enough for 4-5 resident workgroups per CU across the channel groups, few enough that the
 // per-block partials stay small
 static int stem_wgrad_blocks(int ntiles) {
-    static const int cap = getenv("STRAPS_STEM_WGRAD_BLOCKS") ? atoi(getenv("STRAPS_STEM_WGRAD_BLOCKS")) : 256;      // (A/B switch for tools)
+    static const int cap = STRAPS_TOOL_ENV_INT("STRAPS_STEM_WGRAD_BLOCKS", 256);      // (A/B switch for tools)
     return ntiles < cap ? ntiles : cap;
 }
 
@@ -1640,7 +1640,7 @@ static int wgrad_x3_route(int batch, int h, int w, int cin, int cout, int kh, in
     Wgrad3P p3;
     int splits3;
     if (wgrad3_plan(batch, h, w, cin, cout, kh, kw, stride, pad, &p3, &splits3)) return 1;
-    static const bool tap_x3 = !(getenv("STRAPS_WGRAD_TAP_FP32") && atoi(getenv("STRAPS_WGRAD_TAP_FP32")));      // (A/B switch for tools)
+    static const bool tap_x3 = !STRAPS_TOOL_ENV_INT("STRAPS_WGRAD_TAP_FP32", 0);      // (A/B switch for tools)
     // per-tap kernel on the planes where it beats the fp32 one (tools/sweep_wgrad_x3.py: 3x3 / stride 2: 87-93 vs 115-125 us; 1x1 with at
     // least 128 channels on both sides: +0..29 %; with a 64-channel side the fp32 kernel's 4-byte rows win: 52 vs 60 us).  Both stream
     // their operands from memory once per tile of the other channel dimension: bytes, not the matrix pipe, set their rate.
@@ -1679,8 +1679,9 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
             q.chunks_per_split = p64.chunks_per_split;
             splits3 = splits64;
             const size_t lds = (size_t)2 * 3 * (64 + 136) * 64 * sizeof(u16);
-            static const int abl = getenv("STRAPS_WGRAD3_ABL") ? atoi(getenv("STRAPS_WGRAD3_ABL")) : 0;      // (tools: tools/wgrad3_ablate.py)
             const dim3 grid3((cout / 64) * (cin / 64), splits3);
+#ifdef STRAPS_TOOLS
+            static const int abl = STRAPS_TOOL_ENV_INT("STRAPS_WGRAD3_ABL", 0);      // (tools/wgrad3_ablate.py; ablations compute wrong results)
             if (abl) {
                 auto kern = abl == 1 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 1> : abl == 2 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 2>
                           : abl == 3 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 3> : abl == 4 ? conv_wgrad3x3_x3_kernel<W3X_NG, 64, 4> : conv_wgrad3x3_x3_kernel<W3X_NG, 64, 5>;
@@ -1689,6 +1690,7 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
                 STRAPS_CHECK_LAUNCH("conv_wgrad3x3_x3_kernel (ablation)");
                 return STRAPS_OK;
             }
+#endif
             STRAPS_RAISE_LDS((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), lds, "conv_wgrad3x3_x3_kernel");
             hipLaunchKernelGGL((conv_wgrad3x3_x3_kernel<W3X_NG, 64>), grid3, dim3(256 * W3X_NG), lds, st3, q);
         } else {
@@ -1720,7 +1722,7 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         const int splits = wgrad_splits(M, tiles, big, true);
         q.rows_per_split = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
         hipStream_t st = (hipStream_t)stream;
-        static const int nst_env = getenv("STRAPS_WGRAD_TAP_NST") ? atoi(getenv("STRAPS_WGRAD_TAP_NST")) : 2;      // (A/B switch for tools: 3, 4 -- measured slower)
+        static const int nst_env = STRAPS_TOOL_ENV_INT("STRAPS_WGRAD_TAP_NST", 2);      // (A/B switch for tools: 3, 4 -- measured slower)
         constexpr int SB = 3 * 32 * 256 * 2, SS = 3 * 32 * 128 * 2;      // bytes per stage: 128x128 / 64x64 channel block
         if (big) {
             if (nst_env == 3) {
@@ -1782,7 +1784,7 @@ extern "C" int straps_stem_wgrad(const float* x_nchw, const float* dy_nhwc, floa
     hipLaunchKernelGGL(stem_tileact_kernel, dim3((ntiles * groups + 255) / 256), dim3(256), 0, st, nzmask, tact, cin, h, w, tiles_x, tiles_y, ntiles,
                        groups);
     STRAPS_CHECK_LAUNCH("stem_tileact_kernel");
-    static const int rot = getenv("STRAPS_STEM_WGRAD_ROT") ? atoi(getenv("STRAPS_STEM_WGRAD_ROT")) : 97;      // (A/B switch for tools: 0 = plain strided walk)
+    static const int rot = STRAPS_TOOL_ENV_INT("STRAPS_STEM_WGRAD_ROT", 97);      // (A/B switch for tools: 0 = plain strided walk)
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk, groups), dim3(256), 0, st, x_nchw, dy_nhwc, part, tact, batch, cin, h, w, Ho, Wo,
                        tiles_x, tiles_y, Kp, ntiles, rot);
     STRAPS_CHECK_LAUNCH("stem_wgrad_kernel");
@@ -1811,6 +1813,7 @@ extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float*
                                 float* dz_out, unsigned short* draw_planes, long long plane_stride, void* workspace, long long rows, int c,
                                 int accumulate, void* stream) {
     STRAPS_REQUIRE(!draw_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "straps_bn_bwd_x3: plane_stride must be >= rows*c and a multiple of 8");
+    STRAPS_REQUIRE(!draw_planes || (c & 31) == 0, "straps_bn_bwd_x3: chunk-major planes need c %% 32 == 0 (c=%d)", c);
     STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && (draw || draw_planes) && workspace, "straps_bn_bwd: null pointer");
     STRAPS_REQUIRE(rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd: bad shape rows=%lld c=%d", rows, c);
     const int C4 = c >> 2;
@@ -1839,6 +1842,7 @@ extern "C" int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const
                                        float* draw, float* dz_out, unsigned short* draw_planes, long long plane_stride, const double* partials,
                                        int nblk, void* workspace, long long rows, int c, int accumulate, void* stream) {
     STRAPS_REQUIRE(!draw_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "straps_bn_bwd_finish_x3: plane_stride must be >= rows*c and a multiple of 8");
+    STRAPS_REQUIRE(!draw_planes || (c & 31) == 0, "straps_bn_bwd_finish_x3: chunk-major planes need c %% 32 == 0 (c=%d)", c);
     STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && (draw || draw_planes) && workspace && partials && nblk > 0,
                    "straps_bn_bwd_finish_x3: null pointer");
     STRAPS_REQUIRE(rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_bwd_finish_x3: bad shape rows=%lld c=%d", rows, c);
@@ -1922,6 +1926,7 @@ extern "C" int straps_bn_relu_maxpool_fwd_x3(const float* raw, const float* scal
     const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
     const long long n = (long long)batch * Ho * Wo * (c >> 2);
     STRAPS_REQUIRE(!y_planes || (plane_stride >= n * 4 && plane_stride % 8 == 0), "straps_bn_relu_maxpool_fwd_x3: plane_stride must be >= the output size and a multiple of 8");
+    STRAPS_REQUIRE(!y_planes || (c & 31) == 0, "straps_bn_relu_maxpool_fwd_x3: chunk-major planes need c %% 32 == 0 (c=%d)", c);
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(capped_grid(n)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, y_pool, idx, y_planes, plane_stride, batch, h, w, c, Ho, Wo);
     STRAPS_CHECK_LAUNCH("bn_relu_maxpool_kernel");
     return STRAPS_OK;

@@ -12,8 +12,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // error text shared by all translation units (defined in abi.hip)
 void straps_set_error(const char* fmt, ...);
-// device pair the convolution kernels add their (shader ticks, wall ticks) to; NULL unless straps_set_clock_accumulator set it (abi.hip)
-extern unsigned long long* g_straps_clk_acc;
+// device pair the convolution kernels add their (shader ticks, wall ticks) to: the CURRENT device's, NULL unless straps_set_clock_accumulator set it (abi.hip)
+unsigned long long* straps_clk_acc_current();
 
 #define STRAPS_REQUIRE(cond, ...)             \
     do {                                      \
@@ -137,5 +137,15 @@ __device__ __forceinline__ long long cm_index(long long r, int c, long long rows
 __device__ __forceinline__ void store_planes4_cm(u16* __restrict__ planes, long long ps, long long r, int c, long long rows, const f32x4& v) {
     store_planes4(planes, ps, cm_index(r, c, rows), v);
 }
+
+// Measurement switches (ablation instantiations that compute WRONG results, environment-selected A/B variants) exist only in the tools
+// build: `python tools/build_tools_lib.py` compiles the same sources with -DSTRAPS_TOOLS into tools/bin/libstraps_hip_tools.so.  The
+// product library never reads the environment: STRAPS_TOOL_ENV_INT is its compile-time default there.
+#ifdef STRAPS_TOOLS
+#include <stdlib.h>
+#define STRAPS_TOOL_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define STRAPS_TOOL_ENV_INT(name, dflt) (dflt)
+#endif
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

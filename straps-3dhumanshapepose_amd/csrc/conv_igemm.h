@@ -278,7 +278,7 @@ inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, co
                             int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad) {
     p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
-    p.yplanes = nullptr; p.yps = 0; p.clk = g_straps_clk_acc;
+    p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current();
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
     ConvP::Class& c = p.cls[0];
     p.ncls = 1;
@@ -305,7 +305,7 @@ inline int conv_dgrad_problem(ConvP& p, const float* addend, float* dx, int batc
     const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
-    p.yplanes = nullptr; p.yps = 0; p.clk = g_straps_clk_acc;
+    p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current();
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
     p.omul = stride;

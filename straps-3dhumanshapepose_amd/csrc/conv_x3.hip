@@ -629,9 +629,12 @@ int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
     if (halo == 2) return launch_x3h<128, 64, 2, 2, 3, 272>(p, st);
     if (halo == 3) return launch_x3h<128, 64, 2, 2, 2, 272, 1>(p, st);
     const int cfg = pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn, p.ncls, kdim == p.Cin);
-    if ((tile_cfg & 192) == 192) return dispatch_x3_abl<3>(p, cfg, st);      // ablations (tools)
+#ifdef STRAPS_TOOLS
+    // ablation instantiations (wrong results by design: tools/x3_ablate.py) exist only in the tools build; the product library ignores the bits
+    if ((tile_cfg & 192) == 192) return dispatch_x3_abl<3>(p, cfg, st);
     if (tile_cfg & 64) return dispatch_x3_abl<1>(p, cfg, st);
     if (tile_cfg & 128) return dispatch_x3_abl<2>(p, cfg, st);
+#endif
     return dispatch_x3_abl<0>(p, cfg, st);
 }
 

@@ -369,7 +369,8 @@ extern "C" int straps_bn_apply(const float* x, const float* scale, const float* 
 
 extern "C" int straps_bn_apply_x3(const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
                                   unsigned short* y_planes, long long plane_stride, long long rows, int c, void* stream) {
-    STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_apply_x3: bad arguments (c%%4 must be 0)");
+    // (the planes are chunk-major, common.h cm_index: 32-channel chunks outermost -- c % 32 != 0 would index past rows*c)
+    STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 31) == 0, "straps_bn_apply_x3: bad arguments (c%%32 must be 0: chunk-major planes; c=%d)", c);
     STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "straps_bn_apply_x3: plane_stride must be >= rows*c and a multiple of 8");
     const long long n4 = rows * (c >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, y_planes, plane_stride, n4, c >> 2);

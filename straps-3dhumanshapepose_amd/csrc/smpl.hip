@@ -854,23 +854,24 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
     int rc = straps_smpl_launch_pose(model, betas, rotmats, F, Amat, joints, batch, st);
     if (rc != STRAPS_OK) return rc;
     const int split = mode == STRAPS_SMPL_SPLIT_F16 ? 1 : mode == STRAPS_SMPL_SPLIT_F16_LBS ? 2 : 0;
-    // measurement knobs (tools/smpl_ablate.sh; unset in production): STRAPS_SMPL_PF = depth of the fragment ring (default 3 for the
-    // blend-split kernel, 2 for the matrix-pipe-skinning kernel), STRAPS_SMPL_ABLATE (compile-time ablations of the latter),
-    // STRAPS_SMPL_RPC (rounds per workgroup)
-    static int pf_env = -1, ablate = -1, rpc_env = -1;
-    if (pf_env < 0) {
-        const char* e = getenv("STRAPS_SMPL_PF"); pf_env = e ? atoi(e) : 0;
-        e = getenv("STRAPS_SMPL_ABLATE"); ablate = e ? atoi(e) : 0;
-        e = getenv("STRAPS_SMPL_RPC"); rpc_env = e ? atoi(e) : 0;
-    }
+    // measurement knobs of the TOOLS build (tools/smpl_ablate.sh; the product library never reads the environment): STRAPS_SMPL_PF = depth of
+    // the fragment ring (default 3 for the blend-split kernel, 2 for the matrix-pipe-skinning kernel), STRAPS_SMPL_ABLATE (compile-time
+    // ablations of the latter), STRAPS_SMPL_RPC (rounds per workgroup)
+    static const int pf_env = STRAPS_TOOL_ENV_INT("STRAPS_SMPL_PF", 0), rpc_env = STRAPS_TOOL_ENV_INT("STRAPS_SMPL_RPC", 0);
     const int pf = pf_env >= 1 && pf_env <= 4 ? pf_env : (split == 2 ? 2 : 3);
     constexpr int nwv = 8;              // (12 / 16 waves per workgroup need <= 168 / 128 VGPRs: the kernel spills and runs 3.5x slower)
     auto h_kernel = pf == 1 ? smpl_verts_h_kernel<1> : pf == 2 ? smpl_verts_h_kernel<2> : pf == 4 ? smpl_verts_h_kernel<4> : smpl_verts_h_kernel<3>;
-    auto hh_kernel = ablate == 1 ? smpl_verts_hh_kernel<8, 1, 1> : ablate == 2 ? smpl_verts_hh_kernel<8, 1, 2> : ablate == 3 ? smpl_verts_hh_kernel<8, 1, 3>
-                   : ablate == 7 ? smpl_verts_hh_kernel<8, 1, 7> : ablate == 15 ? smpl_verts_hh_kernel<8, 1, 15>
-                   : pd16 == 1 ? (pf == 1 ? smpl_verts_hh_kernel<8, 1, 0, 1> : smpl_verts_hh_kernel<8, 2, 0, 1>)
+    auto hh_kernel = pd16 == 1 ? (pf == 1 ? smpl_verts_hh_kernel<8, 1, 0, 1> : smpl_verts_hh_kernel<8, 2, 0, 1>)
                    : pd16 == 2 ? (pf == 1 ? smpl_verts_hh_kernel<8, 1, 0, 2> : smpl_verts_hh_kernel<8, 2, 0, 2>)
                    : pf == 1 ? smpl_verts_hh_kernel<8, 1, 0> : smpl_verts_hh_kernel<8, 2, 0>;      // (a deeper ring does not fit: PF = 2 uses 255 of the 256 registers two waves per SIMD leave a wave)
+#ifdef STRAPS_TOOLS
+    {   // ablation instantiations (wrong results by design; tools/smpl_ablate.sh) -- tools build only
+        static const int ablate = STRAPS_TOOL_ENV_INT("STRAPS_SMPL_ABLATE", 0);
+        if (!pd16 && ablate)
+            hh_kernel = ablate == 1 ? smpl_verts_hh_kernel<8, 1, 1> : ablate == 2 ? smpl_verts_hh_kernel<8, 1, 2> : ablate == 3 ? smpl_verts_hh_kernel<8, 1, 3>
+                      : ablate == 7 ? smpl_verts_hh_kernel<8, 1, 7> : ablate == 15 ? smpl_verts_hh_kernel<8, 1, 15> : hh_kernel;
+    }
+#endif
     const size_t lds = split == 2 ? (size_t)(BT * FSH + 12 * BT * ASH) * sizeof(float)
                                   : (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
     static unsigned long long lds_raised[5] = {0, 0, 0, 0, 0};          // per kernel variant: bit mask of the devices done
@@ -891,7 +892,7 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
         const int rpc2 = rpc_env > 0 ? (rpc_env > rounds2 ? rounds2 : rpc_env) : resolve_rpc(rounds2, batch, chunks);
         const int nch2 = (rounds2 + rpc2 - 1) / rpc2;
         hipLaunchKernelGGL(hh_kernel, dim3((unsigned)(btiles * nch2)), dim3(nwv * 64), lds, st, *model, F, Amat, verts, joints ? vout : nullptr,
-                           batch, (int)btiles, ntiles, rounds2, rpc2, g_straps_clk_acc);
+                           batch, (int)btiles, ntiles, rounds2, rpc2, straps_clk_acc_current());
     } else if (split)
         hipLaunchKernelGGL(h_kernel, dim3((unsigned)(btiles * nch)), dim3(NW * 64), lds, st, *model, F, Amat, verts,
                            joints ? vout : nullptr, batch, (int)btiles, rounds, rpc);

@@ -46,7 +46,7 @@ class DeviceDraws:
         self.counter.fill_(int(step))
 
 
-_default = {}
+_default = {}          # (device type, index) -> (DeviceDraws, base seed it was built from | None when pinned by manual_seed(seed, device))
 _seed = None          # set by manual_seed(); None: derived from torch's seed and the rank on first use
 
 
@@ -68,13 +68,19 @@ def _base_seed():
 
 def default_draws(device):
     """module-level generator of the function-style augmentation entry points (one per device, created on first use from
-    `_base_seed()`; distinct devices get distinct streams)."""
+    `_base_seed()`; distinct devices get distinct streams: device index x an odd 64-bit constant is added modulo 2^64, so two (seed, device)
+    pairs can in principle meet -- harmless, the streams are still valid).  While device_rng.manual_seed has not been called the generator
+    FOLLOWS torch's seed: a torch.manual_seed() issued after the first draw rebuilds it (step counter back to 0), like the reference's
+    torch-generator draws."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (device.type, idx)
-    if key not in _default:
-        _default[key] = DeviceDraws(_base_seed() + 0x9E3779B97F4A7C15 * idx, torch.device(device.type, idx))
-    return _default[key]
+    base = _base_seed()
+    ent = _default.get(key)
+    if ent is None or (ent[1] is not None and ent[1] != base):
+        ent = (DeviceDraws(base + 0x9E3779B97F4A7C15 * idx, torch.device(device.type, idx)), base)
+        _default[key] = ent
+    return ent[0]
 
 
 def manual_seed(seed, device=None):
@@ -87,5 +93,5 @@ def manual_seed(seed, device=None):
         return default_draws(torch.device('cuda', torch.cuda.current_device()))
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    _default[(device.type, idx)] = DeviceDraws(int(seed) + 0x9E3779B97F4A7C15 * idx, torch.device(device.type, idx))
-    return _default[(device.type, idx)]
+    _default[(device.type, idx)] = (DeviceDraws(int(seed) + 0x9E3779B97F4A7C15 * idx, torch.device(device.type, idx)), None)   # (None: pinned, ignores torch's seed)
+    return _default[(device.type, idx)][0]

@@ -13,30 +13,38 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
 SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'conv_x3.hip', 'stem.hip', 'smpl.hip',
-           'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip', 'raster.hip']
+           'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip', 'raster.hip', 'exchange.hip']
 
 _lib = None
+LINK_LIBS = ['-ldl']
 
 
 def _existing_sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.isfile(os.path.join(CSRC, s))]
 
 
-def build(force=False, verbose=False):
+TOOLS_LIB_PATH = os.path.join(os.path.dirname(_HERE), 'tools', 'bin', 'libstraps_hip_tools.so')
+
+
+def build(force=False, verbose=False, tools=False):
     """Compile every HIP source for gfx950 into csrc/libstraps_hip.so (in-tree, so the .so travels
-    with the repo snapshot).  hipcc cross-compiles without a GPU."""
+    with the repo snapshot).  hipcc cross-compiles without a GPU.
+    tools=True: the same sources with -DSTRAPS_TOOLS into tools/bin/libstraps_hip_tools.so -- the measurement build that carries the
+    ablation instantiations (wrong results by design) and reads the STRAPS_* A/B environment switches.  The product library has
+    neither; tools select the other library explicitly with `use_library(TOOLS_LIB_PATH)` (tools/with_tools_lib.py)."""
     srcs = _existing_sources()
+    lib_path = TOOLS_LIB_PATH if tools else LIB_PATH
     # every header under csrc/ (common.h, conv_igemm.h, ...) and the public header: a change in any of them rebuilds every object --
     # translation units that share a struct (ConvP) can never be linked from different versions of it
     import glob
     hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [HEADER]
     deps = srcs + hdrs
-    if not force and os.path.isfile(LIB_PATH) and all(os.path.getmtime(LIB_PATH) > os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    if not force and os.path.isfile(lib_path) and all(os.path.getmtime(lib_path) > os.path.getmtime(d) for d in deps):
+        return lib_path
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DSTRAPS_TOOLS'] if tools else [])
     # one object per source (csrc/build/*.o, compiled in parallel, rebuilt only when the source or a header is newer), then one link
-    objdir = os.path.join(CSRC, 'build')
+    objdir = os.path.join(os.path.dirname(TOOLS_LIB_PATH), 'build') if tools else os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in srcs:
@@ -50,11 +58,11 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + '.o') for s in srcs]
-    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', lib_path] + objs + LINK_LIBS
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB_PATH
+    return lib_path
 
 
 class SmplModelStruct(C.Structure):
@@ -96,7 +104,7 @@ def gemm_multi(descs):
 _P, _I, _L, _F, _Z, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
-ABI_VERSION = 6      # == STRAPS_ABI_VERSION of include/straps_hip.h (tests/test_abi.py compares the two); load() refuses a library of another version
+ABI_VERSION = 7      # == STRAPS_ABI_VERSION of include/straps_hip.h (tests/test_abi.py compares the two); load() refuses a library of another version
 SIGNATURES = {
     'straps_abi_version': (_I, []),
     'straps_last_error': (C.c_char_p, []),
@@ -192,6 +200,12 @@ SIGNATURES = {
     'straps_project_targets': (_I, [_P, _P, _F, _F, _F, _F, _P, _P, _L, _P]),
     'straps_point_metrics': (_I, [_P, _P, _P, _L, _I, _P]),
     'straps_crop_resize': (_I, [_P, _P, _P, _D, _D, _D, _D, _D, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_comm_unique_id': (_I, [_P]),
+    'straps_comm_init_rank': (_I, [_P, _I, _I, C.POINTER(C.c_void_p)]),
+    'straps_comm_destroy': (_I, [_P]),
+    'straps_comm_size': (_I, [_P]),
+    'straps_comm_library': (C.c_char_p, []),
+    'straps_allreduce_grads': (_I, [_P, _L, _P, _P]),
 }
 
 
@@ -224,6 +238,13 @@ def load(path=None):
 
 def lib():
     return load()
+
+
+def use_library(path):
+    """make `path` THE library of this process (tools only: the -DSTRAPS_TOOLS build under tools/bin/).  Must run before the first call."""
+    global _lib
+    _lib = load(path)
+    return _lib
 
 
 _TRACE = os.environ.get('STRAPS_TRACE_CALLS')      # debugging aid: a file that receives the name of every entry point just launched, followed by a

@@ -79,25 +79,84 @@ class GradientExchange:
     CPU tests), in two buckets so that it overlaps the backward pass.  `start_tail()` is called as soon as the tail of
     the buffer (layer3, layer4, IEF, loss weights: the bulk of the bytes, and the FIRST gradients backward finishes) is
     final and launches its all-reduce asynchronously; `finish()` waits for it, reduces the head (stem, layer1, layer2)
-    and returns the 1/world_size the Adam kernel folds in.  split_off = 0 degenerates to one bucket."""
+    and returns the 1/world_size the Adam kernel folds in.  split_off = 0 degenerates to one bucket.
 
-    def __init__(self, flat_g, split_off, world_size, group=None):
+    backend = 'torch': torch.distributed collectives on the process group (`nccl` == RCCL on ROCm; `gloo` in the CPU tests).
+    backend = 'rccl' : the library's own C-ABI exchange (include/straps_hip.h: straps_comm_* / straps_allreduce_grads) -- a
+                       communicator created through the ABI (its 128-byte id travels over the torch process group when world > 1)
+                       and all-reduces enqueued on a dedicated HIP stream ordered against the step's stream with events: the
+                       path a host without torch takes, exercised here by the same step.
+    force: exchange even when world == 1 (an all-reduce over one rank is the identity): lets a single-GPU box run the real
+           stream / split-graph choreography of the N > 1 step (tests/test_gpu_exchange.py)."""
+
+    def __init__(self, flat_g, split_off, world_size, group=None, force=False, backend='torch', rank=0):
         self.flat_g, self.split_off, self.world, self.group = flat_g, int(split_off), world_size, group
+        self.active = world_size > 1 or bool(force)
+        self.backend = backend
         self._work = None
+        self._comm, self._stream, self._started = None, None, False
+        if backend not in ('torch', 'rccl'):
+            raise ValueError("GradientExchange: backend must be 'torch' or 'rccl' (got %r)" % (backend,))
+        if self.active and backend == 'rccl':
+            self._init_rccl(rank)
+
+    def _init_rccl(self, rank):
+        if not self.flat_g.is_cuda:
+            raise RuntimeError("GradientExchange(backend='rccl') needs the gradient buffer on a GPU")
+        L = hipabi.lib()
+        idbuf = (C.c_char * 128)()
+        if rank == 0:
+            hipabi.check(L.straps_comm_unique_id(idbuf), 'straps_comm_unique_id')
+        if self.world > 1:
+            import torch.distributed as dist
+            box = [bytes(idbuf) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            idbuf = (C.c_char * 128).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        with torch.cuda.device(self.flat_g.device):
+            hipabi.check(L.straps_comm_init_rank(idbuf, self.world, rank, C.byref(comm)), 'straps_comm_init_rank')
+            self._stream = torch.cuda.Stream(device=self.flat_g.device)
+        self._comm = comm
+        assert L.straps_comm_size(comm) == self.world
+
+    def close(self):
+        if self._comm is not None:
+            torch.cuda.synchronize(self.flat_g.device)
+            hipabi.check(hipabi.lib().straps_comm_destroy(self._comm), 'straps_comm_destroy')
+            self._comm = None
+
+    def _rccl_allreduce(self, lo, hi):
+        """sum all-reduce of flat_g[lo:hi] on the exchange stream, ordered after everything the current stream holds so far"""
+        cur = torch.cuda.current_stream(self.flat_g.device)
+        self._stream.wait_stream(cur)
+        hipabi.check(hipabi.lib().straps_allreduce_grads(C.c_void_p(self.flat_g.data_ptr() + 4 * lo), hi - lo, self._comm,
+                                                          C.c_void_p(self._stream.cuda_stream)), 'straps_allreduce_grads')
 
     def start_tail(self):
-        if self.world > 1 and self._work is None:
+        if not self.active:
+            return
+        if self.backend == 'rccl':
+            if not self._started:
+                self._rccl_allreduce(self.split_off, self.flat_g.numel())
+                self._started = True
+        elif self._work is None:
             import torch.distributed as dist
             self._work = dist.all_reduce(self.flat_g[self.split_off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        if self.world > 1:
-            import torch.distributed as dist
+        if self.active:
             self.start_tail()                      # (no-op when the caller already started it)
-            self._work.wait()
-            self._work = None
-            if self.split_off > 0:
-                dist.all_reduce(self.flat_g[:self.split_off], op=dist.ReduceOp.SUM, group=self.group)
+            if self.backend == 'rccl':
+                if self.split_off > 0:
+                    self._rccl_allreduce(0, self.split_off)
+                torch.cuda.current_stream(self.flat_g.device).wait_stream(self._stream)
+                self._started = False
+            else:
+                import torch.distributed as dist
+                self._work.wait()
+                self._work = None
+                if self.split_off > 0:
+                    dist.all_reduce(self.flat_g[:self.split_off], op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world
 
 
@@ -105,8 +164,11 @@ class TrainStep:
     def __init__(self, regressor, smpl, criterion, batch_size, lr=1e-4, rank=0, world_size=1, seed=1234, group=None,
                  mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=False,
                  renderer=None, track_metrics=False, comm_overlap=None, pipeline_data=True, smpl_augment_params=None,
-                 cam_augment_params=None, bbox_augment_params=None, proxy_rep_augment_params=None, global_masked_mean=False):
-        """global_masked_mean (data parallel only; default off = the average of per-rank masked means): the joints2D task
+                 cam_augment_params=None, bbox_augment_params=None, proxy_rep_augment_params=None, global_masked_mean=False,
+                 force_exchange=False, exchange_backend='torch'):
+        """force_exchange / exchange_backend: see GradientExchange (force: run the exchange even when world_size == 1; backend 'rccl' = the
+        library's own C-ABI all-reduce on a dedicated stream instead of torch.distributed).
+        global_masked_mean (data parallel only; default off = the average of per-rank masked means): the joints2D task
         becomes the masked mean over the GLOBAL batch -- one extra 1-float sum all-reduce per step (each rank's visible-joint count,
         issued a step ahead next to the data pipeline, off the critical path).
         use_graph: after two eager warm-up steps, capture data generation + forward + loss + backward (~250 kernel
@@ -117,6 +179,7 @@ class TrainStep:
             raise RuntimeError('TrainStep: regressor parameters must be GPU tensors (call .to(device) first): the STRAPS hot path runs only '
                                'through the HIP library (no CPU fallback)')
         self.dev = p0.device
+        self._force_exchange, self._exchange_backend = bool(force_exchange), exchange_backend
         with torch.cuda.device(self.dev):
             self._init(regressor, smpl, criterion, batch_size, lr, rank, world_size, seed, group, mean_shape, mean_cam_t, pose_pool, use_graph,
                        overlap_wgrad, renderer, track_metrics, comm_overlap, pipeline_data, smpl_augment_params, cam_augment_params,
@@ -144,7 +207,7 @@ class TrainStep:
         # layer1 and the stem (comm_overlap: default on when there is someone to talk to; STRAPS_NO_COMM_OVERLAP=1 turns it off)
         if comm_overlap is None:
             import os
-            comm_overlap = world_size > 1 and os.environ.get('STRAPS_NO_COMM_OVERLAP', '0') != '1'
+            comm_overlap = (world_size > 1 or self._force_exchange) and os.environ.get('STRAPS_NO_COMM_OVERLAP', '0') != '1'
         self.comm_overlap = bool(comm_overlap)
         split_off, off = 0, 0
         for n_, p_ in regressor.named_parameters():
@@ -152,7 +215,8 @@ class TrainStep:
                 split_off = off
                 break
             off += p_.numel()
-        self.exchange = GradientExchange(self.flat_g, split_off if self.comm_overlap else 0, world_size, group)
+        self.exchange = GradientExchange(self.flat_g, split_off if self.comm_overlap else 0, world_size, group, force=self._force_exchange,
+                                         backend=self._exchange_backend, rank=rank)
         self.time_exchange, self.exchange_events = False, []
         self.logvar_params = [getattr(criterion, n + '_log_var') for n in TASKS]
         # the five loss log-variances are the last five floats of the flat buffers, in the criterion's registration order; the
@@ -413,7 +477,7 @@ class TrainStep:
         return self.metrics.summary()
 
     def optimise(self):
-        if self.time_exchange and self.world > 1:
+        if self.time_exchange and self.exchange.active:
             # event pair on the step's stream around the wait for the tail bucket + the head bucket's all-reduce: the part of the exchange
             # that backward did NOT hide (bench.py --gpus N reports it)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -486,17 +550,20 @@ class TrainStep:
                 # the batch of the NEXT step has just been generated (data stream, joined): its count exchange runs under Adam
                 if gm:
                     self._vis_work[self._cur] = allreduce_visible_count(self._bufs[self._cur]['vis_count'], self.world, self.group, async_op=True)
-            if not self.use_graph or self._warm < 2:
-                self._warm += 1
+
+            def eager():
                 loss = self._run(start_tail)
                 self._cur ^= 1
                 count_next()
                 self.optimise()
                 return loss
+            if not self.use_graph or self._warm < 2:
+                self._warm += 1
+                return eager()
             if self.graph is None:
                 self._capture()
-                if not self.use_graph:
-                    return self.step()
+                if not self.use_graph:             # capture failed (on this rank or, data parallel, on any rank): eager launches from here on --
+                    return eager()                 # inline, so the count exchange above is not issued a second time (ADVICE)
             par = self._cur if self.pipeline else 0
             g1, g2, loss = self.graph[par]
             self.last = self._last_by_parity[par]          # the output buffers THIS graph writes (each capture has its own)
@@ -564,9 +631,20 @@ class TrainStep:
             self._cur = start
             self.graph = graphs
             self.graph_tail = next(iter(graphs.values()))[1]
+            ok, why = True, ''
         except Exception as e:                       # noqa: BLE001 -- fall back to eager launches, never to another path
+            ok, why = False, str(e)
+        if self.world > 1:
+            # data parallel: every rank takes the same path -- one rank's failed capture sends all of them to eager launches (ADVICE:
+            # ranks that disagree about graph / eager would issue differently ordered collectives)
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if ok and float(flag.item()) < 1.0:
+                ok, why = False, 'capture failed on another rank'
+        if not ok:
             import warnings
-            warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager launches' % (e,))
+            warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager launches' % (why,))
             self.use_graph, self.graph, self.graph_tail = False, None, None
             torch.cuda.synchronize()
 

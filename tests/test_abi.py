@@ -89,3 +89,18 @@ def test_tile_choice_and_routes_of_the_bf16x3_kernels(lib):
     assert on(B, 64, 64, 64, 128, 1, 1, 2, 0) == 0                                              # 1x1 with a 64-channel side: fp32 kernel
     assert on(B, 28, 28, 128, 512, 1, 1, 1, 0) == 1
     assert on(2, 10, 24, 64, 64, 3, 3, 1, 1) == 1                                               # no halo plan (width 24): per-tap kernel on planes
+
+
+def test_product_library_reads_no_measurement_switches(lib):
+    """ablation instantiations (wrong results by design) and STRAPS_* A/B environment switches live only in the
+    -DSTRAPS_TOOLS build (tools/bin/libstraps_hip_tools.so, hipabi.build(tools=True)).  The product library carries no STRAPS_* string at
+    of a switch -- it cannot even ask for one -- and no source calls getenv."""
+    blob = open(hipabi.LIB_PATH, 'rb').read()
+    # (the only STRAPS_* strings a product build may hold are mode / constant names inside error messages)
+    found = sorted(set(re.findall(rb'STRAPS_[A-Z0-9_]{3,}', blob)))
+    assert all(f.startswith(b'STRAPS_SMPL_SPLIT_') for f in found), found
+    for name in (b'STRAPS_SMPL_ABLATE', b'STRAPS_SMPL_PF', b'STRAPS_SMPL_RPC', b'STRAPS_WGRAD3_ABL', b'STRAPS_WGRAD_', b'STRAPS_STEM_WGRAD_'):
+        assert name not in blob, name
+    for src in hipabi._existing_sources():
+        txt = open(src).read()
+        assert 'getenv' not in txt, '%s reads the environment' % os.path.basename(src)

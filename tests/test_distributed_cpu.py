@@ -213,7 +213,16 @@ def _worker_bn(rank, world, port, q, tmp):
     opt = torch.optim.Adam(list(reg.parameters()) + list(crit.parameters()), lr=1e-4)
     before = float(reg.image_encoder.bn1.running_mean[0])
     path = os.path.join(tmp, 'ck_rank%d.tar' % rank)
-    sd = checkpoint_utils.save_checkpoint(path if rank == 0 else None, 3, reg, opt, crit)
+    # (1) the plain call is NOT a collective: rank 0 alone may write (the `if rank == 0: save_checkpoint(...)` idiom must not hang or
+    #     desynchronise the communicator -- ADVICE round 3); nobody's statistics change
+    if rank == 0:
+        solo = checkpoint_utils.save_checkpoint(os.path.join(tmp, 'solo.tar'), 2, reg, opt, crit)
+        assert float(solo['model_state_dict']['image_encoder.bn1.running_mean'][0]) == before
+    assert float(reg.image_encoder.bn1.running_mean[0]) == before
+    dist.barrier()
+    # (2) the opt-in synchronised save, called on every rank: rank 0's statistics are broadcast, rank 0 writes, the others build nothing
+    sd = checkpoint_utils.save_checkpoint(path if rank == 0 else None, 3, reg, opt, crit, sync_bn=True)
+    assert (sd is None) == (rank != 0)
     after = float(reg.image_encoder.bn1.running_mean[0])
     digest = torch.stack([b.double().sum() for _, b in reg.named_buffers()]).sum().reshape(1)
     allr = [torch.zeros_like(digest) for _ in range(world)]

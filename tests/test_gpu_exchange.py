@@ -1,0 +1,101 @@
+"""GPU: the gradient exchange on RCCL itself, as far as ONE GPU allows.
+
+gloo's blocking CPU collectives (tests/test_distributed_cpu.py, tests/test_gpu_two_ranks.py) prove the arithmetic of the exchange, not
+its stream semantics.  Here the real thing runs, with a world of one rank (an all-reduce over one rank is the identity, but every call
+is a real RCCL call on RCCL's / the exchange's own stream):
+  * the C-ABI exchange of include/straps_hip.h (straps_comm_* / straps_allreduce_grads) on its own;
+  * TrainStep(force_exchange=True) with backend 'torch' (torch.distributed `nccl` == RCCL: async work handle on RCCL's stream between the
+    two split hipGraphs) and backend 'rccl' (the C-ABI all-reduce on a dedicated stream, ordered with events) -- both bit-identical to
+    the step without an exchange over 12 steps, graph capture alive, the exposed-exchange timing populated.
+A world of two needs two GPUs (RCCL refuses two ranks on one device): that is the driver's multi-GPU bench."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exchange_on_one_rank():
+    import straps_amd  # noqa: F401
+    from straps_amd import hipabi
+    L = hipabi.load()
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    idbuf = (C.c_char * 128)()
+    hipabi.check(L.straps_comm_unique_id(idbuf), 'straps_comm_unique_id')
+    assert any(bytes(idbuf))
+    comm = C.c_void_p()
+    hipabi.check(L.straps_comm_init_rank(idbuf, 1, 0, C.byref(comm)), 'straps_comm_init_rank')
+    assert comm.value and L.straps_comm_size(comm) == 1
+    assert b'rccl' in L.straps_comm_library()
+    g = torch.randn(11_909_794, device=dev)                      # resnet18's flat gradient: 11 909 789 + 5 floats
+    want = g.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    # two buckets like the step's: tail first, then head, on a side stream
+    split = 683_072
+    hipabi.check(L.straps_allreduce_grads(C.c_void_p(g.data_ptr() + 4 * split), g.numel() - split, comm, C.c_void_p(s.cuda_stream)), 'tail')
+    hipabi.check(L.straps_allreduce_grads(C.c_void_p(g.data_ptr()), split, comm, C.c_void_p(s.cuda_stream)), 'head')
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)                                  # sum over one rank
+    # argument validation
+    assert L.straps_allreduce_grads(None, 4, comm, None) == 1 and b'null pointer' in L.straps_last_error()
+    assert L.straps_comm_init_rank(idbuf, 2, 2, C.byref(C.c_void_p())) == 1
+    hipabi.check(L.straps_comm_destroy(comm), 'straps_comm_destroy')
+    assert L.straps_comm_destroy(None) == 0
+
+
+def _worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    import straps_amd
+    from straps_amd.train_step import TrainStep
+    mp_ = straps_amd.synthetic_mean_params(0)
+    out = {}
+    for name, kw in (('none', dict()), ('torch', dict(force_exchange=True, exchange_backend='torch')),
+                     ('rccl', dict(force_exchange=True, exchange_backend='rccl'))):
+        torch.manual_seed(1234)
+        reg = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=mp_).to(dev).train()
+        smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=8).to(dev)
+        crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D']).to(dev)
+        ts = TrainStep(reg, smpl, crit, 8, lr=1e-3, rank=0, world_size=1, seed=77, mean_shape=mp_['shape'], use_graph=True, **kw)
+        ts.time_exchange = True
+        losses = [ts.step()[0].clone() for _ in range(12)]
+        torch.cuda.synchronize()
+        exposed = [a.elapsed_time(b) for a, b in ts.exchange_events]
+        out[name] = dict(losses=torch.stack(losses).cpu(), params=ts.flat_p.detach().cpu().clone(), m=ts.exp_avg.detach().cpu().clone(),
+                         graph=ts.graph is not None, split=ts.graph_tail is not None, overlap=ts.comm_overlap, active=ts.exchange.active,
+                         split_off=ts.exchange.split_off, exposed=exposed)
+        ts.exchange.close()
+        del ts, reg, smpl, crit
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_train_step_with_the_exchange_forced_on_rccl_world_one():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(29900 + os.getpid() % 1000, q))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(120)
+    assert p.exitcode == 0
+    ref = out['none']
+    assert ref['graph'] and not ref['split'] and not ref['active'] and ref['exposed'] == []
+    for name in ('torch', 'rccl'):
+        r = out[name]
+        assert r['active'] and r['overlap'] and r['split_off'] > 0              # two buckets, tail started mid-backward
+        assert r['graph'] and r['split'], '%s: the split hipGraph capture fell back to eager launches' % name
+        assert torch.equal(r['losses'], ref['losses']), name                    # 12 steps, bit for bit
+        assert torch.equal(r['params'], ref['params']) and torch.equal(r['m'], ref['m']), name
+        assert len(r['exposed']) == 12 and all(t >= 0.0 for t in r['exposed']), name      # what bench.py reports as exposed_exchange_ms

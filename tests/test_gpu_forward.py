@@ -21,6 +21,7 @@ from straps_amd import hipabi
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MP = straps_amd.synthetic_mean_params(0)
 
 
@@ -601,3 +602,30 @@ def test_calibration_and_utility_entry_points(dev):
         L.straps_set_clock_accumulator(None)
     c, w = (int(v) for v in acc.tolist())
     assert c > 0 and w > 0 and 500 < c / w * khz / 1e3 < 3000
+
+
+def test_measurement_environment_switches_do_not_reach_the_product_library(smpl_model):
+    """STRAPS_SMPL_ABLATE=15 (no stores / loads / MFMAs in the tools build), STRAPS_SMPL_PF, STRAPS_WGRAD3_ABL ... set in the environment
+    of a fresh process: the product library ignores them -- SMPL vertices stay float64-exact to the usual bar."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'oracle'))
+import straps_amd, straps_oracle as O
+from detgen import det_uniform
+dev = torch.device('cuda:0')
+model = straps_amd.synthetic_smpl_model(0)
+smpl = straps_amd.SMPL(model, batch_size=70).to(dev)
+betas = torch.from_numpy(det_uniform((70, 10), 170, -2.5, 2.5))
+R = O.batch_rodrigues(torch.from_numpy(det_uniform((70, 72), 270, -0.9, 0.9)).reshape(-1, 3)).view(70, 24, 3, 3)
+v, j = smpl.forward_arrays(betas.to(dev), R.to(dev), precision='fp16x3_lbs')
+v64, j64 = O.smpl_forward(model, betas.double(), rotmats=R.double(), dtype=torch.float64)
+print('ERR %%.3e %%.3e' %% (float((v.cpu().double() - v64).abs().max()), float((j.cpu().double() - j64).abs().max())))
+''' % (ROOT, ROOT)
+    env = dict(os.environ, STRAPS_SMPL_ABLATE='15', STRAPS_SMPL_PF='1', STRAPS_SMPL_RPC='1', STRAPS_WGRAD3_ABL='2', STRAPS_WGRAD_TAP_FP32='1',
+               STRAPS_STEM_WGRAD_ROT='0')
+    p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-800:]
+    ev, ej = (float(t) for t in [l for l in p.stdout.splitlines() if l.startswith('ERR')][-1].split()[1:])
+    assert ev < 2e-5 and ej < 2e-5, (ev, ej)

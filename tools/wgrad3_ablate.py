@@ -13,7 +13,7 @@ import straps_amd  # noqa: E402,F401
 from straps_amd import hipabi  # noqa: E402
 from straps_amd.encoder_exec import split3  # noqa: E402
 
-L = hipabi.load()
+L = hipabi.use_library(hipabi.build(tools=True))      # the -DSTRAPS_TOOLS build: ablation instantiations + STRAPS_* A/B switches
 dev = torch.device('cuda:0')
 B = 64
 row = 'ABL=%s' % os.environ.get('STRAPS_WGRAD3_ABL', '0')

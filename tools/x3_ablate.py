@@ -12,7 +12,7 @@ import straps_amd  # noqa: E402,F401
 from straps_amd import hipabi  # noqa: E402
 from straps_amd.encoder_exec import split3, weight_planes  # noqa: E402
 
-L = hipabi.load()
+L = hipabi.use_library(hipabi.build(tools=True))      # the -DSTRAPS_TOOLS build: ablation instantiations + STRAPS_* A/B switches
 dev = torch.device('cuda:0')
 SHAPES = [('l1', 64, 64, 64, 11), ('l2', 32, 128, 128, 12), ('l3', 16, 256, 256, 5), ('l4', 8, 512, 512, 7)]
 B = 64
