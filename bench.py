@@ -307,6 +307,8 @@ def main():
                     help='smpl workload: fp32 = exact fp32 MFMA chain; fp16x3 = blend contraction as a three-product fp16 split; fp16x3_lbs (default: every '
                          'product split three ways, fp32-class accuracy) = skinning on the matrix pipe too; _pd16 / _p16 = pose-corrective blend in plain '
                          'fp16 (narrower than fp32: opt-in A/B only, reported beside the headline under "reduced_precision_modes")')
+    ap.add_argument('--smpl-kernel', default='auto', choices=['auto', 'wide', 'narrow'],
+                    help='smpl workload, fp16x3_lbs* modes: auto = by batch size (64-body workgroups from 2048 bodies on), wide / narrow = force one (A/B)')
     ap.add_argument('--no-reduced-ab', action='store_true', help='smpl workload: skip the extra timed pass of the reduced-precision p16 mode')
     ap.add_argument('--conv-precision', default='bf16x3', choices=['fp32', 'bf16x3'],
                     help="encoder convolutions (forward + data gradient): 'fp32' = exact-fp32 MFMA chain, 'bf16x3' = three bf16 planes per fp32 "
@@ -427,7 +429,7 @@ def main():
         smpl_precision = args.smpl_precision
 
         def step():
-            return smpl.forward_arrays(betas, R, want_joints=True, precision=smpl_precision)[0]
+            return smpl.forward_arrays(betas, R, want_joints=True, precision=smpl_precision, kernel=args.smpl_kernel)[0]
         workload = 'configs[4]: SMPL-only forward, %d random (theta,beta) per step x %d steps = %d bodies -> 6890-vertex meshes + 90 joints' % (
             B, args.steps, B * args.steps)
         dominant = 'smpl_fwd'
@@ -518,7 +520,7 @@ def main():
         # the pose-corrective blend in plain fp16 (narrower than the reference's fp32; inside north_star's 1e-4 m): NOT the headline --
         # the same K steps timed again and reported beside it
         def step_p16():
-            return smpl.forward_arrays(betas, R, want_joints=True, precision='fp16x3_lbs_p16')[0]
+            return smpl.forward_arrays(betas, R, want_joints=True, precision='fp16x3_lbs_p16', kernel=args.smpl_kernel)[0]
         for _ in range(3):
             step_p16()
         torch.cuda.synchronize()

@@ -278,8 +278,18 @@ typedef struct {
      * vertices carry their single weight): [tile][kstep 2][hi|lo][lane 64][8], element = split(2^14 *
      * W[vertex = 32*tile + (lane&31)][joint = 16*kstep + 8*(lane>>5) + j]).                                       */
     const void* skin_frag_h;
+    /* the same split weights with the three products packed along K for the 64-body kernel (NULL: that kernel is not used):
+     * T = Ah.Wh + Al.Wh + Ah.Wl = [Ah | Al | Ah | -] . [Wh | Wh | Wl | 0] over 24 + 24 + 24 + 8 = 80 columns = 5 k-steps of 16 (instead of
+     * 3 products x 2 k-steps): [tile][kstep 5][lane 64][8], element = P[vertex = 32*tile + (lane&31)][col = 16*kstep + 8*(lane>>5) + j],
+     * P = [hi(2^14 W)[0:24] | hi(2^14 W)[0:24] | lo(2^14 W)[0:24] | 0 x 8].                                                          */
+    const void* skin_frag_p;
 } straps_smpl_model_t;
 
+/* kernel choice of the STRAPS_SMPL_SPLIT_F16_LBS* modes, OR-ed into `mode` (default 0 = by batch size): _WIDE = 64 bodies per workgroup,
+ * one wave per SIMD with the whole 512-entry register file (every fetched direction fragment feeds two body groups, skinning
+ * products K-packed; the large-batch kernel), _NARROW = 32 bodies per workgroup, two waves per SIMD (small batches).               */
+#define STRAPS_SMPL_KERNEL_WIDE 0x100
+#define STRAPS_SMPL_KERNEL_NARROW 0x200
 /* arithmetic of the blend contraction (v_template + shapedirs + posedirs, K = 218) in straps_smpl_fwd */
 #define STRAPS_SMPL_EXACT_F32 0 /* fp32-input MFMA: exact fmaf chains (the reference's fp32 arithmetic)                  */
 /* three fp16-MFMA products of two-term splits, fp32 accumulate: ~7e-7 relative per product at 16x the matrix rate;

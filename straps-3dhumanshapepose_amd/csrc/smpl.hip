@@ -763,6 +763,374 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
 }
 
 // ------------------------------------------------------------------------------------------
+// The large-batch form of the kernel above (round 4): 64 BODIES PER WORKGROUP, ONE WAVE PER SIMD WITH THE WHOLE 512-ENTRY REGISTER FILE.
+// What bounded smpl_verts_hh_kernel (profiles/r03_smpl_ablate.txt) was structural: every 32-body wave re-streams all direction tiles from
+// L2 (38.9 GB per 65 536 bodies, ~57 B/clk/CU against the ~64 the L2 delivers), and with 256 registers per wave neither a deeper
+// fragment ring nor a second body group fits, so stores, fragment loads and MFMAs added up instead of overlapping.  Here
+//   * a wave holds TWO 32-body groups: every fetched direction fragment (the MFMA's B side) feeds both -- half the L2 -> register bytes,
+//     twice the matrix work (18 MFMAs = 576 cycles) behind each k-step's loads, which are requested PF k-steps ahead;
+//   * the three products of the skinning split are packed along K (skin_frag_p): T = [Ah | Al | Ah | -] . [Wh | Wh | Wl | 0] is 5 MFMAs per
+//     entry instead of 6, with 3 LDS operand reads instead of 4 (k-step 3 re-uses k-step 0's registers, k-step 4 those of k-step 1:
+//     its last 8 columns meet zero weights) -- 186 instead of 198 MFMAs per 32 x 32 tile;
+//   * the skinning chains write VGPRs (TV = 1: the VGPR-destination encoding of the same instruction, through inline assembly): a kernel that
+//     may use more than 256 registers gets every builtin MFMA in its AGPR-destination form, and the fold on the VALU would pay one
+//     v_accvgpr_read per value (16 per entry, as many as the fold's own arithmetic).  The blend accumulators stay in AGPRs (read once);
+//   * joint transforms are staged as packed [Ah 24 | Al 24 | pad 8] rows of 112 bytes (conflict-free b128 reads), 84 KB for 64 bodies next
+//     to the 58 KB of split features: 142 KB of the 160 KB, one workgroup per CU.
+// Same arithmetic class as the kernel above (every product split three ways, fp32 accumulate); the skinning products are added in one
+// K-packed chain, so results may differ from it in the last bit.  Operand roles, output mapping and the store form are unchanged.
+constexpr int WB = 64;                    // bodies per workgroup
+constexpr int NWW = 4;                    // waves per workgroup = one per SIMD
+constexpr int ASP = 56;                   // halves per packed (entry, body) row: [Ah 24 | Al 24 | 8 unused]; 112 bytes = 4 * 7 dwords
+constexpr int KSP = 5;                    // k-steps of the K-packed skinning product
+
+// v_mfma_f32_32x32x16_f16 with VGPR C / D.  The hazard recogniser does not see inside inline assembly; the two rules this kernel relies on
+// (MI355X guide, "inline assembly"; the compiler's own code for the builtin shows the same): an accumulate chain (D of one = C of the next,
+// whole) needs no wait states; any other reader of D needs 11 (8-pass instruction) -- provided by construction, see the skinning loop.
+__device__ __forceinline__ void mfma16h_v0(f32x16& d, const half8& a, const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16h_v(f32x16& d, const half8& a, const half8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+// the first two links of a chain in ONE statement: nothing can be scheduled between them, so whatever follows is >= 2 MFMA issue periods
+// (>= 64 cycles) behind the previous chain's last MFMA
+__device__ __forceinline__ void mfma16h_v01(f32x16& d, const half8& a0, const half8& b0, const half8& a1, const half8& b1) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\tv_mfma_f32_32x32x16_f16 %0, %3, %4, %0" : "=&v"(d) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+
+// ABL (tools build only; wrong results by design -- tools/smpl_w_ab.py --ablate): 1 = no output stores, 2 = no fragment loads after the
+// prologue, 4 = no skinning MFMA chains, 8 = no blend MFMAs, 16 = no fold on the VALU, 32 = no LDS operand reads inside the tile loop
+// SV: store / schedule variant bits -- 1 = non-temporal stores (the 5.5 GB of output stream through L2 without displacing the direction
+// fragments the 32 CUs of an XCD share), 2 = the four waves of a workgroup start a quarter of a tile period apart (the chip's store bursts
+// spread in time), 4 = the stores of tile t are issued inside the blend phase of tile t + 1, right after its last in-tile load request
+template <int PF, int PD16, int TV, int ABL = 0, int SV = 0>
+__global__ __launch_bounds__(NWW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void smpl_verts_w_kernel(straps_smpl_model_t m, const float* __restrict__ F, const float* __restrict__ Amat, float* __restrict__ verts,
+                         float* __restrict__ vout, long long B, int bgroups, int ntiles, int rounds, int rounds_per_chunk,
+                         unsigned long long* clk) {
+    static_assert(PF >= 1 && PF < KS, "prefetch distance");
+    constexpr int R = PF + 1;              // ring slots
+    unsigned long long clk_c0 = 0, clk_w0 = 0;
+    if (clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = __builtin_amdgcn_s_memrealtime(); }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Fh = reinterpret_cast<_Float16*>(smem);            // [64][FSH]
+    _Float16* Fl = Fh + WB * FSH;                                  // [64][FSH]
+    _Float16* Ap = Fl + WB * FSH;                                  // [12][64][ASP]   Ap[(e*64 + body)*ASP + (0|24) + joint]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int il = lane & 31;              // as A-side index: body within its group; as output column: vertex within the tile
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = logical / bgroups;
+    const long long b0 = (long long)(logical - chunk * bgroups) * WB;
+    const int nb = (int)((B - b0) < WB ? (B - b0) : WB);
+
+    // ---- stage: feature rows and joint transforms of the 64 bodies, split into fp16 hi / lo (all loads first, then the conversions) ----
+    {
+        constexpr int FPER = WB * (KP / 4) / (NWW * 64);          // 14 float4 per thread
+        constexpr int APER = WB * 12 / (NWW * 64);                // 3 (body, joint pair) items per thread
+        static_assert(FPER * NWW * 64 == WB * (KP / 4) && APER * NWW * 64 == WB * 12, "staging items must divide evenly");
+        f32x4 fv[FPER], av[APER][6];
+#pragma unroll
+        for (int t = 0; t < FPER; ++t) {
+            const int i = tid + t * NWW * 64;
+            const int b = i / (KP / 4), q = i % (KP / 4);
+            const bool ok = b < nb;
+            fv[t] = *reinterpret_cast<const f32x4*>(F + (b0 + (ok ? b : 0)) * KP + q * 4);
+            if (!ok) fv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < APER; ++t) {
+            const int i = tid + t * NWW * 64;
+            const int b = i / 12, jp = i % 12;
+            const bool ok = b < nb;
+            const float* src = Amat + ((b0 + (ok ? b : 0)) * 24 + 2 * jp) * 12;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                av[t][q] = *reinterpret_cast<const f32x4*>(src + q * 4);
+                if (!ok) av[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < FPER; ++t) {
+            const int i = tid + t * NWW * 64;
+            const int b = i / (KP / 4), q = i % (KP / 4);
+            half4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = sat_h(fv[t][e] * F_SCALE);
+                hi[e] = (_Float16)x;
+                lo[e] = (_Float16)(x - (float)hi[e]);
+            }
+            *reinterpret_cast<half4*>(Fh + b * FSH + q * 4) = hi;
+            *reinterpret_cast<half4*>(Fl + b * FSH + q * 4) = lo;
+        }
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int t = 0; t < APER; ++t) {
+            const int i = tid + t * NWW * 64;
+            const int b = i / 12, jp = i % 12;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const float x0 = sat_h(av[t][e >> 2][e & 3] * A_SCALE), x1 = sat_h(av[t][3 + (e >> 2)][e & 3] * A_SCALE);
+                half2v hi, lo;
+                hi[0] = (_Float16)x0; hi[1] = (_Float16)x1;
+                lo[0] = (_Float16)(x0 - (float)hi[0]); lo[1] = (_Float16)(x1 - (float)hi[1]);
+                _Float16* row = Ap + (e * WB + b) * ASP + 2 * jp;
+                *reinterpret_cast<half2v*>(row) = hi;
+                *reinterpret_cast<half2v*>(row + 24) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int round0 = chunk * rounds_per_chunk;
+    const int round1 = min(round0 + rounds_per_chunk, rounds);
+    const int vrow_floats = (m.n_tiles - NT) * 96;
+    const half8* __restrict__ blend = reinterpret_cast<const half8*>(m.blend_frag_h);
+    const half8* __restrict__ skinp = reinterpret_cast<const half8*>(m.skin_frag_p);
+    const float us_blend = m.blend_h_unscale;
+    const float us_rot = us_blend * W_UNSCALE;       // (T * blend) carries both scales, the translation column only the skin scale
+    const _Float16* fh_row = Fh + il * FSH + 8 * h;  // group g adds 32 * FSH, k-step s adds 16 s
+    const _Float16* fl_row = Fl + il * FSH + 8 * h;
+    const _Float16* a_row = Ap + il * ASP + 8 * h;   // group g adds 32 * ASP, entry e adds 64 * ASP, packed k-step s adds 16 s
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool full = nb == WB;
+
+    auto load_step = [&](half8* slot, const half8* q, int ks) {      // the six fragments [coord][hi|lo] of one k-step
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+            if (!(PD16 && ks >= 1 && (f & 1))) slot[f] = q[f * 64];
+    };
+    // one 12-byte-per-lane store: row r of group g's result tile t.  SV >> 8 selects the form: 0 = plain global store, 1 = non-temporal global
+    // store, 100 + aux = buffer store with that cache policy (gfx940 aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+    constexpr int SP = SV >> 8;
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+    __amdgpu_buffer_rsrc_t rs_mesh, rs_virt;
+    if (SP >= 100) {
+        rs_mesh = __builtin_amdgcn_make_buffer_rsrc(verts + b0 * (long long)(NV * 3), 0, 0x7fffffff, 0x00020000);
+        rs_virt = __builtin_amdgcn_make_buffer_rsrc((vout ? vout : verts) + b0 * (long long)vrow_floats, 0, 0x7fffffff, 0x00020000);
+    }
+    auto store_one = [&](int t, int g, int r, const f32x16* o3, bool guard) {
+        const bool mesh = t < NT;
+        const int v = (mesh ? t : t - NT) * 32 + il;
+        const long long rstride = mesh ? (long long)(NV * 3) : (long long)vrow_floats;
+        const bool vok = t >= 0 && (mesh ? v < NV : (vout != nullptr));
+        const int body = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if ((ABL & 1) && o3[0][r] != 12345.678f) return;          // (never true: keeps the arithmetic alive)
+        if (vok && (!guard || g * 32 + body < nb)) {
+            const int brow = (ABL & 64) ? (body & 7) : g * 32 + body;      // (ABL & 64: every store of the chip lands in the same 8 rows -- L2-resident)
+            if (SP >= 100) {
+                const unsigned off = (unsigned)((brow * (int)rstride + v * 3) * 4);
+                u32x3 t3 = {__float_as_uint(o3[0][r]), __float_as_uint(o3[1][r]), __float_as_uint(o3[2][r])};
+                if (mesh) __builtin_amdgcn_raw_buffer_store_b96(t3, rs_mesh, off, 0, SP - 100);
+                else __builtin_amdgcn_raw_buffer_store_b96(t3, rs_virt, off, 0, SP - 100);
+            } else {
+                float* o = (mesh ? verts : vout) + (((ABL & 64) ? 0 : b0) + brow) * rstride + (long long)v * 3;
+                if (SP == 1) {
+                    f32x3 t3 = {o3[0][r], o3[1][r], o3[2][r]};
+                    __builtin_nontemporal_store(t3, reinterpret_cast<f32x3*>(o));
+                } else {
+                    o[0] = o3[0][r]; o[1] = o3[1][r]; o[2] = o3[2][r];
+                }
+            }
+        }
+    };
+    auto store_group = [&](int t, int g, const f32x16* o3, bool guard) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) store_one(t, g, r, o3, guard);
+    };
+
+    half8 ring[R][6];
+    int tile = round0 * NWW + wave;
+    if (SV & 2) {                                             // wave w starts w quarter periods (~3 700 cycles each; SV & 8: eighths) late
+        for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep((SV & 8) ? 29 : 58);
+    }
+    if (round0 < round1 && tile < ntiles) {
+        const half8* q = blend + (long long)tile * (KS * 6 * 64) + lane;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) load_step(ring[s], q + s * 384, s);
+    }
+    f32x16 outp[2][3];                                        // (SV & 4: the previous tile's results, stored inside this tile's blend phase)
+    int ptile = -1;
+    for (int rd = round0; rd < round1; ++rd, tile += NWW) {
+        if (tile >= ntiles) break;                           // (wave-uniform: the last round may be ragged)
+        const bool has_next = rd + 1 < round1 && tile + NWW < ntiles;
+        const half8* p = blend + (long long)tile * (KS * 6 * 64) + lane;
+        const half8* pn = has_next ? p + (long long)NWW * (KS * 6 * 64) : p;      // (no next tile: the head loads re-read this one, unused)
+        const half8* sp = skinp + (long long)tile * (KSP * 64) + lane;
+        half8 sw[KSP];
+        f32x16 acc[2][3];
+        // ---------------- blend contraction: acc[g][c][body][vertex] = sum_k F[body][k] D[k][vertex][c], both body groups per fragment ----------------
+        // Per k-step: 18 MFMAs (6 accumulators x 3 products), and ONE memory request after every third of them, fenced in place with
+        // sched_barriers (left alone the scheduler issues the step's six loads in a block in front of its MFMAs: ~80 cycles of an idle
+        // matrix pipe per k-step).  The request is k-step s + PF of this tile into the slot step s - 1 freed; in the last PF steps, where
+        // the tile has nothing left to ask for, the slot takes the NEXT tile's head k-step of the same number when there is one (the rest of
+        // the head follows the loop): those loads are then in front of this tile's stores (one in-order counter tracks loads and stores
+        // on gfx9 -- a load issued behind stores can only be waited for by draining them) and land under the skinning phase.
+        half8 fh[2], fl[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            fh[g] = *reinterpret_cast<const half8*>(fh_row + g * 32 * FSH);
+            fl[g] = *reinterpret_cast<const half8*>(fl_row + g * 32 * FSH);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            half8 fhn[2] = {fh[0], fh[1]}, fln[2] = {fl[0], fl[1]};
+            if (s + 1 < KS && !(ABL & 32)) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    fhn[g] = *reinterpret_cast<const half8*>(fh_row + g * 32 * FSH + 16 * (s + 1));
+                    fln[g] = *reinterpret_cast<const half8*>(fl_row + g * 32 * FSH + 16 * (s + 1));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const half8* c = ring[s % R];
+            const bool p2 = !(PD16 && s >= 1), p3 = !(PD16 == 2 && s >= 1);
+            const int nm = 6 * (1 + (p2 ? 1 : 0) + (p3 ? 1 : 0)), stride = nm / 6;
+            const bool in_tile = s + PF < KS;
+            const int hj = (s + R - 1) % R;                  // the slot step s - 1 freed
+            const bool head = !in_tile && hj < PF;
+            const int ks_l = in_tile ? s + PF : hj;          // the k-step requested at this step (of this tile / of the next one)
+            half8* slot = ring[in_tile ? (s + PF) % R : hj];
+            const half8* src = (in_tile ? p : pn) + ks_l * 384;
+#pragma unroll
+            for (int j = 0; j < nm; ++j) {
+                int prod = j / 6;                            // 0: Fh.Dh, then Fh.Dl (unless skipped), then Fl.Dh
+                if (prod == 1 && !p2) prod = 2;
+                const int g = (j % 6) / 3, cc = j % 3;
+                const half8& fa_ = prod == 2 ? fl[g] : fh[g];
+                const half8& cb_ = c[2 * cc + (prod == 1 ? 1 : 0)];
+                if (!(ABL & 8)) acc[g][cc] = mfma16h(fa_, cb_, (s == 0 && j < 6) ? zero16 : acc[g][cc]);
+                else if (s == 0 && j < 6) { acc[g][cc] = zero16; acc[g][cc][0] = (float)fa_[0] + (float)cb_[1]; }
+                if ((SV & 4) && j + 1 == stride && (s == KS - PF || s == KS - PF + 1) && ptile >= 0) {
+                    // the previous tile's stores: behind this tile's last in-tile request, in front of the next tile's head requests, which are
+                    // not waited for before the skinning phase is over
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int gs = s - (KS - PF);
+                    if (full) store_group(ptile, gs, outp[gs], false);
+                    else store_group(ptile, gs, outp[gs], true);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((j + 1) % stride == 0) {
+                    const int f = (j + 1) / stride - 1;      // 0..5
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((in_tile || head) && !(PD16 && ks_l >= 1 && (f & 1)) && !(ABL & 2)) slot[f] = src[f * 64];
+                    if ((SV & 16) && (f & 1) && s * 3 + f / 2 < 32) {      // the previous tile's 32 stores, three per k-step: a steady write stream instead of a burst
+                        const int idx = s * 3 + f / 2;
+                        store_one(ptile, idx >> 4, idx & 15, outp[idx >> 4], !full);
+                    }
+                    if (s == ((SV & 4) ? KS - PF - 2 : KS - 3) && f < KSP) sw[f] = sp[f * 64];      // this tile's packed skinning weights: needed right after the contraction (SV & 4: requested in front of the delayed stores)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { fh[g] = fhn[g]; fl[g] = fln[g]; }
+        }
+        // the head k-steps the loop had no free slot for
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            bool in_loop = false;
+#pragma unroll
+            for (int s2 = KS - PF; s2 < KS; ++s2) in_loop = in_loop || ((s2 + R - 1) % R == j);
+            if (!in_loop && !(ABL & 2)) load_step(ring[j], pn + j * 384, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- skinning on the matrix pipe, K-packed: T_e[body][vertex] = [Ah | Al | Ah | -][body] . [Wh | Wh | Wl | 0][vertex] ----------------
+        // Software pipeline over the twelve entries: [LDS operands of e + 1] -> [5-MFMA chain of e into one of two result buffers] -> [fold of
+        // e - 1 from the other buffer on the VALU while that chain runs].  out_c = (T[4c] x + T[4c+1] y + T[4c+2] z) us_rot + T[4c+3] us_w.
+        // TV = 1 (chains through inline assembly, VGPR results): the fold's reads of T(e - 1) sit behind the FIRST TWO links of chain e
+        // (one asm statement, fenced by sched_barriers), i.e. >= 64 cycles after chain e - 1 issued its last MFMA: the 11 wait states an
+        // 8-pass MFMA result needs before a VALU read; the last entry's fold, which has no chain in front of it, gets them as an s_nop.
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const _Float16* ar = a_row + g * 32 * ASP;
+            half8 a[3], an[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { a[q] = *reinterpret_cast<const half8*>(ar + 16 * q); an[q] = a[q]; }
+            f32x16 T[2], fa = zero16;                         // (two result buffers, alternating)
+            f32x16 out[3];
+            if (!TV || (ABL & 4)) { T[0] = zero16; T[1] = zero16; }
+#pragma unroll
+            for (int e = 0; e <= 12; ++e) {
+                if (e + 1 < 12 && !(ABL & 32)) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) an[q] = *reinterpret_cast<const half8*>(ar + (e + 1) * WB * ASP + 16 * q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL & 4) {
+                    if (e < 12) T[e & 1][0] += (float)a[0][0] + (float)a[1][1] + (float)a[2][2] + (float)sw[e % KSP][3];
+                } else if (TV) {
+                    if (e < 12) mfma16h_v01(T[e & 1], a[0], sw[0], a[1], sw[1]);
+                    else asm volatile("s_nop 11");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (e < 12) {
+                        mfma16h_v(T[e & 1], a[2], sw[2]);
+                        mfma16h_v(T[e & 1], a[0], sw[3]);      // (k-steps 3, 4 re-use the operands of 0, 1)
+                        mfma16h_v(T[e & 1], a[1], sw[4]);
+                    }
+                } else if (e < 12) {
+#pragma unroll
+                    for (int ks = 0; ks < KSP; ++ks) T[e & 1] = mfma16h(a[ks % 3], sw[ks], ks == 0 ? zero16 : T[e & 1]);
+                }
+                if (e > 0) {                                  // fold entry e - 1 while the chain above is in the pipe
+                    const int pe = e - 1, c = pe >> 2, q = pe & 3;
+                    const f32x16& Tp = T[pe & 1];
+                    if (ABL & 16) {
+                        if (q == 3) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) out[c][r] = Tp[r];
+                            out[c][0] += acc[g][c][0];
+                        }
+                    } else if (q == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) fa[r] = Tp[r] * acc[g][0][r];
+                    } else if (q == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) fa[r] += Tp[r] * acc[g][1][r];
+                    } else if (q == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) fa[r] += Tp[r] * acc[g][2][r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) out[c][r] = fa[r] * us_rot + Tp[r] * W_UNSCALE;
+                    }
+                    asm volatile("" : "+v"(fa));              // (pins the fold of THIS entry here: the vectoriser otherwise gathers all four entries of a coordinate at q == 3)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = an[q];
+            }
+            // (lane = vertex, register r = body (r&3) + 8 (r>>2) + 4 h of group g: sixteen 12-byte stores per lane, straight from the registers)
+            if (SV & (4 | 16)) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) outp[g][c] = out[c];
+            } else {
+                if (full) store_group(tile, g, out, false);
+                else store_group(tile, g, out, true);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ptile = tile;
+    }
+    if ((SV & (4 | 16)) && ptile >= 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (full) store_group(ptile, g, outp[g], false);
+            else store_group(ptile, g, outp[g], true);
+        }
+    }
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(clk, (unsigned long long)__builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_w0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Output joints 24..89: 21 picked vertices, then the 45 regressed joints = fixed-order sums of their virtual vertices
 // (contiguous in the scratch row).  One wave per body: the body's scratch row (<= 3 KB) is read once, coalesced, into LDS; each
 // output scalar is then summed by one lane in ascending order -> deterministic, and bit-identical to the former one-thread-per-
@@ -833,6 +1201,9 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                                void* stream) {
     STRAPS_REQUIRE(model && betas && rotmats && verts && workspace, "straps_smpl_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0, "straps_smpl_fwd: batch must be positive (got %lld)", batch);
+    const int kflag = mode & (STRAPS_SMPL_KERNEL_WIDE | STRAPS_SMPL_KERNEL_NARROW);
+    mode &= ~(STRAPS_SMPL_KERNEL_WIDE | STRAPS_SMPL_KERNEL_NARROW);
+    STRAPS_REQUIRE(kflag != (STRAPS_SMPL_KERNEL_WIDE | STRAPS_SMPL_KERNEL_NARROW), "straps_smpl_fwd: STRAPS_SMPL_KERNEL_WIDE and _NARROW exclude each other");
     STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || mode == STRAPS_SMPL_SPLIT_F16 || mode == STRAPS_SMPL_SPLIT_F16_LBS || mode == STRAPS_SMPL_SPLIT_F16_LBS_PD16 ||
                    mode == STRAPS_SMPL_SPLIT_F16_LBS_P16,
                    "straps_smpl_fwd: unknown mode %d", mode);
@@ -885,7 +1256,63 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
         straps_set_error("straps_smpl_fwd: batch %lld exceeds one launch; split it", batch);
         return STRAPS_EUNSUPPORTED;
     }
-    if (split == 2) {
+    // 64-body workgroups (smpl_verts_w_kernel) from 2048 bodies on: below that the grid would be a few dozen 256-thread workgroups
+    const bool wide = split == 2 && model->skin_frag_p && (kflag == STRAPS_SMPL_KERNEL_WIDE || (kflag == 0 && batch >= 2048));
+    STRAPS_REQUIRE(kflag != STRAPS_SMPL_KERNEL_WIDE || wide, "straps_smpl_fwd: STRAPS_SMPL_KERNEL_WIDE needs a STRAPS_SMPL_SPLIT_F16_LBS* mode and skin_frag_p in the model");
+    if (wide) {
+        const int ntiles = joints ? model->n_tiles : NT;
+        const int rounds_w = (ntiles + NWW - 1) / NWW;
+        const long long bgroups = (batch + WB - 1) / WB;
+        // chunks of the tile rounds per body group: one (the staging of 64 bodies amortised over every tile) once the body groups alone fill
+        // the chip, else enough to put ~one workgroup on every CU; split evenly
+        int nchw = chunks > 0 ? chunks : (int)((256 + bgroups - 1) / bgroups);
+        if (nchw > rounds_w) nchw = rounds_w;
+        if (nchw < 1) nchw = 1;
+        const int rpcw = rpc_env > 0 ? (rpc_env > rounds_w ? rounds_w : rpc_env) : (rounds_w + nchw - 1) / nchw;
+        nchw = (rounds_w + rpcw - 1) / rpcw;
+        if (bgroups * nchw > 0x7fffffffLL) {
+            straps_set_error("straps_smpl_fwd: batch %lld exceeds one launch; split it", batch);
+            return STRAPS_EUNSUPPORTED;
+        }
+        // product form (tools/smpl_w_ab.py, profiles/r04_smpl_w_ab.txt): prefetch distance 3, skinning chains with VGPR results, the previous tile's
+        // stores spread over the blend phase as non-temporal buffer stores.  The tools build selects the A/B instantiations:
+        // STRAPS_SMPL_WVAR = 10 * PF + TV (plain stores at the tile end), STRAPS_SMPL_WSV (store forms), STRAPS_SMPL_WABL (ablations, wrong results)
+        constexpr int B_NT = (100 + 2) << 8, SV_PRODUCT = 16 | B_NT;
+        auto w_kernel = pd16 == 1 ? smpl_verts_w_kernel<3, 1, 1, 0, SV_PRODUCT> : pd16 == 2 ? smpl_verts_w_kernel<3, 2, 1, 0, SV_PRODUCT>
+                      : smpl_verts_w_kernel<3, 0, 1, 0, SV_PRODUCT>;
+        int wslot = pd16;
+#ifdef STRAPS_TOOLS
+        static const int wvar = STRAPS_TOOL_ENV_INT("STRAPS_SMPL_WVAR", 0);
+        if (!pd16 && wvar) {
+            w_kernel = wvar == 31 ? smpl_verts_w_kernel<3, 0, 1> : wvar == 30 ? smpl_verts_w_kernel<3, 0, 0> : wvar == 21 ? smpl_verts_w_kernel<2, 0, 1>
+                     : wvar == 41 ? smpl_verts_w_kernel<4, 0, 1> : smpl_verts_w_kernel<4, 0, 0>;
+            wslot = 3;
+        }
+        static const int wsv = STRAPS_TOOL_ENV_INT("STRAPS_SMPL_WSV", 0);      // store forms: SV bits | form << 8
+        if (!pd16 && wsv) {
+            constexpr int NT1 = 1 << 8, B_SYS = (100 + 19) << 8, B_PLAIN = 100 << 8;
+            w_kernel = wsv == 1 ? smpl_verts_w_kernel<3, 0, 1, 0, NT1> : wsv == 2 ? smpl_verts_w_kernel<3, 0, 1, 0, 16> : wsv == 3 ? smpl_verts_w_kernel<3, 0, 1, 0, 16 | NT1>
+                     : wsv == 4 ? smpl_verts_w_kernel<3, 0, 1, 0, B_NT> : wsv == 5 ? smpl_verts_w_kernel<3, 0, 1, 0, B_SYS> : wsv == 7 ? smpl_verts_w_kernel<3, 0, 1, 0, B_PLAIN>
+                     : wsv == 10 ? smpl_verts_w_kernel<3, 0, 1, 0, 4 | NT1> : wsv == 12 ? smpl_verts_w_kernel<4, 0, 1, 0, B_NT> : wsv == 13 ? smpl_verts_w_kernel<4, 0, 1, 0, 16 | B_NT>
+                     : wsv == 16 ? smpl_verts_w_kernel<5, 0, 1, 0, B_NT> : smpl_verts_w_kernel<2, 0, 1, 0, 16 | B_NT>;
+            wslot = 4;
+        }
+        static const int wabl = STRAPS_TOOL_ENV_INT("STRAPS_SMPL_WABL", 0);
+        if (!pd16 && wabl) {
+            w_kernel = wabl == 1 ? smpl_verts_w_kernel<3, 0, 1, 1> : wabl == 2 ? smpl_verts_w_kernel<3, 0, 1, 2> : wabl == 3 ? smpl_verts_w_kernel<3, 0, 1, 3>
+                     : wabl == 4 ? smpl_verts_w_kernel<3, 0, 1, 4> : wabl == 8 ? smpl_verts_w_kernel<3, 0, 1, 8> : wabl == 12 ? smpl_verts_w_kernel<3, 0, 1, 12>
+                     : wabl == 15 ? smpl_verts_w_kernel<3, 0, 1, 15> : wabl == 16 ? smpl_verts_w_kernel<3, 0, 1, 16> : wabl == 32 ? smpl_verts_w_kernel<3, 0, 1, 32>
+                     : wabl == 64 ? smpl_verts_w_kernel<3, 0, 1, 64> : wabl == 66 ? smpl_verts_w_kernel<3, 0, 1, 66> : smpl_verts_w_kernel<3, 0, 1, 63>;
+            wslot = 5;      // (one variant per process: the switches are read once)
+        }
+#endif
+        const size_t ldsw = (size_t)(2 * WB * FSH + 12 * WB * ASP) * sizeof(_Float16);
+        static unsigned long long lds_raised_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hipError_t e = straps_raise_dynamic_lds((const void*)w_kernel, ldsw, lds_raised_w[wslot]);
+        if (e != hipSuccess) { straps_set_error("smpl_verts_w_kernel: cannot raise dynamic LDS to %zu: %s", ldsw, hipGetErrorString(e)); return STRAPS_EHIP; }
+        hipLaunchKernelGGL(w_kernel, dim3((unsigned)(bgroups * nchw)), dim3(NWW * 64), ldsw, st, *model, F, Amat, verts, joints ? vout : nullptr,
+                           batch, (int)bgroups, ntiles, rounds_w, rpcw, straps_clk_acc_current());
+    } else if (split == 2) {
         // own round structure: nwv tiles per round, ragged last round
         const int ntiles = joints ? model->n_tiles : NT;
         const int rounds2 = (ntiles + nwv - 1) / nwv;

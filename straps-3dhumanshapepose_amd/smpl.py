@@ -22,6 +22,7 @@ ModelOutput.__new__.__defaults__ = (None,) * len(ModelOutput._fields)
 V, VPAD, TILES, KP = 6890, 6912, 216, 224
 # STRAPS_SMPL_EXACT_F32 / STRAPS_SMPL_SPLIT_F16 (blend contraction split) / STRAPS_SMPL_SPLIT_F16_LBS (blend + skinning split)
 PRECISIONS = {'fp32': 0, 'fp16x3': 1, 'fp16x3_lbs': 2, 'fp16x3_lbs_pd16': 3, 'fp16x3_lbs_p16': 4}
+KERNELS = {'auto': 0, 'wide': 0x100, 'narrow': 0x200}      # STRAPS_SMPL_KERNEL_WIDE / _NARROW, OR-ed into the mode argument
 
 
 def pack_smpl_model(model):
@@ -112,6 +113,11 @@ def pack_smpl_model(model):
     Wh = Ws.astype(np.float16)
     Wl = (Ws - Wh.astype(np.float32)).astype(np.float16)
     skin_frag_h = np.stack([Wh, Wl], axis=0).reshape(2, n_tiles, 32, 2, 2, 8).transpose(1, 3, 0, 4, 2, 5).copy()
+    # the same weights with the three products of the split packed along K (straps_hip.h: skin_frag_p; the 64-body kernel):
+    #   T = Ah.Wh + Al.Wh + Ah.Wl = [Ah | Al | Ah | .] . [Wh | Wh | Wl | 0]   over 24 + 24 + 24 + 8 = 80 columns = 5 k-steps (not 3 x 2 = 6)
+    # [tile][kstep 5][hh][i][j]  <-  P[32t + i][16 ks + 8 hh + j]
+    Wp = np.concatenate([Wh[:, :24], Wh[:, :24], Wl[:, :24], np.zeros((n_tiles * 32, 8), np.float16)], axis=1)
+    skin_frag_p = Wp.reshape(n_tiles, 32, 5, 2, 8).transpose(0, 2, 3, 1, 4).copy()
     jj, vv = np.nonzero(R45)                                                 # (backward tables below)
     o = np.lexsort((vv, jj))
     jj, vv = jj[o], vv[o]
@@ -153,6 +159,7 @@ def pack_smpl_model(model):
         'jrt_ptr': jrt_ptr, 'jrt_code': (((vs % 32) << 8) | src).astype(np.int32), 'jrt_w': ws,
         'blend_frag': frag.reshape(-1),
         'blend_frag_h': frag_h.reshape(-1), 'blend_h_unscale': float(2.0 ** -(sd_exp + 6)), 'skin_frag_h': skin_frag_h.reshape(-1),
+        'skin_frag_p': skin_frag_p.reshape(-1),
         'j_template': (Jr @ vt).astype(np.float32),
         'j_shapedirs': np.einsum('jv,vcl->jcl', Jr, sd).astype(np.float32),
         'parents': parents, 'depth': depth, 'max_depth': int(depth.max()), 'skin_k': k,
@@ -206,7 +213,7 @@ class SMPL(nn.Module):
         key = self._k_blend_frag.data_ptr()
         if self._struct_key != key:
             s = hipabi.SmplModelStruct()
-            for f in ('blend_frag', 'blend_frag_h', 'skin_frag_h', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
+            for f in ('blend_frag', 'blend_frag_h', 'skin_frag_h', 'skin_frag_p', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
                       'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w', 'dj_ptr', 'dj_code', 'dj_w'):
                 setattr(s, f, getattr(self, '_k_' + f).data_ptr())
             s.max_depth, s.skin_k, s.n_tiles = self.max_depth, self.skin_k, self.n_tiles
@@ -215,7 +222,7 @@ class SMPL(nn.Module):
         return self._struct
 
     @hipabi.on_tensor_device
-    def forward_arrays(self, betas, rotmats, want_joints=True, chunks=0, out_verts=None, out_joints=None, precision=None):
+    def forward_arrays(self, betas, rotmats, want_joints=True, chunks=0, out_verts=None, out_joints=None, precision=None, kernel='auto'):
         """raw entry: betas [B,10], rotmats [B,24,3,3] (contiguous fp32 GPU) -> (verts, joints|None).
         out_verts / out_joints: optional resident output buffers ([B,6890,3] / [B,90,3], contiguous fp32).
         precision: 'fp32' (exact fp32 everywhere), 'fp16x3' (blend contraction as a three-product fp16 split with fp32
@@ -224,7 +231,12 @@ class SMPL(nn.Module):
         Range of the split modes: |beta| and the pose features below 1023, joint transforms (rotations and joint positions in metres)
         below 63, skinning weights below 3.9 -- far outside anything a body model produces; operands beyond it SATURATE at the
         largest fp16 value (finite, clipped meshes; csrc/smpl.hip sat_h) rather than turning the body into NaNs.  'fp32' has
-        no such range."""
+        no such range.
+        kernel (the 'fp16x3_lbs*' modes only): 'auto' = by batch size (64-body workgroups with one 512-register wave per SIMD from 2048
+        bodies on, 32-body workgroups below), 'wide' / 'narrow' force one of the two (A/B and tests; same arithmetic class, results
+        differ in the last bits: the wide kernel adds the three skinning products in one K-packed accumulation chain)."""
+        if kernel not in KERNELS:
+            raise ValueError("SMPL.forward_arrays: kernel must be one of %s" % (sorted(KERNELS),))
         hipabi.require_gpu_tensor(betas, 'betas', torch.float32)
         hipabi.require_gpu_tensor(rotmats, 'rotmats', torch.float32)
         hipabi.require_gpu_tensor(self._k_blend_frag, 'SMPL model buffers (call .to(device))')
@@ -244,7 +256,7 @@ class SMPL(nn.Module):
         ws = torch.empty(L.straps_smpl_workspace_bytes(C.byref(self._model_struct()), B) // 4, device=betas.device, dtype=torch.float32)
         hipabi.check(L.straps_smpl_fwd(C.byref(self._model_struct()), hipabi.ptr(betas), hipabi.ptr(rotmats),
                                        hipabi.ptr(verts), hipabi.ptr(joints), hipabi.ptr(ws), B, chunks,
-                                       PRECISIONS[self.precision if precision is None else precision], hipabi.stream_ptr()), 'straps_smpl_fwd')
+                                       PRECISIONS[self.precision if precision is None else precision] | KERNELS[kernel], hipabi.stream_ptr()), 'straps_smpl_fwd')
         return verts, joints
 
     @hipabi.on_tensor_device

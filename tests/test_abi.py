@@ -98,8 +98,8 @@ def test_product_library_reads_no_measurement_switches(lib):
     blob = open(hipabi.LIB_PATH, 'rb').read()
     # (the only STRAPS_* strings a product build may hold are mode / constant names inside error messages)
     found = sorted(set(re.findall(rb'STRAPS_[A-Z0-9_]{3,}', blob)))
-    assert all(f.startswith(b'STRAPS_SMPL_SPLIT_') for f in found), found
-    for name in (b'STRAPS_SMPL_ABLATE', b'STRAPS_SMPL_PF', b'STRAPS_SMPL_RPC', b'STRAPS_WGRAD3_ABL', b'STRAPS_WGRAD_', b'STRAPS_STEM_WGRAD_'):
+    assert all(f.startswith((b'STRAPS_SMPL_SPLIT_', b'STRAPS_SMPL_KERNEL_')) for f in found), found
+    for name in (b'STRAPS_SMPL_ABLATE', b'STRAPS_SMPL_PF', b'STRAPS_SMPL_RPC', b'STRAPS_SMPL_WVAR', b'STRAPS_WGRAD3_ABL', b'STRAPS_WGRAD_', b'STRAPS_STEM_WGRAD_'):
         assert name not in blob, name
     for src in hipabi._existing_sources():
         txt = open(src).read()

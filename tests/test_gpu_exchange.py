@@ -73,7 +73,9 @@ def _worker(port, q):
         losses = [ts.step()[0].clone() for _ in range(12)]
         torch.cuda.synchronize()
         exposed = [a.elapsed_time(b) for a, b in ts.exchange_events]
-        out[name] = dict(losses=torch.stack(losses).cpu(), params=ts.flat_p.detach().cpu().clone(), m=ts.exp_avg.detach().cpu().clone(),
+        import hashlib
+        digest = lambda t: hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()      # (plain data only through the queue)
+        out[name] = dict(losses=torch.stack(losses).cpu().double().reshape(-1).tolist(), params=digest(ts.flat_p), m=digest(ts.exp_avg),
                          graph=ts.graph is not None, split=ts.graph_tail is not None, overlap=ts.comm_overlap, active=ts.exchange.active,
                          split_off=ts.exchange.split_off, exposed=exposed)
         ts.exchange.close()
@@ -96,6 +98,6 @@ def test_train_step_with_the_exchange_forced_on_rccl_world_one():
         r = out[name]
         assert r['active'] and r['overlap'] and r['split_off'] > 0              # two buckets, tail started mid-backward
         assert r['graph'] and r['split'], '%s: the split hipGraph capture fell back to eager launches' % name
-        assert torch.equal(r['losses'], ref['losses']), name                    # 12 steps, bit for bit
-        assert torch.equal(r['params'], ref['params']) and torch.equal(r['m'], ref['m']), name
+        assert r['losses'] == ref['losses'], name                               # 12 steps, bit for bit
+        assert r['params'] == ref['params'] and r['m'] == ref['m'], name        # (sha256 of the flat parameter / first-moment buffers)
         assert len(r['exposed']) == 12 and all(t >= 0.0 for t in r['exposed']), name      # what bench.py reports as exposed_exchange_ms

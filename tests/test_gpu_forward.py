@@ -629,3 +629,44 @@ print('ERR %%.3e %%.3e' %% (float((v.cpu().double() - v64).abs().max()), float((
     assert p.returncode == 0, p.stderr[-800:]
     ev, ej = (float(t) for t in [l for l in p.stdout.splitlines() if l.startswith('ERR')][-1].split()[1:])
     assert ev < 2e-5 and ej < 2e-5, (ev, ej)
+
+
+@pytest.mark.parametrize('mode', ['fp16x3_lbs', 'fp16x3_lbs_pd16', 'fp16x3_lbs_p16'])
+@pytest.mark.parametrize('B', [1, 70, 200, 2085])
+def test_smpl_wide_kernel_vs_oracle_and_narrow(dev, smpl_model, B, mode):
+    """the 64-body kernel of the matrix-pipe modes (smpl_verts_w_kernel: one 512-register wave per SIMD, every direction fragment feeding two
+    body groups, skinning products K-packed, non-temporal buffer stores spread over the next tile's blend phase) forced at every batch size
+    -- one ragged group, full + ragged groups, > 2048 bodies where it is the automatic choice: float64 bar of every SMPL test (2e-5 m; the
+    north_star bar is 1e-4), agreement with the 32-body kernel to the last bits (the packed chain adds the three skinning products in another
+    order), vertices-only form, chunked launches, batch rows independent of the batch they ride in."""
+    smpl = straps_amd.SMPL(smpl_model, batch_size=B).to(dev)
+    betas = torch.from_numpy(det_uniform((B, 10), 100 + B, -2.5, 2.5))
+    betas[0] = torch.tensor([10.0, -8.0, 6.0, 4.0, -4.0, 3.0, 3.0, -3.0, 2.0, 2.0])          # an extreme body
+    aa = torch.from_numpy(det_uniform((B, 72), 200 + B, -0.9, 0.9))
+    aa[-1] = torch.from_numpy(det_uniform((72,), 7, -3.0, 3.0))                             # rotations up to pi per axis component
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+    bd, Rd = betas.to(dev), R.to(dev)
+    v, j = smpl.forward_arrays(bd, Rd, precision=mode, kernel='wide')
+    vn, jn = smpl.forward_arrays(bd, Rd, precision=mode, kernel='narrow')
+    idx = sorted(set(list(range(min(B, 48))) + list(range(max(0, B - 48), B))))
+    v64, j64 = O.smpl_forward(smpl_model, betas[idx].double(), rotmats=R[idx].double(), dtype=torch.float64)
+    ev, ej = float((v[idx].cpu().double() - v64).abs().max()), float((j[idx].cpu().double() - j64).abs().max())
+    dn = float((v - vn).abs().max())
+    print('SMPL wide kernel B=%d %s: |verts - f64| %.2e  |joints - f64| %.2e  |wide - narrow| %.2e' % (B, mode, ev, ej, dn))
+    assert ev < 2e-5 and ej < 2e-5
+    assert dn < 2e-6 and float((j - jn).abs().max()) < 2e-6
+    assert torch.isfinite(v).all() and torch.isfinite(j).all()
+    v2, none = smpl.forward_arrays(bd, Rd, want_joints=False, precision=mode, kernel='wide')
+    assert none is None and torch.equal(v2, v)
+    v3, j3 = smpl.forward_arrays(bd, Rd, precision=mode, kernel='wide', chunks=3)           # three chunks of tile rounds per body group
+    assert torch.equal(v3, v) and torch.equal(j3, j)
+    va, ja = smpl.forward_arrays(bd, Rd, precision=mode)                                     # the automatic choice
+    ref_v, ref_j = (v, j) if B >= 2048 else (vn, jn)
+    assert torch.equal(va, ref_v) and torch.equal(ja, ref_j)
+    if B > 80:
+        vs, js = smpl.forward_arrays(bd[60:71].contiguous(), Rd[60:71].contiguous(), precision=mode, kernel='wide')
+        assert torch.equal(vs, v[60:71]) and torch.equal(js, j[60:71])
+    with pytest.raises(ValueError):
+        smpl.forward_arrays(bd, Rd, precision=mode, kernel='fast')
+    with pytest.raises(RuntimeError):
+        smpl.forward_arrays(bd, Rd, precision='fp32', kernel='wide')                        # the wide kernel exists for the matrix-pipe modes only

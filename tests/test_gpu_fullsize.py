@@ -70,6 +70,12 @@ def test_smpl_bench_size_slices_are_batch_independent():
     # and three of them against the oracle
     vo, jo = O.smpl_forward(model, betas[:3].cpu(), rotmats=R[:3].cpu())
     assert float((v[:3].cpu() - vo).abs().max()) < 1e-5 and float((j[:3].cpu() - jo).abs().max()) < 1e-5
+    # the same through the kernel bench.py --config 4 times (fp16x3_lbs at this size = the 64-body kernel): slices alone == rows of the big launch
+    vw, jw = smpl.forward_arrays(betas, R, precision='fp16x3_lbs')
+    assert torch.isfinite(vw).all() and float((vw - v).abs().max()) < 1e-5 and float((jw - j).abs().max()) < 1e-5
+    for lo, n in ((0, 33), (31999, 70), (65500, 36)):
+        vs, js = smpl.forward_arrays(betas[lo:lo + n].contiguous(), R[lo:lo + n].contiguous(), precision='fp16x3_lbs', kernel='wide')
+        assert torch.equal(vs, vw[lo:lo + n]) and torch.equal(js, jw[lo:lo + n])
 
 
 def test_rasteriser_b64_equals_per_body_renders():

@@ -285,3 +285,43 @@ def test_split_precision_blend_operand_error_budget():
     e32 = float(np.abs((F @ D[:, :6890].reshape(224, -1).astype(np.float32)) - exact).max())
     print('split-precision blend: max abs error %.2e m (plain fp32 contraction: %.2e m)' % (e, e32))
     assert e < 3e-6 and e <= 1.5 * e32 + 1e-7 and np.isfinite(acc).all()      # no worse than a plain fp32 contraction
+
+
+def test_k_packed_skinning_operand_reproduces_the_three_product_split():
+    """skin_frag_p (smpl.pack_smpl_model; the 64-body SMPL kernel's B operand): the three products of the two-term fp16 split packed along K,
+    T = [Ah | Al | Ah | -] . [Wh | Wh | Wl | 0] over 80 columns (5 k-steps of 16; columns 72..79 carry zero weights, so the A side may hold
+    anything finite there).  Emulated in float64 from the packed array exactly as the kernel reads it -- lane (i, hh) of k-step s holds
+    packed columns 16 s + 8 hh .. + 7, and k-steps 3 / 4 re-use the A registers of k-steps 0 / 1 -- it must equal Ah.Wh + Al.Wh + Ah.Wl, and
+    that must be the fp32-class value of A.W."""
+    import straps_amd
+    from straps_amd.smpl import pack_smpl_model
+    model = straps_amd.synthetic_smpl_model(0)
+    packed = pack_smpl_model(model)
+    n_tiles = packed['n_tiles']
+    P = packed['skin_frag_p'].reshape(n_tiles, 5, 2, 32, 8).astype(np.float64)          # [tile][kstep][hh][i][j]
+    H = packed['skin_frag_h'].reshape(n_tiles, 2, 2, 2, 32, 8).astype(np.float64)       # [tile][kstep][hi|lo][hh][i][j]
+    Wh = H[:, :, 0].transpose(0, 3, 1, 2, 4).reshape(n_tiles * 32, 32)                  # [vertex][joint (24 + 8 zero)]
+    Wl = H[:, :, 1].transpose(0, 3, 1, 2, 4).reshape(n_tiles * 32, 32)
+    assert not Wh[:, 24:].any() and not Wl[:, 24:].any()
+    rng = np.random.default_rng(0)
+    A = rng.uniform(-3, 3, (5, 24)).astype(np.float32)                                  # joint-transform entries of 5 bodies
+    As = (A * np.float32(1024.0)).astype(np.float32)
+    Ah = As.astype(np.float16)
+    Al = (As - Ah.astype(np.float32)).astype(np.float16)
+    Ah64, Al64 = Ah.astype(np.float64), Al.astype(np.float64)
+    # the kernel's A operand per packed k-step: rows [Ah 24 | Al 24]; k-step s, half hh reads 8 halves at 16 s + 8 hh (s < 3); s = 3, 4 re-use 0, 1
+    row = np.concatenate([Ah64, Al64], axis=1)                                          # [body][48]
+    T = np.zeros((5, n_tiles * 32))
+    Pv = P.transpose(0, 3, 1, 2, 4).reshape(n_tiles * 32, 5, 2, 8)                      # [vertex][kstep][hh][j]
+    for s_ in range(5):
+        src = s_ % 3 if s_ < 3 else s_ - 3
+        for hh in range(2):
+            a = row[:, 16 * src + 8 * hh: 16 * src + 8 * hh + 8]                        # [body][8]
+            T += a @ Pv[:, s_, hh].T
+    want = Ah64 @ Wh[:, :24].T + Al64 @ Wh[:, :24].T + Ah64 @ Wl[:, :24].T
+    assert np.array_equal(T, want)
+    W = np.zeros((n_tiles * 32, 24))
+    W[:6890] = np.asarray(model['weights'], np.float64)
+    ref = A.astype(np.float64) @ W.T
+    got = T / (1024.0 * 16384.0)
+    assert np.abs(got[:, :6890] - ref[:, :6890]).max() < 3e-6 * np.abs(ref).max()
