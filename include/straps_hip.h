@@ -273,15 +273,12 @@ typedef struct {
     const void* blend_frag_h;
     float blend_h_unscale;
     int32_t reserved1;
-    /* ---- skinning on the matrix pipe (mode STRAPS_SMPL_SPLIT_F16_LBS; may be NULL otherwise) ----
-     * fp16 two-term split of 2^14 * W, W = dense skinning weights [32*n_tiles][32] (24 joints + zero padding; the virtual
-     * vertices carry their single weight): [tile][kstep 2][hi|lo][lane 64][8], element = split(2^14 *
-     * W[vertex = 32*tile + (lane&31)][joint = 16*kstep + 8*(lane>>5) + j]).                                       */
-    const void* skin_frag_h;
-    /* the same split weights with the three products packed along K for the 64-body kernel (NULL: that kernel is not used):
-     * T = Ah.Wh + Al.Wh + Ah.Wl = [Ah | Al | Ah | -] . [Wh | Wh | Wl | 0] over 24 + 24 + 24 + 8 = 80 columns = 5 k-steps of 16 (instead of
-     * 3 products x 2 k-steps): [tile][kstep 5][lane 64][8], element = P[vertex = 32*tile + (lane&31)][col = 16*kstep + 8*(lane>>5) + j],
-     * P = [hi(2^14 W)[0:24] | hi(2^14 W)[0:24] | lo(2^14 W)[0:24] | 0 x 8].                                                          */
+    /* ---- skinning on the matrix pipe (modes STRAPS_SMPL_SPLIT_F16_LBS*; may be NULL otherwise) ----
+     * fp16 two-term split (hi, lo) of 2^14 * W, W = dense skinning weights [32*n_tiles][24] (the virtual vertices carry their single
+     * weight), with the three products of the split packed along K:
+     *   T = Ah.Wh + Al.Wh + Ah.Wl = [Ah | Al | Ah | -] . [Wh | Wh | Wl | 0]  over 24 + 24 + 24 + 8 = 80 columns = 5 k-steps of 16
+     * (instead of 3 products x 2 k-steps of the 24 joints padded to 32): [tile][kstep 5][lane 64][8], element =
+     * P[vertex = 32*tile + (lane&31)][col = 16*kstep + 8*(lane>>5) + j],  P = [hi[0:24] | hi[0:24] | lo[0:24] | 0 x 8].               */
     const void* skin_frag_p;
 } straps_smpl_model_t;
 

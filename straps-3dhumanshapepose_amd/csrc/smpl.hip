@@ -495,7 +495,13 @@ __global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model
 //     out_c = (T[4c]*x + T[4c+1]*y + T[4c+2]*z) + T[4c+3]
 // is 4 VALU operations per value: 72 MFMAs + ~250 VALU per tile instead of ~1200 VALU + the LDS gathers, any number of
 // non-zero weights per vertex, no joint-index table.  Error of the split products: 3 * 2^-22 relative per product.
-constexpr int ASH = 40;                   // halves per (entry, body) row of the split joint transforms: 80 bytes = 4 * 5 dwords
+// Round 4: the three products of the skinning split are packed along K -- T = Ah.Wh + Al.Wh + Ah.Wl = [Ah | Al | Ah | -] . [Wh | Wh | Wl | 0] over
+// 24 + 24 + 24 + 8 = 80 columns, 5 k-steps of 16 instead of 3 products x 2 k-steps (skin_frag_p, straps_hip.h): 5 MFMAs per entry instead of 6 and
+// 3 LDS operand reads instead of 4 -- k-step 3 re-uses k-step 0's registers and k-step 4 those of k-step 1, whose last 8 columns meet zero
+// weights.  Joint transforms are staged as packed [Ah 24 | Al 24 | 8 unused] rows of 112 bytes (= 4 * 7 dwords: conflict-free b128 reads).
+// Both kernels of this mode (32 and 64 bodies per workgroup) use the same chain, so their results are bit-identical.
+constexpr int ASP = 56;                   // halves per packed (entry, body) row
+constexpr int KSP = 5;                    // k-steps of the K-packed skinning product
 constexpr float A_SCALE = 1024.0f;        // 2^10: |A| < 63 (metres) before fp16 overflows
 constexpr float W_UNSCALE = 1.0f / (16384.0f * 1024.0f);   // weights are scaled 2^14 on the host
 
@@ -522,12 +528,11 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
     // accumulators hold lane = VERTEX, register = body row.  A lane's x,y,z of one (body, vertex) are then 12 contiguous bytes
     // of the output and the 32 lanes of a half-wave cover 384 contiguous bytes of one body's row: the tile leaves as sixteen
     // global_store_dwordx3 straight from the registers -- no LDS transpose, no staging buffer, no wave barrier.
-    // (The fragment packing is symmetric in the two sides: blend_frag_h / skin_frag_h are read exactly as before.)
+    // (The fragment packing is symmetric in the two sides: blend_frag_h / skin_frag_p are read the same way from either side.)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Fh = reinterpret_cast<_Float16*>(smem);            // [32][FSH]
     _Float16* Fl = Fh + BT * FSH;                                  // [32][FSH]
-    _Float16* Ah = Fl + BT * FSH;                                  // [12][32][ASH]  Ah[(e*32 + body)*ASH + joint]
-    _Float16* Al = Ah + 12 * BT * ASH;                             // [12][32][ASH]
+    _Float16* Ap = Fl + BT * FSH;                                  // [12][32][ASP]  Ap[(e*32 + body)*ASP + (0 | 24) + joint]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -594,8 +599,10 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
                 for (int e = 0; e < 12; ++e) {
                     const float x = sat_h(av[t][e >> 2][e & 3] * A_SCALE);
                     const _Float16 hi = (_Float16)x;
-                    Ah[(e * BT + b) * ASH + j] = hi;
-                    Al[(e * BT + b) * ASH + j] = (_Float16)(x - (float)hi);
+                    if (j < 24) {
+                        Ap[(e * BT + b) * ASP + j] = hi;
+                        Ap[(e * BT + b) * ASP + 24 + j] = (_Float16)(x - (float)hi);
+                    }
                 }
             }
         }
@@ -606,12 +613,11 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
     const int round1 = min(round0 + rounds_per_chunk, rounds);
     const int vrow_floats = (m.n_tiles - NT) * 96;
     const half8* __restrict__ blend = reinterpret_cast<const half8*>(m.blend_frag_h);
-    const half8* __restrict__ skin = reinterpret_cast<const half8*>(m.skin_frag_h);
+    const half8* __restrict__ skin = reinterpret_cast<const half8*>(m.skin_frag_p);
     const float us_blend = m.blend_h_unscale;
     const _Float16* fh_row = Fh + bl * FSH + 8 * h;
     const _Float16* fl_row = Fl + bl * FSH + 8 * h;
-    const _Float16* ah_row = Ah + bl * ASH + 8 * h;
-    const _Float16* al_row = Al + bl * ASH + 8 * h;
+    const _Float16* a_row = Ap + bl * ASP + 8 * h;                  // entry e adds 32 * ASP, packed k-step s adds 16 s
 
     half8 ring[PF + 1][6];
     {
@@ -650,8 +656,8 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
         const int tile = rd * NWV + wave;
         if (tile >= ntiles) break;                           // (wave-uniform: the last round may be ragged)
         // skinning-weight fragments of this tile [kstep 2][hi|lo][lane]: issued first, needed after the blend contraction
-        const half8* sp = skin + (long long)tile * 256 + lane;
-        const half8 wh0 = sp[0], wl0 = sp[64], wh1 = sp[128], wl1 = sp[192];
+        const half8* sp = skin + (long long)tile * (KSP * 64) + lane;
+        const half8 sw0 = sp[0], sw1 = sp[64], sw2 = sp[128], sw3 = sp[192], sw4 = sp[256];
         f32x16 ax, ay, az;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ax[r] = 0.f; ay[r] = 0.f; az[r] = 0.f; }
@@ -704,29 +710,26 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
         f32x16 out[3];
         const float us_rot = us_blend * W_UNSCALE;       // (T * blend) carries both scales, the translation column only the skin scale
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        half8 bh0 = *reinterpret_cast<const half8*>(ah_row), bh1 = *reinterpret_cast<const half8*>(ah_row + 16);
-        half8 bl0 = *reinterpret_cast<const half8*>(al_row), bl1 = *reinterpret_cast<const half8*>(al_row + 16);
+        half8 a0 = *reinterpret_cast<const half8*>(a_row), a1 = *reinterpret_cast<const half8*>(a_row + 16), a2 = *reinterpret_cast<const half8*>(a_row + 32);
         f32x16 Tprev = zero16, acc = zero16;
 #pragma unroll
         for (int e = 0; e <= 12; ++e) {
-            half8 nh0 = bh0, nh1 = bh1, nl0 = bl0, nl1 = bl1;
+            half8 n0 = a0, n1 = a1, n2 = a2;
             if (e + 1 < 12) {
-                nh0 = *reinterpret_cast<const half8*>(ah_row + (e + 1) * BT * ASH);
-                nh1 = *reinterpret_cast<const half8*>(ah_row + (e + 1) * BT * ASH + 16);
-                nl0 = *reinterpret_cast<const half8*>(al_row + (e + 1) * BT * ASH);
-                nl1 = *reinterpret_cast<const half8*>(al_row + (e + 1) * BT * ASH + 16);
+                n0 = *reinterpret_cast<const half8*>(a_row + (e + 1) * BT * ASP);
+                n1 = *reinterpret_cast<const half8*>(a_row + (e + 1) * BT * ASP + 16);
+                n2 = *reinterpret_cast<const half8*>(a_row + (e + 1) * BT * ASP + 32);
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x16 T = zero16;
             if (e < 12 && !(ablate & 4)) {
-                T = mfma16h(bh0, wh0, zero16);
-                T = mfma16h(bh1, wh1, T);
-                T = mfma16h(bh0, wl0, T);
-                T = mfma16h(bh1, wl1, T);
-                T = mfma16h(bl0, wh0, T);
-                T = mfma16h(bl1, wh1, T);
+                T = mfma16h(a0, sw0, zero16);
+                T = mfma16h(a1, sw1, T);
+                T = mfma16h(a2, sw2, T);
+                T = mfma16h(a0, sw3, T);                      // (packed k-steps 3, 4: the operands of 0, 1 again)
+                T = mfma16h(a1, sw4, T);
             } else if (e < 12) {
-                T[0] = (float)bh0[0] + (float)bl1[1];
+                T[0] = (float)a0[0] + (float)a2[1];
             }
             if (e > 0) {                                  // fold entry e-1 (Tprev) while the chain above is in the pipe
                 const int pe = e - 1, c = pe >> 2, q = pe & 3;
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
             }
             __builtin_amdgcn_sched_barrier(0);
             Tprev = T;
-            bh0 = nh0; bh1 = nh1; bl0 = nl0; bl1 = nl1;
+            a0 = n0; a1 = n1; a2 = n2;
         }
         // (lane = vertex, register r = body (r&3) + 8 (r>>2) + 4 h: stored after the NEXT tile's blend phase, see above)
 #pragma unroll
@@ -781,8 +784,6 @@ __global__ __launch_bounds__(NWV * 64) void smpl_verts_hh_kernel(straps_smpl_mod
 // K-packed chain, so results may differ from it in the last bit.  Operand roles, output mapping and the store form are unchanged.
 constexpr int WB = 64;                    // bodies per workgroup
 constexpr int NWW = 4;                    // waves per workgroup = one per SIMD
-constexpr int ASP = 56;                   // halves per packed (entry, body) row: [Ah 24 | Al 24 | 8 unused]; 112 bytes = 4 * 7 dwords
-constexpr int KSP = 5;                    // k-steps of the K-packed skinning product
 
 // v_mfma_f32_32x32x16_f16 with VGPR C / D.  The hazard recogniser does not see inside inline assembly; the two rules this kernel relies on
 // (MI355X guide, "inline assembly"; the compiler's own code for the builtin shows the same): an accumulate chain (D of one = C of the next,
@@ -1209,7 +1210,7 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                    "straps_smpl_fwd: unknown mode %d", mode);
     const int pd16 = mode == STRAPS_SMPL_SPLIT_F16_LBS_PD16 ? 1 : mode == STRAPS_SMPL_SPLIT_F16_LBS_P16 ? 2 : 0;
     if (pd16) mode = STRAPS_SMPL_SPLIT_F16_LBS;
-    STRAPS_REQUIRE(mode != STRAPS_SMPL_SPLIT_F16_LBS || model->skin_frag_h, "straps_smpl_fwd: mode STRAPS_SMPL_SPLIT_F16_LBS needs skin_frag_h in the model");
+    STRAPS_REQUIRE(mode != STRAPS_SMPL_SPLIT_F16_LBS || model->skin_frag_p, "straps_smpl_fwd: mode STRAPS_SMPL_SPLIT_F16_LBS needs skin_frag_p in the model");
     STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || (model->blend_frag_h && model->blend_h_unscale > 0.f),
                    "straps_smpl_fwd: split-precision mode needs blend_frag_h / blend_h_unscale in the model");
     STRAPS_REQUIRE(model->skin_k >= 1 && model->skin_k <= 24, "straps_smpl_fwd: skin_k %d out of range", model->skin_k);
@@ -1243,7 +1244,7 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                       : ablate == 7 ? smpl_verts_hh_kernel<8, 1, 7> : ablate == 15 ? smpl_verts_hh_kernel<8, 1, 15> : hh_kernel;
     }
 #endif
-    const size_t lds = split == 2 ? (size_t)(BT * FSH + 12 * BT * ASH) * sizeof(float)
+    const size_t lds = split == 2 ? (size_t)(2 * BT * FSH + 12 * BT * ASP) * sizeof(_Float16)
                                   : (size_t)(BT * (split ? FSH : FS) + BT * AS + NW * BT * HS + NW * 256) * sizeof(float);
     static unsigned long long lds_raised[5] = {0, 0, 0, 0, 0};          // per kernel variant: bit mask of the devices done
     {

@@ -72,7 +72,7 @@ class SmplModelStruct(C.Structure):
                 ('skin_w', C.c_void_p), ('skin_j', C.c_void_p), ('vj_ptr', C.c_void_p), ('n_tiles', C.c_int32),
                 ('reserved0', C.c_int32), ('pick_ids', C.c_void_p), ('blend_frag_t', C.c_void_p), ('children', C.c_void_p),
                 ('jrt_ptr', C.c_void_p), ('jrt_code', C.c_void_p), ('jrt_w', C.c_void_p), ('dj_ptr', C.c_void_p), ('dj_code', C.c_void_p),
-                ('dj_w', C.c_void_p), ('blend_frag_h', C.c_void_p), ('blend_h_unscale', C.c_float), ('reserved1', C.c_int32), ('skin_frag_h', C.c_void_p), ('skin_frag_p', C.c_void_p)]
+                ('dj_w', C.c_void_p), ('blend_frag_h', C.c_void_p), ('blend_h_unscale', C.c_float), ('reserved1', C.c_int32), ('skin_frag_p', C.c_void_p)]
 
 
 class PackDesc(C.Structure):

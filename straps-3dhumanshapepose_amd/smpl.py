@@ -104,16 +104,14 @@ def pack_smpl_model(model):
     if nvirt:
         sw[VPAD:VPAD + nvirt, 0] = np.asarray(vs_, np.float32)
         sj[VPAD:VPAD + nvirt, 0] = np.asarray(vk_, np.int32)
-    # dense skinning weights for the matrix-pipe skinning (straps_hip.h: skin_frag_h): two-term fp16 split of 2^14 * W,
-    # [tile][kstep][hi|lo][hh][i][j]  <-  W[32t + i][16 ks + 8 hh + j]   (24 joints + 8 columns of K padding)
+    # dense skinning weights for the matrix-pipe skinning (straps_hip.h: skin_frag_p): two-term fp16 split of 2^14 * W (24 joints)
     Wd = np.zeros((n_tiles * 32, 32), np.float32)
     np.add.at(Wd, (np.repeat(np.arange(n_tiles * 32), k), sj.reshape(-1)), sw.reshape(-1))
     assert float(np.abs(Wd).max()) < 3.9, 'skinning weight too large for the fp16 split (|w| * 2^14 must stay below 65504)'
     Ws = Wd * np.float32(2.0 ** 14)
     Wh = Ws.astype(np.float16)
     Wl = (Ws - Wh.astype(np.float32)).astype(np.float16)
-    skin_frag_h = np.stack([Wh, Wl], axis=0).reshape(2, n_tiles, 32, 2, 2, 8).transpose(1, 3, 0, 4, 2, 5).copy()
-    # the same weights with the three products of the split packed along K (straps_hip.h: skin_frag_p; the 64-body kernel):
+    # with the three products of the split packed along K:
     #   T = Ah.Wh + Al.Wh + Ah.Wl = [Ah | Al | Ah | .] . [Wh | Wh | Wl | 0]   over 24 + 24 + 24 + 8 = 80 columns = 5 k-steps (not 3 x 2 = 6)
     # [tile][kstep 5][hh][i][j]  <-  P[32t + i][16 ks + 8 hh + j]
     Wp = np.concatenate([Wh[:, :24], Wh[:, :24], Wl[:, :24], np.zeros((n_tiles * 32, 8), np.float16)], axis=1)
@@ -158,8 +156,7 @@ def pack_smpl_model(model):
         'blend_frag_t': frag_t.reshape(-1), 'children': children,
         'jrt_ptr': jrt_ptr, 'jrt_code': (((vs % 32) << 8) | src).astype(np.int32), 'jrt_w': ws,
         'blend_frag': frag.reshape(-1),
-        'blend_frag_h': frag_h.reshape(-1), 'blend_h_unscale': float(2.0 ** -(sd_exp + 6)), 'skin_frag_h': skin_frag_h.reshape(-1),
-        'skin_frag_p': skin_frag_p.reshape(-1),
+        'blend_frag_h': frag_h.reshape(-1), 'blend_h_unscale': float(2.0 ** -(sd_exp + 6)),         'skin_frag_p': skin_frag_p.reshape(-1),
         'j_template': (Jr @ vt).astype(np.float32),
         'j_shapedirs': np.einsum('jv,vcl->jcl', Jr, sd).astype(np.float32),
         'parents': parents, 'depth': depth, 'max_depth': int(depth.max()), 'skin_k': k,
@@ -213,7 +210,7 @@ class SMPL(nn.Module):
         key = self._k_blend_frag.data_ptr()
         if self._struct_key != key:
             s = hipabi.SmplModelStruct()
-            for f in ('blend_frag', 'blend_frag_h', 'skin_frag_h', 'skin_frag_p', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
+            for f in ('blend_frag', 'blend_frag_h', 'skin_frag_p', 'j_template', 'j_shapedirs', 'parents', 'depth', 'skin_w', 'skin_j', 'vj_ptr',
                       'pick_ids', 'blend_frag_t', 'children', 'jrt_ptr', 'jrt_code', 'jrt_w', 'dj_ptr', 'dj_code', 'dj_w'):
                 setattr(s, f, getattr(self, '_k_' + f).data_ptr())
             s.max_depth, s.skin_k, s.n_tiles = self.max_depth, self.skin_k, self.n_tiles

@@ -41,7 +41,7 @@ def child(args):
         v64, j64 = O.smpl_forward(model, betas[sel].double(), rotmats=R[sel].double(), dtype=torch.float64)
         ev = float((v[sel].cpu().double() - v64).abs().max())
         ej = float((j[sel].cpu().double() - j64).abs().max())
-        dn = float((v - vn).abs().max())
+        dn = float((v - vn).abs().max())      # (0: both kernels run the same accumulation chains)
         print('%s  B=%d  |verts - f64| %.2e  |joints - f64| %.2e  |wide - narrow| %.2e  finite %s' % (tag, Bp, ev, ej, dn, bool(torch.isfinite(v).all())))
     # ---- timing ----
     B = args.batch
