@@ -196,7 +196,7 @@ def step_dtype(args):
 
 OTHER_CONFIGS = (('configs[1]', ['--config', '1', '--steps', '20', '--warmup', '3']),
                  ('configs[3] per-GPU shape', ['--config', '3', '--steps', '10', '--warmup', '3']),
-                 ('configs[4]', ['--config', '4', '--steps', '4', '--warmup', '2']))
+                 ('configs[4]', ['--config', '4', '--steps', '16', '--warmup', '3']))
 
 
 def run_other_configs():

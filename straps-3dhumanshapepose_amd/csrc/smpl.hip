@@ -958,8 +958,11 @@ void smpl_verts_w_kernel(straps_smpl_model_t m, const float* __restrict__ F, con
     }
     f32x16 outp[2][3];                                        // (SV & 4: the previous tile's results, stored inside this tile's blend phase)
     int ptile = -1;
+    unsigned long long ph_blend = 0, ph_skin0 = 0, ph_skin1 = 0;      // (ABL & 128: shader cycles per phase, summed over this wave's tiles)
     for (int rd = round0; rd < round1; ++rd, tile += NWW) {
         if (tile >= ntiles) break;                           // (wave-uniform: the last round may be ragged)
+        unsigned long long ph_t0 = 0;
+        if (ABL & 128) ph_t0 = __builtin_amdgcn_s_memtime();
         const bool has_next = rd + 1 < round1 && tile + NWW < ntiles;
         const half8* p = blend + (long long)tile * (KS * 6 * 64) + lane;
         const half8* pn = has_next ? p + (long long)NWW * (KS * 6 * 64) : p;      // (no next tile: the head loads re-read this one, unused)
@@ -1041,6 +1044,7 @@ void smpl_verts_w_kernel(straps_smpl_model_t m, const float* __restrict__ F, con
             if (!in_loop && !(ABL & 2)) load_step(ring[j], pn + j * 384, j);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (ABL & 128) { const unsigned long long t = __builtin_amdgcn_s_memtime(); ph_blend += t - ph_t0; ph_t0 = t; }
         // ---------------- skinning on the matrix pipe, K-packed: T_e[body][vertex] = [Ah | Al | Ah | -][body] . [Wh | Wh | Wl | 0][vertex] ----------------
         // Software pipeline over the twelve entries: [LDS operands of e + 1] -> [5-MFMA chain of e into one of two result buffers] -> [fold of
         // e - 1 from the other buffer on the VALU while that chain runs].  out_c = (T[4c] x + T[4c+1] y + T[4c+2] z) us_rot + T[4c+3] us_w.
@@ -1115,6 +1119,7 @@ void smpl_verts_w_kernel(straps_smpl_model_t m, const float* __restrict__ F, con
                 else store_group(tile, g, out, true);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 128) { const unsigned long long t = __builtin_amdgcn_s_memtime(); (g ? ph_skin1 : ph_skin0) += t - ph_t0; ph_t0 = t; }
         }
         ptile = tile;
     }
@@ -1128,6 +1133,9 @@ void smpl_verts_w_kernel(straps_smpl_model_t m, const float* __restrict__ F, con
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(clk, (unsigned long long)__builtin_amdgcn_s_memtime() - clk_c0);
         atomicAdd(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_w0);
+    }
+    if ((ABL & 128) && clk && lane == 0 && (blockIdx.x % 61) == 0) {      // (tools: a sample of the workgroups; clk points at >= 6 counters then)
+        atomicAdd(clk + 2, ph_blend); atomicAdd(clk + 3, ph_skin0); atomicAdd(clk + 4, ph_skin1); atomicAdd(clk + 5, (unsigned long long)(round1 - round0));
     }
 }
 
@@ -1303,7 +1311,9 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
             w_kernel = wabl == 1 ? smpl_verts_w_kernel<3, 0, 1, 1> : wabl == 2 ? smpl_verts_w_kernel<3, 0, 1, 2> : wabl == 3 ? smpl_verts_w_kernel<3, 0, 1, 3>
                      : wabl == 4 ? smpl_verts_w_kernel<3, 0, 1, 4> : wabl == 8 ? smpl_verts_w_kernel<3, 0, 1, 8> : wabl == 12 ? smpl_verts_w_kernel<3, 0, 1, 12>
                      : wabl == 15 ? smpl_verts_w_kernel<3, 0, 1, 15> : wabl == 16 ? smpl_verts_w_kernel<3, 0, 1, 16> : wabl == 32 ? smpl_verts_w_kernel<3, 0, 1, 32>
-                     : wabl == 64 ? smpl_verts_w_kernel<3, 0, 1, 64> : wabl == 66 ? smpl_verts_w_kernel<3, 0, 1, 66> : smpl_verts_w_kernel<3, 0, 1, 63>;
+                     : wabl == 64 ? smpl_verts_w_kernel<3, 0, 1, 64> : wabl == 66 ? smpl_verts_w_kernel<3, 0, 1, 66> : wabl == 128 ? smpl_verts_w_kernel<3, 0, 1, 128, SV_PRODUCT>
+                     : wabl == 129 ? smpl_verts_w_kernel<3, 0, 1, 129, SV_PRODUCT> : wabl == 130 ? smpl_verts_w_kernel<3, 0, 1, 130, SV_PRODUCT>
+                     : wabl == 131 ? smpl_verts_w_kernel<3, 0, 1, 131, SV_PRODUCT> : smpl_verts_w_kernel<3, 0, 1, 63>;
             wslot = 5;      // (one variant per process: the switches are read once)
         }
 #endif

@@ -44,18 +44,30 @@ def decisions_from_tape(net, tape):
     return {'relu': [a > 0 for a in acts], 'pool': pool, 'act': acts}
 
 
-def compare_encoder_decisions(gpu, rec64):
+ERR_CAP = 2e-5      # a layer's activation error may be at most this fraction of the layer's largest float64 pre-activation (resnet18: measured 4.6e-6)
+ERR_CAP_R50 = 5e-5  # resnet50: 53 convolutions deep, measured 2.1e-5 on its worst layer
+
+
+def compare_encoder_decisions(gpu, rec64, err_cap=ERR_CAP):
     """gpu: gpu_encoder_decisions()[0]; rec64: the oracle's {'record': True} dict after its float64 forward.
     -> (number of differing ReLU decisions, number of differing pooling decisions, worst |z64| of a differing ReLU relative to the
-    activation error observed on its layer, worst float64 gap of a differing window relative to the stem's activation error).
-    A ratio <= ~4 is a tie: the other side of the decision lies within the evaluation error."""
+    activation error observed on its layer, worst float64 gap of a differing window relative to the stem's activation error, worst
+    activation error of a layer relative to its largest float64 pre-activation).
+    A ratio <= ~4 is a tie: the other side of the decision lies within the evaluation error.
+    The tie scale is the GPU's OWN observed error on the layer (max |a - z64| over the units both sides switch on), so it is capped here
+    against the float64 values alone (a layer that was systematically off must not widen its own tie window): the
+    error has to stay below err_cap x max |z64| of the layer -- fp32-class evaluation -- or the comparison fails outright."""
     assert len(gpu['relu']) == len(gpu['act']) == len(rec64['z']), 'the two evaluations list different numbers of ReLUs'
-    n_relu, worst_relu = 0, 0.0
+    n_relu, worst_relu, worst_rel = 0, 0.0, 0.0
     errs = []
-    for m, a, z in zip(gpu['relu'], gpu['act'], rec64['z']):
+    for li, (m, a, z) in enumerate(zip(gpu['relu'], gpu['act'], rec64['z'])):
         z = z.double()
         both = m & (z > 0)
         err = float((a - z)[both].abs().max()) if both.any() else 0.0
+        zmax = float(z.abs().max())
+        assert err <= err_cap * zmax, ('ReLU layer %d: activation error %.3e exceeds %.1e x max|z64| = %.3e -- the layer is off by more than fp32 '
+                                      'evaluation error; its tie window would be meaningless' % (li, err, err_cap, err_cap * zmax))
+        worst_rel = max(worst_rel, err / max(zmax, 1e-30))
         errs.append(err)
         diff = m != (z > 0)
         k = int(diff.sum())
@@ -68,7 +80,7 @@ def compare_encoder_decisions(gpu, rec64):
     diff = chosen < best
     n_pool = int(diff.sum())
     worst_pool = float((best - chosen)[diff].max()) / max(errs[0], 1e-30) if n_pool else 0.0
-    return n_relu, n_pool, worst_relu, worst_pool
+    return n_relu, n_pool, worst_relu, worst_pool, worst_rel
 
 
 def gpu_ief_masks(ief, feat):

@@ -341,7 +341,7 @@ def test_regressor_param_grads_vs_reference_golden(dev, layers):
     rec64 = {'record': True}
     sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     O.regressor_forward(x.cpu().double(), sd64, O.ief_init_estimate(MP['pose'], MP['shape']).double(), layers, 3, training=True, enc_decisions=rec64)
-    n_relu, n_pool, tie_relu, tie_pool = decisions.compare_encoder_decisions(dec, rec64)
+    n_relu, n_pool, tie_relu, tie_pool, act_err = decisions.compare_encoder_decisions(dec, rec64, decisions.ERR_CAP if layers == 18 else decisions.ERR_CAP_R50)
     assert tie_relu <= 4.0 and tie_pool <= 4.0
     sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     for n in names:
@@ -398,7 +398,7 @@ def test_eval_mode_gradients_through_frozen_batchnorm_vs_float64_oracle(dev, lay
     # the decisions the GPU took (taped forward = the forward of the backward above), unit by unit against float64's
     dec, feat = decisions.gpu_encoder_decisions(reg.image_encoder, x)
     masks = decisions.gpu_ief_masks(reg.ief_module, feat)
-    n_relu, n_pool, tie_relu, tie_pool = decisions.compare_encoder_decisions(dec, rec64)
+    n_relu, n_pool, tie_relu, tie_pool, act_err = decisions.compare_encoder_decisions(dec, rec64, decisions.ERR_CAP if layers == 18 else decisions.ERR_CAP_R50)
     n_ief = sum(int((m != (z > 0)).sum()) for pair, zs in zip(masks, taps64) for m, z in zip(pair, zs))
     total_units = sum(m.numel() for m in dec['relu'])
     print('eval-mode r%d %s: %d of %d encoder ReLU decisions, %d of %d pooling windows and %d IEF ReLU decisions differ from float64 '

@@ -179,7 +179,8 @@ def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5, enc_bar=5e
     torch.cuda.synchronize()
     dec = decisions.decisions_from_tape(reg.image_encoder, ts.last['enc_tape'])
     ts.keep_enc_tape, ts.last['enc_tape'] = False, None
-    n_relu, n_pool, tie_relu, tie_pool = decisions.compare_encoder_decisions(dec, rec64)
+    err_cap = decisions.ERR_CAP if layers == 18 else decisions.ERR_CAP_R50
+    n_relu, n_pool, tie_relu, tie_pool, act_err = decisions.compare_encoder_decisions(dec, rec64, err_cap)
     n_units = sum(m.numel() for m in dec['relu'])
     del rec64
     masks, flips, zerr = _ief_relu_flips(ts, taps)
@@ -210,9 +211,9 @@ def _whole_step_vs_float64(ts, reg, crit, layers, tag, loss_rel=1e-5, enc_bar=5e
             bad.append('%-52s gpu %.2e  bar %.2e' % table[-1])
     enc = sorted(t[1] for t in table if t[0].startswith('image_encoder.'))
     print(tag, '%d tensors | %d of %d encoder ReLU decisions, %d of %d pooling windows, %d IEF ReLU decisions differ from float64 (ties: |z64| / gap <= %.2f x / %.2f x '
-          'the layer\'s activation error) | relative gradient error vs the float64 oracle on the GPU\'s decisions: IEF worst %.2e, encoder median %.2e worst %.2e'
+          'the layer\'s activation error, itself <= %.1e of the layer\'s largest float64 pre-activation: cap %.0e) | relative gradient error vs the float64 oracle on the GPU\'s decisions: IEF worst %.2e, encoder median %.2e worst %.2e'
           ' | vs the plain float64 run: worst %s (float32 CPU oracle: %.2e)'
-          % (len(table), n_relu, n_units, n_pool, ts.B * 64 * 64 * 64, len(flips), tie_relu, tie_pool, max(t[1] for t in table if t[0].startswith('ief_module.')),
+          % (len(table), n_relu, n_units, n_pool, ts.B * 64 * 64 * 64, len(flips), tie_relu, tie_pool, act_err, err_cap, max(t[1] for t in table if t[0].startswith('ief_module.')),
              enc[len(enc) // 2], enc[-1], 'same run' if plain_worst is None else '%.2e' % plain_worst, e32))
     assert not bad, '\n'.join(bad)
     for name in O.LOSS_TASKS:

@@ -54,7 +54,7 @@ def child(args):
         smpl.forward_arrays(betas, R, precision=args.mode, kernel=args.kernel, out_verts=verts, out_joints=joints)
     torch.cuda.synchronize()
     L = hipabi.lib()
-    clk = torch.zeros(2, dtype=torch.int64, device=dev)      # (shader ticks, wall ticks) of workgroup 0 of every vertex-kernel launch
+    clk = torch.zeros(8, dtype=torch.int64, device=dev)      # (shader ticks, wall ticks) of workgroup 0 of every vertex-kernel launch (+ WABL & 128: phase cycles)
     hipabi.check(L.straps_set_clock_accumulator(hipabi.ptr(clk)), 'straps_set_clock_accumulator')
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -64,9 +64,13 @@ def child(args):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / args.iters
     hipabi.check(L.straps_set_clock_accumulator(None), 'straps_set_clock_accumulator')
-    c, w = (int(v) for v in clk.tolist())
+    cl = [int(v) for v in clk.tolist()]
+    c, w = cl[0], cl[1]
     mhz = c / w * L.straps_wall_clock_khz() / 1e3 if w > 0 else 0.0
     print('%s  B=%d  %.3f ms/call  %.2f M bodies/s  HBM frac %.3f  sclk %.0f MHz' % (tag, B, ms, B / ms / 1e3, B * 84664.0 / (ms * 1e-3) / 8e12, mhz))
+    if cl[5]:      # (WABL & 128) shader cycles per tile and phase, averaged over the sampled waves: ideal = 252 x 32 = 8064 (blend), 60 x 32 = 1920 per skinning group
+        print('%s  cycles per tile: blend %.0f (MFMA floor 8064)  skin g0 %.0f  skin g1 %.0f (floor 1920 each)  total %.0f (floor 11904)'
+              % (tag, cl[2] / cl[5], cl[3] / cl[5], cl[4] / cl[5], (cl[2] + cl[3] + cl[4]) / cl[5]))
 
 
 def sweep(args):
