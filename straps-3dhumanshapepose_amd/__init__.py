@@ -7,7 +7,7 @@ library / a GPU raises.
 """
 from . import config, hipabi  # noqa: F401
 from .synthetic_smpl import synthetic_smpl_model, synthetic_mean_params, load_smpl_model  # noqa: F401
-from .resnet import ResNet, resnet18, resnet50  # noqa: F401
+from .resnet import ResNet, BasicBlock, Bottleneck, resnet18, resnet50  # noqa: F401
 from .ief_module import IEFModule  # noqa: F401
 from .regressor import SingleInputRegressor  # noqa: F401
 from .smpl import SMPL, ModelOutput, pack_smpl_model  # noqa: F401

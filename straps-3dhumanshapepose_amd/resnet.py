@@ -1,5 +1,5 @@
-"""ResNet-18/50 proxy-representation encoder -- drop-in for reference models/resnet.py (class
-ResNet without the FC head, factories resnet18/resnet50).
+"""ResNet-18/50 proxy-representation encoder -- drop-in for reference models/resnet.py (classes
+BasicBlock / Bottleneck / ResNet(block, layers, in_channels, ...) without the FC head, factories resnet18/resnet50).
 
 The nn.Conv2d / nn.BatchNorm2d objects below are PARAMETER CONTAINERS only: they give the module
 the reference's state-dict keys (`conv1.weight`, `layer2.0.downsample.1.running_var`, ...), its
@@ -15,19 +15,39 @@ from . import hipabi
 BN_EPS = 1e-5
 
 
+def _check_block_args(name, groups, base_width, dilation, norm_layer):
+    """the argument checks of models/resnet.py:44-52 (BasicBlock raises for groups / base_width / dilation itself); this build implements the
+    plain variants the regressor uses -- grouped / wide / dilated bottlenecks and other normalisation layers have no kernel."""
+    if norm_layer is not None and norm_layer is not nn.BatchNorm2d:
+        raise NotImplementedError('%s: only nn.BatchNorm2d is implemented by the HIP encoder (got norm_layer=%r)' % (name, norm_layer))
+    if groups != 1 or base_width != 64:
+        if name == 'BasicBlock':
+            raise ValueError('BasicBlock only supports groups=1 and base_width=64')        # models/resnet.py:49-50
+        raise NotImplementedError('Bottleneck: groups / width_per_group other than 1 / 64 are not implemented by the HIP encoder')
+    if dilation > 1:
+        raise NotImplementedError('Dilation > 1 not supported in %s' % name)              # models/resnet.py:51-52 (BasicBlock); no dilated kernel here
+
+
 class ResidualUnit(nn.Module):
     """One residual block.  kind 'basic': 3x3(s) - 3x3 (models/resnet.py:39-77); kind 'bottleneck':
     1x1 - 3x3(s) - 1x1 with 4x expansion (:80-121).  A 1x1(s)+BN projection on the skip path when the
-    shape changes (:183-187)."""
+    shape changes (:183-187) -- built here (`project`) or handed in by the caller (`downsample`, like the reference's `_make_layer`)."""
 
-    def __init__(self, kind, inplanes, planes, stride, project):
+    def __init__(self, kind, inplanes, planes, stride, project, downsample=None):
         super().__init__()
         self.kind, self.stride = kind, stride
         out_planes = planes * (4 if kind == 'bottleneck' else 1)
         # the reference builds the projection BEFORE the block's own convs (models/resnet.py:183-190);
         # constructing in that order keeps seeded construction bit-identical.
-        proj = None
-        if project:
+        proj = downsample
+        if proj is not None:
+            ok = (isinstance(proj, nn.Sequential) and len(proj) == 2 and isinstance(proj[0], nn.Conv2d) and isinstance(proj[1], nn.BatchNorm2d)
+                  and proj[0].kernel_size == (1, 1) and proj[0].bias is None and proj[0].in_channels == inplanes
+                  and proj[0].out_channels == out_planes and proj[0].stride == (stride, stride))
+            if not ok:
+                raise NotImplementedError('downsample must be nn.Sequential(conv1x1(inplanes, %d, stride=%d, bias=False), nn.BatchNorm2d(%d)) -- the '
+                                          'projection models/resnet.py:183-187 builds; other skip paths have no kernel' % (out_planes, stride, out_planes))
+        elif project:
             proj = nn.Sequential(nn.Conv2d(inplanes, out_planes, 1, stride, bias=False), nn.BatchNorm2d(out_planes))
         if kind == 'basic':
             self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
@@ -48,29 +68,64 @@ class ResidualUnit(nn.Module):
         names = ['1', '2'] + (['3'] if self.kind == 'bottleneck' else [])
         return [(getattr(self, 'conv' + n), getattr(self, 'bn' + n)) for n in names]
 
+    def forward(self, x):
+        raise RuntimeError('residual blocks are parameter containers: the encoder runs as a whole through ResNet.forward (HIP kernels, no per-module '
+                           'forward and no CPU fallback)')
+
+
+class BasicBlock(ResidualUnit):
+    """models/resnet.py:39-77, same constructor."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None):
+        _check_block_args('BasicBlock', groups, base_width, dilation, norm_layer)
+        super().__init__('basic', inplanes, planes, stride, False, downsample)
+
+
+class Bottleneck(ResidualUnit):
+    """models/resnet.py:80-121, same constructor."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None):
+        _check_block_args('Bottleneck', groups, base_width, dilation, norm_layer)
+        super().__init__('bottleneck', inplanes, planes, stride, False, downsample)
+
 
 class ResNet(nn.Module):
-    def __init__(self, kind, counts, in_channels, zero_init_residual=False, conv_precision='bf16x3'):
-        """conv_precision (extension, also an attribute that may be set at any time; NOT part of the state dict): arithmetic of the
+    def __init__(self, block, layers, in_channels, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None, conv_precision='bf16x3'):
+        """The reference's signature (models/resnet.py:124-129): block = BasicBlock | Bottleneck (the strings 'basic' / 'bottleneck' of earlier
+        rounds are still accepted), layers = blocks per stage.  num_classes is accepted and unused like there (the FC head is commented out,
+        :158); groups / width_per_group / replace_stride_with_dilation / norm_layer other than their defaults raise: no kernel implements them.
+        conv_precision (extension, also an attribute that may be set at any time; NOT part of the state dict): arithmetic of the
         3x3 / 1x1 convolutions -- 'bf16x3' (default): fp32 operands as exact bf16 triples on the bf16 matrix pipe, six products per
         term, fp32 accumulate (the fp32 chain's accuracy class: tests/test_gpu_conv_x3.py), 'fp32': the exact fp32-input MFMA chain."""
         super().__init__()
         if conv_precision not in ('fp32', 'bf16x3'):
             raise ValueError("conv_precision must be 'fp32' or 'bf16x3'")
-        self.kind, self.in_channels = kind, in_channels
-        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        inplanes = 64
-        expansion = 4 if kind == 'bottleneck' else 1
-        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), counts)):
-            units = []
-            for bi in range(n):
-                stride = 2 if (li > 0 and bi == 0) else 1
-                project = bi == 0 and (stride != 1 or inplanes != planes * expansion)
-                units.append(ResidualUnit(kind, inplanes, planes, stride, project))
-                inplanes = planes * expansion
-            setattr(self, 'layer%d' % (li + 1), nn.Sequential(*units))
-        self.num_features = inplanes
+        if isinstance(block, str):
+            block = {'basic': BasicBlock, 'bottleneck': Bottleneck}[block]
+        if block not in (BasicBlock, Bottleneck):
+            raise NotImplementedError('ResNet: block must be BasicBlock or Bottleneck (got %r)' % (block,))
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError("replace_stride_with_dilation should be None or a 3-element tuple, got {}".format(replace_stride_with_dilation))   # :139-141
+        if any(replace_stride_with_dilation):
+            raise NotImplementedError('replace_stride_with_dilation: dilated stages are not implemented by the HIP encoder')
+        _check_block_args(block.__name__, groups, width_per_group, 1, norm_layer)
+        if len(layers) != 4:
+            raise ValueError('ResNet: layers must list the blocks of the four stages')
+        self.kind, self.in_channels = ('basic' if block is BasicBlock else 'bottleneck'), in_channels
+        self.groups, self.base_width, self.dilation = groups, width_per_group, 1
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, self.inplanes, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(self.inplanes)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.num_features = self.inplanes
         # models/resnet.py:160-165: kaiming-normal(fan_out, relu) convs, BN gamma=1 beta=0, in modules() order
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -89,6 +144,19 @@ class ResNet(nn.Module):
         # are fp32 MFMA on both routes.
         self.conv_precision = conv_precision
         self._bn_epoch = 0          # bumped by every training-mode forward (running statistics change behind torch's back)
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilate=False):
+        """models/resnet.py:177-199: the projection is built first, then the first block, then the rest (same construction order, same RNG use)"""
+        if dilate:
+            raise NotImplementedError('dilated stages are not implemented by the HIP encoder')
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False), nn.BatchNorm2d(planes * block.expansion))
+        units = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, 1, None)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            units.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width, dilation=self.dilation, norm_layer=None))
+        return nn.Sequential(*units)
 
     # ---- packed-weight / folded-BN caches, refreshed when a parameter's version changes ----
     def _cached(self, key, tensors, make, extra=()):
@@ -222,11 +290,11 @@ def resnet18(in_channels, pretrained=False, progress=True, **kwargs):
     network); the reference always passes False on this path (models/regressor.py:30)."""
     if pretrained:
         raise NotImplementedError('pretrained ImageNet weights are not available in this build')
-    return ResNet('basic', [2, 2, 2, 2], in_channels, **kwargs)
+    return ResNet(BasicBlock, [2, 2, 2, 2], in_channels, **kwargs)
 
 
 def resnet50(in_channels, pretrained=False, progress=True, **kwargs):
     """models/resnet.py:250-258."""
     if pretrained:
         raise NotImplementedError('pretrained ImageNet weights are not available in this build')
-    return ResNet('bottleneck', [3, 4, 6, 3], in_channels, **kwargs)
+    return ResNet(Bottleneck, [3, 4, 6, 3], in_channels, **kwargs)
