@@ -1313,7 +1313,9 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                      : wabl == 15 ? smpl_verts_w_kernel<3, 0, 1, 15> : wabl == 16 ? smpl_verts_w_kernel<3, 0, 1, 16> : wabl == 32 ? smpl_verts_w_kernel<3, 0, 1, 32>
                      : wabl == 64 ? smpl_verts_w_kernel<3, 0, 1, 64> : wabl == 66 ? smpl_verts_w_kernel<3, 0, 1, 66> : wabl == 128 ? smpl_verts_w_kernel<3, 0, 1, 128, SV_PRODUCT>
                      : wabl == 129 ? smpl_verts_w_kernel<3, 0, 1, 129, SV_PRODUCT> : wabl == 130 ? smpl_verts_w_kernel<3, 0, 1, 130, SV_PRODUCT>
-                     : wabl == 131 ? smpl_verts_w_kernel<3, 0, 1, 131, SV_PRODUCT> : smpl_verts_w_kernel<3, 0, 1, 63>;
+                     : wabl == 131 ? smpl_verts_w_kernel<3, 0, 1, 131, SV_PRODUCT> : wabl == 151 ? smpl_verts_w_kernel<3, 0, 1, 151, SV_PRODUCT>
+                     : wabl == 183 ? smpl_verts_w_kernel<3, 0, 1, 183, SV_PRODUCT> : wabl == 135 ? smpl_verts_w_kernel<3, 0, 1, 135, SV_PRODUCT>
+                     : smpl_verts_w_kernel<3, 0, 1, 63>;
             wslot = 5;      // (one variant per process: the switches are read once)
         }
 #endif

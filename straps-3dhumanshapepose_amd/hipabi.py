@@ -17,6 +17,10 @@ SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', '
 
 _lib = None
 LINK_LIBS = ['-ldl']
+# per-source compiler flags.  smpl.hip: the SLP vectoriser packs the fold of the matrix-pipe SMPL kernels into v_pk_fma_f32 / v_pk_mul_f32, which
+# cost several times a scalar v_fma_f32 beside MFMAs (MI355X guide: "packed f32 VALU: an anti-lever beside MFMAs"; measured on the 64-body
+# kernel: 3.00 -> 2.87 ms per 65 536 bodies, profiles/r04_smpl_w_ab.txt)
+EXTRA_FLAGS = {'smpl.hip': ['-fno-slp-vectorize']}
 
 
 def _existing_sources():
@@ -43,6 +47,9 @@ def build(force=False, verbose=False, tools=False):
         return lib_path
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DSTRAPS_TOOLS'] if tools else [])
+    extra = dict(EXTRA_FLAGS)
+    if tools and os.environ.get('STRAPS_TOOLS_SMPL_FLAGS'):      # (build-time A/B of compiler flags for one source: tools library only)
+        extra['smpl.hip'] = extra.get('smpl.hip', []) + os.environ['STRAPS_TOOLS_SMPL_FLAGS'].split()
     # one object per source (csrc/build/*.o, compiled in parallel, rebuilt only when the source or a header is newer), then one link
     objdir = os.path.join(os.path.dirname(TOOLS_LIB_PATH), 'build') if tools else os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)
@@ -50,7 +57,7 @@ def build(force=False, verbose=False, tools=False):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + '.o')
         if force or not os.path.isfile(o) or any(os.path.getmtime(o) <= os.path.getmtime(d) for d in [s] + hdrs):
-            cmd = [hipcc] + flags + ['-c', s, '-o', o]
+            cmd = [hipcc] + flags + extra.get(os.path.basename(s), []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
