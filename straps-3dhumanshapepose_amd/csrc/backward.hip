@@ -1647,6 +1647,35 @@ static int wgrad_x3_route(int batch, int h, int w, int cin, int cout, int kh, in
     return tap_x3 && (kh * kw > 1 || (cin >= 128 && cout >= 128)) ? 2 : 0;
 }
 
+// channel block (BCO x BCI) of the per-tap kernel on the planes.  Every operand is re-read once per block of the OTHER channel dimension
+// (bytes per pixel = 6 (Cout Cin / BCI + Cin Cout / BCO)), every block costs split-K partials, and a block's LDS decides how many workgroups a
+// CU holds: measured cold (operands from HBM, as inside a step) over the resnet50 / resnet18 layers by tools/sweep_wgrad_tiles.py
+// (profiles/r04_wgrad_tile_sweep.txt), the rectangular blocks beat the square ones of round 3 by 8-20 % where the rule below picks them:
+//   1x1, >= 32 768 pixels, Cout % 256 == 0           256 x 128   (l2 shortcut 256>512: 140 -> 112 us, l3.0 512>256: 114 -> 96)
+//   1x1, <= 8 192 pixels                             64 x 128 when Cout > Cin at stride 1, else 128 x 64   (l4 2048>512: 52 -> 43, l4 shortcut: 94 -> 77)
+//   3x3 / stride 2                                   256 x 128 where the channels allow, else 128 x 64   (l4: 113 -> 104, r18 l4.0: 115 -> 106)
+// The tools build takes STRAPS_WGRAD_TILE = 1000 * BCO + BCI per call for the sweep.
+static void wgrad_x3_block(long long M, int cin, int cout, int taps, bool big, int stride, int* bco, int* bci) {
+#ifdef STRAPS_TOOLS
+    const char* e = getenv("STRAPS_WGRAD_TILE");
+    if (e) {
+        const int v = atoi(e), o = v / 1000, i = v % 1000;
+        const bool known = (o == 256 && i == 64) || (o == 64 && i == 256) || (o == 256 && i == 128) || (o == 128 && i == 256) || (o == 128 && i == 64) ||
+                           (o == 64 && i == 128) || (o == 128 && i == 128) || (o == 64 && i == 64);
+        if (known && cout % o == 0 && cin % i == 0 && !(o == 128 && i == 128 && !big)) { *bco = o; *bci = i; }
+        return;
+    }
+#endif
+    if (taps == 1) {
+        if (M >= 32768 && cout % 256 == 0 && cin % 128 == 0) { *bco = 256; *bci = 128; }
+        else if (M <= 8192 && cout % 128 == 0 && cin % 128 == 0) {
+            if (stride == 1 && cout > cin) { *bco = 64; *bci = 128; }
+            else { *bco = 128; *bci = 64; }
+        }
+    } else if (cout % 256 == 0 && cin % 128 == 0) { *bco = 256; *bci = 128; }
+    else if (cout % 128 == 0 && cin % 64 == 0) { *bco = 128; *bci = 64; }
+}
+
 extern "C" int straps_conv_wgrad_x3_on_planes(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
     return wgrad_x3_route(batch, h, w, cin, cout, kh, kw, stride, pad) != 0;
 }
@@ -1716,15 +1745,41 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         STRAPS_REQUIRE(M < (1LL << 31), "straps_conv_wgrad_x3: problem too large");
         q.M = (int)M;
         const bool big = wgrad_big_tile(M, cin, cout, kh * kw);
-        const int tile = big ? 128 : 64;
-        q.ct = cout / tile; q.it = cin / tile;
+        // channel block of a workgroup: square by default (128 x 128 where both sides allow it, else 64 x 64); RECTANGULAR blocks (round 4) where they
+        // cut the operand stream -- every operand is re-read once per block of the OTHER channel dimension, bytes per pixel = 6 (Cout Cin / BCI +
+        // Cin Cout / BCO) -- see wgrad_x3_block
+        int bco = big ? 128 : 64, bci = bco;
+        wgrad_x3_block(M, cin, cout, kh * kw, big, stride, &bco, &bci);
+        q.ct = cout / bco; q.it = cin / bci;
         const int tiles = kh * kw * q.ct * q.it;
-        const int splits = wgrad_splits(M, tiles, big, true);
+        const size_t lds = (size_t)2 * 3 * 32 * (bco + bci) * sizeof(u16);      // two stages of [3 planes][32 pixels][BCO + BCI]
+        int splits;
+        if (bco == bci) splits = wgrad_splits(M, tiles, bco == 128, true);
+        else {
+            const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+            splits = (256 * per_cu + tiles - 1) / tiles;
+            const long long max_s = (M + 127) / 128;
+            if (splits > max_s) splits = (int)max_s;
+            const int cap = wgrad_splits(M, kh * kw * (cout / (big ? 128 : 64)) * (cin / (big ? 128 : 64)), big);      // the shared workspace is sized by the fp32 plan
+            if (splits > cap) splits = cap;
+            if (splits < 1) splits = 1;
+        }
         q.rows_per_split = (int)(((M + splits - 1) / splits + 31) / 32 * 32);
         hipStream_t st = (hipStream_t)stream;
         static const int nst_env = STRAPS_TOOL_ENV_INT("STRAPS_WGRAD_TAP_NST", 2);      // (A/B switch for tools: 3, 4 -- measured slower)
         constexpr int SB = 3 * 32 * 256 * 2, SS = 3 * 32 * 128 * 2;      // bytes per stage: 128x128 / 64x64 channel block
-        if (big) {
+#define STRAPS_WGRAD_X3_LAUNCH(BCO_, BCI_)                                                                              \
+        do {                                                                                                            \
+            STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<BCO_, BCI_, 2>), lds, "conv_wgrad_x3_kernel");                       \
+            hipLaunchKernelGGL((conv_wgrad_x3_kernel<BCO_, BCI_, 2>), dim3(tiles, splits), dim3(256), lds, st, q);      \
+        } while (0)
+        if (bco == 256 && bci == 64) STRAPS_WGRAD_X3_LAUNCH(256, 64);
+        else if (bco == 64 && bci == 256) STRAPS_WGRAD_X3_LAUNCH(64, 256);
+        else if (bco == 256 && bci == 128) STRAPS_WGRAD_X3_LAUNCH(256, 128);
+        else if (bco == 128 && bci == 256) STRAPS_WGRAD_X3_LAUNCH(128, 256);
+        else if (bco == 128 && bci == 64) STRAPS_WGRAD_X3_LAUNCH(128, 64);
+        else if (bco == 64 && bci == 128) STRAPS_WGRAD_X3_LAUNCH(64, 128);
+        else if (bco == 128) {
             if (nst_env == 3) {
                 STRAPS_RAISE_LDS((conv_wgrad_x3_kernel<128, 128, 3>), 3 * SB, "conv_wgrad_x3_kernel");
                 hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128, 3>), dim3(tiles, splits), dim3(256), 3 * SB, st, q);
@@ -1741,6 +1796,7 @@ extern "C" int straps_conv_wgrad_x3(const float* x, const float* dy, const unsig
         } else {
             hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 64, 2>), dim3(tiles, splits), dim3(256), 2 * SS, st, q);
         }
+#undef STRAPS_WGRAD_X3_LAUNCH
         STRAPS_CHECK_LAUNCH("conv_wgrad_x3_kernel");
         const long long n = (long long)cout * kh * kw * cin;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, st, q.part, dw_oihw, splits, cout, cin, kh * kw, accumulate);

@@ -283,7 +283,10 @@ def test_conv_dgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride, cfg):
     # shapes outside the halo plan (odd row count, non-power-of-two width), stride 2, 1x1 (stride 1 and 2), the 128x128 channel tile
     # of the big 1x1 layers (M >= 8192), ragged last step, zero-padded borders: the per-tap kernel on the planes
     (2, 64, 64, 9, 16, 3, 1), (2, 64, 64, 10, 24, 3, 1), (2, 64, 128, 16, 16, 3, 2), (2, 128, 128, 15, 15, 3, 2), (2, 64, 128, 16, 16, 1, 2),
-    (2, 256, 64, 8, 8, 1, 1), (3, 128, 256, 56, 56, 1, 1), (1, 256, 128, 96, 96, 1, 1), (1, 256, 512, 8, 8, 3, 2), (3, 64, 192, 7, 5, 1, 1)])
+    (2, 256, 64, 8, 8, 1, 1), (3, 128, 256, 56, 56, 1, 1), (1, 256, 128, 96, 96, 1, 1), (1, 256, 512, 8, 8, 3, 2), (3, 64, 192, 7, 5, 1, 1),
+    # the rectangular channel blocks of round 4 (csrc/backward.hip wgrad_x3_block): 256 x 128 (1x1 with >= 32 768 pixels; 3x3 / stride 2 above),
+    # 64 x 128 and 128 x 64 (1x1 with <= 8 192 pixels, by the larger side / at stride 2), 128 x 64 (3x3 / stride 2 with 128 output channels above)
+    (2, 128, 256, 128, 128, 1, 1), (2, 128, 256, 32, 32, 1, 1), (2, 256, 128, 32, 32, 1, 1), (2, 128, 256, 64, 64, 1, 2), (3, 384, 256, 20, 20, 1, 1)])
 def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride):
     """weight gradient on the planes: the halo-patch kernel (3x3 / stride 1, every chunk geometry the plan produces: W = 8 .. 64) and
     the per-tap kernel (everything else), transpose-read operand gathers, several splits, accumulate.  Bar: 2e-5 of the maximum,
