@@ -1656,16 +1656,14 @@ static int wgrad_x3_route(int batch, int h, int w, int cin, int cout, int kh, in
 //   3x3 / stride 2                                   256 x 128 where the channels allow, else 128 x 64   (l4: 113 -> 104, r18 l4.0: 115 -> 106)
 // The tools build takes STRAPS_WGRAD_TILE = 1000 * BCO + BCI per call for the sweep.
 static void wgrad_x3_block(long long M, int cin, int cout, int taps, bool big, int stride, int* bco, int* bci) {
-#ifdef STRAPS_TOOLS
-    const char* e = getenv("STRAPS_WGRAD_TILE");
-    if (e) {
-        const int v = atoi(e), o = v / 1000, i = v % 1000;
+    const int v = STRAPS_TOOL_ENV_INT("STRAPS_WGRAD_TILE", 0);      // (tools build: read at every call; the product build compiles this to 0)
+    if (v) {
+        const int o = v / 1000, i = v % 1000;
         const bool known = (o == 256 && i == 64) || (o == 64 && i == 256) || (o == 256 && i == 128) || (o == 128 && i == 256) || (o == 128 && i == 64) ||
                            (o == 64 && i == 128) || (o == 128 && i == 128) || (o == 64 && i == 64);
         if (known && cout % o == 0 && cin % i == 0 && !(o == 128 && i == 128 && !big)) { *bco = o; *bci = i; }
         return;
     }
-#endif
     if (taps == 1) {
         if (M >= 32768 && cout % 256 == 0 && cin % 128 == 0) { *bco = 256; *bci = 128; }
         else if (M <= 8192 && cout % 128 == 0 && cin % 128 == 0) {

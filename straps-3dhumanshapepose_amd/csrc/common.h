@@ -147,5 +147,6 @@ __device__ __forceinline__ void store_planes4_cm(u16* __restrict__ planes, long 
 #else
 #define STRAPS_TOOL_ENV_INT(name, dflt) (dflt)
 #endif
+// (the same macro serves switches a sweep changes from call to call: use it in a non-static expression)
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
