@@ -3,7 +3,7 @@
 
   [no grad]  G1 augment_smpl (:121-126)  G2 augment_cam_t (:127-129)  SMPL#1 targets (:132-135)
              P2 perspective projection (:141-143)  SMPL#2 reposed targets (:144)
-             part segmentation (STAND-IN for the NMR rasteriser + cv2 crop, :155-170 -- SURVEY 8f f1/f2)
+             part segmentation: the HIP rasteriser (nmr_renderer.NMRRenderer, :155) + on-device bbox crop / nearest resize (:161-170) -- SURVEY 8f f1/f2
              G3 proxy augmentation (:173-175)  G4+G5 network input (:178-182)
   forward    regressor (training-mode BatchNorm) -> rot6d -> SMPL#3 (:186-199), SMPL#4 reposed (:206)
   loss       heads (COCO orthographic projection, H36M-LSP joints, visibility) + 5 MSE tasks + gradients
