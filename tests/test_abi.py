@@ -79,8 +79,10 @@ def test_tile_choice_and_routes_of_the_bf16x3_kernels(lib):
     assert sb(B, 16, 16, 256, 256, 3, 3, 1, 1, 0) == B * 16 * 16 // 128
     assert sb(B, 8, 8, 512, 512, 3, 3, 1, 1, 0) == B * 8 * 8 // 128
     assert sb(B, 64, 64, 64, 128, 3, 3, 2, 1, 0) == B * 32 * 32 // 256                      # stride 2: im2col kernel, 256x128 tiles
-    assert sb(3, 10, 24, 128, 128, 3, 3, 1, 1, 0) == -(-3 * 10 * 24 // 128)                 # ragged M: 128x64 three-stage tiles
-    assert sb(3, 10, 24, 128, 128, 3, 3, 1, 1, 512) == -(-3 * 10 * 24 // 128)               # (no halo kernel: M % 128 != 0)
+    assert sb(3, 10, 24, 128, 128, 3, 3, 1, 1, 0) == -(-3 * 10 * 24 // 64)                  # a grid that cannot fill the chip with 128-row tiles: 64x64 (round 4)
+    assert sb(3, 10, 24, 128, 128, 3, 3, 1, 1, 512) == -(-3 * 10 * 24 // 64)                # (no halo kernel: M % 128 != 0)
+    assert sb(32, 8, 8, 512, 512, 3, 3, 1, 1, 0) == 32 * 8 * 8 // 64                        # resnet50's layer4 at 32 bodies: 64x64 tiles, one workgroup per CU
+    assert sb(16, 32, 32, 256, 128, 3, 3, 1, 1, 0) == 16 * 32 * 32 // 128                   # 128 tile equivalents: still 128x64
     for cfg, bm in ((1, 128), (2, 128), (3, 64), (4, 256), (5, 128), (7, 128), (11, 128), (12, 256)):
         assert sb(2, 10, 10, 128, 128, 3, 3, 1, 1, cfg) == -(-200 // bm), cfg
     on = lib.straps_conv_wgrad_x3_on_planes

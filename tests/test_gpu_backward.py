@@ -311,7 +311,9 @@ def test_regressor_param_grads_vs_reference_golden(dev, layers):
     # This B=2 training-mode problem is ill-conditioned: on the CPU the SAME graph in fp64 differs from the reference's
     # fp32 result by 0.24 % in gradient norm and up to 8 % in single elements (ReLU masks / batch statistics of 2
     # samples amplify round-off).  Every kernel is checked tightly on its own above; this end-to-end test guards the
-    # wiring: norms within 1 % of the reference golden, direction (cosine) vs the oracle's autograd >= 0.995 (measured: r18 0.99992, r50 0.9989 worst tensor).
+    # wiring: norms within 1 % (resnet50: 2 % -- which way its tied ReLU decisions fall moves single tensors by 1.1 %, and that changes with the
+    # summation order of a tile choice) of the reference golden, direction (cosine) vs the oracle's autograd >= 0.995 (measured: r18 0.99992, r50 0.9989 worst tensor).
+    # What these loose bars hide is pinned below on the GPU's own decisions.
     sdo = {k: v.clone() for k, v in sd.items()}
     names = [n for n, _ in reg.named_parameters()]
     for n in names:
@@ -328,7 +330,7 @@ def test_regressor_param_grads_vs_reference_golden(dev, layers):
         err = abs(float(g.norm()) - ref_norm) / max(ref_norm, 1e-12)
         cos = float((g @ go) / (g.norm() * go.norm()).clamp_min(1e-30))
         worst, worst_cos = max(worst, err), min(worst_cos, cos)
-        assert err < 1e-2, '%s: grad norm %.6e vs reference %.6e' % (n, float(g.norm()), ref_norm)
+        assert err < (1e-2 if layers == 18 else 2e-2), '%s: grad norm %.6e vs reference %.6e' % (n, float(g.norm()), ref_norm)
         assert cos > 0.995, '%s: cosine vs oracle autograd %.6f' % (n, cos)
     print('r%d worst grad-norm rel err %.2e, worst cosine %.6f' % (layers, worst, worst_cos))
     # ... and what those loose bars hide is decisions, not arithmetic: the float64 oracle evaluated on the ReLU / max-pool decisions the
