@@ -30,7 +30,7 @@ else:
     B = 64
     SHAPES = [('l1 3x3 s1', 64, 64, 64, 3, 1), ('l2.0 3x3 s2', 64, 64, 128, 3, 2), ('l2 3x3 s1', 32, 128, 128, 3, 1), ('l2 ds 1x1 s2', 64, 64, 128, 1, 2),
               ('l3.0 3x3 s2', 32, 128, 256, 3, 2), ('l3 3x3 s1', 16, 256, 256, 3, 1), ('l4.0 3x3 s2', 16, 256, 512, 3, 2), ('l4 3x3 s1', 8, 512, 512, 3, 1)]
-CFGS = (0, 1, 2, 3, 4, 5, 7, 10, 11, 12)
+CFGS = (0, 1, 2, 3, 4, 5, 7, 10, 11, 12, 256, 512, 1536)      # (256 = im2col kernel only, 512 = halo-patch kernel wherever it applies, 1536 = its single-buffer form)
 flush = torch.empty(1 << 28, device=dev)
 
 
@@ -62,7 +62,7 @@ for name, H, Cin, Cout, k, stride in SHAPES:
     dx = torch.empty_like(x)
     row = '%-18s M=%6d %4d->%4d | fwd' % (name, B * Ho * Ho, Cin, Cout)
     for cfg in CFGS:
-        if (cfg & 15) in (1, 4, 5, 6, 8, 9, 12) and Cout % 128:
+        if ((cfg & 15) in (1, 4, 5, 6, 8, 9, 12) and Cout % 128) or (cfg >= 256 and (k != 3 or stride != 1)):
             continue
         nblk = L.straps_conv_x3_stat_blocks(B, H, H, Cin, Cout, k, k, stride, pad, cfg)
         part = torch.empty(max(nblk, 1) * Cout * 2, device=dev)
@@ -71,7 +71,7 @@ for name, H, Cin, Cout, k, stride in SHAPES:
         row += ' c%d %5.1f' % (cfg, t)
     row += ' | dgrad'
     for cfg in CFGS:
-        if (cfg & 15) in (1, 4, 5, 6, 8, 9, 12) and Cin % 128:
+        if ((cfg & 15) in (1, 4, 5, 6, 8, 9, 12) and Cin % 128) or (cfg >= 256 and (k != 3 or stride != 1)):
             continue
         t = cold(lambda: hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(wd3), wdps, None, hipabi.ptr(dx), B, H, H, Cin, Cout, k, k, stride, pad, cfg,
                                                             None), 'dgrad_x3'))
