@@ -71,6 +71,57 @@ def pmc_traffic(args, kernel):
             'traffic_source': rec['source'], 'traffic_measured_in_run': False}
 
 
+def measure_traffic_live(args, kernel):
+    """HBM bytes per launch of `kernel`, MEASURED by this run: two short rocprofv3 passes of this same workload (`--kernel-trace --pmc FETCH_SIZE`,
+    then `... WRITE_SIZE`: separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes; reads carry its gfx950 x2 correction, units
+    KiB), 2 eager steps each, after the timed region.  {} when rocprofv3 is missing or a pass fails -- the committed figure is used then."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return {}
+    flags = ['--workload', args.workload, '--layers', str(args.layers), '--conv-precision', args.conv_precision, '--smpl-in-step', args.smpl_in_step,
+             '--smpl-precision', args.smpl_precision, '--smpl-kernel', args.smpl_kernel, '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-graph',
+             '--no-overlap', '--no-stem-ab', '--no-reduced-ab', '--no-other-configs', '--no-measure-traffic', '--child']
+    if args.batch:
+        flags += ['--batch', str(args.batch)]
+    match = (lambda n: 'smpl_verts' in n) if kernel == 'smpl_fwd' else (lambda n: ('conv_igemm_x3' in n) if kernel == 'conv_igemm_x3_kernel'
+                                                                         else (kernel + '<' in n or kernel + '(' in n))
+    extra = (lambda n: 'smpl_' in n) if kernel == 'smpl_fwd' else match       # (one straps_smpl_fwd call = pose + vertex + joint kernels: bytes of all three per call)
+    means = {}
+    tmp = tempfile.mkdtemp(prefix='straps_pmc_', dir='/tmp')
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, ctr)
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '--', sys.executable, os.path.abspath(__file__)] + flags
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'))
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if p.returncode != 0 or not files:
+                return {}
+            tot, n = 0.0, 0
+            for r in csv.DictReader(open(files[0])):
+                if r['Counter_Name'] != ctr:
+                    continue
+                nm = r['Kernel_Name']
+                if extra(nm):
+                    tot += float(r['Counter_Value'])
+                if match(nm):
+                    n += 1
+            if not n:
+                return {}
+            means[ctr] = tot / n
+    except Exception:           # noqa: BLE001 -- a failed counter pass must not lose the bench line
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    byt = 2.0 * 1024.0 * means['FETCH_SIZE'] + 1024.0 * means['WRITE_SIZE']
+    return {'traffic': round(byt), 'traffic_unit': 'HBM bytes per launch (read x2-corrected + write), launch-weighted mean',
+            'traffic_source': 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over 2 eager steps of this workload',
+            'traffic_measured_in_run': True}
+
+
 def synthetic_proxy_batch(B, device, seed):
     """seeded silhouette (union of ellipses, ~25 % foreground) + 17 Gaussian joint heatmaps
     (16x16 truncated, sigma 4) -- the 18-channel input of run_train.py:35, NCHW fp32."""
@@ -327,6 +378,10 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true',
                     help="default headline run only: skip the short timed passes of BASELINE.json's other GPU configurations (configs[1], configs[3]'s "
                          "per-GPU shape, configs[4]) that are reported under 'other_configs'")
+    ap.add_argument('--measure-traffic', action='store_true',
+                    help="measure roofline.traffic in this run (two short rocprofv3 counter passes after the timed region) instead of reading the "
+                         "committed profiles/pmc_traffic.json; on by default for the driver-style default call")
+    ap.add_argument('--no-measure-traffic', action='store_true')
     ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)      # (a pass launched by the headline run for 'other_configs')
     args = ap.parse_args()
     # the driver's one call (no --workload / --config / --layers / --batch) also times the other GPU configurations, each in a child process of
@@ -591,6 +646,11 @@ def main():
                              'fp32_equivalent_tflops': round(ach, 2), 'fp32_pipe_peak': MFMA_F32_PEAK_TFLOPS,
                              'fp32_equivalent_over_fp32_peak': round(ach / MFMA_F32_PEAK_TFLOPS, 4)})
             roof.update(pmc_traffic(args, dominant))
+            if (args.measure_traffic or headline_default) and world == 1 and not args.no_measure_traffic and not args.child:
+                live = measure_traffic_live(args, dominant)
+                if live:
+                    roof['traffic_committed_profile'] = roof.get('traffic')      # (the figure of profiles/pmc_traffic.json, for comparison)
+                    roof.update(live)
             if dominant == 'conv_igemm_x3_kernel' or (args.workload == 'smpl' and not args.smpl_exact):
                 # the spec peak assumes 2.4 GHz; under its power budget the board runs a pure bf16 / fp16 MFMA stream on real data at ~1.5 GHz
                 # (tools/mfma_lds_probe.hip).  Measured here, in this process, on this board:
