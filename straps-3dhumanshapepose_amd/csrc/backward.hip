@@ -1275,17 +1275,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const long long first = POOL ? (long long)blockIdx.x * POOL_CHUNK + threadIdx.x : (long long)blockIdx.x * 256 + threadIdx.x;
     const long long last = POOL ? (n4 < ((long long)blockIdx.x + 1) * POOL_CHUNK ? n4 : ((long long)blockIdx.x + 1) * POOL_CHUNK) : n4;
     const long long step = POOL ? 256 : (long long)gridDim.x * 256;
-    for (long long idx = first; idx < last; idx += step) {
-        const int c4 = (int)(idx % C4);
+    const long long rows = n4 / C4;
+    // per-channel constants of four channels: 5 float4 + 8 doubles.  Round 4: when the loop stride is a multiple of the row length (the host
+    // sizes the grid so; always for the pooled form's 256-element stride on 64 channels) a thread keeps its four channels for the whole loop
+    // and loads them ONCE -- they were 144 bytes of L1 traffic per 48-64 bytes of payload -- and the row index advances by a constant
+    // instead of a 64-bit division per element.  Same arithmetic either way.
+    struct Consts { f32x4 ksc, ksh, mu, is, k1; double m1[4], m2[4]; };
+    auto load_consts = [&](int c4) {
+        Consts k;
+        if (!yact && msc) { k.ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4); k.ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4); }
+        k.mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        k.is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        k.k1 = *reinterpret_cast<const f32x4*>(k1p + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { k.m1[e] = coefd[c4 * 4 + e]; k.m2[e] = coefd[C + c4 * 4 + e]; }
+        return k;
+    };
+    auto body = [&](long long idx, long long row, int c4, const Consts& k) {
         f32x4 g;
         if constexpr (POOL) {
-            const long long row = idx / C4;
             if (ps.tany) {
                 const int wi = (int)(row % ps.W);
                 const long long t = row / ps.W;
                 const int hi = (int)(t % ps.H);
                 const long long b = t / ps.H;
-                if (!ps.tany[(b * ps.tiles_y + (hi >> 1)) * ps.tiles_x + (wi >> 5)]) continue;
+                if (!ps.tany[(b * ps.tiles_y + (hi >> 1)) * ps.tiles_x + (wi >> 5)]) return;
             }
             g = pool_grad(ps, row, c4, C);
         } else {
@@ -1297,24 +1311,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
         } else if (msc) {
-            const f32x4 ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4);
-            const f32x4 ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = fmaf(xr[e], ksc[e], ksh[e]) > 0.f ? g[e] : 0.f;
+            for (int e = 0; e < 4; ++e) g[e] = fmaf(xr[e], k.ksc[e], k.ksh[e]) > 0.f ? g[e] : 0.f;
         }
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-        const f32x4 k1 = *reinterpret_cast<const f32x4*>(k1p + c4 * 4);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const double m1 = coefd[c4 * 4 + e], m2 = coefd[C + c4 * 4 + e];
-            const double xh = ((double)xr[e] - (double)mu[e]) * (double)is[e];
-            o[e] = (float)((double)k1[e] * (((double)g[e] - m1) - xh * m2));
+            const double xh = ((double)xr[e] - (double)k.mu[e]) * (double)k.is[e];
+            o[e] = (float)((double)k.k1[e] * (((double)g[e] - k.m1[e]) - xh * k.m2[e]));
         }
         if (dz_out) *reinterpret_cast<f32x4*>(dz_out + idx * 4) = g;
         if (draw) *reinterpret_cast<f32x4*>(draw + idx * 4) = o;      // (NULL: only the planes are consumed, see straps_bn_bwd_x3)
-        if (planes) store_planes4_cm(planes, pstride, idx / C4, c4 * 4, n4 / C4, o);      // bf16x3 route: the data-gradient kernel's operand (chunk-major planes)
+        if (planes) store_planes4_cm(planes, pstride, row, c4 * 4, rows, o);      // bf16x3 route: the data-gradient kernel's operand (chunk-major planes)
+    };
+    if (step % C4 == 0) {
+        if (first >= last) return;
+        const int c4 = (int)(first % C4);
+        const Consts k = load_consts(c4);
+        const long long rstep = step / C4;
+        long long row = first / C4;
+        for (long long idx = first; idx < last; idx += step, row += rstep) body(idx, row, c4, k);
+    } else {
+        for (long long idx = first; idx < last; idx += step) {
+            const int c4 = (int)(idx % C4);
+            body(idx, idx / C4, c4, load_consts(c4));
+        }
     }
 }
 
@@ -1517,6 +1538,17 @@ __global__ __launch_bounds__(256) void rot6d_bwd_kernel(const float* __restrict_
 inline unsigned capped_grid(long long n) {
     long long g = (n + 255) / 256;
     return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+// the same with grid x 256 a multiple of the row length C4 (float4 units) where a grid under the cap allows it (see csrc/elementwise.hip)
+inline unsigned capped_grid_rows(long long n, int C4) {
+    unsigned g = capped_grid(n);
+    if (C4 > 0 && (256 % C4) != 0) {
+        long long a = C4, b = 256;
+        while (b) { const long long t = a % b; a = b; b = t; }
+        const long long m = C4 / a;            // smallest m with (m * 256) % C4 == 0
+        if (m <= 256 * 16) { const long long up = ((g + m - 1) / m) * m; g = (unsigned)(up > 256 * 16 ? (256 * 16 / m) * m : up); }
+    }
+    return g;
 }
 
 // 128x128 tiles (32 flop per operand byte instead of 16) for the big 1x1 layers (resnet50): +10 % there; the 3x3 / strided layers
@@ -1883,7 +1915,7 @@ extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float*
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }
@@ -1908,7 +1940,7 @@ extern "C" int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partials, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid(n4)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }
