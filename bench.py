@@ -319,6 +319,12 @@ def instrument(timer):
         def straps_conv_dgrad_x3(self, *a):
             return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3(*a), 1.5 * conv_bytes(*a[6:15]), geo('dgrad', *a[6:15]))
 
+        def straps_conv_dgrad_x3_bn_bits(self, *a):     # (the same launches with ReLU decisions read as bits, round 4; same class names)
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3_bn_bits(*a), 1.5 * conv_bytes(*a[6:15]), geo('dgrad+bn', *a[6:15]))
+
+        def straps_conv_dgrad_x3_bits(self, *a):
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3_bits(*a), 1.5 * conv_bytes(*a[6:15]), geo('dgrad', *a[6:15]))
+
         def straps_conv_wgrad(self, *a):
             return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a), 0.0, geo('wgrad', *a[4:13]))
 
@@ -373,6 +379,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
     ap.add_argument('--no-overlap', action='store_true', help='(default now) weight-gradient kernels stay on the main stream')
+    ap.add_argument('--no-relu-bits', action='store_true', help="A/B: a residual unit's ReLU decisions reach the backward pass as fp32 tensors (rounds 1-3) instead of bits")
     ap.add_argument('--no-stem-ab', action='store_true', help='skip the dense-stem A/B steps after the timed region (profiling runs: keeps the kernel stats clean)')
     ap.add_argument('--overlap-wgrad', action='store_true', help='A/B: run the weight-gradient kernels on a side stream (0.1 ms slower since the data pipeline)')
     ap.add_argument('--no-other-configs', action='store_true',
@@ -390,6 +397,9 @@ def main():
                         and args.conv_precision == 'bf16x3' and not args.dense_stem and not args.no_graph and not args.no_cpu_baseline)
     if args.child:
         args.no_cpu_baseline = args.no_stem_ab = args.no_reduced_ab = True
+    if args.no_relu_bits:
+        from straps_amd import encoder_exec as _ee
+        _ee._RELU_BITS = False
     if args.config:
         args.workload = {1: 'fwd', 2: 'train', 3: 'train', 4: 'smpl'}[args.config]
         if args.config == 3:

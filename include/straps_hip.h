@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STRAPS_ABI_VERSION 7
+#define STRAPS_ABI_VERSION 8
 
 #define STRAPS_OK 0
 #define STRAPS_EINVAL 1       /* bad argument (shape, alignment, null pointer) */
@@ -409,6 +409,39 @@ int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const float* raw
                             const float* mask_shift, float* dgamma, float* dbeta, float* draw, float* dz_out,
                             unsigned short* draw_planes, long long plane_stride, const double* partials,
                             int nblk, void* workspace, long long rows, int c, int accumulate, void* stream);
+/* ReLU decisions as BITS (ABI 8).  The backward pass of a residual unit needs the unit's fp32 activation only for its sign:
+ * as the ReLU mask of the last BatchNorm's two passes, of the sums fused into the data gradient that produces dy, and of the gradient
+ * the skip connection receives (which the fp32 form materialises as dz_out).  straps_bn_apply_bits_x3 (= straps_bn_apply_x3 with
+ * relu = 1) also writes  relu_bits[rows][c / 32]:  bit (ch & 31) of word [row][ch / 32] = (y[row][ch] > 0);  the *_bits forms below
+ * read those words where the plain forms read an fp32 tensor:
+ *   straps_bn_bwd_bits_x3 / straps_bn_bwd_finish_bits_x3   relu_bits instead of yact; no dz_out (consumers mask dy themselves);
+ *   straps_conv_dgrad_x3_bits / _bn_bits                   addend_bits: dx = dgrad + (bit ? addend : 0), the addend being the UNMASKED
+ *                                                          gradient of the later unit's output;  bn_out_bits instead of bn_out
+ *                                                          (either may be NULL: that operand is then used as in the plain form).
+ * Results are bit-identical to the fp32-mask forms (models/resnet.py:72-74,115-117: out += identity; out = relu(out)).
+ * c (cin for the data gradients) must be a multiple of 32. */
+int straps_bn_apply_bits_x3(const float* raw, const float* scale, const float* shift, const float* residual, float* y,
+                            unsigned short* y_planes, long long plane_stride, unsigned* relu_bits, long long rows,
+                            int c, void* stream);
+int straps_bn_bwd_bits_x3(const float* dy, const unsigned* relu_bits, const float* raw, const float* save_mean,
+                          const float* save_invstd, const float* gamma, float* dgamma, float* dbeta, float* draw,
+                          unsigned short* draw_planes, long long plane_stride, void* workspace, long long rows, int c,
+                          int accumulate, void* stream);
+int straps_bn_bwd_finish_bits_x3(const float* dy, const unsigned* relu_bits, const float* raw, const float* save_mean,
+                                 const float* save_invstd, const float* gamma, float* dgamma, float* dbeta, float* draw,
+                                 unsigned short* draw_planes, long long plane_stride, const double* partials, int nblk,
+                                 void* workspace, long long rows, int c, int accumulate, void* stream);
+int straps_conv_dgrad_x3_bits(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk,
+                              long long w_plane_stride, const float* addend, float* dx_nhwc, int batch, int h, int w,
+                              int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg,
+                              const unsigned* addend_bits, void* stream);
+int straps_conv_dgrad_x3_bn_bits(const unsigned short* dy3, long long dy_plane_stride,
+                                 const unsigned short* w3_crsk, long long w_plane_stride, const float* addend,
+                                 float* dx_nhwc, int batch, int h, int w, int cin, int cout, int kh, int kw,
+                                 int stride, int pad, int tile_cfg, const float* bn_raw, const float* bn_out,
+                                 const float* bn_mask_scale, const float* bn_mask_shift, const float* bn_mean,
+                                 const float* bn_invstd, double* bn_partials, const unsigned* addend_bits,
+                                 const unsigned* bn_out_bits, void* stream);
 /* weight gradient on the bf16x3 route: straps_conv_wgrad's arguments plus the planes of x and dy.  3x3 / stride 1 / pad 1
  * layers (power-of-two width >= 8) run the halo-patch kernel on the planes (ds_read_b64_tr_b16 operand gathers); the other
  * 3x3 layers and the 1x1 layers whose channel counts are both >= 128 run the per-tap kernel on the planes; what is left

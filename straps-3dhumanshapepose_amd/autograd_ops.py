@@ -68,9 +68,12 @@ def _packed_dgrad_weight(net, conv):
     return net._cached(('wd', id(conv)), [w], make)
 
 
-def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True):
+def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True, mask_bits=None):
     """BatchNorm(train) + ReLU backward of one tape record; returns (draw, dz|None).
-    planes_sink (bf16x3 route): dict that receives id(draw) -> (draw, planes, plane stride), written by the same kernel pass."""
+    planes_sink (bf16x3 route): dict that receives id(draw) -> (draw, planes, plane stride), written by the same kernel pass.
+    mask_bits: ReLU decisions [rows][C / 32] that mask dy (a residual unit's, for its downsample BatchNorm); a record that carries its own
+    bits (encoder_exec: the last BatchNorm of a residual unit) uses those in place of its fp32 activation.  No dz with bits: the consumers
+    of the masked gradient apply the bits to dy themselves."""
     bn = rec['bn']
     raw, ss = rec['raw'], rec['stats']
     rows, Cc = raw.numel() // raw.shape[-1], raw.shape[-1]
@@ -84,6 +87,9 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True
     # ReLU mask: without a residual the activation is relu(raw*scale + shift), so the kernel re-derives it from raw (one
     # tensor read less); with a residual it has to read the stored activation
     from_raw = masked and rec.get('residual') is None
+    bits = mask_bits if mask_bits is not None else (rec.get('bits') if masked and not from_raw else None)
+    if bits is not None and want_dz:
+        raise RuntimeError('BatchNorm backward on ReLU bits writes no masked gradient (dz)')
     planes, ps = None, 0
     if planes_sink is not None:
         ps = (raw.numel() + 7) // 8 * 8
@@ -91,7 +97,15 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True
         planes_sink[id(draw)] = (draw, planes, ps)
     flags = 2 if rec.get('frozen') else 0         # bit 1: eval-mode BatchNorm, statistics are constants (encoder_exec._bn_train_finish)
     fused = rec.pop('bwd_partials', None)         # (partials, blocks, dy they belong to): the sums came out of the data gradient's epilogue
-    if fused is not None and fused[2] is dy and masked:
+    if bits is not None:
+        args = (hipabi.ptr(dy), hipabi.ptr(bits), hipabi.ptr(raw), hipabi.ptr(ss[2]), hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(dgamma),
+                hipabi.ptr(dbeta), hipabi.ptr(draw if keep_fp32 else None), hipabi.ptr(planes), ps)
+        if fused is not None and fused[2] is dy and masked:
+            hipabi.check(L.straps_bn_bwd_finish_bits_x3(*args, hipabi.ptr(fused[0]), fused[1], hipabi.ptr(ws), rows, Cc, flags, hipabi.stream_ptr()),
+                         'straps_bn_bwd_finish_bits_x3')
+        else:
+            hipabi.check(L.straps_bn_bwd_bits_x3(*args, hipabi.ptr(ws), rows, Cc, flags, hipabi.stream_ptr()), 'straps_bn_bwd_bits_x3')
+    elif fused is not None and fused[2] is dy and masked:
         hipabi.check(L.straps_bn_bwd_finish_x3(hipabi.ptr(dy), hipabi.ptr(rec['out'] if not from_raw else None), hipabi.ptr(raw), hipabi.ptr(ss[2]),
                                                hipabi.ptr(ss[3]), hipabi.ptr(bn.weight), hipabi.ptr(ss[0] if from_raw else None),
                                                hipabi.ptr(ss[1] if from_raw else None), hipabi.ptr(dgamma), hipabi.ptr(dbeta),
@@ -126,10 +140,12 @@ def _conv_wgrad(L, rec, draw, grads, planes_sink=None):
     grads[conv.weight] = dw
 
 
-def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None, bn_next=None):
+def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None, bn_next=None, addend_bits=None):
     """data gradient of one convolution.  bn_next (bf16x3 route): tape record of the BatchNorm (+ ReLU) whose output this convolution
     read -- the returned gradient is that BatchNorm's dy, and the two sums of its backward are accumulated in this launch's epilogue
-    (straps_conv_dgrad_x3_bn) and left in bn_next['bwd_partials'] for _bn_bwd."""
+    (straps_conv_dgrad_x3_bn) and left in bn_next['bwd_partials'] for _bn_bwd.
+    addend_bits: the addend is the UNMASKED gradient of the later unit's output and these are that unit's ReLU decisions (the epilogue adds
+    bit ? addend : 0); a bn_next that carries bits has its sums masked by them instead of by its fp32 activation."""
     conv = rec['conv']
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     dx = torch.empty(B, H, W, Cin, device=draw.device, dtype=torch.float32)
@@ -148,6 +164,16 @@ def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None, bn_next=None):
             from_raw = bn_next.get('residual') is None
             nblk = L.straps_conv_dgrad_x3_bn_blocks(B, H, W, Cin, Cout, k, k, stride, pad, 0)
             part = torch.empty(nblk, Cin, 2, device=dx.device, dtype=torch.float64)
+            nbits = None if from_raw else bn_next.get('bits')
+            if addend_bits is not None or nbits is not None:
+                hipabi.check(L.straps_conv_dgrad_x3_bn_bits(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(dx), B, H, W, Cin,
+                                                            Cout, k, k, stride, pad, 0, hipabi.ptr(bn_next['raw']),
+                                                            hipabi.ptr(None if from_raw or nbits is not None else bn_next['out']),
+                                                            hipabi.ptr(ssn[0] if from_raw else None), hipabi.ptr(ssn[1] if from_raw else None),
+                                                            hipabi.ptr(ssn[2]), hipabi.ptr(ssn[3]), hipabi.ptr(part), hipabi.ptr(addend_bits),
+                                                            hipabi.ptr(nbits), hipabi.stream_ptr()), 'straps_conv_dgrad_x3_bn_bits')
+                bn_next['bwd_partials'] = (part, nblk, dx)
+                return dx
             hipabi.check(L.straps_conv_dgrad_x3_bn(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(dx), B, H, W, Cin, Cout,
                                                    k, k, stride, pad, 0, hipabi.ptr(bn_next['raw']), hipabi.ptr(None if from_raw else bn_next['out']),
                                                    hipabi.ptr(ssn[0] if from_raw else None), hipabi.ptr(ssn[1] if from_raw else None),
@@ -155,9 +181,15 @@ def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None, bn_next=None):
                          'straps_conv_dgrad_x3_bn')
             bn_next['bwd_partials'] = (part, nblk, dx)
             return dx
+        if addend_bits is not None:
+            hipabi.check(L.straps_conv_dgrad_x3_bits(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(dx), B, H, W, Cin, Cout,
+                                                     k, k, stride, pad, 0, hipabi.ptr(addend_bits), hipabi.stream_ptr()), 'straps_conv_dgrad_x3_bits')
+            return dx
         hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(dx), B, H, W, Cin, Cout,
                                             k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_dgrad_x3')
         return dx
+    if addend_bits is not None:
+        raise RuntimeError('ReLU bits exist only on the bf16x3 route')
     hipabi.check(L.straps_conv_dgrad(hipabi.ptr(draw), hipabi.ptr(_packed_dgrad_weight(net, conv)), hipabi.ptr(addend), hipabi.ptr(dx), B, H, W,
                                      Cin, Cout, k, k, stride, pad, 0, hipabi.stream_ptr()), 'straps_conv_dgrad')
     return dx
@@ -189,15 +221,22 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
             ui = units.index(unit)
             prev_last = tape[id(units[ui - 1].conv_bn_pairs()[-1][0])] if ui > 0 else None      # the BatchNorm this unit's input came out of
             rec = tape[id(pairs[-1][0])]
-            draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink, keep(rec))    # ReLU(out) mask; dz feeds the skip connection
+            ubits = rec.get('bits') if sink is not None else None      # the unit's ReLU decisions as bits (encoder_exec._RELU_BITS)
+            dskip_bits = None
+            if ubits is not None:
+                # no masked copy dz of the incoming gradient: whoever needs relu'(out) * dy reads dy and the bits
+                draw, _ = _bn_bwd(L, rec, dy, True, False, grads, sink, keep(rec))
+                dz = dy
+            else:
+                draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink, keep(rec))    # ReLU(out) mask; dz feeds the skip connection
             side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             if unit.downsample is not None:
                 recd = tape[id(unit.downsample[0])]
-                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink, keep(recd))
+                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink, keep(recd), mask_bits=ubits)
                 side.run(lambda recd=recd, drawd=drawd: _conv_wgrad(L, recd, drawd, grads, sink), drawd)
                 dskip = _conv_dgrad(L, net, recd, drawd, None, sink)
             else:
-                dskip = dz
+                dskip, dskip_bits = dz, ubits
             for ci in range(len(pairs) - 1, 0, -1):
                 rec_prev = tape[id(pairs[ci - 1][0])]
                 dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None, sink, bn_next=rec_prev if sink is not None else None)
@@ -205,7 +244,8 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
                 draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink, keep(rec))
                 side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             # (+ skip gradient fused in the epilogue; the result is dy of the PREVIOUS unit's last BatchNorm, whose sums ride along)
-            dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink, bn_next=prev_last if sink is not None else None)
+            dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink, bn_next=prev_last if sink is not None else None,
+                             addend_bits=dskip_bits)
         if li == 3 and after_layer3 is not None:
             side.join()
             after_layer3()

@@ -1103,7 +1103,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ raw, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ msc,
                                                             const float* __restrict__ msh, double* __restrict__ part, long long rows,
-                                                            int C, int rows_per_block, PoolSrc ps) {
+                                                            int C, int rows_per_block, PoolSrc ps, const unsigned* __restrict__ bits) {
+    // (bits: the ReLU decisions of yact as one word per (row, 32 channels) -- straps_bn_apply_bits_x3 -- read instead of yact itself)
     __shared__ double red[256][8];
     constexpr int TR = 16;
     const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
@@ -1128,11 +1129,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 if constexpr (POOL) g[u] = pool_grad(ps, r + (long long)u * TR, c4, C);
                 else g[u] = *reinterpret_cast<const f32x4*>(dy + o);
                 xr[u] = *reinterpret_cast<const f32x4*>(raw + o);
-                if (yact) ya[u] = *reinterpret_cast<const f32x4*>(yact + o);
+                if (bits) ya[u][0] = __uint_as_float(bits[(r + (long long)u * TR) * (C >> 5) + (c4 >> 3)]);
+                else if (yact) ya[u] = *reinterpret_cast<const f32x4*>(yact + o);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (yact) {
+                if (bits) {
+                    const unsigned nib = __float_as_uint(ya[u][0]) >> ((c4 & 7) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[u][e] = ((nib >> e) & 1u) ? g[u][e] : 0.f;
+                } else if (yact) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[u][e] = ya[u][e] > 0.f ? g[u][e] : 0.f;
                 } else if (msc) {
@@ -1152,7 +1158,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             if constexpr (POOL) g = pool_grad(ps, r, c4, C);
             else g = *reinterpret_cast<const f32x4*>(dy + o);
             const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + o);
-            if (yact) {
+            if (bits) {
+                const unsigned nib = bits[r * (C >> 5) + (c4 >> 3)] >> ((c4 & 7) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = ((nib >> e) & 1u) ? g[e] : 0.f;
+            } else if (yact) {
                 const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
@@ -1268,7 +1278,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const double* __restrict__ coefd,
                                                            const float* __restrict__ k1p, const float* __restrict__ msc,
                                                            const float* __restrict__ msh, float* __restrict__ draw, float* dz_out,
-                                                           u16* __restrict__ planes, long long pstride, long long n4, int C, PoolSrc ps) {
+                                                           u16* __restrict__ planes, long long pstride, long long n4, int C, PoolSrc ps,
+                                                           const unsigned* __restrict__ bits) {
     const int C4 = C >> 2;
     // POOL: a workgroup owns POOL_CHUNK consecutive elements (with the tile map most workgroups of an empty region exit at once and the
     // dispatcher hands out the rest: a grid-stride loop would pin every workgroup to one image position -- all work or none)
@@ -1283,7 +1294,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     struct Consts { f32x4 ksc, ksh, mu, is, k1; double m1[4], m2[4]; };
     auto load_consts = [&](int c4) {
         Consts k;
-        if (!yact && msc) { k.ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4); k.ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4); }
+        if (!yact && !bits && msc) { k.ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4); k.ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4); }
         k.mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
         k.is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
         k.k1 = *reinterpret_cast<const f32x4*>(k1p + c4 * 4);
@@ -1306,7 +1317,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             g = *reinterpret_cast<const f32x4*>(dy + idx * 4);
         }
         const f32x4 xr = *reinterpret_cast<const f32x4*>(raw + idx * 4);
-        if (yact) {
+        if (bits) {      // (ReLU decisions of yact as bits: word [row][C / 32], bit c & 31 -- straps_bn_apply_bits_x3)
+            const unsigned nib = bits[row * (C >> 5) + (c4 >> 3)] >> ((c4 & 7) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = ((nib >> e) & 1u) ? g[e] : 0.f;
+        } else if (yact) {
             const f32x4 ya = *reinterpret_cast<const f32x4*>(yact + idx * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = ya[e] > 0.f ? g[e] : 0.f;
@@ -1894,10 +1909,11 @@ extern "C" int straps_bn_bwd_blocks(long long rows, int c) {
     return (int)(b < 1 ? 1 : b);
 }
 
-extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
-                                const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
-                                float* dz_out, unsigned short* draw_planes, long long plane_stride, void* workspace, long long rows, int c,
-                                int accumulate, void* stream) {
+static int bn_bwd_x3_impl(const float* dy, const float* yact, const unsigned* relu_bits, const float* raw, const float* save_mean, const float* save_invstd,
+                          const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
+                          float* dz_out, unsigned short* draw_planes, long long plane_stride, void* workspace, long long rows, int c,
+                          int accumulate, void* stream) {
+    STRAPS_REQUIRE(!relu_bits || (!yact && (c & 31) == 0), "straps_bn_bwd_bits_x3: the bits replace yact (and need c %% 32 == 0; c=%d)", c);
     STRAPS_REQUIRE(!draw_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "straps_bn_bwd_x3: plane_stride must be >= rows*c and a multiple of 8");
     STRAPS_REQUIRE(!draw_planes || (c & 31) == 0, "straps_bn_bwd_x3: chunk-major planes need c %% 32 == 0 (c=%d)", c);
     STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && (draw || draw_planes) && workspace, "straps_bn_bwd: null pointer");
@@ -1910,12 +1926,12 @@ extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float*
     double* part = (double*)workspace;               // [nblk][c][2]
     double* coefd = part + (size_t)nblk * c * 2;     // [2][c]  m1, m2
     float* k1 = (float*)(coefd + 2 * (size_t)c);     // [c]
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, PoolSrc{});
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk, (c + 63) / 64), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, mask_scale, mask_shift, part, rows, c, rpb, PoolSrc{}, relu_bits);
     STRAPS_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }
@@ -1923,10 +1939,30 @@ extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float*
 // straps_bn_bwd_x3 when the two sums already exist as per-tile partials [nblk][c][2] (S1, invstd * S2) -- written by
 // straps_conv_dgrad_x3_bn, the data-gradient launch that produced dy: finalize + apply only, no pass over (dy, raw) for the sums.
 // workspace: (2 c) doubles + c floats.
-extern "C" int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
-                                       const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta,
-                                       float* draw, float* dz_out, unsigned short* draw_planes, long long plane_stride, const double* partials,
-                                       int nblk, void* workspace, long long rows, int c, int accumulate, void* stream) {
+extern "C" int straps_bn_bwd_x3(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
+                                const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta, float* draw,
+                                float* dz_out, unsigned short* draw_planes, long long plane_stride, void* workspace, long long rows, int c,
+                                int accumulate, void* stream) {
+    return bn_bwd_x3_impl(dy, yact, nullptr, raw, save_mean, save_invstd, gamma, mask_scale, mask_shift, dgamma, dbeta, draw, dz_out, draw_planes,
+                          plane_stride, workspace, rows, c, accumulate, stream);
+}
+
+// straps_bn_bwd_x3 with the ReLU mask as bits: relu_bits [rows][c / 32] (bit ch & 31 of word [row][ch / 32] = activation > 0, written by
+// straps_bn_apply_bits_x3) takes the place of the fp32 activation `yact` -- 4 bytes per element less in each of the two passes.  There is no
+// dz_out: the consumers of the masked gradient apply the same bits to dy themselves (straps_conv_dgrad_x3_bits / _bn_bits: addend_bits).
+extern "C" int straps_bn_bwd_bits_x3(const float* dy, const unsigned* relu_bits, const float* raw, const float* save_mean, const float* save_invstd,
+                                     const float* gamma, float* dgamma, float* dbeta, float* draw, unsigned short* draw_planes, long long plane_stride,
+                                     void* workspace, long long rows, int c, int accumulate, void* stream) {
+    STRAPS_REQUIRE(relu_bits, "straps_bn_bwd_bits_x3: null bit mask");
+    return bn_bwd_x3_impl(dy, nullptr, relu_bits, raw, save_mean, save_invstd, gamma, nullptr, nullptr, dgamma, dbeta, draw, nullptr, draw_planes,
+                          plane_stride, workspace, rows, c, accumulate, stream);
+}
+
+static int bn_bwd_finish_x3_impl(const float* dy, const float* yact, const unsigned* relu_bits, const float* raw, const float* save_mean,
+                                 const float* save_invstd, const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma,
+                                 float* dbeta, float* draw, float* dz_out, unsigned short* draw_planes, long long plane_stride, const double* partials,
+                                 int nblk, void* workspace, long long rows, int c, int accumulate, void* stream) {
+    STRAPS_REQUIRE(!relu_bits || (!yact && (c & 31) == 0), "straps_bn_bwd_finish_bits_x3: the bits replace yact (and need c %% 32 == 0; c=%d)", c);
     STRAPS_REQUIRE(!draw_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "straps_bn_bwd_finish_x3: plane_stride must be >= rows*c and a multiple of 8");
     STRAPS_REQUIRE(!draw_planes || (c & 31) == 0, "straps_bn_bwd_finish_x3: chunk-major planes need c %% 32 == 0 (c=%d)", c);
     STRAPS_REQUIRE(dy && raw && save_mean && save_invstd && gamma && dgamma && dbeta && (draw || draw_planes) && workspace && partials && nblk > 0,
@@ -1940,9 +1976,28 @@ extern "C" int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partials, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{});
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
+}
+
+extern "C" int straps_bn_bwd_finish_x3(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
+                                       const float* gamma, const float* mask_scale, const float* mask_shift, float* dgamma, float* dbeta,
+                                       float* draw, float* dz_out, unsigned short* draw_planes, long long plane_stride, const double* partials,
+                                       int nblk, void* workspace, long long rows, int c, int accumulate, void* stream) {
+    return bn_bwd_finish_x3_impl(dy, yact, nullptr, raw, save_mean, save_invstd, gamma, mask_scale, mask_shift, dgamma, dbeta, draw, dz_out, draw_planes,
+                                 plane_stride, partials, nblk, workspace, rows, c, accumulate, stream);
+}
+
+// straps_bn_bwd_finish_x3 with the ReLU mask as bits (see straps_bn_bwd_bits_x3; the partials come from straps_conv_dgrad_x3_bn_bits, which read
+// the same bits)
+extern "C" int straps_bn_bwd_finish_bits_x3(const float* dy, const unsigned* relu_bits, const float* raw, const float* save_mean,
+                                            const float* save_invstd, const float* gamma, float* dgamma, float* dbeta, float* draw,
+                                            unsigned short* draw_planes, long long plane_stride, const double* partials, int nblk, void* workspace,
+                                            long long rows, int c, int accumulate, void* stream) {
+    STRAPS_REQUIRE(relu_bits, "straps_bn_bwd_finish_bits_x3: null bit mask");
+    return bn_bwd_finish_x3_impl(dy, nullptr, relu_bits, raw, save_mean, save_invstd, gamma, nullptr, nullptr, dgamma, dbeta, draw, nullptr, draw_planes,
+                                 plane_stride, partials, nblk, workspace, rows, c, accumulate, stream);
 }
 
 extern "C" int straps_bn_bwd(const float* dy, const float* yact, const float* raw, const float* save_mean, const float* save_invstd,
@@ -2001,7 +2056,7 @@ extern "C" int straps_bn_bwd_pooled_sparse(const float* dy_pool, const uint8_t* 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)((n4 + POOL_CHUNK - 1) / POOL_CHUNK)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)((n4 + POOL_CHUNK - 1) / POOL_CHUNK)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps, (const unsigned*)nullptr);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel<pool>");
     return STRAPS_OK;
 }

@@ -32,6 +32,11 @@ struct ConvP {
     const float* bnr_mean;
     const float* bnr_invstd;
     double* bnr_part;               // [blocks][Cout][2]
+    // ReLU decisions as bits instead of fp32 tensors (round 4; word [pixel][Cout / 32], bit c & 31 = "activation of channel c > 0", written by
+    // straps_bn_apply_bits_x3): bnr_bits replaces bnr_out as the mask of the sums above, res_bits masks the addend (`res` is then the
+    // UNMASKED gradient of a residual unit's output, of which the skip connection receives the part the unit's ReLU let through)
+    const unsigned* bnr_bits;
+    const unsigned* res_bits;
     int bnr_base[4];                // first partial block of each class
     // eval-mode forward on the bf16x3 route: the epilogue's result also as three bf16 planes (the next convolution's operand),
     // y itself may then be NULL when nothing reads the fp32 tensor
@@ -95,8 +100,8 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-                bsc[j] = p.bnr_out ? 0.f : p.bnr_sc[n];
-                bsh[j] = p.bnr_out ? 0.f : p.bnr_sh[n];
+                bsc[j] = (p.bnr_out || p.bnr_bits) ? 0.f : p.bnr_sc[n];
+                bsh[j] = (p.bnr_out || p.bnr_bits) ? 0.f : p.bnr_sh[n];
                 bmu[j] = p.bnr_mean[n];
                 d1[j] = 0.0;
                 d2[j] = 0.0;
@@ -143,6 +148,16 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
                         const int m = mb + (r & 3) + 8 * (r >> 2);
                         rv[r][j] = (FULL || m < cM) ? p.res[pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31)] : 0.f;
                     }
+                if (p.res_bits) {      // (one word per row and 32-channel group, the same for the 32 lanes of a row: a broadcast load)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const int m = mb + (r & 3) + 8 * (r >> 2);
+                            const unsigned wd = (FULL || m < cM) ? p.res_bits[pixr[r] * (p.Cout >> 5) + ((n0 + wn * WTN + j * 32) >> 5)] : 0u;
+                            rv[r][j] = ((wd >> (lane & 31)) & 1u) ? rv[r][j] : 0.f;
+                        }
+                }
             }
             // (BNR: raw -- and, for a residual unit's last BatchNorm, the activation -- of eight rows at a time: fetched together like rv;
             //  two halves keep the 256x128 / 8-wave tile inside its 256 registers)
@@ -159,7 +174,10 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
                                 const int m = mb + (r & 3) + 8 * (r >> 2);
                                 const int o = pixr[r] * p.Cout + n0 + wn * WTN + j * 32 + (lane & 31);
                                 xr[q][j] = (FULL || m < cM) ? p.bnr_raw[o] : 0.f;
-                                yo[q][j] = (p.bnr_out && (FULL || m < cM)) ? p.bnr_out[o] : 0.f;
+                                if (p.bnr_bits)      // (the word rides in the register the activation would occupy)
+                                    yo[q][j] = (FULL || m < cM) ? __uint_as_float(p.bnr_bits[pixr[r] * (p.Cout >> 5) + ((n0 + wn * WTN + j * 32) >> 5)]) : 0.f;
+                                else
+                                    yo[q][j] = (p.bnr_out && (FULL || m < cM)) ? p.bnr_out[o] : 0.f;
                             }
                     }
                 }
@@ -188,7 +206,8 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
                                     p.yplanes[2 * p.yps + oc] = b3;
                                 }
                                 if (bnr) {
-                                    const bool on = p.bnr_out ? yo[q][j] > 0.f : fmaf(xr[q][j], bsc[j], bsh[j]) > 0.f;
+                                    const bool on = p.bnr_bits ? (((__float_as_uint(yo[q][j]) >> (lane & 31)) & 1u) != 0)
+                                                               : (p.bnr_out ? yo[q][j] > 0.f : fmaf(xr[q][j], bsc[j], bsh[j]) > 0.f);
                                     const float g = on ? v : 0.f;
                                     d1[j] += (double)g;
                                     d2[j] += (double)g * ((double)xr[q][j] - (double)bmu[j]);
@@ -277,7 +296,7 @@ __device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&
 inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, const float* residual, int relu, float* y, float* stats_partial,
                             int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad) {
     p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
-    p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
+    p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr; p.bnr_bits = p.res_bits = nullptr;
     p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current();
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
     ConvP::Class& c = p.cls[0];
@@ -304,7 +323,7 @@ inline int conv_dgrad_problem(ConvP& p, const float* addend, float* dx, int batc
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (wdt + 2 * pad - kw) / stride + 1;
     const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
-    p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr;
+    p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr; p.bnr_bits = p.res_bits = nullptr;
     p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current();
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;

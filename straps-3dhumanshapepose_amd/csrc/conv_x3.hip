@@ -729,10 +729,11 @@ extern "C" int straps_conv_fwd_x3p(const unsigned short* x3, long long x_plane_s
     return dispatch_x3(p, tile_cfg, (hipStream_t)stream);
 }
 
-extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
-                                    const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
-                                    int pad, int tile_cfg, void* stream) {
+static int conv_dgrad_x3_impl(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                              const float* addend, const unsigned* addend_bits, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw,
+                              int stride, int pad, int tile_cfg, void* stream) {
     STRAPS_REQUIRE(dy3 && w3_crsk && dx, "straps_conv_dgrad_x3: null pointer");
+    STRAPS_REQUIRE(!addend_bits || (addend && cin % 32 == 0), "straps_conv_dgrad_x3_bits: the ReLU bits mask an addend (and need cin %% 32 == 0)");
     STRAPS_REQUIRE(cout % 32 == 0 && cin % 64 == 0, "straps_conv_dgrad_x3: need cout%%32==0 and cin%%64==0 (cin=%d cout=%d)", cin, cout);
     STRAPS_REQUIRE(stride == 1 || stride == 2, "straps_conv_dgrad_x3: stride must be 1 or 2");
     STRAPS_REQUIRE(kh * kw <= 9 && kh - 1 - pad >= 0 && kw - 1 - pad >= 0, "straps_conv_dgrad_x3: unsupported filter geometry");
@@ -742,7 +743,25 @@ extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plan
     p.xps = dy_plane_stride; p.wps = w_plane_stride;
     const int rc = conv_dgrad_problem(p, addend, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad);
     if (rc != STRAPS_OK) return rc;
+    p.res_bits = addend_bits;
     return p.ncls ? dispatch_x3(p, tile_cfg, (hipStream_t)stream) : STRAPS_OK;
+}
+
+extern "C" int straps_conv_dgrad_x3(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                                    const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
+                                    int pad, int tile_cfg, void* stream) {
+    return conv_dgrad_x3_impl(dy3, dy_plane_stride, w3_crsk, w_plane_stride, addend, nullptr, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad, tile_cfg,
+                              stream);
+}
+
+// straps_conv_dgrad_x3 whose addend is the UNMASKED gradient of a residual unit's output: dx = dgrad + (bit ? addend : 0), with the unit's ReLU
+// decisions as bits (straps_bn_apply_bits_x3: word [pixel][cin / 32], bit c & 31) -- the masked copy `dz` of that gradient is never written
+extern "C" int straps_conv_dgrad_x3_bits(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                                         const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
+                                         int pad, int tile_cfg, const unsigned* addend_bits, void* stream) {
+    STRAPS_REQUIRE(addend_bits, "straps_conv_dgrad_x3_bits: null bit mask");
+    return conv_dgrad_x3_impl(dy3, dy_plane_stride, w3_crsk, w_plane_stride, addend, addend_bits, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad,
+                              tile_cfg, stream);
 }
 
 // number of [cout][2] statistics partials straps_conv_fwd_x3 writes for this geometry (= its M tiles)
@@ -769,13 +788,16 @@ extern "C" int straps_conv_dgrad_x3_bn_blocks(int batch, int h, int w, int cin, 
     return dgrad_x3_blocks(p, tile_cfg);
 }
 
-extern "C" int straps_conv_dgrad_x3_bn(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
-                                       const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
-                                       int pad, int tile_cfg, const float* bn_raw, const float* bn_out, const float* bn_mask_scale,
-                                       const float* bn_mask_shift, const float* bn_mean, const float* bn_invstd, double* bn_partials, void* stream) {
+static int conv_dgrad_x3_bn_impl(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                                 const float* addend, const unsigned* addend_bits, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw,
+                                 int stride, int pad, int tile_cfg, const float* bn_raw, const float* bn_out, const unsigned* bn_out_bits,
+                                 const float* bn_mask_scale, const float* bn_mask_shift, const float* bn_mean, const float* bn_invstd,
+                                 double* bn_partials, void* stream) {
     STRAPS_REQUIRE(dy3 && w3_crsk && dx, "straps_conv_dgrad_x3_bn: null pointer");
-    STRAPS_REQUIRE(bn_raw && bn_mean && bn_invstd && bn_partials && (bn_out || (bn_mask_scale && bn_mask_shift)),
-                   "straps_conv_dgrad_x3_bn: the BatchNorm tensors (raw, mean, invstd, partials, and out or mask scale / shift) are required");
+    STRAPS_REQUIRE(bn_raw && bn_mean && bn_invstd && bn_partials && (bn_out || bn_out_bits || (bn_mask_scale && bn_mask_shift)),
+                   "straps_conv_dgrad_x3_bn: the BatchNorm tensors (raw, mean, invstd, partials, and out / its bits or mask scale / shift) are required");
+    STRAPS_REQUIRE(!addend_bits || addend, "straps_conv_dgrad_x3_bn_bits: the ReLU bits mask an addend");
+    STRAPS_REQUIRE(!(addend_bits || bn_out_bits) || cin % 32 == 0, "straps_conv_dgrad_x3_bn_bits: bit masks need cin %% 32 == 0 (cin=%d)", cin);
     STRAPS_REQUIRE(cout % 32 == 0 && cin % 64 == 0, "straps_conv_dgrad_x3_bn: need cout%%32==0 and cin%%64==0 (cin=%d cout=%d)", cin, cout);
     STRAPS_REQUIRE(stride == 1 || stride == 2, "straps_conv_dgrad_x3_bn: stride must be 1 or 2");
     STRAPS_REQUIRE(kh * kw <= 9 && kh - 1 - pad >= 0 && kw - 1 - pad >= 0, "straps_conv_dgrad_x3_bn: unsupported filter geometry");
@@ -787,7 +809,28 @@ extern "C" int straps_conv_dgrad_x3_bn(const unsigned short* dy3, long long dy_p
     if (rc != STRAPS_OK) return rc;
     p.bnr_raw = bn_raw; p.bnr_out = bn_out; p.bnr_sc = bn_mask_scale; p.bnr_sh = bn_mask_shift; p.bnr_mean = bn_mean; p.bnr_invstd = bn_invstd;
     p.bnr_part = bn_partials;
+    p.bnr_bits = bn_out_bits; p.res_bits = addend_bits;
     return p.ncls ? dispatch_x3(p, tile_cfg, (hipStream_t)stream) : STRAPS_OK;
+}
+
+extern "C" int straps_conv_dgrad_x3_bn(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                                       const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
+                                       int pad, int tile_cfg, const float* bn_raw, const float* bn_out, const float* bn_mask_scale,
+                                       const float* bn_mask_shift, const float* bn_mean, const float* bn_invstd, double* bn_partials, void* stream) {
+    return conv_dgrad_x3_bn_impl(dy3, dy_plane_stride, w3_crsk, w_plane_stride, addend, nullptr, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad, tile_cfg,
+                                 bn_raw, bn_out, nullptr, bn_mask_scale, bn_mask_shift, bn_mean, bn_invstd, bn_partials, stream);
+}
+
+// straps_conv_dgrad_x3_bn with ReLU decisions as bits (word [pixel][cin / 32], bit c & 31; straps_bn_apply_bits_x3) wherever the fp32 form reads
+// a whole activation tensor for its sign: bn_out_bits replaces bn_out as the mask of the BatchNorm sums (4 B per element less), addend_bits
+// masks the addend, which is then the unmasked gradient of the later unit's output (either may be NULL: that operand is used as before)
+extern "C" int straps_conv_dgrad_x3_bn_bits(const unsigned short* dy3, long long dy_plane_stride, const unsigned short* w3_crsk, long long w_plane_stride,
+                                            const float* addend, float* dx, int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride,
+                                            int pad, int tile_cfg, const float* bn_raw, const float* bn_out, const float* bn_mask_scale,
+                                            const float* bn_mask_shift, const float* bn_mean, const float* bn_invstd, double* bn_partials,
+                                            const unsigned* addend_bits, const unsigned* bn_out_bits, void* stream) {
+    return conv_dgrad_x3_bn_impl(dy3, dy_plane_stride, w3_crsk, w_plane_stride, addend, addend_bits, dx, batch, h, wdt, cin, cout, kh, kw, stride, pad,
+                                 tile_cfg, bn_raw, bn_out, bn_out_bits, bn_mask_scale, bn_mask_shift, bn_mean, bn_invstd, bn_partials, stream);
 }
 
 extern "C" int straps_conv_x3_stat_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg) {

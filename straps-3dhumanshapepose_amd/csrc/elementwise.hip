@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res, int relu,
-                                                       float* __restrict__ y, u16* __restrict__ planes, long long ps, long long n4, int C4) {
+                                                       float* __restrict__ y, u16* __restrict__ planes, long long ps, long long n4, int C4,
+                                                       unsigned* __restrict__ bits) {
     const long long first = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
     const long long rows = n4 / C4;
     auto body = [&](long long i, long long r, int c4, const f32x4& sc, const f32x4& sh) {
@@ -249,6 +250,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         if (y) *reinterpret_cast<f32x4*>(y + i * 4) = v;        // (NULL: only the planes are consumed -- bf16x3 route, see straps_bn_apply_x3)
         if (planes) store_planes4_cm(planes, ps, r, c4 * 4, rows, v);      // bf16x3 route: the next convolution's operand (chunk-major planes), written here instead of by a split pass
+        if (bits) {
+            // the ReLU decisions of this output as one word per (row, 32 channels), bit c & 31: what the backward pass needs of a residual unit's
+            // activation (straps_bn_bwd_bits_x3, straps_conv_dgrad_x3_bn_bits) in 1/32 of its bytes.  Eight neighbouring lanes hold the eight
+            // nibbles of a word (C4 % 8 == 0 and n4 % 8 == 0: they are in the same row and leave the loop together)
+            unsigned wd = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << ((c4 & 7) * 4);
+            wd |= __shfl_xor(wd, 1, 64);
+            wd |= __shfl_xor(wd, 2, 64);
+            wd |= __shfl_xor(wd, 4, 64);
+            if ((c4 & 7) == 0) bits[r * (C4 >> 3) + (c4 >> 3)] = wd;
+        }
     };
     if (step % C4 == 0) {
         // round 4: the grid stride is a multiple of the row length (the host sizes the grid so), so a thread keeps ITS four channels for the whole
@@ -389,18 +400,32 @@ extern "C" int straps_bn_apply(const float* x, const float* scale, const float* 
                                long long rows, int c, void* stream) {
     STRAPS_REQUIRE(x && scale && shift && y && rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_apply: bad arguments (c%%4 must be 0)");
     const long long n4 = rows * (c >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, (u16*)nullptr, 0LL, n4, c >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, (u16*)nullptr, 0LL, n4, c >> 2, (unsigned*)nullptr);
+    STRAPS_CHECK_LAUNCH("bn_apply_kernel");
+    return STRAPS_OK;
+}
+
+static int bn_apply_x3_impl(const char* who, const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
+                            unsigned short* y_planes, long long plane_stride, unsigned* relu_bits, long long rows, int c, void* stream) {
+    // (the planes are chunk-major, common.h cm_index: 32-channel chunks outermost -- c % 32 != 0 would index past rows*c; ADVICE round 3)
+    STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 31) == 0, "%s: bad arguments (c%%32 must be 0: chunk-major planes; c=%d)", who, c);
+    STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "%s: plane_stride must be >= rows*c and a multiple of 8", who);
+    const long long n4 = rows * (c >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, y_planes, plane_stride, n4, c >> 2, relu_bits);
     STRAPS_CHECK_LAUNCH("bn_apply_kernel");
     return STRAPS_OK;
 }
 
 extern "C" int straps_bn_apply_x3(const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
                                   unsigned short* y_planes, long long plane_stride, long long rows, int c, void* stream) {
-    // (the planes are chunk-major, common.h cm_index: 32-channel chunks outermost -- c % 32 != 0 would index past rows*c; ADVICE round 3)
-    STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 31) == 0, "straps_bn_apply_x3: bad arguments (c%%32 must be 0: chunk-major planes; c=%d)", c);
-    STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "straps_bn_apply_x3: plane_stride must be >= rows*c and a multiple of 8");
-    const long long n4 = rows * (c >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, y_planes, plane_stride, n4, c >> 2);
-    STRAPS_CHECK_LAUNCH("bn_apply_kernel");
-    return STRAPS_OK;
+    return bn_apply_x3_impl("straps_bn_apply_x3", x, scale, shift, residual, relu, y, y_planes, plane_stride, nullptr, rows, c, stream);
+}
+
+// straps_bn_apply_x3 that also records its ReLU decisions: relu_bits [rows][c / 32] words, bit (ch & 31) of word [row][ch / 32] = (y[row][ch] > 0).
+// The backward pass of a residual unit reads these instead of the fp32 activation (straps_bn_bwd_bits_x3, straps_bn_bwd_finish_bits_x3,
+// straps_conv_dgrad_x3_bn_bits, straps_conv_dgrad_x3_bits).
+extern "C" int straps_bn_apply_bits_x3(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                                       unsigned short* y_planes, long long plane_stride, unsigned* relu_bits, long long rows, int c, void* stream) {
+    STRAPS_REQUIRE(relu_bits, "straps_bn_apply_bits_x3: null bit buffer");
+    return bn_apply_x3_impl("straps_bn_apply_bits_x3", x, scale, shift, residual, 1, y, y_planes, plane_stride, relu_bits, rows, c, stream);
 }

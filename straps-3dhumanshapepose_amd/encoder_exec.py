@@ -10,6 +10,10 @@ import torch
 from . import hipabi
 
 
+# ReLU decisions of a residual unit as bits for the backward pass (straps_bn_apply_bits_x3 and the *_bits backward entry points); False = the
+# fp32-mask forms of rounds 1-3 (tests compare the two: identical gradients)
+_RELU_BITS = True
+
 def _conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
@@ -66,6 +70,16 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=
         # empty tensor that only carries the identity the planes are looked up by.
         y = torch.empty_like(raw) if keep_fp32 else raw.new_empty(0)
         planes, ps = _new_planes(raw)
+        if _RELU_BITS and residual is not None and rec is not None:
+            # the last BatchNorm of a residual unit, with a backward to come: the unit's ReLU decisions also as bits -- the backward reads
+            # them (1/32 of the bytes) wherever it would read this fp32 activation for its sign (autograd_ops._bn_bwd, _conv_dgrad)
+            bits = torch.empty(rows, C // 32, device=raw.device, dtype=torch.int32)
+            hipabi.check(L.straps_bn_apply_bits_x3(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual),
+                                                   hipabi.ptr(y if keep_fp32 else None), hipabi.ptr(planes), ps, hipabi.ptr(bits), rows, C,
+                                                   hipabi.stream_ptr()), 'straps_bn_apply_bits_x3')
+            ctx.planes[id(y)] = (y, planes, ps)
+            rec.update(raw=raw, stats=ss, out=y if keep_fp32 else None, bits=bits)
+            return y
         hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
                                           hipabi.ptr(y if keep_fp32 else None), hipabi.ptr(planes), ps, rows, C, hipabi.stream_ptr()),
                      'straps_bn_apply_x3')

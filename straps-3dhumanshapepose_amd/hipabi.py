@@ -111,7 +111,7 @@ def gemm_multi(descs):
 _P, _I, _L, _F, _Z, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
-ABI_VERSION = 7      # == STRAPS_ABI_VERSION of include/straps_hip.h (tests/test_abi.py compares the two); load() refuses a library of another version
+ABI_VERSION = 8      # == STRAPS_ABI_VERSION of include/straps_hip.h (tests/test_abi.py compares the two); load() refuses a library of another version
 SIGNATURES = {
     'straps_abi_version': (_I, []),
     'straps_last_error': (C.c_char_p, []),
@@ -147,6 +147,12 @@ SIGNATURES = {
     'straps_bn_bwd_finish_x3': (_I, [_P] * 13 + [_L, _P, _I, _P, _L, _I, _I, _P]),
     'straps_conv_wgrad_x3': (_I, [_P, _P, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_bn_bwd_x3': (_I, [_P] * 13 + [_L, _P, _L, _I, _I, _P]),
+    # ReLU decisions as bits (ABI 8)
+    'straps_bn_apply_bits_x3': (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _P]),
+    'straps_bn_bwd_bits_x3': (_I, [_P] * 10 + [_L, _P, _L, _I, _I, _P]),
+    'straps_bn_bwd_finish_bits_x3': (_I, [_P] * 10 + [_L, _P, _I, _P, _L, _I, _I, _P]),
+    'straps_conv_dgrad_x3_bits': (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'straps_conv_dgrad_x3_bn_bits': (_I, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'straps_conv_stat_blocks': (_I, [_I, _I, _I, _I, _I, _I]),
     'straps_conv_fwd': (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'straps_maxpool_fwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -461,6 +461,37 @@ def test_fused_stem_tail_equals_unfused(dev):
             assert torch.equal(ba[n], bb[n]), n
 
 
+@pytest.mark.parametrize('layers', [18, 50])
+def test_relu_bits_backward_equals_the_fp32_mask_backward(dev, layers):
+    """ABI 8 (encoder_exec._RELU_BITS): a residual unit's ReLU decisions travel to the backward pass as bits -- the last BatchNorm's two
+    passes, the sums fused into the data gradient that feeds it and the skip connection's share of the gradient read 1 / 32 of the bytes, and
+    the masked copy dz of the gradient is never written.  Nothing else changes: outputs, running statistics and EVERY parameter gradient of
+    the regressor are bit-identical with the switch off (the fp32-mask entry points of rounds 1-3).  Basic blocks with and without a
+    downsample branch (resnet18), bottlenecks (resnet50)."""
+    from straps_amd import encoder_exec
+    outs = []
+    try:
+        for on in (True, False):
+            encoder_exec._RELU_BITS = on
+            reg, _ = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+            reg.train()
+            x = torch.from_numpy(det_uniform((3, 18, 128, 96), 81, 0.0, 1.0)).to(dev)
+            coef = torch.from_numpy(det_uniform((3, 157), 82)).to(dev)
+            cam, pose, shp = reg(x)
+            (torch.cat([cam, pose, shp], 1) * coef).sum().backward()
+            outs.append((torch.cat([cam, pose, shp], 1).detach().clone(), {n: p.grad.clone() for n, p in reg.named_parameters()},
+                         {n: b.clone() for n, b in reg.named_buffers()}))
+    finally:
+        encoder_exec._RELU_BITS = True
+    (ya, ga, ba), (yb, gb, bb) = outs
+    assert torch.equal(ya, yb)
+    assert all(bool(torch.isfinite(g).all()) for g in ga.values())
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
+    for n in ba:
+        assert torch.equal(ba[n], bb[n]), n
+
+
 def test_sparse_stem_tail_writes_only_what_the_weight_gradient_reads(dev):
     """straps_bn_bwd_pooled_sparse on a proxy-like input (a silhouette box + a few heat-map blobs, whole channels empty): the tiles
     straps_stem_tile_activity marks are written bit for bit as by the dense call, the others are left untouched, dgamma / dbeta are the

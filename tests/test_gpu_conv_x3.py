@@ -380,6 +380,114 @@ def test_dgrad_x3_with_fused_batchnorm_sums(dev, B, Cin, Cout, H, W, k, stride, 
         assert err < 2e-6, (name, err)          # (the same double sums in another order, rounded once to fp32)
 
 
+def _pack_relu_bits(y):
+    """[rows..., C] activation -> int32 words [rows][C / 32], bit (c & 31) of word [row][c / 32] = (y > 0) (include/straps_hip.h, ABI 8)"""
+    C = y.shape[-1]
+    b = (y.reshape(-1, C // 32, 32) > 0).to(torch.int64)
+    wd = (b << torch.arange(32, device=y.device, dtype=torch.int64)).sum(-1)
+    return torch.where(wd >= 2 ** 31, wd - 2 ** 32, wd).to(torch.int32).contiguous()
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
+    (4, 64, 64, 16, 16, 3, 1, 0), (3, 128, 64, 12, 20, 1, 1, 1), (2, 256, 64, 16, 16, 1, 1, 0), (2, 64, 128, 16, 16, 1, 2, 0), (2, 128, 256, 9, 14, 3, 2, 1),
+    (4, 128, 64, 32, 32, 3, 1, 512), (2, 512, 128, 8, 8, 1, 1, 3), (1, 2048, 512, 8, 8, 1, 1, 0)])
+def test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit(dev, B, Cin, Cout, H, W, k, stride, cfg):
+    """ABI 8: a residual unit's ReLU decisions as bits.  straps_bn_apply_bits_x3 writes y / planes as straps_bn_apply_x3 and the words
+    bit (c & 31) of [row][c / 32] = (y > 0); every *_bits backward form -- data gradient with a masked addend (plain and with the fused
+    BatchNorm sums masked by bits), BatchNorm backward in three passes and on fused partials -- equals, bit for bit, the fp32 form fed with the
+    activation itself and with the masked gradient dz the fp32 route materialises.  Ragged M tiles, stride-2 parity classes, halo-patch
+    kernel, 64 ... 2048 channels (both loop forms of the streaming kernels)."""
+    L = hipabi.lib()
+    pad = 1 if k == 3 else 0
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    rows = B * H * W
+    raw = torch.from_numpy(det_uniform((B, H, W, Cin), 5, -2, 2)).to(dev)
+    res = torch.from_numpy(det_uniform((B, H, W, Cin), 8, -1, 1)).to(dev)
+    res[0, 0, :, : Cin // 2] = 0.0
+    raw[0, 0, :, : Cin // 2] = 0.0          # exact zeros after the ReLU's input: y == 0 must read as "off"
+    sc = torch.from_numpy(det_uniform((Cin,), 6, 0.5, 1.5)).to(dev)
+    sh = torch.from_numpy(det_uniform((Cin,), 7, -0.5, 0.5)).to(dev)
+    sh[: Cin // 4] = 0.0
+    ps = (rows * Cin + 7) // 8 * 8
+    # ---- forward: y, planes, bits
+    y0, y1 = torch.empty_like(raw), torch.empty_like(raw)
+    p0, p1 = torch.zeros(3, ps, device=dev, dtype=torch.int16), torch.zeros(3, ps, device=dev, dtype=torch.int16)
+    bits = torch.full((rows, Cin // 32), 0x5a5a5a5a, device=dev, dtype=torch.int32)
+    hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), 1, hipabi.ptr(y0), hipabi.ptr(p0), ps, rows, Cin, None),
+                 'bn_apply_x3')
+    hipabi.check(L.straps_bn_apply_bits_x3(hipabi.ptr(raw), hipabi.ptr(sc), hipabi.ptr(sh), hipabi.ptr(res), hipabi.ptr(y1), hipabi.ptr(p1), ps, hipabi.ptr(bits),
+                                           rows, Cin, None), 'bn_apply_bits_x3')
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    assert torch.equal(bits, _pack_relu_bits(y0))
+    assert 0.2 < float((y0 > 0).float().mean()) < 0.8 and bool((y0[0, 0, :, : Cin // 4] == 0).all())
+    # ---- the gradient arriving at the unit's output, its masked copy (what the fp32 route writes as dz), the convolution's operands
+    w = torch.from_numpy(det_uniform((Cout, Cin, k, k), 2, -1, 1)) * (2.0 / (Cin * k * k)) ** 0.5
+    g = torch.from_numpy(det_uniform((B, Ho, Wo, Cout), 3, -1, 1)).to(dev) * 1e-3
+    g3, gps = _split(g)
+    w3, wps = _wsplit(dev, w, dgrad=True)
+    dy_next = torch.from_numpy(det_uniform((B, H, W, Cin), 4, -1, 1)).to(dev) * 1e-3      # unmasked gradient of the LATER unit's output ...
+    y_next = torch.relu(torch.from_numpy(det_uniform((B, H, W, Cin), 9, -1, 1)).to(dev)).contiguous()      # ... and that unit's activation
+    bits_next = _pack_relu_bits(y_next)
+    dz_next = torch.where(y_next > 0, dy_next, torch.zeros_like(dy_next)).contiguous()
+    mean = raw.mean(dim=(0, 1, 2)).contiguous()
+    invstd = (raw.var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt().contiguous()
+    geo = (B, H, W, Cin, Cout, k, k, stride, pad, cfg)
+    # ---- plain data gradient with a masked addend
+    dxa, dxb = torch.full_like(raw, float('nan')), torch.full_like(raw, float('nan'))
+    hipabi.check(L.straps_conv_dgrad_x3(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(dz_next), hipabi.ptr(dxa), *geo, None), 'dgrad_x3')
+    hipabi.check(L.straps_conv_dgrad_x3_bits(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(dy_next), hipabi.ptr(dxb), *geo, hipabi.ptr(bits_next), None),
+                 'dgrad_x3_bits')
+    assert torch.equal(dxa, dxb)
+    # ---- data gradient + the sums of THIS unit's last BatchNorm: mask = y0 > 0 as fp32 tensor / as bits; addend masked / unmasked + bits
+    nblk = L.straps_conv_dgrad_x3_bn_blocks(*geo)
+    pa = torch.full((nblk, Cin, 2), float('nan'), device=dev, dtype=torch.float64)
+    pb = torch.full_like(pa, float('nan'))
+    dxa.fill_(float('nan')); dxb.fill_(float('nan'))
+    hipabi.check(L.straps_conv_dgrad_x3_bn(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(dz_next), hipabi.ptr(dxa), *geo, hipabi.ptr(raw), hipabi.ptr(y0),
+                                           None, None, hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(pa), None), 'dgrad_x3_bn')
+    hipabi.check(L.straps_conv_dgrad_x3_bn_bits(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(dy_next), hipabi.ptr(dxb), *geo, hipabi.ptr(raw), None,
+                                                None, None, hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(pb), hipabi.ptr(bits_next), hipabi.ptr(bits), None),
+                 'dgrad_x3_bn_bits')
+    assert torch.equal(dxa, dxb) and torch.equal(pa, pb)
+    # (one operand as bits only: the other as in the plain form)
+    dxc, pc = torch.full_like(raw, float('nan')), torch.full_like(pa, float('nan'))
+    hipabi.check(L.straps_conv_dgrad_x3_bn_bits(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, hipabi.ptr(dz_next), hipabi.ptr(dxc), *geo, hipabi.ptr(raw), None,
+                                                None, None, hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(pc), None, hipabi.ptr(bits), None), 'dgrad_x3_bn_bits')
+    assert torch.equal(dxa, dxc) and torch.equal(pa, pc)
+    # ---- BatchNorm backward: three passes and finish-on-partials, planes + fp32
+    gamma = torch.from_numpy(det_uniform((Cin,), 10, 0.5, 1.5)).to(dev)
+    ws = torch.empty(L.straps_bn_bwd_workspace_bytes(rows, Cin) // 4, device=dev)
+    res_ = {}
+    for form in ('fp32', 'bits', 'fp32_finish', 'bits_finish'):
+        dg, db, draw = torch.full((Cin,), float('nan'), device=dev), torch.full((Cin,), float('nan'), device=dev), torch.full_like(raw, float('nan'))
+        dz = torch.full_like(raw, float('nan'))
+        pl = torch.zeros(3, ps, device=dev, dtype=torch.int16)
+        if form == 'fp32':
+            hipabi.check(L.straps_bn_bwd_x3(hipabi.ptr(dxa), hipabi.ptr(y0), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma), None, None,
+                                            hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(dz), hipabi.ptr(pl), ps, hipabi.ptr(ws), rows, Cin, 0, None), form)
+        elif form == 'bits':
+            hipabi.check(L.straps_bn_bwd_bits_x3(hipabi.ptr(dxa), hipabi.ptr(bits), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma),
+                                                 hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(pl), ps, hipabi.ptr(ws), rows, Cin, 0, None), form)
+        elif form == 'fp32_finish':
+            hipabi.check(L.straps_bn_bwd_finish_x3(hipabi.ptr(dxa), hipabi.ptr(y0), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma), None,
+                                                   None, hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(dz), hipabi.ptr(pl), ps, hipabi.ptr(pa), nblk,
+                                                   hipabi.ptr(ws), rows, Cin, 0, None), form)
+        else:
+            hipabi.check(L.straps_bn_bwd_finish_bits_x3(hipabi.ptr(dxa), hipabi.ptr(bits), hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma),
+                                                        hipabi.ptr(dg), hipabi.ptr(db), hipabi.ptr(draw), hipabi.ptr(pl), ps, hipabi.ptr(pa), nblk, hipabi.ptr(ws),
+                                                        rows, Cin, 0, None), form)
+        res_[form] = (dg, db, draw, pl)
+        if form.startswith('fp32'):      # the masked gradient the fp32 forms write is what the bits forms' consumers derive from (dy, bits)
+            assert torch.equal(dz, torch.where(y0 > 0, dxa, torch.zeros_like(dxa)))
+    for a, b in (('fp32', 'bits'), ('fp32_finish', 'bits_finish')):
+        for t0, t1, name in zip(res_[a], res_[b], ('dgamma', 'dbeta', 'draw', 'planes')):
+            assert torch.equal(t0, t1), (a, b, name)
+    # the *_bits forms refuse what they cannot index
+    assert L.straps_bn_bwd_bits_x3(hipabi.ptr(dxa), None, hipabi.ptr(raw), hipabi.ptr(mean), hipabi.ptr(invstd), hipabi.ptr(gamma), hipabi.ptr(dg), hipabi.ptr(db),
+                                   hipabi.ptr(draw), None, 0, hipabi.ptr(ws), rows, Cin, 0, None) == 1      # STRAPS_EINVAL
+    assert L.straps_conv_dgrad_x3_bits(hipabi.ptr(g3), gps, hipabi.ptr(w3), wps, None, hipabi.ptr(dxb), *geo, hipabi.ptr(bits_next), None) == 1
+
+
 @pytest.mark.parametrize('B,Cin,Cout', [(64, 64, 64), (16, 128, 64)])
 def test_single_patch_buffer_halo_kernel_at_layer1_size_forward_dgrad_and_repeats(dev, B, Cin, Cout):
     """conv_igemm_x3h_kernel<PBUF = 1> (the auto rule of every 64-channel 3x3 / stride-1 layer: one patch buffer re-copied at the channel-chunk
