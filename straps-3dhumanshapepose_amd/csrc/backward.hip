@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ k1p, const float* __restrict__ msc,
                                                            const float* __restrict__ msh, float* __restrict__ draw, float* dz_out,
                                                            u16* __restrict__ planes, long long pstride, long long n4, int C, PoolSrc ps,
-                                                           const unsigned* __restrict__ bits) {
+                                                           const unsigned* __restrict__ bits, int tiled) {
     const int C4 = C >> 2;
     // POOL: a workgroup owns POOL_CHUNK consecutive elements (with the tile map most workgroups of an empty region exit at once and the
     // dispatcher hands out the rest: a grid-stride loop would pin every workgroup to one image position -- all work or none)
@@ -1339,7 +1339,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         if (draw) *reinterpret_cast<f32x4*>(draw + idx * 4) = o;      // (NULL: only the planes are consumed, see straps_bn_bwd_x3)
         if (planes) store_planes4_cm(planes, pstride, row, c4 * 4, rows, o);      // bf16x3 route: the data-gradient kernel's operand (chunk-major planes)
     };
-    if (step % C4 == 0) {
+    if (!POOL && tiled) {
+        // a wave = 4 rows x 2 chunks of 32 channels: whole 256-byte runs of every chunk-major plane per wave store; `tiled` = the column
+        // groups of 64 channels the workgroup's waves sit on side by side (bn_apply_kernel's tiled form, csrc/elementwise.hip; the host
+        // passes it only for row / channel counts that tile exactly, with a grid that is a multiple of the column blocks)
+        const int l = threadIdx.x & 63, w = threadIdx.x >> 6, wcg = tiled, ncb = (C4 >> 4) / wcg, trows = 16 / wcg;
+        const int c4 = ((int)(blockIdx.x % ncb) * wcg + w % wcg) * 16 + (l >> 5) * 8 + (l & 7);
+        const Consts k = load_consts(c4);
+        const long long rstep = (long long)(gridDim.x / ncb) * trows;
+        for (long long row = (long long)(blockIdx.x / ncb) * trows + (w / wcg) * 4 + ((l >> 3) & 3); row < rows; row += rstep) body(row * C4 + c4, row, c4, k);
+    } else if (step % C4 == 0) {
         if (first >= last) return;
         const int c4 = (int)(first % C4);
         const Consts k = load_consts(c4);
@@ -1553,6 +1562,21 @@ __global__ __launch_bounds__(256) void rot6d_bwd_kernel(const float* __restrict_
 inline unsigned capped_grid(long long n) {
     long long g = (n + 255) / 256;
     return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+// tiled form of the two streaming BatchNorm kernels (see csrc/elementwise.hip)
+inline int bn_tiled(long long rows, int C4) {      // 0 = linear form; else the column groups (16 float4 = 64 channels each) a workgroup takes
+    static const int mode = STRAPS_TOOL_ENV_INT("STRAPS_BN_TILED", 1);      // (A/B switch of the tools build: 0 off, 1 C >= 256 only, 2 also C = 64 / 128)
+    if (!mode || (C4 & 15)) return 0;
+    const int ncg = C4 >> 4;
+    if (!(ncg == 1 || ncg == 2 || (ncg & 3) == 0) || (mode == 1 && ncg < 4)) return 0;
+    const int wcg = ncg < 4 ? ncg : 4;
+    return (rows % (16 / wcg)) == 0 ? wcg : 0;
+}
+inline unsigned bn_tiled_grid(long long rows, int C4, int wcg) {
+    const long long ncb = (C4 >> 4) / wcg, tiles = rows / (16 / wcg) * ncb;
+    long long g = tiles < 256 * 16 ? tiles : 256 * 16;
+    g = g / ncb * ncb;
+    return (unsigned)(g < ncb ? ncb : g);
 }
 // the same with grid x 256 a multiple of the row length C4 (float4 units) where a grid under the cap allows it (see csrc/elementwise.hip)
 inline unsigned capped_grid_rows(long long n, int C4) {
@@ -1931,7 +1955,8 @@ static int bn_bwd_x3_impl(const float* dy, const float* yact, const unsigned* re
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits);
+    const int tiled = bn_tiled(rows, c >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(tiled ? bn_tiled_grid(rows, c >> 2, tiled) : capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits, tiled);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }
@@ -1976,7 +2001,8 @@ static int bn_bwd_finish_x3_impl(const float* dy, const float* yact, const unsig
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partials, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits);
+    const int tiled = bn_tiled(rows, c >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(tiled ? bn_tiled_grid(rows, c >> 2, tiled) : capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits, tiled);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }
@@ -2056,7 +2082,7 @@ extern "C" int straps_bn_bwd_pooled_sparse(const float* dy_pool, const uint8_t* 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)((n4 + POOL_CHUNK - 1) / POOL_CHUNK)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps, (const unsigned*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)((n4 + POOL_CHUNK - 1) / POOL_CHUNK)), dim3(256), 0, st, nullptr, nullptr, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, nullptr, (u16*)nullptr, 0LL, n4, c, ps, (const unsigned*)nullptr, 0);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel<pool>");
     return STRAPS_OK;
 }

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res, int relu,
                                                        float* __restrict__ y, u16* __restrict__ planes, long long ps, long long n4, int C4,
-                                                       unsigned* __restrict__ bits) {
+                                                       unsigned* __restrict__ bits, int tiled) {
     const long long first = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
     const long long rows = n4 / C4;
     auto body = [&](long long i, long long r, int c4, const f32x4& sc, const f32x4& sh) {
@@ -261,7 +261,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             if ((c4 & 7) == 0) bits[r * (C4 >> 3) + (c4 >> 3)] = wd;
         }
     };
-    if (step % C4 == 0) {
+    if (tiled) {
+        // round 4: a wave takes 4 rows x 2 chunks of 32 channels, 16 lanes 2 rows of one chunk -- every wave store covers 2 x 256 contiguous
+        // bytes of each chunk-major plane (8 lanes = the 64 bytes of one row's chunk, the next row's 64 follow) instead of one row's 64-byte
+        // pieces in up to 8 chunks, and every 8 lanes read one whole 128-byte line of the fp32 row.  The workgroup's 4 waves sit side by
+        // side on `tiled` (1, 2 or 4) column groups of 64 channels and stack 4 / tiled deep in rows; gridDim.x is a multiple of the column
+        // blocks (bn_tiled_grid): a thread's channels stay fixed.
+        const int l = threadIdx.x & 63, w = threadIdx.x >> 6, wcg = tiled, ncb = (C4 >> 4) / wcg, trows = 16 / wcg;
+        const int c4 = ((int)(blockIdx.x % ncb) * wcg + w % wcg) * 16 + (l >> 5) * 8 + (l & 7);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        const long long rstep = (long long)(gridDim.x / ncb) * trows;
+        for (long long r = (long long)(blockIdx.x / ncb) * trows + (w / wcg) * 4 + ((l >> 3) & 3); r < rows; r += rstep) body(r * C4 + c4, r, c4, sc, sh);
+    } else if (step % C4 == 0) {
         // round 4: the grid stride is a multiple of the row length (the host sizes the grid so), so a thread keeps ITS four channels for the whole
         // loop: scale / shift are loaded once, the row index advances by a constant -- no per-element 64-bit division, two 16-byte constant loads
         // less per 16 bytes of payload (the per-channel loads were 40-60 % of what went through the vector L1; same arithmetic, same results)
@@ -296,6 +308,22 @@ __global__ void bn_fold_stats_kernel(const float* __restrict__ g, const float* _
 inline unsigned capped_grid(long long n) {
     long long g = (n + 255) / 256;
     return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+// the tiled form of bn_apply_kernel / bn_bwd_apply_kernel (4 rows x 256 channels per workgroup trip): applies when the rows come in fours and
+// the channels in 256s; the grid is a multiple of the column blocks
+inline int bn_tiled(long long rows, int C4) {      // 0 = linear form; else the column groups (16 float4 = 64 channels each) a workgroup takes
+    static const int mode = STRAPS_TOOL_ENV_INT("STRAPS_BN_TILED", 1);      // (A/B switch of the tools build: 0 off, 1 C >= 256 only, 2 also C = 64 / 128)
+    if (!mode || (C4 & 15)) return 0;
+    const int ncg = C4 >> 4;
+    if (!(ncg == 1 || ncg == 2 || (ncg & 3) == 0) || (mode == 1 && ncg < 4)) return 0;
+    const int wcg = ncg < 4 ? ncg : 4;
+    return (rows % (16 / wcg)) == 0 ? wcg : 0;
+}
+inline unsigned bn_tiled_grid(long long rows, int C4, int wcg) {
+    const long long ncb = (C4 >> 4) / wcg, tiles = rows / (16 / wcg) * ncb;
+    long long g = tiles < 256 * 16 ? tiles : 256 * 16;
+    g = g / ncb * ncb;
+    return (unsigned)(g < ncb ? ncb : g);
 }
 // the same, with grid x 256 a multiple of the row length C4 (float4 units) whenever some grid <= the cap allows it: a grid-stride thread then keeps
 // its channels (bn_apply_kernel / bn_bwd_apply_kernel hoist the per-channel constants out of their loops)
@@ -400,7 +428,7 @@ extern "C" int straps_bn_apply(const float* x, const float* scale, const float* 
                                long long rows, int c, void* stream) {
     STRAPS_REQUIRE(x && scale && shift && y && rows > 0 && c > 0 && (c & 3) == 0, "straps_bn_apply: bad arguments (c%%4 must be 0)");
     const long long n4 = rows * (c >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, (u16*)nullptr, 0LL, n4, c >> 2, (unsigned*)nullptr);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, (u16*)nullptr, 0LL, n4, c >> 2, (unsigned*)nullptr, 0);
     STRAPS_CHECK_LAUNCH("bn_apply_kernel");
     return STRAPS_OK;
 }
@@ -411,7 +439,9 @@ static int bn_apply_x3_impl(const char* who, const float* x, const float* scale,
     STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 31) == 0, "%s: bad arguments (c%%32 must be 0: chunk-major planes; c=%d)", who, c);
     STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "%s: plane_stride must be >= rows*c and a multiple of 8", who);
     const long long n4 = rows * (c >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(capped_grid_rows(n4, c >> 2)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual, relu, y, y_planes, plane_stride, n4, c >> 2, relu_bits);
+    const int tiled = bn_tiled(rows, c >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(tiled ? bn_tiled_grid(rows, c >> 2, tiled) : capped_grid_rows(n4, c >> 2)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       residual, relu, y, y_planes, plane_stride, n4, c >> 2, relu_bits, tiled);
     STRAPS_CHECK_LAUNCH("bn_apply_kernel");
     return STRAPS_OK;
 }

@@ -138,10 +138,11 @@ def test_stem_wgrad_zero_skipping_is_exact(dev):
     assert _relerr(outs[0], w.grad) < 2e-5
 
 
-@pytest.mark.parametrize('C,relu', [(64, True), (512, True), (2048, False), (128, False)])
-def test_bn_backward(dev, C, relu):
+@pytest.mark.parametrize('C,relu,B,H', [(64, True, 3, 7), (512, True, 3, 7), (2048, False, 3, 7), (128, False, 3, 7),
+                                        # rows % 4 == 0 and C % 256 == 0: the tiled form of the apply pass (4 rows x 256 channels per trip)
+                                        (256, True, 2, 6), (512, True, 4, 8), (2048, False, 1, 4), (1024, True, 5, 10)])
+def test_bn_backward(dev, C, relu, B, H):
     L = hipabi.lib()
-    B, H = 3, 7
     rows = B * H * H
     x = torch.from_numpy(det_uniform((B, C, H, H), 8, -1, 1)).double().requires_grad_()
     g = torch.from_numpy(det_uniform((C,), 9, 0.5, 1.5)).double().requires_grad_()

@@ -597,11 +597,12 @@ def test_conv_fwd_x3p_planes_equal_a_split_pass(dev, B, Cin, Cout, H, k, stride,
             assert torch.equal(y, y0)
 
 
-def test_fused_plane_outputs_equal_a_split_pass(dev):
+@pytest.mark.parametrize('B,H,W,C', [(3, 10, 14, 64), (2, 8, 8, 256), (1, 4, 12, 512), (1, 3, 5, 256), (2, 4, 4, 2048), (3, 10, 14, 128), (5, 6, 8, 1024)])
+def test_fused_plane_outputs_equal_a_split_pass(dev, B, H, W, C):
     """straps_bn_apply_x3 / straps_bn_relu_maxpool_fwd_x3 / straps_bn_bwd_x3 write the same fp32 outputs as their plain forms and the
-    planes a straps_split3_bf16 pass over that output would (bit for bit)."""
+    planes a straps_split3_bf16 pass over that output would (bit for bit).  Shapes with rows % 4 == 0 and C % 256 == 0 run the tiled form
+    of the streaming kernels (the plain straps_bn_apply never does: an independent index mapping), the others the linear forms."""
     L = hipabi.lib()
-    B, H, W, C = 3, 10, 14, 64
     rows = B * H * W
     raw = torch.from_numpy(det_uniform((B, H, W, C), 21, -2, 2)).to(dev)
     sc = torch.from_numpy(det_uniform((C,), 22, 0.5, 1.5)).to(dev)
