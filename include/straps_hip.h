@@ -534,6 +534,11 @@ int straps_build_proxy_input(const float* seg, const float* joints2d, float* out
  * 4 std x 4 std samples of torch.linspace(-2 std, 2 std, 4 std)); straps_build_proxy_input is std = 4, the value of every call site. */
 int straps_build_proxy_input_std(const float* seg, const float* joints2d, float* out_nchw, int batch,
                                  int nj, int wh, int std, void* stream);
+/* the same, and in the same pass the non-zero bit map of the planes it writes: nzmask[straps_stem_nzmask_words(batch, nj + 1, wh, wh)] ==
+ * what straps_stem_nzmask(out_nchw, ...) would read back from them (the 302 MB read of that pass at 64 bodies is not made; cells that cannot
+ * intersect a joint's window are written as zeros without evaluating the Gaussian).  wh % 8 == 0. */
+int straps_build_proxy_input_nz(const float* seg, const float* joints2d, float* out_nchw, uint32_t* nzmask,
+                                int batch, int nj, int wh, int std, void* stream);
 /* prediction heads + HomoscedasticUncertaintyWeightedMultiTaskLoss (losses/multi_task_loss.py:76-119,
  * reduction 'mean') fused with its own backward.  From pred joints [B,90,3], cam [B,3] (row
  * stride ld_est) it forms joints2D = orthographic projection of the 17 COCO joints

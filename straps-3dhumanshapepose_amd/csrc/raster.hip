@@ -58,6 +58,7 @@ __device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by,
     return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
 }
 
+template <int G>      // lanes per face: they take the samples of its bounding box round-robin (the z-buffer minimum does not depend on who visits what)
 __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
                                                           unsigned long long* __restrict__ zbuf, long long n, int nverts,
                                                           int nfaces, int wh, float near, float far) {
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restric
     for (int k = threadIdx.x; k < wh; k += 256) sample[k] = (float)(2 * k + 1 - wh) / (float)wh;
     __syncthreads();
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long i = gid >> 4;                  // (body, face)
-    const int sub = (int)(gid & 15);               // lane within the face's 16-lane group
+    const long long i = gid / G;                   // (body, face)
+    const int sub = (int)(gid & (G - 1));          // lane within the face's group of G
     if (i >= n) return;
     const long long b = i / nfaces;
     const int f = (int)(i - b * nfaces);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restric
     if (xb < xa || yb < ya) return;
     unsigned long long* zb = zbuf + b * (long long)wh * wh;
     const int bw = xb - xa + 1;
-    // the group's 16 lanes take the box samples round-robin in row-major order
+    // the group's G lanes take the box samples round-robin in row-major order
     int xi = xa + sub, yi = ya;
     while (xi > xb) { xi -= bw; ++yi; }
     for (; yi <= yb;) {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restric
             }
             }
         }
-        xi += 16;
+        xi += G;
         while (xi > xb) { xi -= bw; ++yi; }
     }
 }
@@ -165,7 +166,17 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     hipLaunchKernelGGL(raster_project_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, verts, cam_K, cam_R, cam_t, ndc, nv, nverts,
                        cam_per_body, (float)wh, vert_noise_u, (float)noise_lo, (float)(noise_hi - noise_lo));
     STRAPS_CHECK_LAUNCH("raster_project_kernel");
-    hipLaunchKernelGGL(raster_face_kernel, dim3((unsigned)((nf * 16 + 255) / 256)), dim3(256), (size_t)wh * sizeof(float), st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far);
+    // lanes per face: a face of the 13 776-face mesh at 256 x 256 covers one or two samples and its box four to nine
+    static const int lanes = STRAPS_TOOL_ENV_INT("STRAPS_RASTER_LANES", 16);      // (A/B switch of the tools build)
+#define STRAPS_RASTER_LAUNCH(G) hipLaunchKernelGGL(raster_face_kernel<G>, dim3((unsigned)((nf * G + 255) / 256)), dim3(256), (size_t)wh * sizeof(float), st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far)
+    if (lanes == 1) STRAPS_RASTER_LAUNCH(1);
+    else if (lanes == 2) STRAPS_RASTER_LAUNCH(2);
+    else if (lanes == 4) STRAPS_RASTER_LAUNCH(4);
+    else if (lanes == 8) STRAPS_RASTER_LAUNCH(8);
+    else if (lanes == 32) STRAPS_RASTER_LAUNCH(32);
+    else if (lanes == 64) STRAPS_RASTER_LAUNCH(64);
+    else STRAPS_RASTER_LAUNCH(16);
+#undef STRAPS_RASTER_LAUNCH
     STRAPS_CHECK_LAUNCH("raster_face_kernel");
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, zbuf, face_parts, parts, depth, np, wh, far);
     STRAPS_CHECK_LAUNCH("raster_resolve_kernel");

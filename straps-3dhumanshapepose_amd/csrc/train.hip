@@ -64,6 +64,65 @@ __global__ __launch_bounds__(256) void build_proxy_kernel(const float* __restric
     }
 }
 
+// The same planes AND the stem's non-zero bit map in one pass (round 4): the layout of stem_nzmask_kernel (csrc/stem.hip) -- a wave owns one
+// mask word = 4 rows x 256 columns of a plane, 32 cells of 4 x 8 -- with the values computed instead of loaded.  Lane l writes the four
+// rows of half (l >> 5) of cell (l & 31): every store instruction of the wave is one contiguous KiB; a cell's bit is the OR of its two
+// halves, which one 64-lane ballot delivers as (m | m >> 32).  Cells that cannot intersect the joint's window are written as zeros without
+// evaluating anything -- all but 4-9 of a heat-map plane's 2048.  Bit-identical planes, and the map straps_stem_nzmask would read back
+// from them (the 302 MB read of that pass -- 105-113 us at 64 bodies -- is gone).
+__global__ __launch_bounds__(256) void build_proxy_nz_kernel(const float* __restrict__ seg, const float* __restrict__ j2d, float* __restrict__ out,
+                                                             unsigned* __restrict__ mask, long long nwords, int NJ, int WH, int size, float step,
+                                                             float two_var) {
+    const int lane = threadIdx.x & 63;
+    const long long word = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= nwords) return;                         // (whole waves leave: the ballot below is among the lanes of one word)
+    const int HC = (WH + 3) >> 2, WW = (WH + 255) >> 8;
+    const int ww = (int)(word % WW);
+    const long long t = word / WW;
+    const int hc = (int)(t % HC);
+    const int plane = (int)(t / HC);                    // b * (NJ + 1) + ch
+    const int b = plane / (NJ + 1), ch = plane - b * (NJ + 1);
+    const int x0 = ww * 256 + (lane & 31) * 8 + (lane >> 5) * 4, y0 = hc * 4;
+    const int npix = WH * WH;
+    float* o = out + (long long)plane * npix;
+    bool nz = false;
+    if (x0 < WH) {
+        f32x4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ch == 0) {
+            const float* s = seg + (long long)b * npix;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (y0 + r < WH) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(s + (y0 + r) * WH + x0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[r][e] = a[e] != 0.f ? 1.f : 0.f;
+                }
+        } else {
+            const int jx = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 0];     // truncation toward zero == .int()
+            const int jy = (int)j2d[((long long)b * NJ + ch - 1) * 2 + 1];
+            // heat_value is zero outside [j - size, j + size) in x and y: skip the cells that lie outside (a conservative test; the values
+            // inside are evaluated by the same function as build_proxy_kernel's)
+            if (x0 + 3 >= jx - size && x0 < jx + size && y0 + 3 >= jy - size && y0 < jy + size) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (y0 + r < WH)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[r][e] = heat_value(x0 + e, y0 + r, jx, jy, WH, size, step, two_var);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (y0 + r < WH) {
+                *reinterpret_cast<f32x4*>(o + (y0 + r) * WH + x0) = v[r];
+                nz = nz || v[r][0] != 0.f || v[r][1] != 0.f || v[r][2] != 0.f || v[r][3] != 0.f;
+            }
+    }
+    const unsigned long long m = __ballot(nz);
+    if (lane == 0) mask[word] = (unsigned)(m | (m >> 32));
+}
+
 // =====================================================================================================
 // heads + loss
 // =====================================================================================================
@@ -255,6 +314,24 @@ extern "C" int straps_build_proxy_input_std(const float* seg, const float* joint
     hipLaunchKernelGGL(build_proxy_kernel, dim3(gx < 64 ? gx : 64, batch * (nj + 1)), dim3(256), 0, (hipStream_t)stream, seg, joints2d, out_nchw, batch, nj, wh,
                        size, step, two_var);
     STRAPS_CHECK_LAUNCH("build_proxy_kernel");
+    return STRAPS_OK;
+}
+
+// straps_build_proxy_input_std that also writes the non-zero bit map of its output -- what straps_stem_nzmask(out_nchw, ...) would compute,
+// [straps_stem_nzmask_words(batch, nj + 1, wh, wh)] words -- in the same pass.  wh must be a multiple of 8.
+extern "C" int straps_build_proxy_input_nz(const float* seg, const float* joints2d, float* out_nchw, uint32_t* nzmask, int batch, int nj, int wh,
+                                           int std, void* stream) {
+    STRAPS_REQUIRE(seg && joints2d && out_nchw && nzmask && batch > 0 && nj > 0 && wh > 16, "straps_build_proxy_input_nz: bad arguments");
+    STRAPS_REQUIRE(std >= 1 && 4 * std <= wh, "straps_build_proxy_input_nz: std must be an integer in [1, wh / 4] (got %d)", std);
+    STRAPS_REQUIRE((wh & 7) == 0 && wh <= 16384, "straps_build_proxy_input_nz: wh must be a multiple of 8 (got %d)", wh);
+    const long long nwords = (long long)batch * (nj + 1) * ((wh + 3) / 4) * ((wh + 255) / 256);
+    STRAPS_REQUIRE((nwords + 3) / 4 < (1LL << 31) && (long long)batch * (nj + 1) * wh * wh < (1LL << 40), "straps_build_proxy_input_nz: input too large for one launch");
+    const int size = 2 * std;
+    const float step = (float)(2 * size) / (float)(2 * size - 1);          // torch.linspace's fp32 step: (end - start) / (steps - 1)
+    const float two_var = (float)(2.0 * std * std);
+    hipLaunchKernelGGL(build_proxy_nz_kernel, dim3((unsigned)((nwords + 3) / 4)), dim3(256), 0, (hipStream_t)stream, seg, joints2d, out_nchw, nzmask, nwords, nj,
+                       wh, size, step, two_var);
+    STRAPS_CHECK_LAUNCH("build_proxy_nz_kernel");
     return STRAPS_OK;
 }
 

@@ -192,6 +192,7 @@ SIGNATURES = {
     'straps_rot6d_bwd': (_I, [_P, _L, _I, _P, _P, _L, _L, _P]),
     'straps_build_proxy_input': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'straps_build_proxy_input_std': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'straps_build_proxy_input_nz': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'straps_loss_workspace_bytes': (_Z, [_L]),
     'straps_loss_fwd_bwd': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     'straps_loss_fwd_bwd_gm': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _F, _P]),

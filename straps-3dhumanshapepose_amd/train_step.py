@@ -388,9 +388,10 @@ class TrainStep:
                                                    float(hr[1]), hipabi.ptr(j2d_in), B, st), 'straps_deviate_joints2d')
         # G4 + G5
         x = out['input']
-        hipabi.check(L.straps_build_proxy_input(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), B, 17, 256, st), 'straps_build_proxy_input')
-        # non-zero map of the input for the stem's zero skipping: made here, next to the input, off the step's critical path
-        hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(out['nzmask']), B, 18, 256, 256, st), 'straps_stem_nzmask')
+        # ... and, in the same pass, the non-zero map of the input for the stem's zero skipping (round 4: straps_stem_nzmask's read of the
+        # 302 MB input is gone)
+        hipabi.check(L.straps_build_proxy_input_nz(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), hipabi.ptr(out['nzmask']), B, 17, 256, 4, st),
+                     'straps_build_proxy_input_nz')
         # this rank's visible target joints (global masked mean under data parallel: summed over the ranks before the loss runs)
         hipabi.check(L.straps_count_visible(hipabi.ptr(tgt_j2d), hipabi.ptr(out['vis_count']), B, 17, config.REGRESSOR_IMG_WH, st), 'straps_count_visible')
         if keep is not None:

@@ -763,6 +763,35 @@ def test_build_proxy_input_vs_reference_golden(dev):
     assert torch.equal(x[:, 1:], hm)
 
 
+@pytest.mark.parametrize('B,NJ,WH,std', [(3, 17, 256, 4), (2, 5, 264, 4), (2, 17, 64, 2), (1, 3, 520, 8)])
+def test_build_proxy_input_with_nonzero_map_equals_the_two_passes(dev, B, NJ, WH, std):
+    """straps_build_proxy_input_nz (round 4: the training step's input and the stem's non-zero bit map in ONE pass, cells outside a joint's
+    window written without evaluating the Gaussian) against straps_build_proxy_input_std followed by straps_stem_nzmask: the same planes and
+    the same words, bit for bit.  Joints inside, on every border, in the corners, outside the image and negative (the truncation toward
+    zero of .int()); sizes whose last mask word is partial (264, 520) and a small one (64)."""
+    L = hipabi.lib()
+    j = torch.from_numpy(det_uniform((B, NJ, 2), 41, -12.0, WH + 12.0))
+    edge = [(0.0, 0.0), (WH - 1.0, WH - 1.0), (0.4, WH - 0.6), (WH - 1.0, 3.0), (-0.9, 17.2), (WH + 7.9, 40.0), (2 * std - 1.0, 2 * std + 0.0), (-2.0 * std, 50.0),
+            (WH - 2.0 * std, WH / 2.0), (WH + 2.0 * std - 1.0, 9.0)]
+    for k, (ex, ey) in enumerate(edge):
+        j[k % B, k % NJ] = torch.tensor([ex, ey])
+    seg = ((torch.from_numpy(det_uniform((B, WH, WH), 42, 0.0, 1.0)) > 0.9).float() * torch.from_numpy(np.floor(det_uniform((B, WH, WH), 43, 1.0, 6.999))))
+    seg[:, : WH // 2, : WH // 3] = 0.0              # whole cells and words of the silhouette empty
+    seg, j = seg.to(dev), j.to(dev)
+    x0 = torch.full((B, NJ + 1, WH, WH), float('nan'), device=dev)
+    x1 = torch.full((B, NJ + 1, WH, WH), float('nan'), device=dev)
+    nw = L.straps_stem_nzmask_words(B, NJ + 1, WH, WH)
+    m0 = torch.full((nw,), 0x5a5a5a5a, device=dev, dtype=torch.int32)
+    m1 = torch.full((nw,), 0x5a5a5a5a, device=dev, dtype=torch.int32)
+    hipabi.check(L.straps_build_proxy_input_std(hipabi.ptr(seg), hipabi.ptr(j), hipabi.ptr(x0), B, NJ, WH, std, None), 'build_proxy_input_std')
+    hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x0), hipabi.ptr(m0), B, NJ + 1, WH, WH, None), 'stem_nzmask')
+    hipabi.check(L.straps_build_proxy_input_nz(hipabi.ptr(seg), hipabi.ptr(j), hipabi.ptr(x1), hipabi.ptr(m1), B, NJ, WH, std, None), 'build_proxy_input_nz')
+    assert torch.equal(x0, x1)
+    assert torch.equal(m0, m1)
+    assert 0 < int((x0[:, 1:] != 0).sum()) and int((m0 != 0).sum()) < nw      # some heat-maps drawn, some words empty
+    assert L.straps_build_proxy_input_nz(hipabi.ptr(seg), hipabi.ptr(j), hipabi.ptr(x1), hipabi.ptr(m1), B, NJ, WH + 4, std, None) == 1      # wh % 8
+
+
 def test_adam_vs_reference_golden(dev):
     small = np.load(os.path.join(GOLD, 'small_golden.npz'))
     man = json.load(open(os.path.join(GOLD, 'state_dict_keys_r18.json')))
