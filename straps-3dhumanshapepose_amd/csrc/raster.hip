@@ -62,10 +62,19 @@ template <int G>      // lanes per face: they take the samples of its bounding b
 __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
                                                           unsigned long long* __restrict__ zbuf, long long n, int nverts,
                                                           int nfaces, int wh, float near, float far) {
-    // pixel-centre coordinates (2k + 1 - wh) / wh once per workgroup instead of two IEEE divisions per sample
+    // pixel-centre coordinates (2k + 1 - wh) / wh, computed per sample on purpose.  Rounds 2-4 read them from a table in LDS (filled per
+    // workgroup, one barrier); round 4 found that form NOT bit-reproducible when -- and only when -- bf16x3 convolution kernels run on
+    // another stream: a handful of z-buffer keys per launch differ, faces drawn a pixel off with other depths, although every table entry
+    // read back equals the value written (tools/datagen_determinism_probe.py, PROBE_LOAD=conv; profiles/r04_raster_determinism.txt).  The
+    // training step's data stream runs exactly there, and two replays of a resnet50 step graph differed in about one 60-step run of three.
+    // Without LDS and barrier the kernel is reproducible under the same load (no key differs in 1500 launches, 16 of 16 long runs equal).
+    const bool pow2 = (wh & (wh - 1)) == 0;
+    const float inv_wh = 1.f / (float)wh;
+#ifdef STRAPS_RASTER_LDS_TABLE      // (the form of rounds 2-4, kept for the reproducer: STRAPS_TOOLS_RASTER_FLAGS=-DSTRAPS_RASTER_LDS_TABLE builds it into the tools library)
     extern __shared__ float sample[];
     for (int k = threadIdx.x; k < wh; k += 256) sample[k] = (float)(2 * k + 1 - wh) / (float)wh;
     __syncthreads();
+#endif
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long i = gid / G;                   // (body, face)
     const int sub = (int)(gid & (G - 1));          // lane within the face's group of G
@@ -99,8 +108,20 @@ __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restric
     while (xi > xb) { xi -= bw; ++yi; }
     for (; yi <= yb;) {
         {
-            const float yp = sample[yi];
-            const float xp = sample[xi];
+            float yp, xp;
+#ifdef STRAPS_RASTER_LDS_TABLE
+            if (wh > 0) {
+                yp = sample[yi];
+                xp = sample[xi];
+            } else
+#endif
+            if (pow2) {        // (wh a power of two, 256 everywhere in the training step: the product with 1 / wh IS the quotient, bit for bit)
+                yp = (float)(2 * yi + 1 - wh) * inv_wh;
+                xp = (float)(2 * xi + 1 - wh) * inv_wh;
+            } else {
+                yp = (float)(2 * yi + 1 - wh) / (float)wh;
+                xp = (float)(2 * xi + 1 - wh) / (float)wh;
+            }
             const float e0 = edge_fn(x1, y1, x2, y2, xp, yp);     // weight of vertex 0
             const float e1 = edge_fn(x2, y2, x0, y0, xp, yp);
             const float e2 = edge_fn(x0, y0, x1, y1, xp, yp);
@@ -168,7 +189,12 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     STRAPS_CHECK_LAUNCH("raster_project_kernel");
     // lanes per face: a face of the 13 776-face mesh at 256 x 256 covers one or two samples and its box four to nine
     static const int lanes = STRAPS_TOOL_ENV_INT("STRAPS_RASTER_LANES", 16);      // (A/B switch of the tools build)
-#define STRAPS_RASTER_LAUNCH(G) hipLaunchKernelGGL(raster_face_kernel<G>, dim3((unsigned)((nf * G + 255) / 256)), dim3(256), (size_t)wh * sizeof(float), st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far)
+#ifdef STRAPS_RASTER_LDS_TABLE
+#define STRAPS_RASTER_LDS_BYTES ((size_t)wh * sizeof(float))
+#else
+#define STRAPS_RASTER_LDS_BYTES 0
+#endif
+#define STRAPS_RASTER_LAUNCH(G) hipLaunchKernelGGL(raster_face_kernel<G>, dim3((unsigned)((nf * G + 255) / 256)), dim3(256), STRAPS_RASTER_LDS_BYTES, st, ndc, faces, zbuf, nf, nverts, nfaces, wh, near, far)
     if (lanes == 1) STRAPS_RASTER_LAUNCH(1);
     else if (lanes == 2) STRAPS_RASTER_LAUNCH(2);
     else if (lanes == 4) STRAPS_RASTER_LAUNCH(4);

@@ -50,6 +50,8 @@ def build(force=False, verbose=False, tools=False):
     extra = dict(EXTRA_FLAGS)
     if tools and os.environ.get('STRAPS_TOOLS_SMPL_FLAGS'):      # (build-time A/B of compiler flags for one source: tools library only)
         extra['smpl.hip'] = extra.get('smpl.hip', []) + os.environ['STRAPS_TOOLS_SMPL_FLAGS'].split()
+    if tools and os.environ.get('STRAPS_TOOLS_RASTER_FLAGS'):
+        extra['raster.hip'] = extra.get('raster.hip', []) + os.environ['STRAPS_TOOLS_RASTER_FLAGS'].split()
     # one object per source (csrc/build/*.o, compiled in parallel, rebuilt only when the source or a header is newer), then one link
     objdir = os.path.join(os.path.dirname(TOOLS_LIB_PATH), 'build') if tools else os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)

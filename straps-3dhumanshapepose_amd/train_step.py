@@ -74,6 +74,9 @@ def allreduce_visible_count(count, world_size, group=None, async_op=False):
     return None
 
 
+# A/B switch (both forms write the same input and the same non-zero map): one pass (round 4) / straps_build_proxy_input + straps_stem_nzmask
+_FUSED_PROXY_NZ = True
+
 class GradientExchange:
     """The step's gradient exchange: a sum all-reduce of the flat fp32 gradient buffer (RCCL over xGMI on GPUs, gloo in the
     CPU tests), in two buckets so that it overlaps the backward pass.  `start_tail()` is called as soon as the tail of
@@ -388,10 +391,14 @@ class TrainStep:
                                                    float(hr[1]), hipabi.ptr(j2d_in), B, st), 'straps_deviate_joints2d')
         # G4 + G5
         x = out['input']
-        # ... and, in the same pass, the non-zero map of the input for the stem's zero skipping (round 4: straps_stem_nzmask's read of the
-        # 302 MB input is gone)
-        hipabi.check(L.straps_build_proxy_input_nz(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), hipabi.ptr(out['nzmask']), B, 17, 256, 4, st),
-                     'straps_build_proxy_input_nz')
+        if _FUSED_PROXY_NZ:
+            # ... and, in the same pass, the non-zero map of the input for the stem's zero skipping (round 4: straps_stem_nzmask's read of
+            # the 302 MB input is gone)
+            hipabi.check(L.straps_build_proxy_input_nz(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), hipabi.ptr(out['nzmask']), B, 17, 256, 4, st),
+                         'straps_build_proxy_input_nz')
+        else:
+            hipabi.check(L.straps_build_proxy_input(hipabi.ptr(seg_aug), hipabi.ptr(j2d_in), hipabi.ptr(x), B, 17, 256, st), 'straps_build_proxy_input')
+            hipabi.check(L.straps_stem_nzmask(hipabi.ptr(x), hipabi.ptr(out['nzmask']), B, 18, 256, 256, st), 'straps_stem_nzmask')
         # this rank's visible target joints (global masked mean under data parallel: summed over the ranks before the loss runs)
         hipabi.check(L.straps_count_visible(hipabi.ptr(tgt_j2d), hipabi.ptr(out['vis_count']), B, 17, config.REGRESSOR_IMG_WH, st), 'straps_count_visible')
         if keep is not None:

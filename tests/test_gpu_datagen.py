@@ -241,3 +241,56 @@ def test_make_batch_switches_follow_run_train_dictionaries():
     want_seg = O.rasterize_parts(batch['verts'].cpu().numpy(), model['faces'], model['face_parts'], O.intrinsics_matrix().astype(np.float32), np.eye(3),
                                  batch['cam_t'].cpu().numpy())
     np.testing.assert_array_equal(keep['seg'].cpu().numpy(), want_seg)
+
+
+def test_rasteriser_is_reproducible_beside_convolution_kernels():
+    """Round 4 (profiles/r04_raster_determinism.txt): the part rasteriser must give the same z-buffer, bit for bit, whatever runs on
+    another stream.  With its pixel-centre table in LDS it did not -- a few keys per launch differed whenever bf16x3 convolution kernels
+    (a replayed hipGraph of them, so that the chip stays full) ran beside it, which is exactly where the training step's data stream puts
+    it; two replays of a resnet50 step then differed in one 60-step run of three.  300 launches beside such a graph: every part map and
+    every projected vertex equals the first launch's."""
+    from straps_amd.encoder_exec import split3, weight_planes
+    from straps_amd.nmr_renderer import NMRRenderer
+    from straps_amd import config
+    L = hipabi.lib()
+    B = 4
+    g = torch.Generator().manual_seed(0)
+    smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=1).to(DEV)
+    betas = torch.randn(B, 10, generator=g).to(DEV)
+    R = straps_amd.batch_rodrigues((torch.randn(B, 72, generator=g) * 0.4).to(DEV).view(-1, 3)).view(B, 24, 3, 3).contiguous()
+    verts, _ = smpl.forward_arrays(betas, R)
+    K = torch.tensor([[config.FOCAL_LENGTH, 0., 128.], [0., config.FOCAL_LENGTH, 128.], [0., 0., 1.]])
+    rend = NMRRenderer(B, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(DEV)
+    cam_t = torch.tensor([0., 0.2, 42.], device=DEV).expand(B, 3).contiguous()
+    noise = torch.rand(B, 6890, 2, generator=g).to(DEV)
+    # the load: four launches of a layer3-sized bf16x3 convolution forward per replay
+    x = torch.randn(32, 32, 32, 256, generator=g).to(DEV)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(DEV)
+    x3, xps = split3(L, x)
+    w3, wps = weight_planes(L, w)
+    y = torch.empty(32, 32, 32, 256, device=DEV)
+    part = torch.empty(max(L.straps_conv_x3_stat_blocks(32, 32, 32, 256, 256, 3, 3, 1, 1, 0), 1) * 512, device=DEV)
+
+    def conv():
+        hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(y), hipabi.ptr(part), 32, 32, 32, 256, 256, 3, 3, 1,
+                                          1, 0, hipabi.stream_ptr()), 'straps_conv_fwd_x3')
+    conv()
+    torch.cuda.synchronize()
+    load = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(load):
+        for _ in range(4):
+            conv()
+    work = torch.cuda.Stream()
+    ref, ref_depth = rend.render_arrays(verts, cam_t, want_depth=True, vert_noise_u=noise, noise_range=(-0.01, 0.01))
+    ref, ref_depth = ref.clone(), ref_depth.clone()
+    assert 0.1 < float((ref > 0).float().mean()) < 0.6
+    bad = torch.zeros(2, device=DEV, dtype=torch.int64)
+    torch.cuda.synchronize()
+    for _ in range(300):
+        load.replay()
+        with torch.cuda.stream(work):
+            seg, depth = rend.render_arrays(verts, cam_t, want_depth=True, vert_noise_u=noise, noise_range=(-0.01, 0.01))
+            bad[0] += (seg != ref).sum()
+            bad[1] += (depth != ref_depth).sum()
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0], 'part map / depth elements that differed from the first launch: %s' % bad.tolist()

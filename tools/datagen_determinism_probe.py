@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""tools/datagen_determinism_probe.py [batch] [iters] -- which stage of the data generation is not bit-reproducible under load?
+
+Round 4: two hipGraph runs of the resnet50 training step with the data pipeline differ in about one 60-step run of three, and the first thing
+that differs is the NEXT batch's network input, by one or two silhouette pixels (tools/graph_long_run.py, LONGRUN_TRACE=1).  This probe runs
+every stage of TrainStep.make_batch that lies between the target vertices and the network input -- rasteriser, crop + resize, segmentation
+augmentation, input construction -- over and over on FIXED inputs while a second stream keeps the chip busy with large matrix products, and
+counts, on the device, the elements that differ from the first result of that stage.
+
+    PROBE_LOAD = 1 (large torch.mm on a second stream) | 0 | train (a replayed training-step graph on the main stream; PROBE_LAYERS) |
+                 raster | smpl | conv | fill (one library kernel, captured and replayed on the main stream)
+    PROBE_RASTER_PARTS = 1: only the rasteriser, through the C ABI, with its z-buffer keys and projected vertices compared as well
+    PROBE_GRAPH = 1: the stages as one replayed hipGraph instead of eager launches
+    PROBE_TOOLS = 1: against the tools build (STRAPS_TOOLS_RASTER_FLAGS=-DSTRAPS_RASTER_LDS_TABLE at its build time = the rasteriser of rounds 2-4)
+
+What it found (profiles/r04_raster_determinism.txt): with its pixel-centre table in LDS the rasteriser differs from itself in a few z-buffer keys per
+launch whenever bf16x3 convolution kernels run beside it; without the table it never does."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import straps_amd  # noqa: E402
+from straps_amd import hipabi, config  # noqa: E402
+from straps_amd.nmr_renderer import NMRRenderer  # noqa: E402
+from straps_amd.image_utils import batch_crop_and_resize  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+load = os.environ.get('PROBE_LOAD', '1') == '1'
+L = hipabi.use_library(hipabi.build(tools=True)) if os.environ.get('PROBE_TOOLS') else hipabi.load()
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(0)
+smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=1).to(dev)
+betas = torch.randn(B, 10, generator=g).to(dev)
+R = straps_amd.batch_rodrigues((torch.randn(B, 72, generator=g) * 0.4).to(dev).view(-1, 3)).view(B, 24, 3, 3).contiguous()
+verts, joints = smpl.forward_arrays(betas, R)
+K = torch.tensor([[config.FOCAL_LENGTH, 0., 128.], [0., config.FOCAL_LENGTH, 128.], [0., 0., 1.]])
+rend = NMRRenderer(B, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(dev)
+cam_t = torch.tensor([0., 0.2, 42.], device=dev).expand(B, 3).contiguous()
+noise = torch.rand(B, 6890, 2, generator=g).to(dev)
+ucrop = torch.rand(B, 3, generator=g).to(dev)
+useg = torch.rand(B * 9, generator=g).to(dev)
+j2d = (torch.rand(B, 17, 2, generator=g) * 150 + 50).to(dev)
+remove_prob = torch.full((6,), 0.1, device=dev)
+
+side = torch.cuda.Stream()
+a = torch.randn(4096, 4096, device=dev)
+bad = torch.zeros(5, device=dev, dtype=torch.int64)
+
+
+def stages():
+    if os.environ.get('PROBE_RASTER_PARTS'):
+        # the rasteriser through the C ABI with a workspace of our own: its z-buffer (final 64-bit keys) and projected vertices are compared too
+        seg = torch.empty(B, 256, 256, device=dev)
+        ws = torch.empty(L.straps_rasterize_workspace_bytes(B, 6890, 256) // 8, device=dev, dtype=torch.int64)
+        hipabi.check(L.straps_rasterize_parts(hipabi.ptr(verts), hipabi.ptr(rend.faces), hipabi.ptr(rend.face_parts), hipabi.ptr(rend.cam_K), hipabi.ptr(rend.cam_R),
+                                              hipabi.ptr(cam_t), hipabi.ptr(seg), None, hipabi.ptr(ws), B, 6890, rend.faces.shape[0], 256, 0, rend.near, rend.far,
+                                              hipabi.ptr(noise), -0.01, 0.01, hipabi.stream_ptr()), 'rasterize')
+        return seg, ws[:B * 65536], ws[B * 65536:]
+    seg = rend.render_arrays(verts, cam_t, vert_noise_u=noise, noise_range=(-0.01, 0.01))
+    seg_c, j_c, boxes = batch_crop_and_resize(seg, j2d, 256, 1.2, (-0.2, 0.2), (-5, 5), uniforms=ucrop)
+    seg_aug = torch.empty_like(seg_c)
+    hipabi.check(L.straps_augment_seg(hipabi.ptr(seg_c), hipabi.ptr(useg), hipabi.ptr(remove_prob), 0.5, 48, hipabi.ptr(seg_aug), B, 256, hipabi.stream_ptr()), 'augment_seg')
+    x = torch.empty(B, 18, 256, 256, device=dev)
+    m = torch.empty(L.straps_stem_nzmask_words(B, 18, 256, 256), device=dev, dtype=torch.int32)
+    hipabi.check(L.straps_build_proxy_input_nz(hipabi.ptr(seg_aug), hipabi.ptr(j_c), hipabi.ptr(x), hipabi.ptr(m), B, 17, 256, 4, hipabi.stream_ptr()), 'proxy')
+    return seg, seg_c, seg_aug, x, m
+
+
+ref = [t.clone() for t in stages()]
+torch.cuda.synchronize()
+use_graph = os.environ.get('PROBE_GRAPH', '0') == '1'
+train_load = os.environ.get('PROBE_LOAD', '1') == 'train'
+work = torch.cuda.Stream()          # the stages run here (eager or as one captured graph), the load on `side`
+graph, gout = None, None
+if use_graph:
+    graph = torch.cuda.CUDAGraph()
+    work.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(work):
+        graph.capture_begin(capture_error_mode='thread_local')
+        gout = stages()
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(work)
+ts = None
+if train_load:
+    from straps_amd.train_step import TrainStep
+    MP = straps_amd.synthetic_mean_params(0)
+    torch.manual_seed(6)
+    reg = straps_amd.SingleInputRegressor(18, int(os.environ.get('PROBE_LAYERS', '50')), 3, mean_params=MP).to(dev).train()
+    sm = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=4, precision='fp16x3_lbs').to(dev)
+    crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
+                                                                    init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}).to(dev)
+    ts = TrainStep(reg, sm, crit, 4, lr=1e-4, mean_shape=MP['shape'], use_graph=True, pipeline_data=False)
+    for _ in range(4):
+        ts.step()
+    torch.cuda.synchronize()
+worst = ref[0].clone()
+worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') else None
+# other loads, each captured as a hipGraph and replayed on the main stream: PROBE_LOAD = raster (a second rasteriser on its own meshes),
+# smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
+other = os.environ.get('PROBE_LOAD', '1')
+lgraph = None
+if other in ('raster', 'smpl', 'conv', 'fill'):
+    rend2 = NMRRenderer(8, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(dev)
+    v2, _ = smpl.forward_arrays(torch.randn(8, 10, generator=g).to(dev), straps_amd.batch_rodrigues((torch.randn(8, 72, generator=g) * 0.4).to(dev).view(-1, 3)).view(8, 24, 3, 3).contiguous())
+    ct2 = torch.tensor([0., 0.2, 42.], device=dev).expand(8, 3).contiguous()
+    big = torch.empty(1 << 28, device=dev)
+    if other == 'conv':
+        from straps_amd.encoder_exec import split3, weight_planes
+        xx = torch.randn(32, 32, 32, 256, device=dev)
+        ww = torch.randn(256, 256, 3, 3, device=dev) * 0.02
+        x3, xps = split3(L, xx)
+        w3, wps = weight_planes(L, ww)
+        yy = torch.empty(32, 32, 32, 256, device=dev)
+        nblk = L.straps_conv_x3_stat_blocks(32, 32, 32, 256, 256, 3, 3, 1, 1, 0)
+        part = torch.empty(max(nblk, 1) * 256 * 2, device=dev)
+
+    def load_body():
+        if other == 'raster':
+            for _ in range(4):
+                rend2.render_arrays(v2, ct2)
+        elif other == 'smpl':
+            for _ in range(8):
+                smpl.forward_arrays(betas, R)
+        elif other == 'fill':
+            big.fill_(1.0)
+        else:
+            for _ in range(8):
+                hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(yy), hipabi.ptr(part), 32, 32, 32, 256, 256, 3, 3, 1, 1, 0,
+                                                  hipabi.stream_ptr()), 'conv')
+    load_body()
+    torch.cuda.synchronize()
+    lgraph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(lgraph):
+        load_body()
+    load = other
+for i in range(iters):
+    if lgraph is not None:
+        lgraph.replay()
+    elif train_load:
+        ts.step()                                   # (main stream: a replayed training-step graph + its eager Adam)
+    elif load and other == '1' and i % 2 == 0:
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                torch.mm(a, a)
+    with torch.cuda.stream(work):
+        if use_graph:
+            graph.replay()
+            out = gout
+        else:
+            out = stages()
+        for k, (o, r) in enumerate(zip(out, ref)):
+            bad[k] += (o != r).sum()
+        worst = torch.where((out[0] != ref[0]).any(), out[0], worst)          # (the last differing part map, selected on the device)
+        if os.environ.get('PROBE_RASTER_PARTS'):
+            worst_z = torch.where((out[1] != ref[1]).any(), out[1], worst_z)
+torch.cuda.synchronize()
+if worst_z is not None:
+    dz = (worst_z != ref[1]).nonzero().flatten()
+    print('last differing z-buffer: %d keys differ' % dz.numel())
+    rz, wz = ref[1], worst_z
+    for idx in dz[:24].tolist():
+        b_, rem = idx // 65536, idx % 65536
+        kr, kw = int(rz[idx]) & ((1 << 64) - 1), int(wz[idx]) & ((1 << 64) - 1)
+        fr, fw = kr & 0xffffffff, kw & 0xffffffff
+        body = wz[b_ * 65536:(b_ + 1) * 65536]
+        still = int(((body & 0xffffffff) == fr).sum()) if kr != (1 << 64) - 1 else -1
+        was = int(((rz[b_ * 65536:(b_ + 1) * 65536] & 0xffffffff) == fr).sum()) if kr != (1 << 64) - 1 else -1
+        print('   body %d pixel (%3d, %3d): face %5d z-bits %08x  ->  %s ; the first face held %d pixels of this body before, holds %d now' % (
+            b_, rem // 256, rem % 256, fr, kr >> 32, ('face %5d z-bits %08x' % (fw, kw >> 32)) if kw != (1 << 64) - 1 else 'EMPTY', was, still))
+d = (worst != ref[0]).nonzero()
+if d.numel():
+    print('last differing part map: %d pixels differ; (body, row, col): first result -> this one' % d.shape[0])
+    for b_, y_, x_ in d[:12].tolist():
+        nb = ref[0][b_, max(0, y_ - 1):y_ + 2, max(0, x_ - 1):x_ + 2].flatten().tolist()
+        print('   (%d, %3d, %3d): %g -> %g     3x3 neighbourhood in the first result: %s' % (b_, y_, x_, float(ref[0][b_, y_, x_]), float(worst[b_, y_, x_]), ' '.join('%g' % v for v in nb)))
+load = 'training step (graph) on the main stream' if train_load else load
+print('stages %s; ' % ('as ONE replayed hipGraph' if use_graph else 'as eager launches'), end='')
+if os.environ.get('PROBE_RASTER_PARTS'):
+    print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- part map %d, z-buffer keys %d, projected vertices (as int64 pairs) %d'
+          % ((B, iters, load) + tuple(int(v) for v in bad.tolist()[:3])))
+else:
+    print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- rasteriser %d, crop + resize %d, '
+          'augment_seg %d, network input %d, non-zero map %d' % ((B, iters, load) + tuple(int(v) for v in bad.tolist())))
