@@ -58,6 +58,10 @@ __device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by,
     return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
 }
 
+#ifdef STRAPS_RASTER_CHECK_LOADS
+__device__ unsigned g_raster_report[1 + 4 * 64];
+#endif
+
 template <int G>      // lanes per face: they take the samples of its bounding box round-robin (the z-buffer minimum does not depend on who visits what)
 __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
                                                           unsigned long long* __restrict__ zbuf, long long n, int nverts,
@@ -70,6 +74,14 @@ __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restric
     // Without LDS and barrier the kernel is reproducible under the same load (no key differs in 1500 launches, 16 of 16 long runs equal).
     const bool pow2 = (wh & (wh - 1)) == 0;
     const float inv_wh = 1.f / (float)wh;
+#if defined(STRAPS_RASTER_WRITE_TABLE) && !defined(STRAPS_RASTER_LDS_TABLE)      // (reproducer variants: table written + barrier, never read)
+    extern __shared__ float sample[];
+    for (int k = threadIdx.x; k < wh; k += 256) sample[k] = (float)(2 * k + 1 - wh) / (float)wh;
+    __syncthreads();
+#endif
+#ifdef STRAPS_RASTER_DUMMY_BARRIER
+    __syncthreads();
+#endif
 #ifdef STRAPS_RASTER_LDS_TABLE      // (the form of rounds 2-4, kept for the reproducer: STRAPS_TOOLS_RASTER_FLAGS=-DSTRAPS_RASTER_LDS_TABLE builds it into the tools library)
     extern __shared__ float sample[];
     for (int k = threadIdx.x; k < wh; k += 256) sample[k] = (float)(2 * k + 1 - wh) / (float)wh;
@@ -141,6 +153,22 @@ __global__ __launch_bounds__(256) void raster_face_kernel(const float* __restric
         xi += G;
         while (xi > xb) { xi -= bw; ++yi; }
     }
+#ifdef STRAPS_RASTER_CHECK_LOADS
+    // (reproducer builds only: did the nine coordinates this lane has been computing with come back from memory as they are stored there?)
+    {
+        const volatile float* q0 = p0; const volatile float* q1 = p1; const volatile float* q2 = p2;
+        const float r[9] = {q0[0], q0[1], q0[2], q1[0], q1[1], q1[2], q2[0], q2[1], q2[2]};
+        const float h[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};
+        for (int e = 0; e < 9; ++e)
+            if (__float_as_uint(r[e]) != __float_as_uint(h[e])) {
+                const unsigned k = atomicAdd(g_raster_report, 1u);
+                if (k < 64) {
+                    g_raster_report[1 + 4 * k + 0] = blockIdx.x; g_raster_report[1 + 4 * k + 1] = threadIdx.x | ((unsigned)e << 16) | ((unsigned)f << 20);
+                    g_raster_report[1 + 4 * k + 2] = __float_as_uint(h[e]); g_raster_report[1 + 4 * k + 3] = __float_as_uint(r[e]);
+                }
+            }
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const unsigned long long* __restrict__ zbuf,
@@ -189,7 +217,7 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     STRAPS_CHECK_LAUNCH("raster_project_kernel");
     // lanes per face: a face of the 13 776-face mesh at 256 x 256 covers one or two samples and its box four to nine
     static const int lanes = STRAPS_TOOL_ENV_INT("STRAPS_RASTER_LANES", 16);      // (A/B switch of the tools build)
-#ifdef STRAPS_RASTER_LDS_TABLE
+#if defined(STRAPS_RASTER_LDS_TABLE) || defined(STRAPS_RASTER_WRITE_TABLE) || defined(STRAPS_RASTER_DUMMY_LDS)
 #define STRAPS_RASTER_LDS_BYTES ((size_t)wh * sizeof(float))
 #else
 #define STRAPS_RASTER_LDS_BYTES 0
@@ -208,3 +236,12 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     STRAPS_CHECK_LAUNCH("raster_resolve_kernel");
     return STRAPS_OK;
 }
+
+#ifdef STRAPS_RASTER_CHECK_LOADS
+// reproducer builds only (-DSTRAPS_RASTER_CHECK_LOADS): copies out and clears what raster_face_kernel reported
+extern "C" int straps_tool_raster_report(unsigned* host_out) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_raster_report), sizeof(unsigned) * (1 + 4 * 64)) != hipSuccess) return STRAPS_EHIP;
+    unsigned zero[1 + 4 * 64] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_raster_report), zero, sizeof(zero)) == hipSuccess ? STRAPS_OK : STRAPS_EHIP;
+}
+#endif

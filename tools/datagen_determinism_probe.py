@@ -51,6 +51,11 @@ bad = torch.zeros(5, device=dev, dtype=torch.int64)
 
 
 def stages():
+    if os.environ.get('PROBE_SMPL'):
+        # the SMPL forward of the data stream (target vertices and joints; reposed vertices): LDS operand rows read in its inner loops
+        v1, j1 = smpl.forward_arrays(betas, R)
+        v2, _ = smpl.forward_arrays(betas, torch.eye(3, device=dev).expand(B, 24, 3, 3).contiguous(), want_joints=False)
+        return v1, j1, v2
     if os.environ.get('PROBE_RASTER_PARTS'):
         # the rasteriser through the C ABI with a workspace of our own: its z-buffer (final 64-bit keys) and projected vertices are compared too
         seg = torch.empty(B, 256, 256, device=dev)
@@ -97,7 +102,7 @@ if train_load:
         ts.step()
     torch.cuda.synchronize()
 worst = ref[0].clone()
-worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') else None
+worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.environ.get('PROBE_SMPL') else None
 # other loads, each captured as a hipGraph and replayed on the main stream: PROBE_LOAD = raster (a second rasteriser on its own meshes),
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
 other = os.environ.get('PROBE_LOAD', '1')
@@ -154,7 +159,7 @@ for i in range(iters):
         for k, (o, r) in enumerate(zip(out, ref)):
             bad[k] += (o != r).sum()
         worst = torch.where((out[0] != ref[0]).any(), out[0], worst)          # (the last differing part map, selected on the device)
-        if os.environ.get('PROBE_RASTER_PARTS'):
+        if worst_z is not None:
             worst_z = torch.where((out[1] != ref[1]).any(), out[1], worst_z)
 torch.cuda.synchronize()
 if worst_z is not None:
@@ -178,9 +183,20 @@ if d.numel():
         print('   (%d, %3d, %3d): %g -> %g     3x3 neighbourhood in the first result: %s' % (b_, y_, x_, float(ref[0][b_, y_, x_]), float(worst[b_, y_, x_]), ' '.join('%g' % v for v in nb)))
 load = 'training step (graph) on the main stream' if train_load else load
 print('stages %s; ' % ('as ONE replayed hipGraph' if use_graph else 'as eager launches'), end='')
-if os.environ.get('PROBE_RASTER_PARTS'):
+if os.environ.get('PROBE_SMPL'):
+    print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- SMPL vertices %d, joints %d, reposed vertices %d' % ((B, iters, load) + tuple(int(v) for v in bad.tolist()[:3])))
+elif os.environ.get('PROBE_RASTER_PARTS'):
     print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- part map %d, z-buffer keys %d, projected vertices (as int64 pairs) %d'
           % ((B, iters, load) + tuple(int(v) for v in bad.tolist()[:3])))
 else:
     print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- rasteriser %d, crop + resize %d, '
           'augment_seg %d, network input %d, non-zero map %d' % ((B, iters, load) + tuple(int(v) for v in bad.tolist())))
+if os.environ.get('PROBE_LOAD_REPORT'):      # (tools build with -DSTRAPS_RASTER_CHECK_LOADS)
+    import ctypes
+    rep = (ctypes.c_uint * 257)()
+    rc = ctypes.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_raster_report(rep)
+    print('raster_face_kernel re-read its vertex coordinates at the end of every lane (rc %d): %d differ from what the lane computed with' % (rc, rep[0]))
+    f32 = lambda u: ctypes.c_float.from_buffer(ctypes.c_uint(u)).value
+    for k in range(min(rep[0], 16)):
+        print('   workgroup %6d thread %3d coordinate %d of face %5d: used 0x%08x (%.7g), memory holds 0x%08x (%.7g)' % (
+            rep[1 + 4 * k], rep[2 + 4 * k] & 0xffff, (rep[2 + 4 * k] >> 16) & 15, rep[2 + 4 * k] >> 20, rep[3 + 4 * k], f32(rep[3 + 4 * k]), rep[4 + 4 * k], f32(rep[4 + 4 * k])))
