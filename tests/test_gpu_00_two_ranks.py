@@ -8,6 +8,9 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+# (the file sorts FIRST among the GPU tests on purpose: its ranks are two fresh processes sharing device 0, and run before this pytest process
+#  has created a GPU context of its own they are the only two clients of the chip -- behind the rest of the suite they were three, and the
+#  bit-comparison below failed in two of three whole-suite runs at the end of round 4 while passing every time the file ran alone)
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
