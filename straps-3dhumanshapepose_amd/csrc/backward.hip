@@ -1563,32 +1563,6 @@ inline unsigned capped_grid(long long n) {
     long long g = (n + 255) / 256;
     return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
 }
-// tiled form of the two streaming BatchNorm kernels (see csrc/elementwise.hip)
-inline int bn_tiled(long long rows, int C4) {      // 0 = linear form; else the column groups (16 float4 = 64 channels each) a workgroup takes
-    static const int mode = STRAPS_TOOL_ENV_INT("STRAPS_BN_TILED", 1);      // (A/B switch of the tools build: 0 off, 1 C >= 256 only, 2 also C = 64 / 128)
-    if (!mode || (C4 & 15)) return 0;
-    const int ncg = C4 >> 4;
-    if (!(ncg == 1 || ncg == 2 || (ncg & 3) == 0) || (mode == 1 && ncg < 4)) return 0;
-    const int wcg = ncg < 4 ? ncg : 4;
-    return (rows % (16 / wcg)) == 0 ? wcg : 0;
-}
-inline unsigned bn_tiled_grid(long long rows, int C4, int wcg) {
-    const long long ncb = (C4 >> 4) / wcg, tiles = rows / (16 / wcg) * ncb;
-    long long g = tiles < 256 * 16 ? tiles : 256 * 16;
-    g = g / ncb * ncb;
-    return (unsigned)(g < ncb ? ncb : g);
-}
-// the same with grid x 256 a multiple of the row length C4 (float4 units) where a grid under the cap allows it (see csrc/elementwise.hip)
-inline unsigned capped_grid_rows(long long n, int C4) {
-    unsigned g = capped_grid(n);
-    if (C4 > 0 && (256 % C4) != 0) {
-        long long a = C4, b = 256;
-        while (b) { const long long t = a % b; a = b; b = t; }
-        const long long m = C4 / a;            // smallest m with (m * 256) % C4 == 0
-        if (m <= 256 * 16) { const long long up = ((g + m - 1) / m) * m; g = (unsigned)(up > 256 * 16 ? (256 * 16 / m) * m : up); }
-    }
-    return g;
-}
 
 // 128x128 tiles (32 flop per operand byte instead of 16) for the big 1x1 layers (resnet50): +10 % there; the 3x3 / strided layers
 // and small pixel counts do better with 64x64 (more workgroups per tap)
@@ -1955,8 +1929,8 @@ static int bn_bwd_x3_impl(const float* dy, const float* yact, const unsigned* re
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, part, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    const int tiled = bn_tiled(rows, c >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(tiled ? bn_tiled_grid(rows, c >> 2, tiled) : capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits, tiled);
+    const int tiled = straps_bn_tiled(rows, c >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(tiled ? straps_bn_tiled_grid(rows, c >> 2, tiled) : straps_grid256_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits, tiled);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }
@@ -2001,8 +1975,8 @@ static int bn_bwd_finish_x3_impl(const float* dy, const float* yact, const unsig
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partials, nblk, c, bn_bwd_count(rows, accumulate), gamma, save_invstd, dgamma, dbeta, coefd, k1, accumulate & 1);
     STRAPS_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     const long long n4 = rows * C4;
-    const int tiled = bn_tiled(rows, c >> 2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(tiled ? bn_tiled_grid(rows, c >> 2, tiled) : capped_grid_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits, tiled);
+    const int tiled = straps_bn_tiled(rows, c >> 2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(tiled ? straps_bn_tiled_grid(rows, c >> 2, tiled) : straps_grid256_rows(n4, c >> 2)), dim3(256), 0, st, dy, yact, raw, save_mean, save_invstd, coefd, k1, mask_scale, mask_shift, draw, dz_out, draw_planes, plane_stride, n4, c, PoolSrc{}, relu_bits, tiled);
     STRAPS_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return STRAPS_OK;
 }

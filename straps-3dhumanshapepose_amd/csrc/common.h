@@ -150,3 +150,39 @@ __device__ __forceinline__ void store_planes4_cm(u16* __restrict__ planes, long 
 // (the same macro serves switches a sweep changes from call to call: use it in a non-static expression)
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- launch geometry of the streaming BatchNorm kernels (bn_apply_kernel, csrc/elementwise.hip; bn_bwd_apply_kernel, csrc/backward.hip) ----
+// 256-thread workgroups over n float4 elements, at most 4096 of them (grid-stride loops)
+static inline unsigned straps_grid256(long long n) {
+    const long long g = (n + 255) / 256;
+    return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+// the same, with grid x 256 a multiple of the row length C4 (float4 units) whenever a grid under the cap allows it: a grid-stride thread then
+// keeps its four channels, and the kernels hoist the per-channel constants out of their loops
+static inline unsigned straps_grid256_rows(long long n, int C4) {
+    unsigned g = straps_grid256(n);
+    if (C4 > 0 && (256 % C4) != 0) {
+        long long a = C4, b = 256;
+        while (b) { const long long t = a % b; a = b; b = t; }
+        const long long m = C4 / a;            // smallest m with (m * 256) % C4 == 0
+        if (m <= 256 * 16) { const long long up = ((g + m - 1) / m) * m; g = (unsigned)(up > 256 * 16 ? (256 * 16 / m) * m : up); }
+    }
+    return g;
+}
+// tiled form (a wave = 4 rows x 2 chunks of 32 channels: 256-byte runs of the chunk-major planes per wave store): 0 = use the linear form,
+// else the column groups of 64 channels a workgroup's four waves sit on side by side (1, 2 or 4).  Product: C >= 256 with the rows in fours.
+static inline int straps_bn_tiled(long long rows, int C4) {
+    static const int mode = STRAPS_TOOL_ENV_INT("STRAPS_BN_TILED", 1);      // (A/B switch of the tools build: 0 off, 1 C >= 256 only, 2 also C = 64 / 128)
+    if (!mode || (C4 & 15)) return 0;
+    const int ncg = C4 >> 4;
+    if (!(ncg == 1 || ncg == 2 || (ncg & 3) == 0) || (mode == 1 && ncg < 4)) return 0;
+    const int wcg = ncg < 4 ? ncg : 4;
+    return (rows % (16 / wcg)) == 0 ? wcg : 0;
+}
+// grid of the tiled form: a multiple of the column blocks, so that a thread's channels stay fixed over its trips
+static inline unsigned straps_bn_tiled_grid(long long rows, int C4, int wcg) {
+    const long long ncb = (C4 >> 4) / wcg, tiles = rows / (16 / wcg) * ncb;
+    long long g = tiles < 256 * 16 ? tiles : 256 * 16;
+    g = g / ncb * ncb;
+    return (unsigned)(g < ncb ? ncb : g);
+}

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         // bytes of each chunk-major plane (8 lanes = the 64 bytes of one row's chunk, the next row's 64 follow) instead of one row's 64-byte
         // pieces in up to 8 chunks, and every 8 lanes read one whole 128-byte line of the fp32 row.  The workgroup's 4 waves sit side by
         // side on `tiled` (1, 2 or 4) column groups of 64 channels and stack 4 / tiled deep in rows; gridDim.x is a multiple of the column
-        // blocks (bn_tiled_grid): a thread's channels stay fixed.
+        // blocks (straps_bn_tiled_grid, common.h): a thread's channels stay fixed.
         const int l = threadIdx.x & 63, w = threadIdx.x >> 6, wcg = tiled, ncb = (C4 >> 4) / wcg, trows = 16 / wcg;
         const int c4 = ((int)(blockIdx.x % ncb) * wcg + w % wcg) * 16 + (l >> 5) * 8 + (l & 7);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
@@ -308,34 +308,6 @@ __global__ void bn_fold_stats_kernel(const float* __restrict__ g, const float* _
 inline unsigned capped_grid(long long n) {
     long long g = (n + 255) / 256;
     return (unsigned)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
-}
-// the tiled form of bn_apply_kernel / bn_bwd_apply_kernel (4 rows x 256 channels per workgroup trip): applies when the rows come in fours and
-// the channels in 256s; the grid is a multiple of the column blocks
-inline int bn_tiled(long long rows, int C4) {      // 0 = linear form; else the column groups (16 float4 = 64 channels each) a workgroup takes
-    static const int mode = STRAPS_TOOL_ENV_INT("STRAPS_BN_TILED", 1);      // (A/B switch of the tools build: 0 off, 1 C >= 256 only, 2 also C = 64 / 128)
-    if (!mode || (C4 & 15)) return 0;
-    const int ncg = C4 >> 4;
-    if (!(ncg == 1 || ncg == 2 || (ncg & 3) == 0) || (mode == 1 && ncg < 4)) return 0;
-    const int wcg = ncg < 4 ? ncg : 4;
-    return (rows % (16 / wcg)) == 0 ? wcg : 0;
-}
-inline unsigned bn_tiled_grid(long long rows, int C4, int wcg) {
-    const long long ncb = (C4 >> 4) / wcg, tiles = rows / (16 / wcg) * ncb;
-    long long g = tiles < 256 * 16 ? tiles : 256 * 16;
-    g = g / ncb * ncb;
-    return (unsigned)(g < ncb ? ncb : g);
-}
-// the same, with grid x 256 a multiple of the row length C4 (float4 units) whenever some grid <= the cap allows it: a grid-stride thread then keeps
-// its channels (bn_apply_kernel / bn_bwd_apply_kernel hoist the per-channel constants out of their loops)
-inline unsigned capped_grid_rows(long long n, int C4) {
-    unsigned g = capped_grid(n);
-    if (C4 > 0 && (256 % C4) != 0) {
-        long long a = C4, b = 256;
-        while (b) { const long long t = a % b; a = b; b = t; }
-        const long long m = C4 / a;            // smallest m with (m * 256) % C4 == 0
-        if (m <= 256 * 16) { const long long up = ((g + m - 1) / m) * m; g = (unsigned)(up > 256 * 16 ? (256 * 16 / m) * m : up); }
-    }
-    return g;
 }
 
 }  // namespace
@@ -439,8 +411,8 @@ static int bn_apply_x3_impl(const char* who, const float* x, const float* scale,
     STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 31) == 0, "%s: bad arguments (c%%32 must be 0: chunk-major planes; c=%d)", who, c);
     STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "%s: plane_stride must be >= rows*c and a multiple of 8", who);
     const long long n4 = rows * (c >> 2);
-    const int tiled = bn_tiled(rows, c >> 2);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(tiled ? bn_tiled_grid(rows, c >> 2, tiled) : capped_grid_rows(n4, c >> 2)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+    const int tiled = straps_bn_tiled(rows, c >> 2);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(tiled ? straps_bn_tiled_grid(rows, c >> 2, tiled) : straps_grid256_rows(n4, c >> 2)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
                        residual, relu, y, y_planes, plane_stride, n4, c >> 2, relu_bits, tiled);
     STRAPS_CHECK_LAUNCH("bn_apply_kernel");
     return STRAPS_OK;
