@@ -603,8 +603,13 @@ def main():
         elapsed = float(t.item())
         # per-rank view: each rank's own time to finish its K steps (before the closing barrier) and the part of the gradient
         # exchange its backward did not hide
+        # (+ a digest of this replica's parameters after the timed steps: data parallelism keeps the replicas bit-identical, and a corrupted
+        #  gradient exchange is the one failure that a throughput number would not show)
+        dig = [0.0, 0.0, 1.0]
+        if args.workload == 'train':
+            dig = [float(ts.flat_p.double().sum()), float(ts.flat_p.double().abs().sum()), 1.0 if bool(torch.isfinite(ts.flat_p).all()) else 0.0]
         mine = torch.tensor([local_elapsed / args.steps * 1e3, -1.0 if exposed_exchange_ms is None else exposed_exchange_ms,
-                             -1.0 if sclk_mhz is None else sclk_mhz], device=dev, dtype=torch.float64)
+                             -1.0 if sclk_mhz is None else sclk_mhz] + dig, device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         tab = torch.stack(allr).cpu()
@@ -616,6 +621,10 @@ def main():
                                                      '(started mid-backward) + the head bucket all-reduce = what backward did not hide'})
         if float(tab[:, 2].max()) > 0:
             rank_ms['per_rank_sclk_mhz'] = [round(float(v), 1) for v in tab[:, 2]]
+        if args.workload == 'train':
+            rank_ms['replicas_in_sync'] = bool((tab[:, 3] == tab[0, 3]).all() and (tab[:, 4] == tab[0, 4]).all())
+            rank_ms['parameters_finite'] = bool((tab[:, 5] == 1.0).all())
+            rank_ms['replicas_note'] = 'parameter digests (sum, sum of magnitudes, in float64) of every rank after the timed steps, compared bit for bit'
 
     out = None
     if rank == 0:

@@ -132,4 +132,5 @@ def test_bench_launched_the_way_the_driver_launches_it_two_ranks():
     assert len(r['per_rank_ms_per_step']) == 2 and r['ms_per_step_min'] <= r['ms_per_step_max'] <= d['ms_per_step'] * 1.02
     assert len(r['per_rank_sclk_mhz']) == 2
     assert 0 <= r['exposed_exchange_ms_mean'] <= r['exposed_exchange_ms_max'] < d['ms_per_step']
+    assert r['replicas_in_sync'] is True and r['parameters_finite'] is True                # the digests of both replicas after the timed steps, bit for bit
     assert d['roofline']['kernel'].startswith('conv_igemm') and 0 < d['roofline']['frac'] < 1
