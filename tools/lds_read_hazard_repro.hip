@@ -1,0 +1,153 @@
+// tools/lds_read_hazard_repro.hip -- stand-alone form of the rasteriser finding of round 4 (profiles/r04_raster_determinism.txt):
+// is a kernel that READS a small LDS table with data-dependent addresses inside a divergent loop bit-reproducible while, on another stream,
+// workgroups stream global memory into LDS with LDS-DMA (global_load_lds_dwordx4) -- the operand path of the bf16x3 convolution kernels?
+//
+// Written at the end of round 4 and run ONCE with the round's last GPU seconds (150 launches per cell, profiles/r04_lds_read_hazard_repro.txt):
+// 0 differing launches in all four cells -- THIS aggressor (LDS-DMA copies + a few LDS reads, no MFMA, no operand re-use) is not sufficient;
+// the library's convolution kernel is (tools/datagen_determinism_probe.py PROBE_LOAD=conv).  Next: make the aggressor more like it, one
+// ingredient at a time (MFMA stream, eight waves, 140 KB of LDS, ds_read_b128 fragment traffic).  No torch, no library of this repository.
+//
+//   victim    : raster_face_kernel's skeleton -- 256 threads fill a 256-entry float table in LDS, barrier, then every 16-lane group walks a
+//               pseudo-random box of (row, column) pairs round-robin, reads table[row] and table[column], runs the three edge functions and the
+//               depth interpolation of csrc/raster.hip on them, and combines the results with atomicMin into a 64-bit key buffer.
+//               Variant 1 reads the table (the round 2-4 form); variant 0 computes the same two values arithmetically (the product form).
+//   aggressor : workgroups of 256 threads with 128 KB of LDS that copy a large buffer into it, 8 KB per trip, with global_load_lds_dwordx4,
+//               wait and barrier, and fold a few ds_read_b128 of what arrived into a checksum (so that nothing is optimised away); replayed
+//               as a hipGraph of four launches to keep the chip full, like tools/datagen_determinism_probe.py's PROBE_LOAD=conv.
+//   check     : the victim's key buffer of launch i against that of launch 0 (same inputs), on the host, for `reps` launches; with and
+//               without the aggressor; for both variants.  Expected if the finding is what it looks like: differences only for
+//               (variant 1, aggressor on).
+//
+//     hipcc --offload-arch=gfx950 -O3 tools/lds_read_hazard_repro.hip -o tools/bin/lds_read_hazard_repro && tools/bin/lds_read_hazard_repro [reps]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+#pragma clang fp contract(off)
+
+constexpr int WH = 256, NFACE = 13776, NBODY = 4;
+
+__device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) { return (px - ax) * (by - ay) - (py - ay) * (bx - ax); }
+
+template <int TABLE>
+__global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ tri, unsigned long long* __restrict__ zbuf, long long n) {
+    extern __shared__ float sample[];
+    if (TABLE) {
+        for (int k = threadIdx.x; k < WH; k += 256) sample[k] = (float)(2 * k + 1 - WH) / (float)WH;
+        __syncthreads();
+    }
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = gid >> 4;
+    const int sub = (int)(gid & 15);
+    if (i >= n) return;
+    const long long b = i / NFACE;
+    const int f = (int)(i - b * NFACE);
+    const float* p = tri + i * 9;
+    const float x0 = p[0], y0 = p[1], z0 = p[2], x1 = p[3], y1 = p[4], z1 = p[5], x2 = p[6], y2 = p[7], z2 = p[8];
+    const float area = edge_fn(x0, y0, x1, y1, x2, y2);
+    if (!(fabsf(area) > 1e-12f)) return;
+    const float fw = (float)WH;
+    const float xmin = fminf(x0, fminf(x1, x2)), xmax = fmaxf(x0, fmaxf(x1, x2));
+    const float ymin = fminf(y0, fminf(y1, y2)), ymax = fmaxf(y0, fmaxf(y1, y2));
+    int xa = (int)floorf((fmaxf(xmin, -1.f) * fw + fw - 1.f) * 0.5f), xb = (int)ceilf((fminf(xmax, 1.f) * fw + fw - 1.f) * 0.5f);
+    int ya = (int)floorf((fmaxf(ymin, -1.f) * fw + fw - 1.f) * 0.5f), yb = (int)ceilf((fminf(ymax, 1.f) * fw + fw - 1.f) * 0.5f);
+    xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
+    xb = xb > WH - 1 ? WH - 1 : xb; yb = yb > WH - 1 ? WH - 1 : yb;
+    if (xb < xa || yb < ya) return;
+    unsigned long long* zb = zbuf + b * (long long)WH * WH;
+    const int bw = xb - xa + 1;
+    int xi = xa + sub, yi = ya;
+    while (xi > xb) { xi -= bw; ++yi; }
+    for (; yi <= yb;) {
+        const float yp = TABLE ? sample[yi] : (float)(2 * yi + 1 - WH) * (1.f / (float)WH);
+        const float xp = TABLE ? sample[xi] : (float)(2 * xi + 1 - WH) * (1.f / (float)WH);
+        const float e0 = edge_fn(x1, y1, x2, y2, xp, yp), e1 = edge_fn(x2, y2, x0, y0, xp, yp), e2 = edge_fn(x0, y0, x1, y1, xp, yp);
+        const bool in = (e0 >= 0.f && e1 >= 0.f && e2 >= 0.f) || (e0 <= 0.f && e1 <= 0.f && e2 <= 0.f);
+        if (in) {
+            float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+            w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
+            const float ws = (w0 + w1) + w2;
+            w0 = w0 / ws; w1 = w1 / ws; w2 = w2 / ws;
+            const float zp = 1.f / ((w0 / z0 + w1 / z1) + w2 / z2);
+            if (zp > 0.1f && zp < 100.f) atomicMin(zb + (long long)yi * WH + xi, ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)f);
+        }
+        xi += 16;
+        while (xi > xb) { xi -= bw; ++yi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void aggressor_kernel(const unsigned* __restrict__ src, long long words, unsigned* __restrict__ sink, int trips) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 128 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned acc = 0;
+    for (int t = 0; t < trips; ++t) {
+        const long long base = (((long long)blockIdx.x * trips + t) * 2048) % (words - 2048);           // 8 KB per trip
+        unsigned* dst = lds + (t & 15) * 2048;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + base + ((r * 4 + wave) * 64 + lane) * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + (r * 4 + wave) * 256), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const uint4 v = *reinterpret_cast<const uint4*>(dst + ((tid * 4) & 2047));
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+        __builtin_amdgcn_s_barrier();
+    }
+    if (acc == 0x12345678u) sink[blockIdx.x] = acc;          // (never true in practice: keeps the reads alive)
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 400;
+    const long long n = (long long)NBODY * NFACE;
+    // triangles: a few pixels wide, scattered over the middle of the image, depths around 42 (the training step's geometry in spirit)
+    std::vector<float> tri(n * 9);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.f; };
+    for (long long i = 0; i < n; ++i) {
+        const float cx = (rnd() - 0.5f) * 0.9f, cy = (rnd() - 0.5f) * 1.6f, z = 41.f + rnd() * 2.f;
+        for (int v = 0; v < 3; ++v) { tri[i * 9 + v * 3 + 0] = cx + (rnd() - 0.5f) * 0.03f; tri[i * 9 + v * 3 + 1] = cy + (rnd() - 0.5f) * 0.03f; tri[i * 9 + v * 3 + 2] = z + rnd() * 0.1f; }
+    }
+    float* dtri; unsigned long long* dz; unsigned* dsrc; unsigned* dsink;
+    const long long words = 1LL << 26;           // 256 MB of source for the aggressor
+    const size_t zbytes = (size_t)NBODY * WH * WH * 8;
+    CK(hipMalloc(&dtri, tri.size() * 4)); CK(hipMalloc(&dz, zbytes)); CK(hipMalloc(&dsrc, words * 4)); CK(hipMalloc(&dsink, 4096 * 4));
+    CK(hipMemcpy(dtri, tri.data(), tri.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dsrc, 0x5a, words * 4));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    hipStream_t sv, sa;
+    CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(sa, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(aggressor_kernel, dim3(512), dim3(256), 128 * 1024, sa, dsrc, words, dsink, 64);
+    CK(hipStreamEndCapture(sa, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    std::vector<unsigned long long> ref(zbytes / 8), cur(zbytes / 8);
+    const unsigned grid = (unsigned)((n * 16 + 255) / 256);
+    for (int table = 1; table >= 0; --table)
+        for (int aggress = 0; aggress < 2; ++aggress) {
+            long long differing = 0; int bad_launches = 0;
+            for (int r = 0; r <= reps; ++r) {
+                if (aggress) CK(hipGraphLaunch(ge, sa));
+                CK(hipMemsetAsync(dz, 0xff, zbytes, sv));
+                if (table) hipLaunchKernelGGL(victim_kernel<1>, dim3(grid), dim3(256), WH * 4, sv, dtri, dz, n);
+                else hipLaunchKernelGGL(victim_kernel<0>, dim3(grid), dim3(256), 0, sv, dtri, dz, n);
+                CK(hipMemcpyAsync(r == 0 ? ref.data() : cur.data(), dz, zbytes, hipMemcpyDeviceToHost, sv));
+                CK(hipStreamSynchronize(sv));
+                if (r) {
+                    long long d = 0;
+                    for (size_t k = 0; k < ref.size(); ++k) d += ref[k] != cur[k];
+                    differing += d; bad_launches += d != 0;
+                }
+            }
+            CK(hipStreamSynchronize(sa));
+            printf("victim %s, LDS-DMA aggressor %s: %d of %d launches differ from the first (%lld keys in all)\n",
+                   table ? "READS its LDS table" : "computes the coordinates", aggress ? "ON " : "off", bad_launches, reps, differing);
+        }
+    return 0;
+}
