@@ -2,10 +2,12 @@
 // is a kernel that READS a small LDS table with data-dependent addresses inside a divergent loop bit-reproducible while, on another stream,
 // workgroups stream global memory into LDS with LDS-DMA (global_load_lds_dwordx4) -- the operand path of the bf16x3 convolution kernels?
 //
-// Written at the end of round 4 and run ONCE with the round's last GPU seconds (150 launches per cell, profiles/r04_lds_read_hazard_repro.txt):
-// 0 differing launches in all four cells -- THIS aggressor (LDS-DMA copies + a few LDS reads, no MFMA, no operand re-use) is not sufficient;
-// the library's convolution kernel is (tools/datagen_determinism_probe.py PROBE_LOAD=conv).  Next: make the aggressor more like it, one
-// ingredient at a time (MFMA stream, eight waves, 140 KB of LDS, ds_read_b128 fragment traffic).  No torch, no library of this repository.
+// Written at the end of round 4 and run twice with the round's last GPU seconds (150 launches per cell, profiles/r04_lds_read_hazard_repro.txt):
+// 0 differing launches in all four cells, with aggressor mode 0 (LDS-DMA copies + a few LDS reads) and mode 3 (+ 12 bf16 MFMAs per wave and
+// trip, eight waves) -- neither is sufficient; the library's convolution kernel is (tools/datagen_determinism_probe.py PROBE_LOAD=conv).
+// Open: what else of that kernel matters (its 140 KB of LDS and one workgroup per CU, the swizzled ds_read_b128 fragment traffic, the padding
+// source, the epilogue), or whether this victim -- synchronised with the host after every launch -- simply does not meet the aggressor the way
+// the probe's back-to-back launches do.  No torch, no library of this repository.
 //
 //   victim    : raster_face_kernel's skeleton -- 256 threads fill a 256-entry float table in LDS, barrier, then every 16-lane group walks a
 //               pseudo-random box of (row, column) pairs round-robin, reads table[row] and table[column], runs the three edge functions and the
@@ -18,7 +20,7 @@
 //               without the aggressor; for both variants.  Expected if the finding is what it looks like: differences only for
 //               (variant 1, aggressor on).
 //
-//     hipcc --offload-arch=gfx950 -O3 tools/lds_read_hazard_repro.hip -o tools/bin/lds_read_hazard_repro && tools/bin/lds_read_hazard_repro [reps]
+//     hipcc --offload-arch=gfx950 -O3 tools/lds_read_hazard_repro.hip -o tools/bin/lds_read_hazard_repro && tools/bin/lds_read_hazard_repro [reps] [aggressor mode 0..3]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -80,11 +82,18 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ t
     }
 }
 
-__global__ __launch_bounds__(256) void aggressor_kernel(const unsigned* __restrict__ src, long long words, unsigned* __restrict__ sink, int trips) {
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+
+// MODE bit 0: an MFMA block per trip on what arrived (12 x v_mfma_f32_32x32x16_bf16 per wave, operands by ds_read_b128: the convolution's inner loop
+// in spirit); the host launches 256 or 512 threads (argv[2]) -- the steps towards "more like the convolution kernel" that the header names
+template <int MODE>
+__global__ __launch_bounds__(512) void aggressor_kernel(const unsigned* __restrict__ src, long long words, unsigned* __restrict__ sink, int trips) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 128 KB
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
     unsigned acc = 0;
+    f32x16_t c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < trips; ++t) {
         const long long base = (((long long)blockIdx.x * trips + t) * 2048) % (words - 2048);           // 8 KB per trip
         unsigned* dst = lds + (t & 15) * 2048;
@@ -97,8 +106,17 @@ __global__ __launch_bounds__(256) void aggressor_kernel(const unsigned* __restri
         asm volatile("" ::: "memory");
         const uint4 v = *reinterpret_cast<const uint4*>(dst + ((tid * 4) & 2047));
         acc += v.x ^ v.y ^ v.z ^ v.w;
+        if (MODE & 1) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(dst + ((lane * 4 + k * 256) & 2047));
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(dst + ((lane * 4 + k * 256 + 1024) & 2047));
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_s_barrier();
     }
+    if (MODE & 1) acc += (unsigned)(c[0] + c[5] + c[15] == 12345.678f);
     if (acc == 0x12345678u) sink[blockIdx.x] = acc;          // (never true in practice: keeps the reads alive)
 }
 
@@ -119,12 +137,19 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dtri, tri.size() * 4)); CK(hipMalloc(&dz, zbytes)); CK(hipMalloc(&dsrc, words * 4)); CK(hipMalloc(&dsink, 4096 * 4));
     CK(hipMemcpy(dtri, tri.data(), tri.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dsrc, 0x5a, words * 4));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    const int amode = argc > 2 ? atoi(argv[2]) : 0;           // 0: LDS-DMA copies only; 1: + an MFMA block per trip; 2: 512 threads; 3: both
+    const int athreads = (amode & 2) ? 512 : 256;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     hipStream_t sv, sa;
     CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(sa, hipStreamCaptureModeThreadLocal));
-    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(aggressor_kernel, dim3(512), dim3(256), 128 * 1024, sa, dsrc, words, dsink, 64);
+    for (int k = 0; k < 4; ++k) {
+        if (amode & 1) hipLaunchKernelGGL(aggressor_kernel<1>, dim3(512), dim3(athreads), 128 * 1024, sa, dsrc, words, dsink, 64);
+        else hipLaunchKernelGGL(aggressor_kernel<0>, dim3(512), dim3(athreads), 128 * 1024, sa, dsrc, words, dsink, 64);
+    }
+    printf("aggressor mode %d: %d threads per workgroup, 128 KB of LDS, LDS-DMA copies%s\n", amode, athreads, (amode & 1) ? " + 12 bf16 MFMAs per wave and trip" : "");
     CK(hipStreamEndCapture(sa, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     std::vector<unsigned long long> ref(zbytes / 8), cur(zbytes / 8);
