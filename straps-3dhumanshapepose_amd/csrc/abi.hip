@@ -100,12 +100,13 @@ extern "C" int straps_selftest_mfma_peak(const float* seed512, float* out, int b
 // One accumulator PER DEVICE (the pointer is device memory of the device that was current when it was set; ADVICE round 3: a process-global
 // pointer would have been handed to launches on other GPUs).  The owner clears it -- straps_set_clock_accumulator(NULL) -- before freeing the
 // buffer; launches captured into a hipGraph keep the pointer they were captured with, so a graph must not outlive the buffer either.
-static unsigned long long* g_straps_clk_acc[64] = {nullptr};
+constexpr int kMaxClkDevices = 64;      // (device ordinals beyond the table get no accumulator -- never another device's)
+static unsigned long long* g_straps_clk_acc[kMaxClkDevices] = {nullptr};
 
 unsigned long long* straps_clk_acc_current() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    return g_straps_clk_acc[dev & 63];
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxClkDevices) return nullptr;
+    return g_straps_clk_acc[dev];
 }
 
 extern "C" int straps_wall_clock_khz(void) {
@@ -118,7 +119,8 @@ extern "C" int straps_wall_clock_khz(void) {
 extern "C" int straps_set_clock_accumulator(unsigned long long* acc2) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { straps_set_error("straps_set_clock_accumulator: no current device"); return STRAPS_EHIP; }
-    g_straps_clk_acc[dev & 63] = acc2;          // (kernel arguments are fixed at launch / graph-capture time: set it before capturing)
+    STRAPS_REQUIRE(dev >= 0 && dev < kMaxClkDevices, "straps_set_clock_accumulator: device ordinal %d outside the table of %d", dev, kMaxClkDevices);
+    g_straps_clk_acc[dev] = acc2;          // (kernel arguments are fixed at launch / graph-capture time: set it before capturing)
     return STRAPS_OK;
 }
 

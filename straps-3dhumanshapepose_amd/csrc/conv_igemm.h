@@ -4,6 +4,7 @@
 #pragma once
 #include "common.h"
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -45,6 +46,9 @@ struct ConvP {
     // measurement aid (straps_set_clock_accumulator; NULL in library use): workgroup 0 of every launch adds the shader-clock and the
     // constant-rate wall-clock ticks it lived for to clk[0] / clk[1] -- their ratio is the clock the kernel really ran at
     unsigned long long* clk;
+    // 1 = the look-ahead epilogue (IgemmEpilogue below: memory operands fetched ahead of their use), 0 = the row-by-row form of rounds 1-4
+    // (A/B switch of the tools build, STRAPS_EPI; the product library always takes 1)
+    int epi;
     // Up to four independent sub-problems per launch (blockIdx.y): the output-parity classes of a stride-2 data gradient
     // are GEMMs over a quarter of the pixels each with their own tap subset -- launched together they fill the chip
     // instead of queueing as four small grids.  A forward conv / stride-1 gradient is the single class 0.
@@ -222,6 +226,203 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
     if (full) rows(std::true_type{}); else rows(std::false_type{});
 }
 
+// ---- round 5: the look-ahead epilogue ------------------------------------------------------------------------------------------------
+// What the row-by-row epilogue above costs when it has memory OPERANDS (a data gradient's addend; the BatchNorm input `raw` and the ReLU
+// bits of the fused BatchNorm-backward sums): per 32-row block it fetches the addend rows, waits, then twice (fetch eight raw rows + eight
+// bit words, wait, compute, store) -- and because loads and stores retire through ONE in-order counter on this part, every wait behind a
+// batch of stores also waits for those stores to be acknowledged by memory.  Six dependent memory round trips per workgroup of a 128-row
+// tile, 1.5-2.5 us each under load, at the end of a main loop of 7-14 us, with two workgroups per CU to hide them: `dgrad+bn` launches
+// ran 16-54 us behind the forward convolution of the same FLOPs (190 vs 122 us on layer1's 64 -> 64 3x3, profiles/r04_bench_train_b64.json).
+// Here a UNIT is one 32x32 accumulator block (i, j) of a wave -- 16 elements per lane -- and its operands (16 addend values, 16 raw values,
+// one word of ReLU bits per operand tensor) are fetched one unit AHEAD of their use: unit 0 before the matrix work of the last K chunk
+// (`prefetch()`, called by the kernels where no copy wait follows any more), unit k + 1 before unit k is computed and stored.  No load ever
+// waits behind a store (a younger store does not hold back an older load in the in-order counter), and one round trip -- partly under the last
+// chunk's MFMAs -- is exposed instead of six.  Same arithmetic in the same order per lane as the row-by-row form: results are bit-identical
+// (tests/test_gpu_conv_x3.py::test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit runs the fp32-mask form -- still row by row -- against it
+// on every tile configuration).
+//
+// ReLU bits: the word of (pixel row, 32-channel group) is the same for the 32 lanes of a row.  The row-by-row form loads it once per (lane,
+// row): 16 broadcast loads and 16 registers per unit and operand.  Here lane q = l & 15 of each 16-lane DPP row loads the word of the block
+// row its HALF-wave will need as its q-th -- (q & 3) + 8 (q >> 2) + 4 (l >> 5), the accumulator layout's row order -- and element r reads it
+// with `v_mov_b32_dpp row_newbcast:r`: one load and one register per unit and operand.
+template <int R>
+__device__ __forceinline__ unsigned epi_row_word(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + R, 0xf, 0xf, false); }
+template <typename F, int... Rs>
+__device__ __forceinline__ void epi_for16(F&& f, std::integer_sequence<int, Rs...>) { (f(std::integral_constant<int, Rs>{}), ...); }
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): expanded by the front end (a `#pragma unroll` loop over units is NOT reliable
+// here -- one unit's body is a few thousand instructions, and beyond the pragma-unroll threshold the loop stays a loop, its unit and accumulator
+// arrays get indexed at run time and land in scratch memory)
+template <int N, typename F>
+__device__ __forceinline__ void epi_static_for(F&& f) { epi_for16(f, std::make_integer_sequence<int, N>{}); }
+
+struct EpiUnit {
+    float rv[16];       // addend (p.res) of the lane's 16 rows
+    float xr[16];       // BatchNorm input (p.bnr_raw)
+    unsigned bw, rbw;   // ReLU-bit words (p.bnr_bits / p.res_bits), one block row per lane of a DPP row (see above)
+};
+
+// DEPTH: units whose operands may be in flight at once (34 registers each).  init() copies the handful of wave-uniform values the epilogue needs
+// out of the kernel argument block (scalar registers): a reference to the 800-byte ConvP kept in a member, or captured by the per-row
+// lambdas, makes the compiler materialise the whole block in scratch.
+// (eight-wave workgroups share a SIMD's 512 registers between two waves: their four-unit tiles keep two units in flight)
+template <int BM, int BN, int WGM, int WGN, int DEPTH = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 2 : (BM / WGM / 32) * (BN / WGN / 32)>
+struct IgemmEpilogue {
+    static constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32, NU = MI * NI;
+    static_assert(DEPTH >= 1 && DEPTH <= NU, "look-ahead depth");
+    int m0, n0, lane, wm, wn;
+    bool look, full, remap, bnr;
+    EpiUnit u[DEPTH];
+    // wave-uniform copies (see above)
+    const float *g_raw, *g_res, *g_scale, *g_shift, *g_bsc, *g_bsh, *g_mean;
+    const unsigned *g_bits, *g_rbits;
+    float* g_y;
+    int Cout, relu, OH, OW, omul, oah, oaw, cMh, cMw, cM;
+
+    __device__ __forceinline__ void init(const ConvP& p, const ConvP::Class& c, int m0_, int n0_) {
+        const int tid = threadIdx.x, wave = tid >> 6;
+        m0 = m0_; n0 = n0_;
+        lane = tid & 63; wm = wave / WGN; wn = wave % WGN;
+        bnr = p.bnr_raw != nullptr;
+        // the look-ahead form covers every launch that HAS memory operands, except the two forms kept row by row: the fp32-activation mask of
+        // the BatchNorm sums (bnr_out: the A/B reference of the bit form) and the eval-mode plane output (yplanes)
+        // ... and a ragged last M tile (one workgroup row of a launch at most), which keeps the row-by-row form with its per-row range tests
+        full = m0 + BM <= c.M;
+        look = p.epi != 0 && (bnr || p.res != nullptr) && p.bnr_out == nullptr && p.yplanes == nullptr && p.y != nullptr && full;
+        remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
+        g_raw = p.bnr_raw; g_res = p.res; g_scale = p.scale; g_shift = p.shift; g_bsc = p.bnr_sc; g_bsh = p.bnr_sh; g_mean = p.bnr_mean;
+        g_bits = p.bnr_bits; g_rbits = p.res_bits; g_y = p.y;
+        Cout = p.Cout; relu = p.relu; OH = p.OH; OW = p.OW; omul = p.omul; oah = c.oah; oaw = c.oaw; cMh = c.Mh; cMw = c.Mw; cM = c.M;
+    }
+
+    // walk over the physical output pixels of the lane's 16 rows of block row i (rows m = mb + (r & 3) + 8 (r >> 2)): f(r, pixel).  A remapped
+    // class (a parity class of a stride-2 data gradient) finds the first pixel by division and walks on, as igemm_store_rows_impl does.
+    template <bool REMAP, typename F>
+    __device__ __forceinline__ void for_rows(int i, F&& f) const {
+        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+        if constexpr (!REMAP) {
+            epi_static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; f(rc, mb + (r & 3) + 8 * (r >> 2)); });
+        } else {
+            const int MhMw = cMh * cMw;
+            int b_ = mb / MhMw;
+            const int rem = mb - b_ * MhMw;
+            int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
+            epi_static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                f(rc, (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw);
+                wo_ += (r & 3) == 3 ? 5 : 1;
+                while (wo_ >= cMw) {
+                    wo_ -= cMw;
+                    if (++ho_ == cMh) { ho_ = 0; ++b_; }
+                }
+            });
+        }
+    }
+    template <bool FULL, bool REMAP>
+    __device__ __forceinline__ void issue(int i, int j, EpiUnit& un) const {
+        const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+        for_rows<REMAP>(i, [&](auto rc, int pix) {
+            constexpr int r = decltype(rc)::value;
+            const bool ok = FULL || mb + (r & 3) + 8 * (r >> 2) < cM;
+            if (bnr) un.xr[r] = ok ? g_raw[pix * Cout + n] : 0.f;
+            if (g_res) un.rv[r] = ok ? g_res[pix * Cout + n] : 0.f;
+        });
+        if (g_bits || g_rbits) {
+            // the block row whose bit words this lane fetches: the q-th row of its half-wave, q = lane & 15
+            const int q = lane & 15;
+            const int ml = m0 + wm * WTM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const bool okl = FULL || ml < cM;
+            int pixl = ml;
+            if constexpr (REMAP) {
+                const int MhMw = cMh * cMw;
+                const int mc = okl ? ml : 0;
+                const int b_ = mc / MhMw, rem = mc - b_ * MhMw;
+                const int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
+                pixl = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
+            }
+            const int wi = pixl * (Cout >> 5) + ((n0 + wn * WTN + j * 32) >> 5);
+            un.bw = (g_bits && okl) ? g_bits[wi] : 0u;
+            un.rbw = (g_rbits && okl) ? g_rbits[wi] : 0u;
+        }
+    }
+    // unit 0's operands, ahead of the last chunk's matrix work.  The kernels call this exactly once, where no copy wait follows (every later
+    // s_waitcnt vmcnt of the main loop would wait for these loads too), on a path peeled out of the chunk loop -- inside the loop the unit's
+    // registers would be live across every iteration.
+    __device__ __forceinline__ void prefetch() {
+        if (!look) return;
+        if (remap) issue<true, true>(0, 0, u[0]); else issue<true, false>(0, 0, u[0]);
+    }
+
+    template <bool FULL, bool REMAP>
+    __device__ __forceinline__ void consume(int i, int j, const EpiUnit& un, const f32x16& acc, float& s1, float& s2,
+                                            double& d1, double& d2, float sc, float sh, float bsc, float bsh, float bmu) const {
+        const int cl = lane & 31;
+        const int n = n0 + wn * WTN + j * 32 + cl;
+        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+        for_rows<REMAP>(i, [&](auto rc, int pix) {
+            constexpr int r = decltype(rc)::value;
+            const bool ok = FULL || mb + (r & 3) + 8 * (r >> 2) < cM;
+            float v = acc[r];
+            const float vs = ok ? v : 0.f;
+            s1 += vs;
+            s2 = fmaf(vs, vs, s2);
+            if (g_scale) v = fmaf(v, sc, sh);
+            if (g_res) {
+                float a = un.rv[r];
+                if (g_rbits) a = ((epi_row_word<r>(un.rbw) >> cl) & 1u) ? a : 0.f;
+                v += a;
+            }
+            if (relu) v = fmaxf(v, 0.f);
+            if (bnr) {
+                const bool on = g_bits ? (((epi_row_word<r>(un.bw) >> cl) & 1u) != 0) : fmaf(un.xr[r], bsc, bsh) > 0.f;
+                const float g = (on && ok) ? v : 0.f;
+                d1 += (double)g;
+                d2 += (double)g * ((double)un.xr[r] - (double)bmu);
+            }
+            if (ok) g_y[pix * Cout + n] = v;
+        });
+    }
+
+    // PRE: prefetch() has run (unit 0 is in flight)
+    template <bool FULL, bool REMAP, bool PRE>
+    __device__ __forceinline__ void run(const f32x16 (&acc)[MI][NI], float (&s1)[NI], float (&s2)[NI], double (&d1)[NI], double (&d2)[NI]) {
+        float sc[NI], sh[NI], bsc[NI], bsh[NI], bmu[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+            sc[j] = g_scale ? g_scale[n] : 1.f;
+            sh[j] = g_shift ? g_shift[n] : 0.f;
+            s1[j] = 0.f; s2[j] = 0.f; d1[j] = 0.0; d2[j] = 0.0;
+            bsc[j] = (bnr && !g_bits) ? g_bsc[n] : 0.f;
+            bsh[j] = (bnr && !g_bits) ? g_bsh[n] : 0.f;
+            bmu[j] = bnr ? g_mean[n] : 0.f;
+        }
+        // units k .. k + DEPTH - 1 in flight (slot k % DEPTH): every load is issued in front of the stores of DEPTH - 1 units, none behind a
+        // store it would have to wait for
+        if constexpr (!PRE) issue<FULL, REMAP>(0, 0, u[0]);
+        epi_static_for<DEPTH - 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value + 1;
+            issue<FULL, REMAP>(k / NI, k % NI, u[k]);
+        });
+        epi_static_for<NU>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
+            consume<FULL, REMAP>(i, j, u[k % DEPTH], acc[i][j], s1[j], s2[j], d1[j], d2[j], sc[j], sh[j], bsc[j], bsh[j], bmu[j]);
+            if constexpr (k + DEPTH < NU) issue<FULL, REMAP>((k + DEPTH) / NI, (k + DEPTH) % NI, u[k % DEPTH]);
+        });
+    }
+
+    // the whole epilogue of the tile's rows: look-ahead form where it applies, else the row-by-row form
+    template <bool PRE = true>
+    __device__ __forceinline__ void finish(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[MI][NI], float (&s1)[NI], float (&s2)[NI],
+                                           double (&d1)[NI], double (&d2)[NI]) {
+        if (!look) {
+            igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, d1, d2);
+            return;
+        }
+        if (remap) run<true, true, PRE>(acc, s1, s2, d1, d2); else run<true, false, PRE>(acc, s1, s2, d1, d2);
+    }
+};
+
 template <int BM, int BN, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0,
                                                  float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32]) {
@@ -297,7 +498,7 @@ inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, co
                             int batch, int h, int wdt, int cin, int cout, int kh, int kw, int stride, int pad) {
     p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr; p.bnr_bits = p.res_bits = nullptr;
-    p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current();
+    p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current(); p.epi = STRAPS_TOOL_ENV_INT("STRAPS_EPI", 1);
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
     ConvP::Class& c = p.cls[0];
     p.ncls = 1;
@@ -324,7 +525,7 @@ inline int conv_dgrad_problem(ConvP& p, const float* addend, float* dx, int batc
     const int padh = kh - 1 - pad, padw = kw - 1 - pad;
     p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr; p.bnr_bits = p.res_bits = nullptr;
-    p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current();
+    p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current(); p.epi = STRAPS_TOOL_ENV_INT("STRAPS_EPI", 1);
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
     p.omul = stride;

@@ -63,6 +63,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     const int lc = (tid & 3) ^ swz3(lr);                       // 16-byte K group it fetches for its slot tid & 3
     const u16* xg = reinterpret_cast<const u16*>(p.x);
     const u16* wg = reinterpret_cast<const u16*>(p.w);
+    IgemmEpilogue<BM, BN, WGM, WGN> ep;
+    ep.init(p, c, m0, n0);
 
     int a_hi0[AP], a_wi0[AP], a_base[AP];
     const int MhMw = cMh * cMw;
@@ -164,13 +166,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
 
     // MORE: chunk q + NST - 1 exists and is issued between this chunk's MFMAs into the stage that chunk q - 1 was read from.
     // INFLIGHT: copies of younger chunks that may stay outstanding while this chunk's are awaited (the counter retires in order).
-    auto chunk = [&](int stage, int nstage, auto more_c, auto inflight_c) {
+    auto chunk = [&](int stage, int nstage, auto more_c, auto inflight_c, auto last_c) {
         constexpr bool MORE = decltype(more_c)::value;
         constexpr int INFLIGHT = decltype(inflight_c)::value;
         // my copies of this chunk have landed, then everybody's have -- and every wave is done reading the stage refilled next
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // the last chunk: no copy wait follows -- the epilogue's first operands are fetched under this chunk's matrix work (conv_igemm.h)
+        if constexpr (decltype(last_c)::value) ep.prefetch();
         const u16* Ab = As + (stage * 3 * BM + wm * WTM) * 32;
         const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
         int cnt = 0;
@@ -252,13 +256,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
             load_frags(0, 0, 0);
         }
         int stage = 0;
-        auto body = [&](int q, auto more_c) {
+        auto body = [&](int q, auto more_c, auto last_c) {
             const int nxt = stage + 1 == NST ? 0 : stage + 1;
             load_frags(stage, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_block(0, 0, std::false_type{});
             __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 < nchunks) {
+            if constexpr (!decltype(last_c)::value) {
                 // chunk q+1 (issued NST chunks ago) has landed -- the NST - 2 chunks after it may still be in flight
                 if (q + NST - 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NPIECE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -266,6 +270,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 load_frags(nxt, 0, 0);
+            } else {
+                // the last chunk, first fragment set consumed: no copy wait follows -- the epilogue's first operands are fetched under the
+                // second MFMA block (conv_igemm.h)
+                ep.prefetch();
             }
             __builtin_amdgcn_sched_barrier(0);
             mfma_block(1, stage, more_c);                     // refill this chunk's stage (chunk q + NST): no wave reads it any more
@@ -273,8 +281,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
             stage = nxt;
         };
         int q = 0;
-        for (; q + NST < nchunks; ++q) body(q, std::true_type{});
-        for (; q < nchunks; ++q) body(q, std::false_type{});
+        for (; q + NST < nchunks; ++q) body(q, std::true_type{}, std::false_type{});
+        for (; q + 1 < nchunks; ++q) body(q, std::false_type{}, std::false_type{});
+        if (q < nchunks) body(q, std::false_type{}, std::true_type{});      // (peeled: the prefetched unit's registers are live from here on only)
     } else {
     int stage = 0, nstage = NST - 1;
     auto next = [&]() {
@@ -282,16 +291,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
         nstage = nstage + 1 == NST ? 0 : nstage + 1;
     };
     int q = 0;
-    for (; q + NST - 1 < nchunks; ++q) { chunk(stage, nstage, std::true_type{}, std::integral_constant<int, (NST - 2) * NPIECE>{}); next(); }
+    for (; q + NST - 1 < nchunks; ++q) { chunk(stage, nstage, std::true_type{}, std::integral_constant<int, (NST - 2) * NPIECE>{}, std::false_type{}); next(); }
     if constexpr (NST == 3) {
-        if (q + 1 < nchunks) { chunk(stage, nstage, std::false_type{}, std::integral_constant<int, NPIECE>{}); next(); ++q; }
+        if (q + 1 < nchunks) { chunk(stage, nstage, std::false_type{}, std::integral_constant<int, NPIECE>{}, std::false_type{}); next(); ++q; }
     }
-    if (q < nchunks) chunk(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{});
+    if (q < nchunks) chunk(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
     }
 
     float s1[NI], s2[NI];
     double bd1[NI], bd2[NI];
-    igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
+    ep.finish(p, c, acc, s1, s2, bd1, bd2);
     igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
     igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
     clk_end(p, clk);
@@ -337,6 +346,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     const u16* xg = reinterpret_cast<const u16*>(p.x);
     const u16* wg = reinterpret_cast<const u16*>(p.w);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    IgemmEpilogue<BM, BN, WGM, WGN> ep;
+    ep.init(p, c, m0, n0);
 
     // ---- tile geometry: nimg images x rows_t rows x W columns; patch (rows_t + 2) x (W + 2) slots per image
     const int HW = p.H * p.W, PW = p.W + 2;
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
     constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
     int c_tap = 0, c_cc = 0;                                    // compute stream position
-    auto step = [&](int stage, int nstage, auto more_c, auto inflight_c) {
+    auto step = [&](int stage, int nstage, auto more_c, auto inflight_c, auto last_c) {
         constexpr bool MORE = decltype(more_c)::value;
         constexpr int INFLIGHT = decltype(inflight_c)::value;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
@@ -450,6 +461,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
                 asm volatile("" ::: "memory");
             }
         }
+        // the last step: no copy wait follows -- the epilogue's first operands are fetched under this step's matrix work (conv_igemm.h)
+        if constexpr (decltype(last_c)::value) ep.prefetch();
         const u16* Ap = As + (PBUF == 2 ? (c_cc & 1) : 0) * (3 * PS * 32);
         const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
         const int tsh = __builtin_amdgcn_readlane(v_sh, c_tap);
@@ -495,15 +508,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
         nstage = nstage + 1 == NST ? 0 : nstage + 1;
     };
     int q = 0;
-    for (; q + NST - 1 < nsteps; ++q) { step(stage, nstage, std::true_type{}, std::integral_constant<int, (NST - 2) * NPB>{}); next(); }
+    for (; q + NST - 1 < nsteps; ++q) { step(stage, nstage, std::true_type{}, std::integral_constant<int, (NST - 2) * NPB>{}, std::false_type{}); next(); }
     if constexpr (NST == 3) {
-        if (q + 1 < nsteps) { step(stage, nstage, std::false_type{}, std::integral_constant<int, NPB>{}); next(); ++q; }
+        if (q + 1 < nsteps) { step(stage, nstage, std::false_type{}, std::integral_constant<int, NPB>{}, std::false_type{}); next(); ++q; }
     }
-    if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{});
+    if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
 
     float s1[NI], s2[NI];
     double bd1[NI], bd2[NI];
-    igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
+    ep.finish(p, c, acc, s1, s2, bd1, bd2);
     igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
     igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
     clk_end(p, clk);
@@ -557,7 +570,7 @@ int launch_x3(const ConvP& p0, hipStream_t st) {
 }
 
 // tile_cfg & 15: 0 = auto, 1 = 128x128 (8 waves, 3 stages), 2 = 128x64 (4 waves, 2 stages, two workgroups per CU), 3 = 64x64 (4 waves, 3 stages),
-// 4 = 256x128 (8 waves, 2 stages), 5 = 128x128 (4 waves, 3 stages), 6 = 256x128 (4 waves, 2 stages), 7 = 128x64 (4 waves, 3 stages);
+// 4 = 256x128 (8 waves, 2 stages), 5 = 128x128 (4 waves, 3 stages), 6 = alias of 4 (a four-wave 256x128 tile until round 5), 7 = 128x64 (4 waves, 3 stages);
 // software-pipelined loop (PIPE): 8 = as 5, 9 = as 1, 10 = as 7, 11 = as 2, 12 = as 4
 // auto rule from tools/sweep_conv_x3.py (resnet18 shapes, B = 64): 64-channel outputs take 128x64 tiles, two workgroups per CU; otherwise
 // the largest tile that still gives every CU a workgroup: 256x128 from 512 128x128-tiles on (layer2: 63 vs 68 us), 128x128 from 256
@@ -569,6 +582,7 @@ int launch_x3(const ConvP& p0, hipStream_t st) {
 inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& bn, int ncls = 1, bool one_tap = false) {
     (void)kdim;
     cfg &= 15;
+    if (cfg == 6) cfg = 4;      // (the four-wave 256x128 tile spilled registers from round 3 on and no rule ever chose it: retired in round 5, an alias of 4)
     if (cfg == 0) {
         const long long t128 = ((M + 127) / 128) * (cout / 128);
         if (cout % 128 != 0) cfg = 11;
@@ -611,7 +625,6 @@ int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
         case 3: return launch_x3<64, 64, 2, 2, 3, ABL>(p, st);
         case 4: return launch_x3<256, 128, 4, 2, 2, ABL>(p, st);
         case 5: return launch_x3<128, 128, 2, 2, 3, ABL>(p, st);
-        case 6: return launch_x3<256, 128, 2, 2, 2, ABL>(p, st);
         case 8: return launch_x3<128, 128, 2, 2, 3, 0, true>(p, st);
         case 9: return launch_x3<128, 128, 4, 2, 3, 0, true>(p, st);
         case 10: return launch_x3<128, 64, 2, 2, 3, 0, true>(p, st);

@@ -16,11 +16,23 @@
 #include <dlfcn.h>
 #include <string.h>
 
-#include <rccl/rccl.h>
-
 #include "common.h"
 
 namespace {
+
+// The slice of the NCCL / RCCL C ABI used here, declared locally: the library must build on hosts without the RCCL development headers
+// (single-GPU users, cross-compile boxes -- ADVICE round 4), and RCCL stays a RUN-time dependency only.  These five types are the
+// stable public ABI of nccl.h (NCCL 2.x and every RCCL release): an opaque communicator pointer, a 128-byte id passed BY VALUE, and three
+// int-sized enums of which this file names four values.
+struct ncclComm;
+typedef ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclFloat32 = 7;      // nccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5, ncclFloat16 6, ncclFloat32 7
+constexpr ncclRedOp_t ncclSum = 0;
 
 struct RcclApi {
     void* handle = nullptr;

@@ -104,29 +104,48 @@ class GradientExchange:
             self._init_rccl(rank)
 
     def _init_rccl(self, rank):
+        """rank: the caller's rank in the JOB; the communicator is created over `group` (None = the default group), so its rank is the
+        caller's rank INSIDE that group and the 128-byte id comes from the group's rank 0, whoever that is in the job."""
         if not self.flat_g.is_cuda:
             raise RuntimeError("GradientExchange(backend='rccl') needs the gradient buffer on a GPU")
         L = hipabi.lib()
-        idbuf = (C.c_char * 128)()
-        if rank == 0:
-            hipabi.check(L.straps_comm_unique_id(idbuf), 'straps_comm_unique_id')
+        grank = rank
         if self.world > 1:
             import torch.distributed as dist
-            box = [bytes(idbuf) if rank == 0 else None]
+            grank = dist.get_rank(self.group)
+            if grank < 0:
+                raise RuntimeError("GradientExchange(backend='rccl'): this process is not a member of the group it was given")
+            if dist.get_world_size(self.group) != self.world:
+                raise RuntimeError("GradientExchange(backend='rccl'): world_size %d != size of the process group %d" % (self.world, dist.get_world_size(self.group)))
+        idbuf = (C.c_char * 128)()
+        if grank == 0:
+            hipabi.check(L.straps_comm_unique_id(idbuf), 'straps_comm_unique_id')
+        if self.world > 1:
+            box = [bytes(idbuf) if grank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             idbuf = (C.c_char * 128).from_buffer_copy(box[0])
         comm = C.c_void_p()
         with torch.cuda.device(self.flat_g.device):
-            hipabi.check(L.straps_comm_init_rank(idbuf, self.world, rank, C.byref(comm)), 'straps_comm_init_rank')
+            hipabi.check(L.straps_comm_init_rank(idbuf, self.world, grank, C.byref(comm)), 'straps_comm_init_rank')
             self._stream = torch.cuda.Stream(device=self.flat_g.device)
         self._comm = comm
-        assert L.straps_comm_size(comm) == self.world
+        if L.straps_comm_size(comm) != self.world:
+            n = L.straps_comm_size(comm)
+            self.close()
+            raise RuntimeError("GradientExchange(backend='rccl'): the communicator reports %d ranks, expected %d" % (n, self.world))
 
     def close(self):
+        """destroy the C-ABI communicator (idempotent; TrainStep.close() / __del__ call it)"""
         if self._comm is not None:
+            comm, self._comm = self._comm, None
             torch.cuda.synchronize(self.flat_g.device)
-            hipabi.check(hipabi.lib().straps_comm_destroy(self._comm), 'straps_comm_destroy')
-            self._comm = None
+            hipabi.check(hipabi.lib().straps_comm_destroy(comm), 'straps_comm_destroy')
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown: the library or the device may already be gone
+            pass
 
     def _rccl_allreduce(self, lo, hi):
         """sum all-reduce of flat_g[lo:hi] on the exchange stream, ordered after everything the current stream holds so far"""
@@ -218,6 +237,7 @@ class TrainStep:
                 split_off = off
                 break
             off += p_.numel()
+        self.tail_offset = split_off            # first element of the tail bucket (layer3 on), whether or not the exchange is split there
         self.exchange = GradientExchange(self.flat_g, split_off if self.comm_overlap else 0, world_size, group, force=self._force_exchange,
                                          backend=self._exchange_backend, rank=rank)
         self.time_exchange, self.exchange_events = False, []
@@ -626,9 +646,9 @@ class TrainStep:
         Nothing executes during capture.  Any failure falls back to eager launches of the same kernels."""
         torch.cuda.synchronize()
         self._pool = None
+        start, last0, by_parity0 = self._cur, self.last, dict(self._last_by_parity)      # (restored if a capture throws, ADVICE round 4)
         try:
             graphs = {}
-            start = self._cur
             for par in ((start, 1 - start) if self.pipeline else (0,)):
                 self._cur = par
                 # every captured step must re-pack the weights itself: drop what the previous capture left in the caches
@@ -654,7 +674,25 @@ class TrainStep:
             import warnings
             warnings.warn('hipGraph capture of the training step failed (%s); continuing with eager launches' % (why,))
             self.use_graph, self.graph, self.graph_tail = False, None, None
+            # nothing executed during capture: the batch in flight is still the one in self._bufs[start] and no draw was consumed on the device
+            # (the generator's step counter lives there), but the Python side ran: put the buffer parity, the output record and the weight caches
+            # back so that the eager step that follows trains on the batch it would have trained on, on every rank alike
+            self._cur, self.last, self._last_by_parity = start, last0, by_parity0
+            self.reg.image_encoder._cache.clear()
+            self.reg.ief_module._cache = {}
             torch.cuda.synchronize()
+
+    def close(self):
+        """release what the step holds outside torch's allocator: the C-ABI communicator of exchange_backend='rccl' (idempotent)."""
+        ex = getattr(self, 'exchange', None)
+        if ex is not None:
+            ex.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
 
     def state_dict(self):
         """optimiser state in torch.optim.Adam's schema (checkpoint key 'optimiser_state_dict')."""

@@ -390,7 +390,14 @@ def _pack_relu_bits(y):
 
 @pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg', [
     (4, 64, 64, 16, 16, 3, 1, 0), (3, 128, 64, 12, 20, 1, 1, 1), (2, 256, 64, 16, 16, 1, 1, 0), (2, 64, 128, 16, 16, 1, 2, 0), (2, 128, 256, 9, 14, 3, 2, 1),
-    (4, 128, 64, 32, 32, 3, 1, 512), (2, 512, 128, 8, 8, 1, 1, 3), (1, 2048, 512, 8, 8, 1, 1, 0)])
+    (4, 128, 64, 32, 32, 3, 1, 512), (2, 512, 128, 8, 8, 1, 1, 3), (1, 2048, 512, 8, 8, 1, 1, 0),
+    # round 5: the bit forms (and every data gradient with an addend) run the LOOK-AHEAD epilogue of csrc/conv_igemm.h, the fp32-mask form of the
+    # fused sums still runs the row-by-row epilogue of rounds 1-4 -- this test is their bit-for-bit comparison, so every tile configuration the
+    # rule can choose is listed: 256x128 and 128x128 eight-wave tiles (two of four / two units in flight), four-wave 128x128 (four units), 128x64
+    # pipelined and plain, 64x64, both halo-patch kernels, ragged last tiles (row-by-row inside a look-ahead launch), stride-2 parity classes
+    (5, 128, 128, 24, 24, 3, 1, 12), (4, 128, 128, 16, 16, 3, 1, 12), (3, 128, 128, 8, 8, 3, 1, 5), (5, 128, 128, 24, 24, 3, 1, 9), (5, 64, 64, 7, 7, 3, 1, 11),
+    (4, 64, 64, 16, 16, 3, 1, 11), (2, 64, 64, 16, 16, 3, 1, 7), (4, 64, 64, 8, 8, 3, 1, 1024), (2, 128, 64, 16, 16, 3, 2, 12), (2, 256, 256, 16, 16, 3, 1, 512),
+    (2, 128, 128, 16, 16, 3, 1, 4), (3, 128, 192, 12, 12, 1, 1, 8), (2, 64, 128, 32, 32, 3, 2, 0)])
 def test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit(dev, B, Cin, Cout, H, W, k, stride, cfg):
     """ABI 8: a residual unit's ReLU decisions as bits.  straps_bn_apply_bits_x3 writes y / planes as straps_bn_apply_x3 and the words
     bit (c & 31) of [row][c / 32] = (y > 0); every *_bits backward form -- data gradient with a masked addend (plain and with the fused
