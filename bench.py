@@ -375,6 +375,13 @@ def main():
     ap.add_argument('--global-masked-mean', action='store_true',
                     help='train workload, N > 1: the joints2D task as the masked mean over the GLOBAL batch (one extra 1-float all-reduce per step, '
                          'issued a step ahead); default = the average of per-rank masked means')
+    ap.add_argument('--force-exchange', action='store_true',
+                    help='train workload: run the gradient exchange even at --gpus 1 (an all-reduce over one rank is the identity, but every call is a real '
+                         'RCCL call between the two split hipGraphs): the exact code path of a multi-GPU run, with ranks.exposed_exchange_ms_* and '
+                         'ranks.replicas_in_sync on the bench line')
+    ap.add_argument('--exchange-backend', default='torch', choices=['torch', 'rccl'],
+                    help="gradient exchange through torch.distributed ('torch': the nccl backend == RCCL) or through the library's own C ABI "
+                         "('rccl': straps_comm_* / straps_allreduce_grads on a dedicated stream)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
@@ -421,9 +428,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_exchange and args.exchange_backend == 'torch'):
+        # (--force-exchange at one rank: torch's nccl backend needs a process group of one; the C-ABI backend needs none)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', str(29400 + os.getpid() % 500))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         backend = os.environ.get('STRAPS_DIST_BACKEND', 'nccl')  # nccl == RCCL on ROCm
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
@@ -461,7 +473,7 @@ def main():
             ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
             init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}).to(dev)
         ts = TrainStep(reg, smpl, crit, B, lr=1e-4, rank=rank, world_size=world, seed=1234, mean_shape=mp['shape'], use_graph=not args.no_graph, overlap_wgrad=args.overlap_wgrad and not args.no_overlap,
-                       global_masked_mean=args.global_masked_mean)
+                       global_masked_mean=args.global_masked_mean, force_exchange=args.force_exchange, exchange_backend=args.exchange_backend)
         step = ts.step
         workload = '%s: full synthetic OTF training step (augmentation + proxy construction + forward + multi-task loss ' \
                    '+ backward + Adam), %s, 18x256x256 proxy' % ('configs[3] per-GPU shape' if args.layers == 50 else 'configs[2]', net)
@@ -597,10 +609,11 @@ def main():
         reduced = {'fp16x3_lbs_p16': {'value': round(B * args.steps / dt2, 1), 'unit': 'bodies/s (this rank)', 'ms_per_step': round(dt2 / args.steps * 1e3, 4),
                                       'launch_mode': 'eager', 'note': 'pose-corrective blend as ONE plain-fp16 product per term: reduced precision, opt-in'}}
     rank_ms = None
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if dist is not None or (args.workload == 'train' and args.force_exchange):
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         # per-rank view: each rank's own time to finish its K steps (before the closing barrier) and the part of the gradient
         # exchange its backward did not hide
         # (+ a digest of this replica's parameters after the timed steps: data parallelism keeps the replicas bit-identical, and a corrupted
@@ -611,7 +624,10 @@ def main():
         mine = torch.tensor([local_elapsed / args.steps * 1e3, -1.0 if exposed_exchange_ms is None else exposed_exchange_ms,
                              -1.0 if sclk_mhz is None else sclk_mhz] + dig, device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+        if dist is not None:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]                  # (--force-exchange --exchange-backend rccl at one rank: no torch process group exists)
         tab = torch.stack(allr).cpu()
         rank_ms = {'ms_per_step_min': round(float(tab[:, 0].min()), 4), 'ms_per_step_max': round(float(tab[:, 0].max()), 4),
                    'per_rank_ms_per_step': [round(float(v), 4) for v in tab[:, 0]]}
@@ -625,6 +641,10 @@ def main():
             rank_ms['replicas_in_sync'] = bool((tab[:, 3] == tab[0, 3]).all() and (tab[:, 4] == tab[0, 4]).all())
             rank_ms['parameters_finite'] = bool((tab[:, 5] == 1.0).all())
             rank_ms['replicas_note'] = 'parameter digests (sum, sum of magnitudes, in float64) of every rank after the timed steps, compared bit for bit'
+            rank_ms['exchange'] = {'backend': args.exchange_backend + (' (torch.distributed nccl == RCCL)' if args.exchange_backend == 'torch' else ' (C ABI: straps_allreduce_grads)'),
+                                   'forced_at_one_rank': bool(args.force_exchange and world == 1), 'two_buckets': bool(ts.comm_overlap),
+                                   'split_graphs': ts.graph_tail is not None, 'tail_bucket_floats': int(ts.flat_g.numel() - ts.exchange.split_off),
+                                   'head_bucket_floats': int(ts.exchange.split_off)}
 
     out = None
     if rank == 0:
@@ -743,6 +763,8 @@ def main():
                                          "CPU baseline); 'value' above is configs[2] alone")
         print(json.dumps(out))
     probe.close()
+    if args.workload == 'train':
+        ts.close()                         # (the C-ABI communicator of --exchange-backend rccl)
     if dist is not None:
         dist.destroy_process_group()
     return out

@@ -38,6 +38,8 @@ def build(force=False, verbose=False, tools=False):
     neither; tools select the other library explicitly with `use_library(TOOLS_LIB_PATH)` (tools/with_tools_lib.py)."""
     srcs = _existing_sources()
     lib_path = TOOLS_LIB_PATH if tools else LIB_PATH
+    if tools and not force and os.environ.get('STRAPS_TOOLS_NO_BUILD') == '1' and os.path.isfile(lib_path):
+        return lib_path      # (GPU-box runs of the tools: use the library that travelled with the snapshot, whatever the copy did to the time stamps)
     # every header under csrc/ (common.h, conv_igemm.h, ...) and the public header: a change in any of them rebuilds every object --
     # translation units that share a struct (ConvP) can never be linked from different versions of it
     import glob

@@ -230,8 +230,9 @@ class SMPL(nn.Module):
         largest fp16 value (finite, clipped meshes; csrc/smpl.hip sat_h) rather than turning the body into NaNs.  'fp32' has
         no such range.
         kernel (the 'fp16x3_lbs*' modes only): 'auto' = by batch size (64-body workgroups with one 512-register wave per SIMD from 2048
-        bodies on, 32-body workgroups below), 'wide' / 'narrow' force one of the two (A/B and tests; same arithmetic class, results
-        differ in the last bits: the wide kernel adds the three skinning products in one K-packed accumulation chain)."""
+        bodies on, 32-body workgroups below), 'wide' / 'narrow' force one of the two (A/B and tests).  The two kernels are
+        BIT-IDENTICAL -- the same accumulation chain per output value, so the automatic switch at 2048 bodies changes no result
+        (tests/test_gpu_forward.py::test_smpl_wide_kernel_vs_oracle_and_narrow asserts torch.equal at every batch size)."""
         if kernel not in KERNELS:
             raise ValueError("SMPL.forward_arrays: kernel must be one of %s" % (sorted(KERNELS),))
         hipabi.require_gpu_tensor(betas, 'betas', torch.float32)

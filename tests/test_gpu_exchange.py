@@ -101,3 +101,29 @@ def test_train_step_with_the_exchange_forced_on_rccl_world_one():
         assert r['losses'] == ref['losses'], name                               # 12 steps, bit for bit
         assert r['params'] == ref['params'] and r['m'] == ref['m'], name        # (sha256 of the flat parameter / first-moment buffers)
         assert len(r['exposed']) == 12 and all(t >= 0.0 for t in r['exposed']), name      # what bench.py reports as exposed_exchange_ms
+
+
+@pytest.mark.parametrize('backend', ['torch', 'rccl'])
+def test_bench_line_with_the_exchange_forced_at_one_rank(backend):
+    """`python bench.py --gpus 1 --force-exchange --exchange-backend torch|rccl`: the code path of the first multi-GPU run
+    -- split hipGraphs, tail bucket on RCCL under the rest of backward, head bucket, Adam -- driver-visible on a one-GPU box: the bench line carries
+    ranks.exposed_exchange_ms_*, ranks.replicas_in_sync and which backend ran."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '3', '--force-exchange', '--exchange-backend', backend,
+           '--no-cpu-baseline', '--no-other-configs', '--no-measure-traffic', '--no-stem-ab']
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['metric'] == 'bodies/sec'
+    r = d['ranks']
+    assert r['exchange']['forced_at_one_rank'] is True and r['exchange']['two_buckets'] is True and r['exchange']['split_graphs'] is True
+    assert r['exchange']['backend'].startswith(backend)
+    assert r['exchange']['tail_bucket_floats'] > r['exchange']['head_bucket_floats'] > 0
+    assert 0 <= r['exposed_exchange_ms_mean'] <= r['exposed_exchange_ms_max'] < d['ms_per_step']
+    assert r['replicas_in_sync'] is True and r['parameters_finite'] is True

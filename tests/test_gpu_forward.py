@@ -128,6 +128,51 @@ def test_smpl_pd16_mode_vs_oracle(dev, smpl_model, B, mode):
         assert torch.equal(vs, v[30:37]) and torch.equal(js, j[30:37])
 
 
+def _real_magnitude_model(model):
+    """the synthetic SMPL model with its blend directions scaled to the real model's magnitudes (missing #3): the synthetic
+    posedirs are uniform +-1e-3 where SMPL_NEUTRAL's largest entries are one to two orders larger, and the shape directions about three times
+    smaller than the real ones -- every 'm from float64' figure of the split-precision modes above is a statement about the SMALL directions."""
+    big = dict(model)
+    big['posedirs'] = (np.asarray(model['posedirs'], dtype=np.float64) * 50.0).astype(np.float32)
+    big['shapedirs'] = (np.asarray(model['shapedirs'], dtype=np.float64) * 3.0).astype(np.float32)
+    return big
+
+
+# mode -> bar in metres at the real model's magnitudes: the defaults keep the 2e-5 of every SMPL test here, the opt-in throughput modes are held
+# to north_star's 1e-4 (BASELINE.json) -- measured values in DESIGN section 4
+_REAL_MAGNITUDE_BARS = {'fp32': 2e-5, 'fp16x3': 2e-5, 'fp16x3_lbs': 2e-5, 'fp16x3_lbs_pd16': 1e-4, 'fp16x3_lbs_p16': 1e-4}
+
+
+@pytest.mark.parametrize('kernel', ['narrow', 'wide'])
+@pytest.mark.parametrize('mode', ['fp32', 'fp16x3', 'fp16x3_lbs', 'fp16x3_lbs_pd16', 'fp16x3_lbs_p16'])
+def test_smpl_precision_modes_at_real_model_magnitudes(dev, smpl_model, mode, kernel):
+    """every SMPL precision mode against the float64 oracle on a model whose pose-corrective directions are 50x and whose shape directions are
+    3x the synthetic model's (the real model's scale), with an extreme body (|beta| up to 10) and a body whose joint rotations reach pi --
+    the only check that stands in for models/smpl_official.py:27-41 on real data while the licensed model file is absent."""
+    if mode in ('fp32', 'fp16x3') and kernel == 'wide':
+        pytest.skip('the 64-body kernel exists for the fp16x3_lbs* modes only')
+    big = _real_magnitude_model(smpl_model)
+    B = 70
+    smpl = straps_amd.SMPL(big, batch_size=B).to(dev)
+    betas = torch.from_numpy(det_uniform((B, 10), 100 + B, -2.5, 2.5))
+    betas[0] = torch.tensor([10.0, -8.0, 6.0, 4.0, -4.0, 3.0, 3.0, -3.0, 2.0, 2.0])
+    aa = torch.from_numpy(det_uniform((B, 72), 200 + B, -0.9, 0.9))
+    aa[-1] = torch.from_numpy(det_uniform((72,), 7, -3.0, 3.0))                             # rotations up to pi per axis component
+    aa[-2] = torch.from_numpy(det_uniform((72,), 8, -1.8, 1.8))
+    R = O.batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+    kw = {} if mode in ('fp32', 'fp16x3') else {'kernel': kernel}
+    v, j = smpl.forward_arrays(betas.to(dev), R.to(dev), precision=mode, **kw)
+    v64, j64 = O.smpl_forward(big, betas.double(), rotmats=R.double(), dtype=torch.float64)
+    ev, ej = float((v.cpu().double() - v64).abs().max()), float((j.cpu().double() - j64).abs().max())
+    span = float((v64 - O.smpl_forward(smpl_model, betas.double(), rotmats=R.double(), dtype=torch.float64)[0]).abs().max())
+    print('SMPL at real magnitudes, %s / %s kernel: max |err| vs float64 verts %.2e joints %.2e (the scaled directions move vertices by up to %.2f m)'
+          % (mode, kernel, ev, ej, span))
+    assert span > 0.05                                   # the scaled directions do matter
+    bar = _REAL_MAGNITUDE_BARS[mode]
+    assert ev < bar and ej < bar, 'mode %s: %.2e / %.2e m from float64 at the real model\'s magnitudes (bar %.0e)' % (mode, ev, ej, bar)
+    assert torch.isfinite(v).all() and torch.isfinite(j).all()
+
+
 @pytest.mark.parametrize('mode', ['fp16x3', 'fp16x3_lbs', 'fp16x3_lbs_p16'])
 def test_smpl_split_modes_saturate_out_of_range_operands(dev, smpl_model, mode):
     """a diverging regressor can predict betas in the thousands: the split kernels' fp16 operands then SATURATE (finite output for that

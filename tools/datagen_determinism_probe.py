@@ -9,6 +9,11 @@ counts, on the device, the elements that differ from the first result of that st
 
     PROBE_LOAD = 1 (large torch.mm on a second stream) | 0 | train (a replayed training-step graph on the main stream; PROBE_LAYERS) |
                  raster | smpl | conv | fill (one library kernel, captured and replayed on the main stream)
+    PROBE_CONV_KIND (with PROBE_LOAD = conv; round 5: WHICH convolution kernel family disturbs the victim?) =
+                 x3 (default: bf16x3 im2col kernel, automatic tile = 256x128 pipelined) | x3:<tile_cfg> (an explicit tile / loop form) |
+                 halo (bf16x3 halo-patch kernel) | wgrad3 (bf16x3 3x3 weight gradient: ds_read_b64_tr_b16 gathers) |
+                 fp32 (exact-fp32 kernel, LDS-DMA staging) | fp32reg (the same kernel, register-staged: NO LDS-DMA) |
+                 abl1 / abl2 / abl3 (tools build only: the x3 kernel with operand copies only / without operand copies / MFMAs + barriers alone)
     PROBE_RASTER_PARTS = 1: only the rasteriser, through the C ABI, with its z-buffer keys and projected vertices compared as well
     PROBE_GRAPH = 1: the stages as one replayed hipGraph instead of eager launches
     PROBE_TOOLS = 1: against the tools build (STRAPS_TOOLS_RASTER_FLAGS=-DSTRAPS_RASTER_LDS_TABLE at its build time = the rasteriser of rounds 2-4)
@@ -114,13 +119,21 @@ if other in ('raster', 'smpl', 'conv', 'fill'):
     big = torch.empty(1 << 28, device=dev)
     if other == 'conv':
         from straps_amd.encoder_exec import split3, weight_planes
+        kind = os.environ.get('PROBE_CONV_KIND', 'x3')
+        ccfg = {'x3': 0, 'halo': 512, 'abl1': 64, 'abl2': 128, 'abl3': 192, 'fp32': 0, 'fp32reg': 16, 'wgrad3': 0}.get(kind)
+        if ccfg is None:
+            ccfg = int(kind.split(':')[1])
         xx = torch.randn(32, 32, 32, 256, device=dev)
         ww = torch.randn(256, 256, 3, 3, device=dev) * 0.02
         x3, xps = split3(L, xx)
         w3, wps = weight_planes(L, ww)
         yy = torch.empty(32, 32, 32, 256, device=dev)
-        nblk = L.straps_conv_x3_stat_blocks(32, 32, 32, 256, 256, 3, 3, 1, 1, 0)
+        nblk = L.straps_conv_x3_stat_blocks(32, 32, 32, 256, 256, 3, 3, 1, 1, ccfg & ~(64 | 128))
         part = torch.empty(max(nblk, 1) * 256 * 2, device=dev)
+        wk = torch.randn(256, 3, 3, 256, device=dev) * 0.02                       # [cout][r][s][cin]: the fp32 kernel's packed weights
+        dwo = torch.empty(256, 256, 3, 3, device=dev)
+        wgws = torch.empty(max(L.straps_conv_wgrad_workspace_bytes(32, 32, 32, 256, 256, 3, 3, 1, 1), 16) // 4, device=dev)
+        load_name = 'conv[%s]' % kind
 
     def load_body():
         if other == 'raster':
@@ -131,16 +144,24 @@ if other in ('raster', 'smpl', 'conv', 'fill'):
                 smpl.forward_arrays(betas, R)
         elif other == 'fill':
             big.fill_(1.0)
+        elif kind == 'wgrad3':
+            for _ in range(6):
+                hipabi.check(L.straps_conv_wgrad_x3(None, None, hipabi.ptr(x3), xps, hipabi.ptr(x3), xps, hipabi.ptr(dwo), hipabi.ptr(wgws), 32, 32, 32, 256, 256, 3, 3, 1, 1, 0,
+                                                    hipabi.stream_ptr()), 'wgrad3')
+        elif kind in ('fp32', 'fp32reg'):
+            for _ in range(4):
+                hipabi.check(L.straps_conv_fwd(hipabi.ptr(xx), hipabi.ptr(wk), None, None, None, 0, hipabi.ptr(yy), None, 32, 32, 32, 256, 256, 3, 3, 1, 1, ccfg,
+                                               hipabi.stream_ptr()), 'conv_fp32')
         else:
             for _ in range(8):
-                hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(yy), hipabi.ptr(part), 32, 32, 32, 256, 256, 3, 3, 1, 1, 0,
+                hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(yy), hipabi.ptr(part), 32, 32, 32, 256, 256, 3, 3, 1, 1, ccfg,
                                                   hipabi.stream_ptr()), 'conv')
     load_body()
     torch.cuda.synchronize()
     lgraph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(lgraph):
         load_body()
-    load = other
+    load = load_name if other == 'conv' else other
 for i in range(iters):
     if lgraph is not None:
         lgraph.replay()
