@@ -298,6 +298,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     if (q < nchunks) chunk(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
     }
 
+    // (a class without taps -- the dead parity classes of a 1x1 / stride-2 data gradient: dx = addend there -- never reaches a last chunk)
+    if (nchunks <= 0) ep.prefetch();
     float s1[NI], s2[NI];
     double bd1[NI], bd2[NI];
     ep.finish(p, c, acc, s1, s2, bd1, bd2);
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     }
     if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
 
+    if (nsteps <= 0) ep.prefetch();
     float s1[NI], s2[NI];
     double bd1[NI], bd2[NI];
     ep.finish(p, c, acc, s1, s2, bd1, bd2);

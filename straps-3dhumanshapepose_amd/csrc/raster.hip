@@ -218,7 +218,10 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     // lanes per face: a face of the 13 776-face mesh at 256 x 256 covers one or two samples and its box four to nine
     static const int lanes = STRAPS_TOOL_ENV_INT("STRAPS_RASTER_LANES", 16);      // (A/B switch of the tools build)
 #if defined(STRAPS_RASTER_LDS_TABLE) || defined(STRAPS_RASTER_WRITE_TABLE) || defined(STRAPS_RASTER_DUMMY_LDS)
-#define STRAPS_RASTER_LDS_BYTES ((size_t)wh * sizeof(float))
+    // (round 5 reproducer switch: STRAPS_RASTER_LDS_EXTRA bytes of LDS the kernel never touches -- with 20 KB a workgroup no longer fits beside a
+    //  convolution workgroup that holds 140-147 KB of a CU's 160 KB: co-residency on one CU switched off without touching the code)
+    static const int lds_extra = STRAPS_TOOL_ENV_INT("STRAPS_RASTER_LDS_EXTRA", 0);
+#define STRAPS_RASTER_LDS_BYTES ((size_t)wh * sizeof(float) + (size_t)lds_extra)
 #else
 #define STRAPS_RASTER_LDS_BYTES 0
 #endif
@@ -236,6 +239,29 @@ extern "C" int straps_rasterize_parts(const float* verts, const int32_t* faces, 
     STRAPS_CHECK_LAUNCH("raster_resolve_kernel");
     return STRAPS_OK;
 }
+
+#ifdef STRAPS_TOOLS
+// tools build only (round 5, tools/datagen_determinism_probe.py PROBE_LOAD=occupy): workgroups that HOLD `lds_bytes` of LDS and sleep for about
+// `microseconds` -- no LDS traffic, no matrix work, no memory traffic.  Beside them a small-LDS kernel is placed on the same CU, its allocation
+// above theirs: does the victim of DESIGN section 1 need the convolution kernels' traffic, or only their LDS footprint?
+namespace {
+__global__ __launch_bounds__(256) void lds_occupier_kernel(int microseconds, unsigned* sink) {
+    extern __shared__ unsigned occ[];
+    if (threadIdx.x == 0) occ[0] = blockIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz constant-rate counter
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)microseconds * 100ull) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0 && occ[0] == 0xffffffffu) sink[0] = 1;          // (never true: keeps the LDS store alive)
+}
+}  // namespace
+extern "C" int straps_tool_lds_occupier(size_t lds_bytes, int microseconds, int blocks, unsigned* sink, void* stream) {
+    STRAPS_REQUIRE(lds_bytes >= 4 && lds_bytes <= 160 * 1024 && blocks > 0 && sink, "straps_tool_lds_occupier: bad arguments");
+    STRAPS_RAISE_LDS(lds_occupier_kernel, 160 * 1024, "lds_occupier_kernel");
+    hipLaunchKernelGGL(lds_occupier_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, microseconds, sink);
+    STRAPS_CHECK_LAUNCH("lds_occupier_kernel");
+    return STRAPS_OK;
+}
+#endif
 
 #ifdef STRAPS_RASTER_CHECK_LOADS
 // reproducer builds only (-DSTRAPS_RASTER_CHECK_LOADS): copies out and clears what raster_face_kernel reported

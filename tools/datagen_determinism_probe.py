@@ -14,6 +14,10 @@ counts, on the device, the elements that differ from the first result of that st
                  halo (bf16x3 halo-patch kernel) | wgrad3 (bf16x3 3x3 weight gradient: ds_read_b64_tr_b16 gathers) |
                  fp32 (exact-fp32 kernel, LDS-DMA staging) | fp32reg (the same kernel, register-staged: NO LDS-DMA) |
                  abl1 / abl2 / abl3 (tools build only: the x3 kernel with operand copies only / without operand copies / MFMAs + barriers alone)
+    PROBE_LOAD = occupy (tools build only): workgroups that merely HOLD PROBE_OCCUPY_KB (default 147) KB of LDS each and sleep -- no LDS-DMA,
+                 no MFMA, no memory traffic: is the aggressors' LDS FOOTPRINT (the victim's allocation then sits above it on the same CU) enough?
+    STRAPS_RASTER_LDS_EXTRA = bytes (tools build, read by the library): the victim asks for that much more LDS than it uses (20480: it no longer
+                 fits beside a 140-147 KB convolution workgroup, i.e. co-residency on one CU is switched off)
     PROBE_RASTER_PARTS = 1: only the rasteriser, through the C ABI, with its z-buffer keys and projected vertices compared as well
     PROBE_GRAPH = 1: the stages as one replayed hipGraph instead of eager launches
     PROBE_TOOLS = 1: against the tools build (STRAPS_TOOLS_RASTER_FLAGS=-DSTRAPS_RASTER_LDS_TABLE at its build time = the rasteriser of rounds 2-4)
@@ -112,7 +116,7 @@ worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.envi
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
 other = os.environ.get('PROBE_LOAD', '1')
 lgraph = None
-if other in ('raster', 'smpl', 'conv', 'fill'):
+if other in ('raster', 'smpl', 'conv', 'fill', 'occupy'):
     rend2 = NMRRenderer(8, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(dev)
     v2, _ = smpl.forward_arrays(torch.randn(8, 10, generator=g).to(dev), straps_amd.batch_rodrigues((torch.randn(8, 72, generator=g) * 0.4).to(dev).view(-1, 3)).view(8, 24, 3, 3).contiguous())
     ct2 = torch.tensor([0., 0.2, 42.], device=dev).expand(8, 3).contiguous()
@@ -121,8 +125,8 @@ if other in ('raster', 'smpl', 'conv', 'fill'):
         from straps_amd.encoder_exec import split3, weight_planes
         kind = os.environ.get('PROBE_CONV_KIND', 'x3')
         ccfg = {'x3': 0, 'halo': 512, 'abl1': 64, 'abl2': 128, 'abl3': 192, 'fp32': 0, 'fp32reg': 16, 'wgrad3': 0}.get(kind)
-        if ccfg is None:
-            ccfg = int(kind.split(':')[1])
+        if ccfg is None:                       # 'x3:<tile_cfg>' / 'fp32:<tile_cfg>'
+            kind, ccfg = kind.split(':')[0], int(kind.split(':')[1])
         xx = torch.randn(32, 32, 32, 256, device=dev)
         ww = torch.randn(256, 256, 3, 3, device=dev) * 0.02
         x3, xps = split3(L, xx)
@@ -133,10 +137,20 @@ if other in ('raster', 'smpl', 'conv', 'fill'):
         wk = torch.randn(256, 3, 3, 256, device=dev) * 0.02                       # [cout][r][s][cin]: the fp32 kernel's packed weights
         dwo = torch.empty(256, 256, 3, 3, device=dev)
         wgws = torch.empty(max(L.straps_conv_wgrad_workspace_bytes(32, 32, 32, 256, 256, 3, 3, 1, 1), 16) // 4, device=dev)
-        load_name = 'conv[%s]' % kind
+        load_name = 'conv[%s]' % os.environ.get('PROBE_CONV_KIND', 'x3')
+
+    if other == 'occupy':
+        import ctypes
+        tl = ctypes.CDLL(hipabi.TOOLS_LIB_PATH)
+        tl.straps_tool_lds_occupier.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        occ_sink = torch.zeros(4, device=dev, dtype=torch.int32)
+        occ_kb = int(os.environ.get('PROBE_OCCUPY_KB', '147'))
 
     def load_body():
-        if other == 'raster':
+        if other == 'occupy':
+            rc = tl.straps_tool_lds_occupier(occ_kb * 1024, 800, 256, occ_sink.data_ptr(), hipabi.stream_ptr())
+            assert rc == 0, L.straps_last_error()
+        elif other == 'raster':
             for _ in range(4):
                 rend2.render_arrays(v2, ct2)
         elif other == 'smpl':
@@ -161,7 +175,7 @@ if other in ('raster', 'smpl', 'conv', 'fill'):
     lgraph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(lgraph):
         load_body()
-    load = load_name if other == 'conv' else other
+    load = load_name if other == 'conv' else ('occupy[%d KB]' % occ_kb if other == 'occupy' else other)
 for i in range(iters):
     if lgraph is not None:
         lgraph.replay()
