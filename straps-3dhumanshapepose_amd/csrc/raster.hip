@@ -254,6 +254,74 @@ __global__ __launch_bounds__(256) void lds_occupier_kernel(int microseconds, uns
     if (threadIdx.x == 0 && occ[0] == 0xffffffffu) sink[0] = 1;          // (never true: keeps the LDS store alive)
 }
 }  // namespace
+// ... and workgroups that do nothing but the convolution kernels' operand-fragment reads: LDS filled once, then ds_read_b128 of 64-byte swizzled rows
+// (csrc/conv_x3.hip's addressing) feeding v_mfma_f32_32x32x16_bf16 (mfma != 0) or a checksum, one barrier per "chunk"; no memory traffic
+namespace {
+typedef __bf16 tool_bf16x8 __attribute__((ext_vector_type(8)));
+template <int MFMA>
+__global__ __launch_bounds__(256) void lds_frag_reader_kernel(unsigned* __restrict__ sink, int trips) {
+    extern __shared__ __attribute__((aligned(16))) unsigned fr_lds[];      // 147 KB = 3 stages x 3 planes x (128 + 128) rows x 64 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 147 * 256; i += 256) fr_lds[i] = 0x3f803f80u ^ (unsigned)(i * 2654435761u >> 20);
+    __syncthreads();
+    const unsigned short* As = reinterpret_cast<const unsigned short*>(fr_lds);
+    const int wm = wave >> 1, wn = wave & 1;
+    int fo[2];
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ (((lane & 31) >> 3) & 3)) << 3);
+    f32x16 c[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
+    unsigned acc = 0;
+    int stage = 0;
+    for (int t = 0; t < trips; ++t) {
+        const unsigned short* Ab = As + (stage * 3 * 256 + wm * 64) * 32;
+        const unsigned short* Bb = As + (stage * 3 * 256 + 128 + wn * 64) * 32;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            tool_bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i][pl] = *reinterpret_cast<const tool_bf16x8*>(Ab + (pl * 256 + i * 32) * 32 + fo[kk]);
+                    b[i][pl] = *reinterpret_cast<const tool_bf16x8*>(Bb + (pl * 256 + i * 32) * 32 + fo[kk]);
+                }
+            if (MFMA) {
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[j][TB[q]], c[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const uint4 ua = *reinterpret_cast<const uint4*>(&a[i][pl]), ub = *reinterpret_cast<const uint4*>(&b[i][pl]);
+                        acc += (ua.x ^ ua.y ^ ua.z ^ ua.w) + (ub.x ^ ub.y ^ ub.z ^ ub.w);
+                    }
+            }
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+        __builtin_amdgcn_s_barrier();
+    }
+    if (MFMA) acc += (unsigned)(c[0][0][0] + c[0][1][5] + c[1][0][15] + c[1][1][7] == 12345.678f);
+    if (acc == 0x12345678u) sink[blockIdx.x] = acc;
+}
+}  // namespace
+extern "C" int straps_tool_lds_frag_reader(int mfma, int trips, int blocks, unsigned* sink, void* stream) {
+    STRAPS_REQUIRE(trips > 0 && blocks > 0 && sink, "straps_tool_lds_frag_reader: bad arguments");
+    if (mfma) {
+        STRAPS_RAISE_LDS(lds_frag_reader_kernel<1>, 147 * 1024, "lds_frag_reader_kernel");
+        hipLaunchKernelGGL(lds_frag_reader_kernel<1>, dim3(blocks), dim3(256), 147 * 1024, (hipStream_t)stream, sink, trips);
+    } else {
+        STRAPS_RAISE_LDS(lds_frag_reader_kernel<0>, 147 * 1024, "lds_frag_reader_kernel");
+        hipLaunchKernelGGL(lds_frag_reader_kernel<0>, dim3(blocks), dim3(256), 147 * 1024, (hipStream_t)stream, sink, trips);
+    }
+    STRAPS_CHECK_LAUNCH("lds_frag_reader_kernel");
+    return STRAPS_OK;
+}
 extern "C" int straps_tool_lds_occupier(size_t lds_bytes, int microseconds, int blocks, unsigned* sink, void* stream) {
     STRAPS_REQUIRE(lds_bytes >= 4 && lds_bytes <= 160 * 1024 && blocks > 0 && sink, "straps_tool_lds_occupier: bad arguments");
     STRAPS_RAISE_LDS(lds_occupier_kernel, 160 * 1024, "lds_occupier_kernel");

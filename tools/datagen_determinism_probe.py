@@ -14,6 +14,8 @@ counts, on the device, the elements that differ from the first result of that st
                  halo (bf16x3 halo-patch kernel) | wgrad3 (bf16x3 3x3 weight gradient: ds_read_b64_tr_b16 gathers) |
                  fp32 (exact-fp32 kernel, LDS-DMA staging) | fp32reg (the same kernel, register-staged: NO LDS-DMA) |
                  abl1 / abl2 / abl3 (tools build only: the x3 kernel with operand copies only / without operand copies / MFMAs + barriers alone)
+    PROBE_LOAD = frag | fragsum (tools build only): workgroups that do nothing but the convolution kernels' operand-fragment reads out of LDS
+                 (ds_read_b128, swizzled 64-byte rows), feeding bf16 MFMAs (frag) or a checksum (fragsum)
     PROBE_LOAD = occupy (tools build only): workgroups that merely HOLD PROBE_OCCUPY_KB (default 147) KB of LDS each and sleep -- no LDS-DMA,
                  no MFMA, no memory traffic: is the aggressors' LDS FOOTPRINT (the victim's allocation then sits above it on the same CU) enough?
     STRAPS_RASTER_LDS_EXTRA = bytes (tools build, read by the library): the victim asks for that much more LDS than it uses (20480: it no longer
@@ -116,7 +118,7 @@ worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.envi
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
 other = os.environ.get('PROBE_LOAD', '1')
 lgraph = None
-if other in ('raster', 'smpl', 'conv', 'fill', 'occupy'):
+if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum'):
     rend2 = NMRRenderer(8, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(dev)
     v2, _ = smpl.forward_arrays(torch.randn(8, 10, generator=g).to(dev), straps_amd.batch_rodrigues((torch.randn(8, 72, generator=g) * 0.4).to(dev).view(-1, 3)).view(8, 24, 3, 3).contiguous())
     ct2 = torch.tensor([0., 0.2, 42.], device=dev).expand(8, 3).contiguous()
@@ -146,9 +148,23 @@ if other in ('raster', 'smpl', 'conv', 'fill', 'occupy'):
         occ_sink = torch.zeros(4, device=dev, dtype=torch.int32)
         occ_kb = int(os.environ.get('PROBE_OCCUPY_KB', '147'))
 
+    if other in ('frag', 'fragsum'):
+        import ctypes
+        tl = ctypes.CDLL(hipabi.TOOLS_LIB_PATH)
+        tl.straps_tool_lds_frag_reader.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        occ_sink = torch.zeros(4096, device=dev, dtype=torch.int32)
+
     def load_body():
-        if other == 'occupy':
-            rc = tl.straps_tool_lds_occupier(occ_kb * 1024, 800, 256, occ_sink.data_ptr(), hipabi.stream_ptr())
+        if other in ('frag', 'fragsum'):
+            # (the convolution kernels' fragment reads alone, tools build: one 147 KB workgroup per CU, ~0.3 ms per launch)
+            # PROBE_FRAG_TRIPS / PROBE_FRAG_BLOCKS: chunks per workgroup and workgroups per launch (400 x 256: one long-lived workgroup per CU;
+            # 12 x 4096: short-lived ones, sixteen generations per CU and launch -- the convolution kernels' churn of LDS allocations)
+            for _ in range(3):
+                rc = tl.straps_tool_lds_frag_reader(1 if other == 'frag' else 0, int(os.environ.get('PROBE_FRAG_TRIPS', '400')), int(os.environ.get('PROBE_FRAG_BLOCKS', '256')),
+                                                    occ_sink.data_ptr(), hipabi.stream_ptr())
+                assert rc == 0, L.straps_last_error()
+        elif other == 'occupy':
+            rc = tl.straps_tool_lds_occupier(occ_kb * 1024, int(os.environ.get('PROBE_OCCUPY_US', '800')), int(os.environ.get('PROBE_OCCUPY_BLOCKS', '256')), occ_sink.data_ptr(), hipabi.stream_ptr())
             assert rc == 0, L.straps_last_error()
         elif other == 'raster':
             for _ in range(4):

@@ -120,6 +120,65 @@ __global__ __launch_bounds__(512) void aggressor_kernel(const unsigned* __restri
     if (acc == 0x12345678u) sink[blockIdx.x] = acc;          // (never true in practice: keeps the reads alive)
 }
 
+// Round 5 (tools/conv_family_probe2.sh, profiles/r05_conv_family_probe2.txt): inside the library the victim is disturbed by a CO-RESIDENT convolution
+// workgroup exactly when that workgroup streams its operand FRAGMENTS out of LDS (ds_read_b128) -- with its LDS-DMA copies removed it still
+// is, with the fragment reads removed (copies + barriers, or MFMAs + barriers) it is not, and a workgroup that merely holds the LDS is harmless.
+// Aggressor modes 4 / 5 are that ingredient alone: one four-wave workgroup per CU (147 KB of LDS, so that nothing but a small-LDS kernel fits
+// beside it), LDS filled once, then nothing but the convolution kernel's fragment reads -- 64-byte rows, the XOR swizzle of csrc/conv_x3.hip --
+// feeding v_mfma_f32_32x32x16_bf16 (mode 4) or a checksum (mode 5), one barrier per "chunk".  No global memory traffic after the fill.
+__device__ __forceinline__ int swz3(int r) { return (r >> 3) & 3; }
+template <int MFMA>
+__global__ __launch_bounds__(256) void frag_reader_kernel(unsigned* __restrict__ sink, int trips) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 147 KB = 3 stages x 3 planes x (128 + 128) rows x 64 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 147 * 256; i += 256) lds[i] = 0x3f803f80u ^ (unsigned)(i * 2654435761u >> 20);      // (bf16 values near 1)
+    __syncthreads();
+    const unsigned short* As = reinterpret_cast<const unsigned short*>(lds);
+    const int wm = wave >> 1, wn = wave & 1;
+    int fo[2];
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ swz3(lane & 31)) << 3);
+    f32x16_t c[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
+    unsigned acc = 0;
+    int stage = 0;
+    for (int t = 0; t < trips; ++t) {
+        const unsigned short* Ab = As + (stage * 3 * 256 + wm * 64) * 32;
+        const unsigned short* Bb = As + (stage * 3 * 256 + 128 + wn * 64) * 32;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i][pl] = *reinterpret_cast<const bf16x8_t*>(Ab + (pl * 256 + i * 32) * 32 + fo[kk]);
+                    b[i][pl] = *reinterpret_cast<const bf16x8_t*>(Bb + (pl * 256 + i * 32) * 32 + fo[kk]);
+                }
+            if (MFMA) {
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[q]], b[j][TB[q]], c[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const uint4 ua = *reinterpret_cast<const uint4*>(&a[i][pl]), ub = *reinterpret_cast<const uint4*>(&b[i][pl]);
+                        acc += (ua.x ^ ua.y ^ ua.z ^ ua.w) + (ub.x ^ ub.y ^ ub.z ^ ub.w);
+                    }
+            }
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+        __builtin_amdgcn_s_barrier();
+    }
+    if (MFMA) acc += (unsigned)(c[0][0][0] + c[0][1][5] + c[1][0][15] + c[1][1][7] == 12345.678f);
+    if (acc == 0x12345678u) sink[blockIdx.x] = acc;
+}
+
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 400;
     const long long n = (long long)NBODY * NFACE;
@@ -137,19 +196,25 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dtri, tri.size() * 4)); CK(hipMalloc(&dz, zbytes)); CK(hipMalloc(&dsrc, words * 4)); CK(hipMalloc(&dsink, 4096 * 4));
     CK(hipMemcpy(dtri, tri.data(), tri.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dsrc, 0x5a, words * 4));
-    const int amode = argc > 2 ? atoi(argv[2]) : 0;           // 0: LDS-DMA copies only; 1: + an MFMA block per trip; 2: 512 threads; 3: both
+    const int amode = argc > 2 ? atoi(argv[2]) : 0;           // 0: LDS-DMA copies only; 1: + an MFMA block per trip; 2: 512 threads; 3: both; 4 / 5: fragment-read stream with / without MFMAs
     const int athreads = (amode & 2) ? 512 : 256;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(frag_reader_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 147 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(frag_reader_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 147 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     hipStream_t sv, sa;
     CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(sa, hipStreamCaptureModeThreadLocal));
+    const int ftrips = argc > 3 ? atoi(argv[3]) : 400;
     for (int k = 0; k < 4; ++k) {
-        if (amode & 1) hipLaunchKernelGGL(aggressor_kernel<1>, dim3(512), dim3(athreads), 128 * 1024, sa, dsrc, words, dsink, 64);
+        if (amode == 4) hipLaunchKernelGGL(frag_reader_kernel<1>, dim3(256), dim3(256), 147 * 1024, sa, dsink, ftrips);
+        else if (amode == 5) hipLaunchKernelGGL(frag_reader_kernel<0>, dim3(256), dim3(256), 147 * 1024, sa, dsink, ftrips);
+        else if (amode & 1) hipLaunchKernelGGL(aggressor_kernel<1>, dim3(512), dim3(athreads), 128 * 1024, sa, dsrc, words, dsink, 64);
         else hipLaunchKernelGGL(aggressor_kernel<0>, dim3(512), dim3(athreads), 128 * 1024, sa, dsrc, words, dsink, 64);
     }
-    printf("aggressor mode %d: %d threads per workgroup, 128 KB of LDS, LDS-DMA copies%s\n", amode, athreads, (amode & 1) ? " + 12 bf16 MFMAs per wave and trip" : "");
+    if (amode >= 4) printf("aggressor mode %d: one 256-thread workgroup per CU holding 147 KB of LDS, fragment reads (ds_read_b128, 64-byte swizzled rows)%s, %d chunks per launch, no memory traffic\n", amode, amode == 4 ? " feeding 48 bf16 MFMAs per wave and chunk" : " into a checksum", ftrips);
+    else printf("aggressor mode %d: %d threads per workgroup, 128 KB of LDS, LDS-DMA copies%s\n", amode, athreads, (amode & 1) ? " + 12 bf16 MFMAs per wave and trip" : "");
     CK(hipStreamEndCapture(sa, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     std::vector<unsigned long long> ref(zbytes / 8), cur(zbytes / 8);
