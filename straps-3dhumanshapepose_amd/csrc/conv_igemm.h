@@ -226,27 +226,35 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
     if (full) rows(std::true_type{}); else rows(std::false_type{});
 }
 
-// ---- round 5: the look-ahead epilogue ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+__device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&bd1)[BN / WGN / 32], const double (&bd2)[BN / WGN / 32], int blk, int n0, float* smem);
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+__device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&s1)[BN / WGN / 32], const float (&s2)[BN / WGN / 32], int mt, int n0, float* smem);
+
+// ---- round 5: the look-ahead ROW epilogue ---------------------------------------------------------------------------------------------
 // What the row-by-row epilogue above costs when it has memory OPERANDS (a data gradient's addend; the BatchNorm input `raw` and the ReLU
 // bits of the fused BatchNorm-backward sums): per 32-row block it fetches the addend rows, waits, then twice (fetch eight raw rows + eight
 // bit words, wait, compute, store) -- and because loads and stores retire through ONE in-order counter on this part, every wait behind a
 // batch of stores also waits for those stores to be acknowledged by memory.  Six dependent memory round trips per workgroup of a 128-row
 // tile, 1.5-2.5 us each under load, at the end of a main loop of 7-14 us, with two workgroups per CU to hide them: `dgrad+bn` launches
 // ran 16-54 us behind the forward convolution of the same FLOPs (190 vs 122 us on layer1's 64 -> 64 3x3, profiles/r04_bench_train_b64.json).
-// Here a UNIT is one 32x32 accumulator block (i, j) of a wave -- 16 elements per lane -- and its operands (16 addend values, 16 raw values,
-// one word of ReLU bits per operand tensor) are fetched one unit AHEAD of their use: unit 0 before the matrix work of the last K chunk
-// (`prefetch()`, called by the kernels where no copy wait follows any more), unit k + 1 before unit k is computed and stored.  No load ever
-// waits behind a store (a younger store does not hold back an older load in the in-order counter), and one round trip -- partly under the last
-// chunk's MFMAs -- is exposed instead of six.  Same arithmetic in the same order per lane as the row-by-row form: results are bit-identical
-// (tests/test_gpu_conv_x3.py::test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit runs the fp32-mask form -- still row by row -- against it
-// on every tile configuration).
+// And every access of that form is 4 bytes per lane (the accumulator layout: lane = channel): the launches that are ALL epilogue -- resnet50's
+// 1x1 layers, K = 2-8 chunks -- moved their 200-450 MB at 2.4-3.0 TB/s where the streaming kernels of this library reach 5.
 //
-// ReLU bits: the word of (pixel row, 32-channel group) is the same for the 32 lanes of a row.  The row-by-row form loads it once per (lane,
-// row): 16 broadcast loads and 16 registers per unit and operand.  Here lane q = l & 15 of each 16-lane DPP row loads the word of the block
-// row its HALF-wave will need as its q-th -- (q & 3) + 8 (q >> 2) + 4 (l >> 5), the accumulator layout's row order -- and element r reads it
-// with `v_mov_b32_dpp row_newbcast:r`: one load and one register per unit and operand.
-template <int R>
-__device__ __forceinline__ unsigned epi_row_word(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + R, 0xf, 0xf, false); }
+// Two changes (the first measured alone: profiles/r05_epilogue_ab.txt, resnet18 step 8.57 -> 8.28 ms, resnet50 14.88 -> 14.24 ms):
+//  * LOOK-AHEAD.  A UNIT is one 32x32 accumulator block (i, j) of a wave and its operands are fetched AHEAD of their use: unit 0 before the
+//    matrix work of the last K chunk (`prefetch()`, called by the kernels where no copy wait follows any more), the others -- up to DEPTH
+//    in flight -- before unit 0 is computed and stored.  No load ever waits behind a store (a younger store does not hold back an older load
+//    in the in-order counter), and one round trip, partly under the last chunk's MFMAs, is exposed instead of six.
+//  * ROWS.  The unit's 32x32 values go through a per-wave LDS slice once (16 ds_write_b32 in the accumulator layout, 4 ds_read_b128 back):
+//    afterwards lane l holds FOUR CONSECUTIVE CHANNELS (l & 7) * 4 .. + 3 of rows (l >> 3) + 8 t, t = 0..3, and every global access of the
+//    epilogue -- addend, raw, the fp32 result -- is 16 bytes per lane, eight whole 128-byte lines per wave instruction; a row's word of ReLU
+//    bits is one broadcast load for its eight lanes.  The batch-statistics sums and the BatchNorm-backward sums are kept per lane for its four
+//    channels and combined over the eight row lanes and the M waves through LDS in a fixed order (igemm_row_stats / igemm_row_bnr below).
+// Every launch takes this path on every tile that lies inside the problem -- all mask forms of the fused sums included, so that they stay
+// bit-identical to each other (tests/test_gpu_conv_x3.py::test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit); a ragged last M tile
+// and the eval-mode plane output keep the row-by-row form.  The sums are the same terms in another order than in rounds 1-4 (per lane over
+// its rows, then lanes, then waves): fixed, so every launch of a shape is bit-reproducible, but not the bits of round 4.
 template <typename F, int... Rs>
 __device__ __forceinline__ void epi_for16(F&& f, std::integer_sequence<int, Rs...>) { (f(std::integral_constant<int, Rs>{}), ...); }
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): expanded by the front end (a `#pragma unroll` loop over units is NOT reliable
@@ -256,12 +264,14 @@ template <int N, typename F>
 __device__ __forceinline__ void epi_static_for(F&& f) { epi_for16(f, std::make_integer_sequence<int, N>{}); }
 
 struct EpiUnit {
-    float rv[16];       // addend (p.res) of the lane's 16 rows
-    float xr[16];       // BatchNorm input (p.bnr_raw)
-    unsigned bw, rbw;   // ReLU-bit words (p.bnr_bits / p.res_bits), one block row per lane of a DPP row (see above)
+    f32x4 rv[4];            // addend (p.res): rows (l >> 3) + 8 t, channels (l & 7) * 4 .. + 3
+    f32x4 xr[4];            // BatchNorm input (p.bnr_raw)
+    unsigned bw[4], rbw[4]; // the rows' words of ReLU bits (p.bnr_bits / p.res_bits)
 };
+constexpr int EPI_TLD = 36;                          // floats per row of the transposition slice (32 + 4: 144-byte rows, 16-byte aligned)
+constexpr int EPI_TSLICE = 32 * EPI_TLD;             // floats per wave
 
-// DEPTH: units whose operands may be in flight at once (34 registers each).  init() copies the handful of wave-uniform values the epilogue needs
+// DEPTH: units whose operands may be in flight at once (40 registers each).  init() copies the handful of wave-uniform values the epilogue needs
 // out of the kernel argument block (scalar registers): a reference to the 800-byte ConvP kept in a member, or captured by the per-row
 // lambdas, makes the compiler materialise the whole block in scratch.
 // (eight-wave workgroups share a SIMD's 512 registers between two waves: their four-unit tiles keep two units in flight)
@@ -269,47 +279,48 @@ template <int BM, int BN, int WGM, int WGN, int DEPTH = (WGM * WGN >= 8 && (BM /
 struct IgemmEpilogue {
     static constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32, NU = MI * NI;
     static_assert(DEPTH >= 1 && DEPTH <= NU, "look-ahead depth");
-    int m0, n0, lane, wm, wn;
+    static_assert(WGM * WGN * EPI_TSLICE * 4 <= 40 * 1024 && WGM * 8 * BN * 2 * 8 <= 72 * 1024, "epilogue LDS use exceeds the smallest kernel's allocation");
+    int m0, n0, lane, wave, wm, wn, rq, cq;
     bool look, full, remap, bnr;
     EpiUnit u[DEPTH];
     // wave-uniform copies (see above)
-    const float *g_raw, *g_res, *g_scale, *g_shift, *g_bsc, *g_bsh, *g_mean;
+    const float *g_raw, *g_res, *g_scale, *g_shift, *g_bsc, *g_bsh, *g_mean, *g_out;
     const unsigned *g_bits, *g_rbits;
     float* g_y;
     int Cout, relu, OH, OW, omul, oah, oaw, cMh, cMw, cM;
 
     __device__ __forceinline__ void init(const ConvP& p, const ConvP::Class& c, int m0_, int n0_) {
-        const int tid = threadIdx.x, wave = tid >> 6;
+        const int tid = threadIdx.x;
+        wave = tid >> 6;
         m0 = m0_; n0 = n0_;
         lane = tid & 63; wm = wave / WGN; wn = wave % WGN;
+        rq = lane >> 3; cq = (lane & 7) * 4;
         bnr = p.bnr_raw != nullptr;
-        // the look-ahead form covers every launch that HAS memory operands, except the two forms kept row by row: the fp32-activation mask of
-        // the BatchNorm sums (bnr_out: the A/B reference of the bit form) and the eval-mode plane output (yplanes)
-        // ... and a ragged last M tile (one workgroup row of a launch at most), which keeps the row-by-row form with its per-row range tests
         full = m0 + BM <= c.M;
-        look = p.epi != 0 && (bnr || p.res != nullptr) && p.bnr_out == nullptr && p.yplanes == nullptr && p.y != nullptr && full;
+        look = p.epi != 0 && p.yplanes == nullptr && p.y != nullptr && full;
         remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
-        g_raw = p.bnr_raw; g_res = p.res; g_scale = p.scale; g_shift = p.shift; g_bsc = p.bnr_sc; g_bsh = p.bnr_sh; g_mean = p.bnr_mean;
+        g_raw = p.bnr_raw; g_res = p.res; g_scale = p.scale; g_shift = p.shift; g_bsc = p.bnr_sc; g_bsh = p.bnr_sh; g_mean = p.bnr_mean; g_out = p.bnr_out;
         g_bits = p.bnr_bits; g_rbits = p.res_bits; g_y = p.y;
         Cout = p.Cout; relu = p.relu; OH = p.OH; OW = p.OW; omul = p.omul; oah = c.oah; oaw = c.oaw; cMh = c.Mh; cMw = c.Mw; cM = c.M;
     }
 
-    // walk over the physical output pixels of the lane's 16 rows of block row i (rows m = mb + (r & 3) + 8 (r >> 2)): f(r, pixel).  A remapped
-    // class (a parity class of a stride-2 data gradient) finds the first pixel by division and walks on, as igemm_store_rows_impl does.
+    // f(t, element offset of the lane's four channels in row (rq + 8 t) of unit (i, j)), t = 0..3.  A remapped class (a parity class of a
+    // stride-2 data gradient) finds the first pixel by division and walks on eight logical rows at a time.
     template <bool REMAP, typename F>
-    __device__ __forceinline__ void for_rows(int i, F&& f) const {
-        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
+    __device__ __forceinline__ void for_rows(int i, int j, F&& f) const {
+        const int mb = m0 + wm * WTM + i * 32 + rq;
+        const int nb = n0 + wn * WTN + j * 32 + cq;
         if constexpr (!REMAP) {
-            epi_static_for<16>([&](auto rc) { constexpr int r = decltype(rc)::value; f(rc, mb + (r & 3) + 8 * (r >> 2)); });
+            epi_static_for<4>([&](auto tc) { constexpr int t = decltype(tc)::value; f(tc, (mb + 8 * t) * Cout + nb, mb + 8 * t); });
         } else {
             const int MhMw = cMh * cMw;
             int b_ = mb / MhMw;
             const int rem = mb - b_ * MhMw;
             int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
-            epi_static_for<16>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                f(rc, (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw);
-                wo_ += (r & 3) == 3 ? 5 : 1;
+            epi_static_for<4>([&](auto tc) {
+                const int pix = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
+                f(tc, pix * Cout + nb, pix);
+                wo_ += 8;
                 while (wo_ >= cMw) {
                     wo_ -= cMw;
                     if (++ho_ == cMh) { ho_ = 0; ++b_; }
@@ -317,109 +328,170 @@ struct IgemmEpilogue {
             });
         }
     }
-    template <bool FULL, bool REMAP>
+    template <bool REMAP>
     __device__ __forceinline__ void issue(int i, int j, EpiUnit& un) const {
-        const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
-        for_rows<REMAP>(i, [&](auto rc, int pix) {
-            constexpr int r = decltype(rc)::value;
-            const bool ok = FULL || mb + (r & 3) + 8 * (r >> 2) < cM;
-            if (bnr) un.xr[r] = ok ? g_raw[pix * Cout + n] : 0.f;
-            if (g_res) un.rv[r] = ok ? g_res[pix * Cout + n] : 0.f;
+        const int wcol = (n0 + wn * WTN + j * 32) >> 5;
+        for_rows<REMAP>(i, j, [&](auto tc, int off, int pix) {
+            constexpr int t = decltype(tc)::value;
+            if (bnr) un.xr[t] = *reinterpret_cast<const f32x4*>(g_raw + off);
+            if (g_res) un.rv[t] = *reinterpret_cast<const f32x4*>(g_res + off);
+            if (g_bits) un.bw[t] = g_bits[pix * (Cout >> 5) + wcol];
+            if (g_rbits) un.rbw[t] = g_rbits[pix * (Cout >> 5) + wcol];
         });
-        if (g_bits || g_rbits) {
-            // the block row whose bit words this lane fetches: the q-th row of its half-wave, q = lane & 15
-            const int q = lane & 15;
-            const int ml = m0 + wm * WTM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            const bool okl = FULL || ml < cM;
-            int pixl = ml;
-            if constexpr (REMAP) {
-                const int MhMw = cMh * cMw;
-                const int mc = okl ? ml : 0;
-                const int b_ = mc / MhMw, rem = mc - b_ * MhMw;
-                const int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
-                pixl = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
-            }
-            const int wi = pixl * (Cout >> 5) + ((n0 + wn * WTN + j * 32) >> 5);
-            un.bw = (g_bits && okl) ? g_bits[wi] : 0u;
-            un.rbw = (g_rbits && okl) ? g_rbits[wi] : 0u;
-        }
     }
     // unit 0's operands, ahead of the last chunk's matrix work.  The kernels call this exactly once, where no copy wait follows (every later
     // s_waitcnt vmcnt of the main loop would wait for these loads too), on a path peeled out of the chunk loop -- inside the loop the unit's
     // registers would be live across every iteration.
     __device__ __forceinline__ void prefetch() {
         if (!look) return;
-        if (remap) issue<true, true>(0, 0, u[0]); else issue<true, false>(0, 0, u[0]);
+        if (remap) issue<true>(0, 0, u[0]); else issue<false>(0, 0, u[0]);
     }
 
-    template <bool FULL, bool REMAP>
-    __device__ __forceinline__ void consume(int i, int j, const EpiUnit& un, const f32x16& acc, float& s1, float& s2,
-                                            double& d1, double& d2, float sc, float sh, float bsc, float bsh, float bmu) const {
-        const int cl = lane & 31;
-        const int n = n0 + wn * WTN + j * 32 + cl;
-        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
-        for_rows<REMAP>(i, [&](auto rc, int pix) {
-            constexpr int r = decltype(rc)::value;
-            const bool ok = FULL || mb + (r & 3) + 8 * (r >> 2) < cM;
-            float v = acc[r];
-            const float vs = ok ? v : 0.f;
-            s1 += vs;
-            s2 = fmaf(vs, vs, s2);
-            if (g_scale) v = fmaf(v, sc, sh);
-            if (g_res) {
-                float a = un.rv[r];
-                if (g_rbits) a = ((epi_row_word<r>(un.rbw) >> cl) & 1u) ? a : 0.f;
-                v += a;
+    // the unit's 32x32 values from the accumulator layout (lane = channel, register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) into the row
+    // layout, through this wave's LDS slice; LDS operations of one wave execute in issue order, the compiler is told not to reorder them
+    __device__ __forceinline__ void transpose(const f32x16& acc, float* T, f32x4 (&v)[4]) const {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_TLD + (lane & 31)] = acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4*>(T + (rq + 8 * t) * EPI_TLD + cq);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    template <bool REMAP>
+    __device__ __forceinline__ void consume(int i, int j, const EpiUnit& un, const f32x16& acc, float* T, f32x4& s1, f32x4& s2, double (&d1)[4], double (&d2)[4]) const {
+        f32x4 v[4];
+        transpose(acc, T, v);
+        const int nb = n0 + wn * WTN + j * 32 + cq;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bsc = sh, bsh = sh, bmu = sh;
+        if (g_scale) { sc = *reinterpret_cast<const f32x4*>(g_scale + nb); sh = *reinterpret_cast<const f32x4*>(g_shift + nb); }
+        if (bnr) {
+            bmu = *reinterpret_cast<const f32x4*>(g_mean + nb);
+            if (!g_bits && !g_out) { bsc = *reinterpret_cast<const f32x4*>(g_bsc + nb); bsh = *reinterpret_cast<const f32x4*>(g_bsh + nb); }
+        }
+        for_rows<REMAP>(i, j, [&](auto tc, int off, int) {
+            constexpr int t = decltype(tc)::value;
+            f32x4 o;
+            f32x4 yo = {0.f, 0.f, 0.f, 0.f};
+            if (bnr && g_out) yo = *reinterpret_cast<const f32x4*>(g_out + off);      // (the fp32-mask form, kept as the A/B reference of the bits: fetched late)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[t][e];
+                s1[e] += x;
+                s2[e] = fmaf(x, x, s2[e]);
+                if (g_scale) x = fmaf(x, sc[e], sh[e]);
+                if (g_res) {
+                    float a = un.rv[t][e];
+                    if (g_rbits) a = ((un.rbw[t] >> (cq + e)) & 1u) ? a : 0.f;
+                    x += a;
+                }
+                if (relu) x = fmaxf(x, 0.f);
+                if (bnr) {
+                    const bool on = g_bits ? (((un.bw[t] >> (cq + e)) & 1u) != 0) : (g_out ? yo[e] > 0.f : fmaf(un.xr[t][e], bsc[e], bsh[e]) > 0.f);
+                    const float g = on ? x : 0.f;
+                    d1[e] += (double)g;
+                    d2[e] += (double)g * ((double)un.xr[t][e] - (double)bmu[e]);
+                }
+                o[e] = x;
             }
-            if (relu) v = fmaxf(v, 0.f);
-            if (bnr) {
-                const bool on = g_bits ? (((epi_row_word<r>(un.bw) >> cl) & 1u) != 0) : fmaf(un.xr[r], bsc, bsh) > 0.f;
-                const float g = (on && ok) ? v : 0.f;
-                d1 += (double)g;
-                d2 += (double)g * ((double)un.xr[r] - (double)bmu);
-            }
-            if (ok) g_y[pix * Cout + n] = v;
+            *reinterpret_cast<f32x4*>(g_y + off) = o;
         });
     }
 
     // PRE: prefetch() has run (unit 0 is in flight)
-    template <bool FULL, bool REMAP, bool PRE>
-    __device__ __forceinline__ void run(const f32x16 (&acc)[MI][NI], float (&s1)[NI], float (&s2)[NI], double (&d1)[NI], double (&d2)[NI]) {
-        float sc[NI], sh[NI], bsc[NI], bsh[NI], bmu[NI];
+    template <bool REMAP, bool PRE>
+    __device__ __forceinline__ void run(const f32x16 (&acc)[MI][NI], float* smem, f32x4 (&s1)[NI], f32x4 (&s2)[NI], double (&d1)[NI][4], double (&d2)[NI][4]) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-            sc[j] = g_scale ? g_scale[n] : 1.f;
-            sh[j] = g_shift ? g_shift[n] : 0.f;
-            s1[j] = 0.f; s2[j] = 0.f; d1[j] = 0.0; d2[j] = 0.0;
-            bsc[j] = (bnr && !g_bits) ? g_bsc[n] : 0.f;
-            bsh[j] = (bnr && !g_bits) ? g_bsh[n] : 0.f;
-            bmu[j] = bnr ? g_mean[n] : 0.f;
+            s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d1[j][e] = 0.0; d2[j][e] = 0.0; }
         }
-        // units k .. k + DEPTH - 1 in flight (slot k % DEPTH): every load is issued in front of the stores of DEPTH - 1 units, none behind a
-        // store it would have to wait for
-        if constexpr (!PRE) issue<FULL, REMAP>(0, 0, u[0]);
+        // units 0 .. DEPTH - 1 in flight, then unit k + DEPTH is requested as soon as unit k's registers are free (slot k % DEPTH): every load
+        // is issued in front of the stores of the units before it, none behind a store it would have to wait for
+        if constexpr (!PRE) issue<REMAP>(0, 0, u[0]);
         epi_static_for<DEPTH - 1>([&](auto kc) {
             constexpr int k = decltype(kc)::value + 1;
-            issue<FULL, REMAP>(k / NI, k % NI, u[k]);
+            issue<REMAP>(k / NI, k % NI, u[k]);
         });
+        __syncthreads();                                   // every wave is done with the last chunk's fragment reads: LDS is free
+        float* T = smem + wave * EPI_TSLICE;
         epi_static_for<NU>([&](auto kc) {
             constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
-            consume<FULL, REMAP>(i, j, u[k % DEPTH], acc[i][j], s1[j], s2[j], d1[j], d2[j], sc[j], sh[j], bsc[j], bsh[j], bmu[j]);
-            if constexpr (k + DEPTH < NU) issue<FULL, REMAP>((k + DEPTH) / NI, (k + DEPTH) % NI, u[k % DEPTH]);
+            consume<REMAP>(i, j, u[k % DEPTH], acc[i][j], T, s1[j], s2[j], d1[j], d2[j]);
+            if constexpr (k + DEPTH < NU) issue<REMAP>((k + DEPTH) / NI, (k + DEPTH) % NI, u[k % DEPTH]);
         });
     }
 
-    // the whole epilogue of the tile's rows: look-ahead form where it applies, else the row-by-row form
+    // per-channel (sum, sum of squares) partials of this M tile -> stats[mt][Cout][2]: lane (rq, cq) holds them for its four channels; the eight
+    // row lanes and the M waves are added in a fixed order by thread c < BN
+    __device__ __forceinline__ void row_stats(float* stats, int mt, float* smem, const f32x4 (&s1)[NI], const f32x4 (&s2)[NI]) const {
+        if (!stats) return;
+        __syncthreads();                                   // (the transposition slices are dead)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int c = wn * WTN + j * 32 + cq;
+            *reinterpret_cast<f32x4*>(smem + ((0 * WGM + wm) * 8 + rq) * BN + c) = s1[j];
+            *reinterpret_cast<f32x4*>(smem + ((1 * WGM + wm) * 8 + rq) * BN + c) = s2[j];
+        }
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < BN) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM * 8; ++w) { t1 += smem[w * BN + tid]; t2 += smem[(WGM * 8 + w) * BN + tid]; }
+            float* o = stats + ((long long)mt * Cout + n0 + tid) * 2;
+            o[0] = t1;
+            o[1] = t2;
+        }
+    }
+    // BatchNorm-backward partial of this M tile -> part[blk][Cout][2] = (S1, invstd * S2), the same way in double
+    __device__ __forceinline__ void row_bnr(double* part, const float* invstd, int blk, float* smem, const double (&d1)[NI][4], const double (&d2)[NI][4]) const {
+        if (!bnr) return;
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = wn * WTN + j * 32 + cq + e;
+                red[((0 * WGM + wm) * 8 + rq) * BN + c] = d1[j][e];
+                red[((1 * WGM + wm) * 8 + rq) * BN + c] = d2[j][e];
+            }
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < BN) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < WGM * 8; ++w) { t1 += red[w * BN + tid]; t2 += red[(WGM * 8 + w) * BN + tid]; }
+            double* o = part + ((long long)blk * Cout + n0 + tid) * 2;
+            o[0] = t1;
+            o[1] = t2 * (double)invstd[n0 + tid];
+        }
+    }
+
+    // the whole epilogue of the tile: rows, batch-statistics partial, BatchNorm-backward partial -- look-ahead row form where it applies, else
+    // the row-by-row form of rounds 1-4
     template <bool PRE = true>
-    __device__ __forceinline__ void finish(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[MI][NI], float (&s1)[NI], float (&s2)[NI],
-                                           double (&d1)[NI], double (&d2)[NI]) {
+    __device__ __forceinline__ void finish(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[MI][NI], int mt, int bnr_blk, float* smem) {
         if (!look) {
-            igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, d1, d2);
+            float s1[NI], s2[NI];
+            double bd1[NI], bd2[NI];
+            igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
+            igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+            igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, bnr_blk, n0, smem);
             return;
         }
-        if (remap) run<true, true, PRE>(acc, s1, s2, d1, d2); else run<true, false, PRE>(acc, s1, s2, d1, d2);
+        f32x4 s1[NI], s2[NI];
+        double d1[NI][4], d2[NI][4];
+        if (remap) run<true, PRE>(acc, smem, s1, s2, d1, d2); else run<false, PRE>(acc, smem, s1, s2, d1, d2);
+        row_stats(p.stats, mt, smem, s1, s2);
+        row_bnr(p.bnr_part, p.bnr_invstd, bnr_blk, smem, d1, d2);
     }
 };
 
@@ -431,7 +503,7 @@ __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Cl
 }
 
 // BatchNorm-backward partial of one M tile -> bnr_part[blk][Cout][2] = (S1, invstd * S2), summed in a fixed order
-template <int BM, int BN, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&bd1)[BN / WGN / 32], const double (&bd2)[BN / WGN / 32], int blk, int n0,
                                                 float* smem) {
     constexpr int WTN = BN / WGN, NI = WTN / 32;
@@ -462,7 +534,7 @@ __device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&b
 }
 
 // per-channel (sum, sum of squares) partials of one M tile -> stats[mt][Cout][2]
-template <int BM, int BN, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&s1)[BN / WGN / 32], const float (&s2)[BN / WGN / 32], int mt, int n0, float* smem) {
     constexpr int WTN = BN / WGN, NI = WTN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

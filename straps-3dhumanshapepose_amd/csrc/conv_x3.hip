@@ -300,11 +300,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
 
     // (a class without taps -- the dead parity classes of a 1x1 / stride-2 data gradient: dx = addend there -- never reaches a last chunk)
     if (nchunks <= 0) ep.prefetch();
-    float s1[NI], s2[NI];
-    double bd1[NI], bd2[NI];
-    ep.finish(p, c, acc, s1, s2, bd1, bd2);
-    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
-    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
+    ep.finish(p, c, acc, mt, p.bnr_base[blockIdx.y] + mt, smem);
     clk_end(p, clk);
 }
 
@@ -517,11 +513,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
 
     if (nsteps <= 0) ep.prefetch();
-    float s1[NI], s2[NI];
-    double bd1[NI], bd2[NI];
-    ep.finish(p, c, acc, s1, s2, bd1, bd2);
-    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
-    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
+    ep.finish(p, c, acc, mt, p.bnr_base[blockIdx.y] + mt, smem);
     clk_end(p, clk);
 }
 
@@ -637,7 +629,14 @@ int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
     }
 }
 
-int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
+int dispatch_x3(const ConvP& p0, int tile_cfg, hipStream_t st) {
+    ConvP p = p0;
+    // the row epilogue (conv_igemm.h) moves 16 bytes per lane: every tensor it touches must be 16-byte aligned (torch allocations are;
+    // a caller's odd view falls back to the row-by-row form, 4 bytes per lane)
+    if ((reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.res) | reinterpret_cast<uintptr_t>(p.bnr_raw) | reinterpret_cast<uintptr_t>(p.bnr_out) |
+         reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift) | reinterpret_cast<uintptr_t>(p.bnr_sc) | reinterpret_cast<uintptr_t>(p.bnr_sh) |
+         reinterpret_cast<uintptr_t>(p.bnr_mean)) & 15)
+        p.epi = 0;
     int bm, bn, kdim = 0;
     long long M = 0;
     for (int i = 0; i < p.ncls; ++i) {
