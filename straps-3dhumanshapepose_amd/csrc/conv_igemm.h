@@ -251,10 +251,12 @@ __device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&
 //    epilogue -- addend, raw, the fp32 result -- is 16 bytes per lane, eight whole 128-byte lines per wave instruction; a row's word of ReLU
 //    bits is one broadcast load for its eight lanes.  The batch-statistics sums and the BatchNorm-backward sums are kept per lane for its four
 //    channels and combined over the eight row lanes and the M waves through LDS in a fixed order (igemm_row_stats / igemm_row_bnr below).
-// Every launch takes this path on every tile that lies inside the problem -- all mask forms of the fused sums included, so that they stay
-// bit-identical to each other (tests/test_gpu_conv_x3.py::test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit); a ragged last M tile
-// and the eval-mode plane output keep the row-by-row form.  The sums are the same terms in another order than in rounds 1-4 (per lane over
-// its rows, then lanes, then waves): fixed, so every launch of a shape is bit-reproducible, but not the bits of round 4.
+// Every training-mode launch takes this path on every tile that lies inside the problem; a ragged last M tile, the eval-mode forms (folded
+// scale / shift, plane output) and the fp32-activation mask of the fused sums -- the A/B reference of the bit form -- keep the row-by-row form.
+// The sums are the same terms in another order than there (per lane over its rows, then lanes, then waves): fixed, so every launch of a shape
+// is bit-reproducible, but the double partials of the two forms agree to rounding (1e-13), not bit for bit; the gradient itself is bit-identical
+// (tests/test_gpu_conv_x3.py::test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit: the row form against the row-by-row form on every tile
+// configuration).
 template <typename F, int... Rs>
 __device__ __forceinline__ void epi_for16(F&& f, std::integer_sequence<int, Rs...>) { (f(std::integral_constant<int, Rs>{}), ...); }
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): expanded by the front end (a `#pragma unroll` loop over units is NOT reliable
@@ -271,20 +273,31 @@ struct EpiUnit {
 constexpr int EPI_TLD = 36;                          // floats per row of the transposition slice (32 + 4: 144-byte rows, 16-byte aligned)
 constexpr int EPI_TSLICE = 32 * EPI_TLD;             // floats per wave
 
+// workgroup barrier for LDS hand-offs ONLY: __syncthreads() also drains the vector-memory counter (its release fence), i.e. it would wait
+// for the operands requested ahead and for every result store to be acknowledged -- exactly the round trips this epilogue exists to avoid
+__device__ __forceinline__ void epi_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // DEPTH: units whose operands may be in flight at once (40 registers each).  init() copies the handful of wave-uniform values the epilogue needs
 // out of the kernel argument block (scalar registers): a reference to the 800-byte ConvP kept in a member, or captured by the per-row
 // lambdas, makes the compiler materialise the whole block in scratch.
 // (eight-wave workgroups share a SIMD's 512 registers between two waves: their four-unit tiles keep two units in flight)
-template <int BM, int BN, int WGM, int WGN, int DEPTH = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 2 : (BM / WGM / 32) * (BN / WGN / 32)>
+// PF: how many of them are requested under the last chunk's matrix work (the fragments of that chunk are still live there: one unit for the
+// eight-wave four-unit tile, all of them elsewhere)
+template <int BM, int BN, int WGM, int WGN, int DEPTH = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 2 : (BM / WGM / 32) * (BN / WGN / 32),
+          int PF = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 1 : DEPTH>
 struct IgemmEpilogue {
     static constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32, NU = MI * NI;
-    static_assert(DEPTH >= 1 && DEPTH <= NU, "look-ahead depth");
+    static_assert(DEPTH >= 1 && DEPTH <= NU && PF >= 1 && PF <= DEPTH, "look-ahead depth");
     static_assert(WGM * WGN * EPI_TSLICE * 4 <= 40 * 1024 && WGM * 8 * BN * 2 * 8 <= 72 * 1024, "epilogue LDS use exceeds the smallest kernel's allocation");
     int m0, n0, lane, wave, wm, wn, rq, cq;
     bool look, full, remap, bnr;
     EpiUnit u[DEPTH];
     // wave-uniform copies (see above)
-    const float *g_raw, *g_res, *g_scale, *g_shift, *g_bsc, *g_bsh, *g_mean, *g_out;
+    const float *g_raw, *g_res, *g_bsc, *g_bsh, *g_mean;
     const unsigned *g_bits, *g_rbits;
     float* g_y;
     int Cout, relu, OH, OW, omul, oah, oaw, cMh, cMw, cM;
@@ -297,94 +310,107 @@ struct IgemmEpilogue {
         rq = lane >> 3; cq = (lane & 7) * 4;
         bnr = p.bnr_raw != nullptr;
         full = m0 + BM <= c.M;
-        look = p.epi != 0 && p.yplanes == nullptr && p.y != nullptr && full;
+        // (the eval-mode forms -- folded scale / shift, plane output -- and the fp32-activation mask of the fused sums, the A/B reference of the
+        //  bit form, keep the row-by-row epilogue: every conditional load of this one sits in issue(), in straight-line code)
+        // (and a class without taps -- the dead parity classes of a 1x1 / stride-2 data gradient, dx = addend there -- which has no last chunk to
+        //  prefetch under: a second prefetch site behind the loop would merge two definitions of unit 0 and wait for the loads where they meet)
+        look = p.epi != 0 && p.yplanes == nullptr && p.y != nullptr && full && p.scale == nullptr && p.bnr_out == nullptr && c.ntaps > 0;
         remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
-        g_raw = p.bnr_raw; g_res = p.res; g_scale = p.scale; g_shift = p.shift; g_bsc = p.bnr_sc; g_bsh = p.bnr_sh; g_mean = p.bnr_mean; g_out = p.bnr_out;
+        g_raw = p.bnr_raw; g_res = p.res; g_bsc = p.bnr_sc; g_bsh = p.bnr_sh; g_mean = p.bnr_mean;
         g_bits = p.bnr_bits; g_rbits = p.res_bits; g_y = p.y;
         Cout = p.Cout; relu = p.relu; OH = p.OH; OW = p.OW; omul = p.omul; oah = c.oah; oaw = c.oaw; cMh = c.Mh; cMw = c.Mw; cM = c.M;
     }
 
-    // f(t, element offset of the lane's four channels in row (rq + 8 t) of unit (i, j)), t = 0..3.  A remapped class (a parity class of a
-    // stride-2 data gradient) finds the first pixel by division and walks on eight logical rows at a time.
-    template <bool REMAP, typename F>
-    __device__ __forceinline__ void for_rows(int i, int j, F&& f) const {
+    // physical output pixels of the lane's four rows (rq + 8 t) of block row i: a remapped class -- a parity class of a stride-2 data gradient --
+    // finds its first pixel by division and walks on eight logical rows at a time
+    __device__ __forceinline__ void pixels(int i, int (&pix)[4]) const {
         const int mb = m0 + wm * WTM + i * 32 + rq;
-        const int nb = n0 + wn * WTN + j * 32 + cq;
-        if constexpr (!REMAP) {
-            epi_static_for<4>([&](auto tc) { constexpr int t = decltype(tc)::value; f(tc, (mb + 8 * t) * Cout + nb, mb + 8 * t); });
+        if (!remap) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pix[t] = mb + 8 * t;
         } else {
             const int MhMw = cMh * cMw;
             int b_ = mb / MhMw;
             const int rem = mb - b_ * MhMw;
             int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
-            epi_static_for<4>([&](auto tc) {
-                const int pix = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
-                f(tc, pix * Cout + nb, pix);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                pix[t] = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
                 wo_ += 8;
                 while (wo_ >= cMw) {
                     wo_ -= cMw;
                     if (++ho_ == cMh) { ho_ = 0; ++b_; }
                 }
-            });
+            }
         }
     }
-    template <bool REMAP>
+    // the unit's operands: first the row offsets (integer work), then the loads, in ONE straight-line block: loads issued inside the two arms
+    // of a branch would be awaited where the arms meet (their destination registers are merged there)
     __device__ __forceinline__ void issue(int i, int j, EpiUnit& un) const {
-        const int wcol = (n0 + wn * WTN + j * 32) >> 5;
-        for_rows<REMAP>(i, j, [&](auto tc, int off, int pix) {
-            constexpr int t = decltype(tc)::value;
-            if (bnr) un.xr[t] = *reinterpret_cast<const f32x4*>(g_raw + off);
-            if (g_res) un.rv[t] = *reinterpret_cast<const f32x4*>(g_res + off);
-            if (g_bits) un.bw[t] = g_bits[pix * (Cout >> 5) + wcol];
-            if (g_rbits) un.rbw[t] = g_rbits[pix * (Cout >> 5) + wcol];
-        });
+        const int nb = n0 + wn * WTN + j * 32 + cq;
+        int pix[4];
+        pixels(i, pix);
+        const int wcol = (n0 + wn * WTN + j * 32) >> 5, wld = Cout >> 5;
+        if (bnr) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) un.xr[t] = *reinterpret_cast<const f32x4*>(g_raw + pix[t] * Cout + nb);
+        }
+        if (g_res) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) un.rv[t] = *reinterpret_cast<const f32x4*>(g_res + pix[t] * Cout + nb);
+        }
+        if (g_bits) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) un.bw[t] = g_bits[pix[t] * wld + wcol];
+        }
+        if (g_rbits) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) un.rbw[t] = g_rbits[pix[t] * wld + wcol];
+        }
     }
-    // unit 0's operands, ahead of the last chunk's matrix work.  The kernels call this exactly once, where no copy wait follows (every later
-    // s_waitcnt vmcnt of the main loop would wait for these loads too), on a path peeled out of the chunk loop -- inside the loop the unit's
-    // registers would be live across every iteration.
+    // the operands of the first DEPTH units, ahead of the last chunk's matrix work.  The kernels call this exactly once, where no copy wait
+    // follows (every later s_waitcnt vmcnt of the main loop would wait for these loads too), on a path peeled out of the chunk loop -- inside
+    // the loop the units' registers would be live across every iteration.  ALL of them here, not unit 0 alone: behind the loop the compiler
+    // drains the vector-memory counter once (it cannot see the hand-written waits that retired the LDS-DMA copies and protects the first LDS
+    // access of the epilogue), so whatever is requested later starts a second round trip.
     __device__ __forceinline__ void prefetch() {
         if (!look) return;
-        if (remap) issue<true>(0, 0, u[0]); else issue<false>(0, 0, u[0]);
+        epi_static_for<PF>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            issue(k / NI, k % NI, u[k]);
+        });
     }
 
     // the unit's 32x32 values from the accumulator layout (lane = channel, register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) into the row
-    // layout, through this wave's LDS slice; LDS operations of one wave execute in issue order, the compiler is told not to reorder them
+    // layout, through this wave's LDS slice.  LDS operations of one wave execute in issue order: the compiler only has to keep them in
+    // program order (no fence: a fence would also drain the vector-memory counter, see epi_lds_barrier)
     __device__ __forceinline__ void transpose(const f32x16& acc, float* T, f32x4 (&v)[4]) const {
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_TLD + (lane & 31)] = acc[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4*>(T + (rq + 8 * t) * EPI_TLD + cq);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the slice is rewritten by the next unit: its reads have returned)
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
-    template <bool REMAP>
-    __device__ __forceinline__ void consume(int i, int j, const EpiUnit& un, const f32x16& acc, float* T, f32x4& s1, f32x4& s2, double (&d1)[4], double (&d2)[4]) const {
+    __device__ __forceinline__ void consume(int i, int j, const EpiUnit& un, const f32x16& acc, float* T, f32x4& s1, f32x4& s2, double (&d1)[4], double (&d2)[4],
+                                            const f32x4& bsc, const f32x4& bsh, const f32x4& bmu) const {
         f32x4 v[4];
         transpose(acc, T, v);
         const int nb = n0 + wn * WTN + j * 32 + cq;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bsc = sh, bsh = sh, bmu = sh;
-        if (g_scale) { sc = *reinterpret_cast<const f32x4*>(g_scale + nb); sh = *reinterpret_cast<const f32x4*>(g_shift + nb); }
-        if (bnr) {
-            bmu = *reinterpret_cast<const f32x4*>(g_mean + nb);
-            if (!g_bits && !g_out) { bsc = *reinterpret_cast<const f32x4*>(g_bsc + nb); bsh = *reinterpret_cast<const f32x4*>(g_bsh + nb); }
-        }
-        for_rows<REMAP>(i, j, [&](auto tc, int off, int) {
-            constexpr int t = decltype(tc)::value;
+        int pix[4];
+        pixels(i, pix);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
             f32x4 o;
-            f32x4 yo = {0.f, 0.f, 0.f, 0.f};
-            if (bnr && g_out) yo = *reinterpret_cast<const f32x4*>(g_out + off);      // (the fp32-mask form, kept as the A/B reference of the bits: fetched late)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = v[t][e];
                 s1[e] += x;
                 s2[e] = fmaf(x, x, s2[e]);
-                if (g_scale) x = fmaf(x, sc[e], sh[e]);
                 if (g_res) {
                     float a = un.rv[t][e];
                     if (g_rbits) a = ((un.rbw[t] >> (cq + e)) & 1u) ? a : 0.f;
@@ -392,19 +418,19 @@ struct IgemmEpilogue {
                 }
                 if (relu) x = fmaxf(x, 0.f);
                 if (bnr) {
-                    const bool on = g_bits ? (((un.bw[t] >> (cq + e)) & 1u) != 0) : (g_out ? yo[e] > 0.f : fmaf(un.xr[t][e], bsc[e], bsh[e]) > 0.f);
+                    const bool on = g_bits ? (((un.bw[t] >> (cq + e)) & 1u) != 0) : fmaf(un.xr[t][e], bsc[e], bsh[e]) > 0.f;
                     const float g = on ? x : 0.f;
                     d1[e] += (double)g;
                     d2[e] += (double)g * ((double)un.xr[t][e] - (double)bmu[e]);
                 }
                 o[e] = x;
             }
-            *reinterpret_cast<f32x4*>(g_y + off) = o;
-        });
+            *reinterpret_cast<f32x4*>(g_y + pix[t] * Cout + nb) = o;
+        }
     }
 
-    // PRE: prefetch() has run (unit 0 is in flight)
-    template <bool REMAP, bool PRE>
+    // PRE: prefetch() has run (units 0 .. DEPTH - 1 are in flight)
+    template <bool PRE>
     __device__ __forceinline__ void run(const f32x16 (&acc)[MI][NI], float* smem, f32x4 (&s1)[NI], f32x4 (&s2)[NI], double (&d1)[NI][4], double (&d2)[NI][4]) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -412,19 +438,31 @@ struct IgemmEpilogue {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { d1[j][e] = 0.0; d2[j][e] = 0.0; }
         }
-        // units 0 .. DEPTH - 1 in flight, then unit k + DEPTH is requested as soon as unit k's registers are free (slot k % DEPTH): every load
+        // per-channel constants of the fused sums (mean; scale / shift of the recomputed mask): loaded here, in front of everything that waits
+        f32x4 bsc[NI], bsh[NI], bmu[NI];
+        if (bnr) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bmu[j] = *reinterpret_cast<const f32x4*>(g_mean + n0 + wn * WTN + j * 32 + cq);
+            if (!g_bits) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    bsc[j] = *reinterpret_cast<const f32x4*>(g_bsc + n0 + wn * WTN + j * 32 + cq);
+                    bsh[j] = *reinterpret_cast<const f32x4*>(g_bsh + n0 + wn * WTN + j * 32 + cq);
+                }
+            }
+        }
+        // units 0 .. DEPTH - 1 are in flight; unit k + DEPTH is requested as soon as unit k's registers are free (slot k % DEPTH): every load
         // is issued in front of the stores of the units before it, none behind a store it would have to wait for
-        if constexpr (!PRE) issue<REMAP>(0, 0, u[0]);
-        epi_static_for<DEPTH - 1>([&](auto kc) {
-            constexpr int k = decltype(kc)::value + 1;
-            issue<REMAP>(k / NI, k % NI, u[k]);
+        epi_static_for<DEPTH - (PRE ? PF : 0)>([&](auto kc) {
+            constexpr int k = decltype(kc)::value + (PRE ? PF : 0);
+            issue(k / NI, k % NI, u[k]);
         });
-        __syncthreads();                                   // every wave is done with the last chunk's fragment reads: LDS is free
+        epi_lds_barrier();                                 // every wave is done with the last chunk's fragment reads: LDS is free
         float* T = smem + wave * EPI_TSLICE;
         epi_static_for<NU>([&](auto kc) {
             constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
-            consume<REMAP>(i, j, u[k % DEPTH], acc[i][j], T, s1[j], s2[j], d1[j], d2[j]);
-            if constexpr (k + DEPTH < NU) issue<REMAP>((k + DEPTH) / NI, (k + DEPTH) % NI, u[k % DEPTH]);
+            consume(i, j, u[k % DEPTH], acc[i][j], T, s1[j], s2[j], d1[j], d2[j], bsc[j], bsh[j], bmu[j]);
+            if constexpr (k + DEPTH < NU) issue((k + DEPTH) / NI, (k + DEPTH) % NI, u[k % DEPTH]);
         });
     }
 
@@ -432,14 +470,14 @@ struct IgemmEpilogue {
     // row lanes and the M waves are added in a fixed order by thread c < BN
     __device__ __forceinline__ void row_stats(float* stats, int mt, float* smem, const f32x4 (&s1)[NI], const f32x4 (&s2)[NI]) const {
         if (!stats) return;
-        __syncthreads();                                   // (the transposition slices are dead)
+        epi_lds_barrier();                                 // (the transposition slices are dead)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int c = wn * WTN + j * 32 + cq;
             *reinterpret_cast<f32x4*>(smem + ((0 * WGM + wm) * 8 + rq) * BN + c) = s1[j];
             *reinterpret_cast<f32x4*>(smem + ((1 * WGM + wm) * 8 + rq) * BN + c) = s2[j];
         }
-        __syncthreads();
+        epi_lds_barrier();
         const int tid = threadIdx.x;
         if (tid < BN) {
             float t1 = 0.f, t2 = 0.f;
@@ -453,7 +491,7 @@ struct IgemmEpilogue {
     // BatchNorm-backward partial of this M tile -> part[blk][Cout][2] = (S1, invstd * S2), the same way in double
     __device__ __forceinline__ void row_bnr(double* part, const float* invstd, int blk, float* smem, const double (&d1)[NI][4], const double (&d2)[NI][4]) const {
         if (!bnr) return;
-        __syncthreads();
+        epi_lds_barrier();
         double* red = reinterpret_cast<double*>(smem);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -463,7 +501,7 @@ struct IgemmEpilogue {
                 red[((0 * WGM + wm) * 8 + rq) * BN + c] = d1[j][e];
                 red[((1 * WGM + wm) * 8 + rq) * BN + c] = d2[j][e];
             }
-        __syncthreads();
+        epi_lds_barrier();
         const int tid = threadIdx.x;
         if (tid < BN) {
             double t1 = 0.0, t2 = 0.0;
@@ -489,7 +527,7 @@ struct IgemmEpilogue {
         }
         f32x4 s1[NI], s2[NI];
         double d1[NI][4], d2[NI][4];
-        if (remap) run<true, PRE>(acc, smem, s1, s2, d1, d2); else run<false, PRE>(acc, smem, s1, s2, d1, d2);
+        run<PRE>(acc, smem, s1, s2, d1, d2);
         row_stats(p.stats, mt, smem, s1, s2);
         row_bnr(p.bnr_part, p.bnr_invstd, bnr_blk, smem, d1, d2);
     }

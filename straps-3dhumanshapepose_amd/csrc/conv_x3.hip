@@ -298,8 +298,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     if (q < nchunks) chunk(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
     }
 
-    // (a class without taps -- the dead parity classes of a 1x1 / stride-2 data gradient: dx = addend there -- never reaches a last chunk)
-    if (nchunks <= 0) ep.prefetch();
     ep.finish(p, c, acc, mt, p.bnr_base[blockIdx.y] + mt, smem);
     clk_end(p, clk);
 }
@@ -512,7 +510,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     }
     if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
 
-    if (nsteps <= 0) ep.prefetch();
     ep.finish(p, c, acc, mt, p.bnr_base[blockIdx.y] + mt, smem);
     clk_end(p, clk);
 }
