@@ -74,6 +74,14 @@ __device__ __forceinline__ void clk_end(const ConvP& p, const ClkSample& s) {
     }
 }
 
+// workgroup barrier for LDS hand-offs ONLY: __syncthreads() also drains the vector-memory counter (its release fence), i.e. it would wait for
+// loads requested ahead of their use and for every result store to be acknowledged by memory
+__device__ __forceinline__ void epi_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Epilogue of a BM x BN block tile held as 32x32 accumulator blocks by 2x2 waves (C layout: lane = output channel, reg = pixel
 // row): BN scale/shift, residual/addend, ReLU fused; returns the per-lane (sum, sum of squares) of the raw values for the
 // training-mode batch statistics.
@@ -226,37 +234,32 @@ __device__ __forceinline__ void igemm_store_rows_impl(const ConvP& p, const Conv
     if (full) rows(std::true_type{}); else rows(std::false_type{});
 }
 
-template <int BM, int BN, int WGM = 2, int WGN = 2>
-__device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&bd1)[BN / WGN / 32], const double (&bd2)[BN / WGN / 32], int blk, int n0, float* smem);
-template <int BM, int BN, int WGM = 2, int WGN = 2>
-__device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&s1)[BN / WGN / 32], const float (&s2)[BN / WGN / 32], int mt, int n0, float* smem);
-
-// ---- round 5: the look-ahead ROW epilogue ---------------------------------------------------------------------------------------------
+// ---- round 5: the look-ahead epilogue ------------------------------------------------------------------------------------------------
 // What the row-by-row epilogue above costs when it has memory OPERANDS (a data gradient's addend; the BatchNorm input `raw` and the ReLU
 // bits of the fused BatchNorm-backward sums): per 32-row block it fetches the addend rows, waits, then twice (fetch eight raw rows + eight
 // bit words, wait, compute, store) -- and because loads and stores retire through ONE in-order counter on this part, every wait behind a
 // batch of stores also waits for those stores to be acknowledged by memory.  Six dependent memory round trips per workgroup of a 128-row
 // tile, 1.5-2.5 us each under load, at the end of a main loop of 7-14 us, with two workgroups per CU to hide them: `dgrad+bn` launches
 // ran 16-54 us behind the forward convolution of the same FLOPs (190 vs 122 us on layer1's 64 -> 64 3x3, profiles/r04_bench_train_b64.json).
-// And every access of that form is 4 bytes per lane (the accumulator layout: lane = channel): the launches that are ALL epilogue -- resnet50's
-// 1x1 layers, K = 2-8 chunks -- moved their 200-450 MB at 2.4-3.0 TB/s where the streaming kernels of this library reach 5.
+// Here a UNIT is one 32x32 accumulator block (i, j) of a wave -- 16 elements per lane -- and its operands (16 addend values, 16 raw values,
+// one word of ReLU bits per operand tensor) are fetched AHEAD of their use: the first PF units before the matrix work of the last K chunk
+// (`prefetch()`, called by the kernels where no copy wait follows any more), unit k + DEPTH as soon as unit k is computed and stored.  No load
+// ever waits behind a store (a younger store does not hold back an older load in the in-order counter), and one round trip -- under the last
+// chunk's MFMAs -- is exposed instead of six.  Three details decide whether that works (each found in the ISA, round 5):
+//   * the loads of a unit sit in ONE straight-line block behind the integer work that finds its pixels: loads issued in the two arms of a
+//     branch (remapped class or not) are awaited where the arms meet, because their destination registers are merged there;
+//   * ONE prefetch site: a second one behind the loop (for classes without taps) merges two definitions of the same registers -- same wait;
+//   * the workgroup barriers of the epilogue are LDS-only (epi_lds_barrier): __syncthreads() drains the vector-memory counter too, i.e. it waits
+//     for the operands requested ahead and for every result store to be acknowledged.  Same arithmetic in the same order per lane as the row-by-row form: results are bit-identical
+// (tests/test_gpu_conv_x3.py::test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit runs the fp32-mask form -- still row by row -- against it
+// on every tile configuration).
 //
-// Two changes (the first measured alone: profiles/r05_epilogue_ab.txt, resnet18 step 8.57 -> 8.28 ms, resnet50 14.88 -> 14.24 ms):
-//  * LOOK-AHEAD.  A UNIT is one 32x32 accumulator block (i, j) of a wave and its operands are fetched AHEAD of their use: unit 0 before the
-//    matrix work of the last K chunk (`prefetch()`, called by the kernels where no copy wait follows any more), the others -- up to DEPTH
-//    in flight -- before unit 0 is computed and stored.  No load ever waits behind a store (a younger store does not hold back an older load
-//    in the in-order counter), and one round trip, partly under the last chunk's MFMAs, is exposed instead of six.
-//  * ROWS.  The unit's 32x32 values go through a per-wave LDS slice once (16 ds_write_b32 in the accumulator layout, 4 ds_read_b128 back):
-//    afterwards lane l holds FOUR CONSECUTIVE CHANNELS (l & 7) * 4 .. + 3 of rows (l >> 3) + 8 t, t = 0..3, and every global access of the
-//    epilogue -- addend, raw, the fp32 result -- is 16 bytes per lane, eight whole 128-byte lines per wave instruction; a row's word of ReLU
-//    bits is one broadcast load for its eight lanes.  The batch-statistics sums and the BatchNorm-backward sums are kept per lane for its four
-//    channels and combined over the eight row lanes and the M waves through LDS in a fixed order (igemm_row_stats / igemm_row_bnr below).
-// Every training-mode launch takes this path on every tile that lies inside the problem; a ragged last M tile, the eval-mode forms (folded
-// scale / shift, plane output) and the fp32-activation mask of the fused sums -- the A/B reference of the bit form -- keep the row-by-row form.
-// The sums are the same terms in another order than there (per lane over its rows, then lanes, then waves): fixed, so every launch of a shape
-// is bit-reproducible, but the double partials of the two forms agree to rounding (1e-13), not bit for bit; the gradient itself is bit-identical
-// (tests/test_gpu_conv_x3.py::test_relu_bits_forms_equal_the_fp32_mask_forms_bit_for_bit: the row form against the row-by-row form on every tile
-// configuration).
+// ReLU bits: the word of (pixel row, 32-channel group) is the same for the 32 lanes of a row.  The row-by-row form loads it once per (lane,
+// row): 16 broadcast loads and 16 registers per unit and operand.  Here lane q = l & 15 of each 16-lane DPP row loads the word of the block
+// row its HALF-wave will need as its q-th -- (q & 3) + 8 (q >> 2) + 4 (l >> 5), the accumulator layout's row order -- and element r reads it
+// with `v_mov_b32_dpp row_newbcast:r`: one load and one register per unit and operand.
+template <int R>
+__device__ __forceinline__ unsigned epi_row_word(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + R, 0xf, 0xf, false); }
 template <typename F, int... Rs>
 __device__ __forceinline__ void epi_for16(F&& f, std::integer_sequence<int, Rs...>) { (f(std::integral_constant<int, Rs>{}), ...); }
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): expanded by the front end (a `#pragma unroll` loop over units is NOT reliable
@@ -265,78 +268,85 @@ __device__ __forceinline__ void epi_for16(F&& f, std::integer_sequence<int, Rs..
 template <int N, typename F>
 __device__ __forceinline__ void epi_static_for(F&& f) { epi_for16(f, std::make_integer_sequence<int, N>{}); }
 
+__device__ __attribute__((aligned(16))) const float k_epi_consts[2] = {0.f, 1.f};      // stand-ins for absent per-channel tensors (IgemmEpilogue::constants)
+
 struct EpiUnit {
-    f32x4 rv[4];            // addend (p.res): rows (l >> 3) + 8 t, channels (l & 7) * 4 .. + 3
-    f32x4 xr[4];            // BatchNorm input (p.bnr_raw)
-    unsigned bw[4], rbw[4]; // the rows' words of ReLU bits (p.bnr_bits / p.res_bits)
+    float rv[16];       // addend (p.res) of the lane's 16 rows
+    float xr[16];       // BatchNorm input (p.bnr_raw)
+    unsigned bw, rbw;   // ReLU-bit words (p.bnr_bits / p.res_bits), one block row per lane of a DPP row (see above)
 };
-constexpr int EPI_TLD = 36;                          // floats per row of the transposition slice (32 + 4: 144-byte rows, 16-byte aligned)
-constexpr int EPI_TSLICE = 32 * EPI_TLD;             // floats per wave
 
-// workgroup barrier for LDS hand-offs ONLY: __syncthreads() also drains the vector-memory counter (its release fence), i.e. it would wait
-// for the operands requested ahead and for every result store to be acknowledged -- exactly the round trips this epilogue exists to avoid
-__device__ __forceinline__ void epi_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// DEPTH: units whose operands may be in flight at once (40 registers each).  init() copies the handful of wave-uniform values the epilogue needs
-// out of the kernel argument block (scalar registers): a reference to the 800-byte ConvP kept in a member, or captured by the per-row
-// lambdas, makes the compiler materialise the whole block in scratch.
-// (eight-wave workgroups share a SIMD's 512 registers between two waves: their four-unit tiles keep two units in flight)
-// PF: how many of them are requested under the last chunk's matrix work (the fragments of that chunk are still live there: one unit for the
-// eight-wave four-unit tile, all of them elsewhere)
+// DEPTH: units whose operands may be in flight at once (34 registers each); PF: how many of them are requested under the last chunk's matrix
+// work (the fragments of that chunk are still live there).  init() copies the handful of wave-uniform values the epilogue needs out of the
+// kernel argument block (scalar registers): a reference to the 800-byte ConvP kept in a member, or captured by the per-row lambdas, makes the
+// compiler materialise the whole block in scratch.
+// (eight-wave workgroups share a SIMD's 512 registers between two waves: their four-unit tiles keep two units in flight, one of them early)
 template <int BM, int BN, int WGM, int WGN, int DEPTH = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 2 : (BM / WGM / 32) * (BN / WGN / 32),
           int PF = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 1 : DEPTH>
 struct IgemmEpilogue {
     static constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32, NU = MI * NI;
     static_assert(DEPTH >= 1 && DEPTH <= NU && PF >= 1 && PF <= DEPTH, "look-ahead depth");
-    static_assert(WGM * WGN * EPI_TSLICE * 4 <= 40 * 1024 && WGM * 8 * BN * 2 * 8 <= 72 * 1024, "epilogue LDS use exceeds the smallest kernel's allocation");
-    int m0, n0, lane, wave, wm, wn, rq, cq;
+    int m0, n0, lane, wm, wn;
     bool look, full, remap, bnr;
     EpiUnit u[DEPTH];
+    float k_sc[NI], k_sh[NI], k_bsc[NI], k_bsh[NI], k_bmu[NI];      // per-channel constants of the lane's NI columns (constants())
     // wave-uniform copies (see above)
-    const float *g_raw, *g_res, *g_bsc, *g_bsh, *g_mean;
+    const float *g_raw, *g_res, *g_scale, *g_shift, *g_bsc, *g_bsh, *g_mean;
     const unsigned *g_bits, *g_rbits;
     float* g_y;
     int Cout, relu, OH, OW, omul, oah, oaw, cMh, cMw, cM;
 
     __device__ __forceinline__ void init(const ConvP& p, const ConvP::Class& c, int m0_, int n0_) {
-        const int tid = threadIdx.x;
-        wave = tid >> 6;
+        const int tid = threadIdx.x, wave = tid >> 6;
         m0 = m0_; n0 = n0_;
         lane = tid & 63; wm = wave / WGN; wn = wave % WGN;
-        rq = lane >> 3; cq = (lane & 7) * 4;
         bnr = p.bnr_raw != nullptr;
+        // the look-ahead form covers every launch that HAS memory operands, except: the fp32-activation mask of the BatchNorm sums (bnr_out: the
+        // A/B reference of the bit form) and the eval-mode plane output (yplanes), kept row by row; a ragged last M tile (one workgroup row of
+        // a launch at most), which keeps the row-by-row form with its per-row range tests; and a class without taps (the dead parity classes of a
+        // 1x1 / stride-2 data gradient: dx = addend there), which has no last chunk to prefetch under
         full = m0 + BM <= c.M;
-        // (the eval-mode forms -- folded scale / shift, plane output -- and the fp32-activation mask of the fused sums, the A/B reference of the
-        //  bit form, keep the row-by-row epilogue: every conditional load of this one sits in issue(), in straight-line code)
-        // (and a class without taps -- the dead parity classes of a 1x1 / stride-2 data gradient, dx = addend there -- which has no last chunk to
-        //  prefetch under: a second prefetch site behind the loop would merge two definitions of unit 0 and wait for the loads where they meet)
-        look = p.epi != 0 && p.yplanes == nullptr && p.y != nullptr && full && p.scale == nullptr && p.bnr_out == nullptr && c.ntaps > 0;
+        look = p.epi != 0 && (bnr || p.res != nullptr) && p.bnr_out == nullptr && p.yplanes == nullptr && p.y != nullptr && full && c.ntaps > 0;
         remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
-        g_raw = p.bnr_raw; g_res = p.res; g_bsc = p.bnr_sc; g_bsh = p.bnr_sh; g_mean = p.bnr_mean;
+        g_raw = p.bnr_raw; g_res = p.res; g_scale = p.scale; g_shift = p.shift; g_bsc = p.bnr_sc; g_bsh = p.bnr_sh; g_mean = p.bnr_mean;
         g_bits = p.bnr_bits; g_rbits = p.res_bits; g_y = p.y;
         Cout = p.Cout; relu = p.relu; OH = p.OH; OW = p.OW; omul = p.omul; oah = c.oah; oaw = c.oaw; cMh = c.Mh; cMw = c.Mw; cM = c.M;
     }
 
-    // physical output pixels of the lane's four rows (rq + 8 t) of block row i: a remapped class -- a parity class of a stride-2 data gradient --
-    // finds its first pixel by division and walks on eight logical rows at a time
-    __device__ __forceinline__ void pixels(int i, int (&pix)[4]) const {
-        const int mb = m0 + wm * WTM + i * 32 + rq;
+    // per-channel constants (folded scale / shift of the eval forms; mean and the recomputed mask's scale / shift of the fused sums).  Loads
+    // whose result would be merged with a literal where a flag is off are awaited at the merge: the POINTER is selected instead (a pair of
+    // constants stands in for the absent tensor) and every load is unconditional
+    __device__ __forceinline__ void constants() {
+        const float* one = k_epi_consts + 1;
+        const float* zero = k_epi_consts;
+        asm volatile("" : "+s"(one), "+s"(zero));          // (opaque: otherwise the selects fold back into branches around the loads)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+            k_sc[j] = *(g_scale ? g_scale + n : one);
+            k_sh[j] = *(g_shift ? g_shift + n : zero);
+            k_bsc[j] = *((bnr && !g_bits) ? g_bsc + n : zero);
+            k_bsh[j] = *((bnr && !g_bits) ? g_bsh + n : zero);
+            k_bmu[j] = *(bnr ? g_mean + n : zero);
+        }
+    }
+
+    // physical output pixels of the lane's 16 rows of block row i (rows m = mb + (r & 3) + 8 (r >> 2)).  A remapped class (a parity class of a
+    // stride-2 data gradient) finds the first pixel by division and walks on, as igemm_store_rows_impl does.  Integer work only.
+    __device__ __forceinline__ void pixels(int i, int (&pix)[16]) const {
+        const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
         if (!remap) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) pix[t] = mb + 8 * t;
+            for (int r = 0; r < 16; ++r) pix[r] = mb + (r & 3) + 8 * (r >> 2);
         } else {
             const int MhMw = cMh * cMw;
             int b_ = mb / MhMw;
             const int rem = mb - b_ * MhMw;
             int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                pix[t] = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
-                wo_ += 8;
+            for (int r = 0; r < 16; ++r) {
+                pix[r] = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
+                wo_ += (r & 3) == 3 ? 5 : 1;
                 while (wo_ >= cMw) {
                     wo_ -= cMw;
                     if (++ho_ == cMh) { ho_ = 0; ++b_; }
@@ -344,192 +354,104 @@ struct IgemmEpilogue {
             }
         }
     }
-    // the unit's operands: first the row offsets (integer work), then the loads, in ONE straight-line block: loads issued inside the two arms
-    // of a branch would be awaited where the arms meet (their destination registers are merged there)
+    // the unit's operands (full tiles only): the pixels first, then every load in one straight-line block
     __device__ __forceinline__ void issue(int i, int j, EpiUnit& un) const {
-        const int nb = n0 + wn * WTN + j * 32 + cq;
-        int pix[4];
+        const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+        int pix[16];
         pixels(i, pix);
-        const int wcol = (n0 + wn * WTN + j * 32) >> 5, wld = Cout >> 5;
+        int pixl = 0;
+        if (g_bits || g_rbits) {
+            // the block row whose bit words this lane fetches: the q-th row of its half-wave, q = lane & 15
+            const int q = lane & 15;
+            const int ml = m0 + wm * WTM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            pixl = ml;
+            if (remap) {
+                const int MhMw = cMh * cMw;
+                const int b_ = ml / MhMw, rem = ml - b_ * MhMw;
+                const int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
+                pixl = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
+            }
+        }
         if (bnr) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) un.xr[t] = *reinterpret_cast<const f32x4*>(g_raw + pix[t] * Cout + nb);
+            for (int r = 0; r < 16; ++r) un.xr[r] = g_raw[pix[r] * Cout + n];
         }
         if (g_res) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) un.rv[t] = *reinterpret_cast<const f32x4*>(g_res + pix[t] * Cout + nb);
+            for (int r = 0; r < 16; ++r) un.rv[r] = g_res[pix[r] * Cout + n];
         }
-        if (g_bits) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) un.bw[t] = g_bits[pix[t] * wld + wcol];
-        }
-        if (g_rbits) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) un.rbw[t] = g_rbits[pix[t] * wld + wcol];
-        }
+        const int wi = pixl * (Cout >> 5) + ((n0 + wn * WTN + j * 32) >> 5);
+        if (g_bits) un.bw = g_bits[wi];
+        if (g_rbits) un.rbw = g_rbits[wi];
     }
-    // the operands of the first DEPTH units, ahead of the last chunk's matrix work.  The kernels call this exactly once, where no copy wait
-    // follows (every later s_waitcnt vmcnt of the main loop would wait for these loads too), on a path peeled out of the chunk loop -- inside
-    // the loop the units' registers would be live across every iteration.  ALL of them here, not unit 0 alone: behind the loop the compiler
-    // drains the vector-memory counter once (it cannot see the hand-written waits that retired the LDS-DMA copies and protects the first LDS
-    // access of the epilogue), so whatever is requested later starts a second round trip.
+    // the operands of the first PF units, ahead of the last chunk's matrix work.  The kernels call this exactly once, where no copy wait follows
+    // (every later s_waitcnt vmcnt of the main loop would wait for these loads too), on a path peeled out of the chunk loop -- inside the loop
+    // the units' registers would be live across every iteration.
     __device__ __forceinline__ void prefetch() {
         if (!look) return;
+        constants();
         epi_static_for<PF>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             issue(k / NI, k % NI, u[k]);
         });
     }
 
-    // the unit's 32x32 values from the accumulator layout (lane = channel, register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) into the row
-    // layout, through this wave's LDS slice.  LDS operations of one wave execute in issue order: the compiler only has to keep them in
-    // program order (no fence: a fence would also drain the vector-memory counter, see epi_lds_barrier)
-    __device__ __forceinline__ void transpose(const f32x16& acc, float* T, f32x4 (&v)[4]) const {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_TLD + (lane & 31)] = acc[r];
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4*>(T + (rq + 8 * t) * EPI_TLD + cq);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the slice is rewritten by the next unit: its reads have returned)
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    __device__ __forceinline__ void consume(int i, int j, const EpiUnit& un, const f32x16& acc, float* T, f32x4& s1, f32x4& s2, double (&d1)[4], double (&d2)[4],
-                                            const f32x4& bsc, const f32x4& bsh, const f32x4& bmu) const {
-        f32x4 v[4];
-        transpose(acc, T, v);
-        const int nb = n0 + wn * WTN + j * 32 + cq;
-        int pix[4];
+    __device__ __forceinline__ void consume(int i, int j, const EpiUnit& un, const f32x16& acc, float& s1, float& s2, double& d1, double& d2,
+                                            float sc, float sh, float bsc, float bsh, float bmu) const {
+        const int cl = lane & 31;
+        const int n = n0 + wn * WTN + j * 32 + cl;
+        int pix[16];
         pixels(i, pix);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[t][e];
-                s1[e] += x;
-                s2[e] = fmaf(x, x, s2[e]);
-                if (g_res) {
-                    float a = un.rv[t][e];
-                    if (g_rbits) a = ((un.rbw[t] >> (cq + e)) & 1u) ? a : 0.f;
-                    x += a;
-                }
-                if (relu) x = fmaxf(x, 0.f);
-                if (bnr) {
-                    const bool on = g_bits ? (((un.bw[t] >> (cq + e)) & 1u) != 0) : fmaf(un.xr[t][e], bsc[e], bsh[e]) > 0.f;
-                    const float g = on ? x : 0.f;
-                    d1[e] += (double)g;
-                    d2[e] += (double)g * ((double)un.xr[t][e] - (double)bmu[e]);
-                }
-                o[e] = x;
+        epi_static_for<16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            float v = acc[r];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+            if (g_scale) v = fmaf(v, sc, sh);
+            if (g_res) {
+                float a = un.rv[r];
+                if (g_rbits) a = ((epi_row_word<r>(un.rbw) >> cl) & 1u) ? a : 0.f;
+                v += a;
             }
-            *reinterpret_cast<f32x4*>(g_y + pix[t] * Cout + nb) = o;
-        }
+            if (relu) v = fmaxf(v, 0.f);
+            if (bnr) {
+                const bool on = g_bits ? (((epi_row_word<r>(un.bw) >> cl) & 1u) != 0) : fmaf(un.xr[r], bsc, bsh) > 0.f;
+                const float g = on ? v : 0.f;
+                d1 += (double)g;
+                d2 += (double)g * ((double)un.xr[r] - (double)bmu);
+            }
+            g_y[pix[r] * Cout + n] = v;
+        });
     }
 
-    // PRE: prefetch() has run (units 0 .. DEPTH - 1 are in flight)
+    // PRE: prefetch() has run (units 0 .. PF - 1 are in flight)
     template <bool PRE>
-    __device__ __forceinline__ void run(const f32x16 (&acc)[MI][NI], float* smem, f32x4 (&s1)[NI], f32x4 (&s2)[NI], double (&d1)[NI][4], double (&d2)[NI][4]) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            s1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[j] = s1[j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { d1[j][e] = 0.0; d2[j][e] = 0.0; }
-        }
-        // per-channel constants of the fused sums (mean; scale / shift of the recomputed mask): loaded here, in front of everything that waits
-        f32x4 bsc[NI], bsh[NI], bmu[NI];
-        if (bnr) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bmu[j] = *reinterpret_cast<const f32x4*>(g_mean + n0 + wn * WTN + j * 32 + cq);
-            if (!g_bits) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    bsc[j] = *reinterpret_cast<const f32x4*>(g_bsc + n0 + wn * WTN + j * 32 + cq);
-                    bsh[j] = *reinterpret_cast<const f32x4*>(g_bsh + n0 + wn * WTN + j * 32 + cq);
-                }
-            }
-        }
-        // units 0 .. DEPTH - 1 are in flight; unit k + DEPTH is requested as soon as unit k's registers are free (slot k % DEPTH): every load
-        // is issued in front of the stores of the units before it, none behind a store it would have to wait for
+    __device__ __forceinline__ void run(const f32x16 (&acc)[MI][NI], float (&s1)[NI], float (&s2)[NI], double (&d1)[NI], double (&d2)[NI]) {
+        // the rest of the first DEPTH units; afterwards unit k + DEPTH is requested as soon as unit k's registers are free (slot k % DEPTH): every
+        // load is issued in front of the stores of the units before it, none behind a store it would have to wait for
         epi_static_for<DEPTH - (PRE ? PF : 0)>([&](auto kc) {
             constexpr int k = decltype(kc)::value + (PRE ? PF : 0);
             issue(k / NI, k % NI, u[k]);
         });
-        epi_lds_barrier();                                 // every wave is done with the last chunk's fragment reads: LDS is free
-        float* T = smem + wave * EPI_TSLICE;
+        if constexpr (!PRE) constants();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { s1[j] = 0.f; s2[j] = 0.f; d1[j] = 0.0; d2[j] = 0.0; }
         epi_static_for<NU>([&](auto kc) {
             constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
-            consume(i, j, u[k % DEPTH], acc[i][j], T, s1[j], s2[j], d1[j], d2[j], bsc[j], bsh[j], bmu[j]);
+            consume(i, j, u[k % DEPTH], acc[i][j], s1[j], s2[j], d1[j], d2[j], k_sc[j], k_sh[j], k_bsc[j], k_bsh[j], k_bmu[j]);
             if constexpr (k + DEPTH < NU) issue((k + DEPTH) / NI, (k + DEPTH) % NI, u[k % DEPTH]);
         });
     }
 
-    // per-channel (sum, sum of squares) partials of this M tile -> stats[mt][Cout][2]: lane (rq, cq) holds them for its four channels; the eight
-    // row lanes and the M waves are added in a fixed order by thread c < BN
-    __device__ __forceinline__ void row_stats(float* stats, int mt, float* smem, const f32x4 (&s1)[NI], const f32x4 (&s2)[NI]) const {
-        if (!stats) return;
-        epi_lds_barrier();                                 // (the transposition slices are dead)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int c = wn * WTN + j * 32 + cq;
-            *reinterpret_cast<f32x4*>(smem + ((0 * WGM + wm) * 8 + rq) * BN + c) = s1[j];
-            *reinterpret_cast<f32x4*>(smem + ((1 * WGM + wm) * 8 + rq) * BN + c) = s2[j];
-        }
-        epi_lds_barrier();
-        const int tid = threadIdx.x;
-        if (tid < BN) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM * 8; ++w) { t1 += smem[w * BN + tid]; t2 += smem[(WGM * 8 + w) * BN + tid]; }
-            float* o = stats + ((long long)mt * Cout + n0 + tid) * 2;
-            o[0] = t1;
-            o[1] = t2;
-        }
-    }
-    // BatchNorm-backward partial of this M tile -> part[blk][Cout][2] = (S1, invstd * S2), the same way in double
-    __device__ __forceinline__ void row_bnr(double* part, const float* invstd, int blk, float* smem, const double (&d1)[NI][4], const double (&d2)[NI][4]) const {
-        if (!bnr) return;
-        epi_lds_barrier();
-        double* red = reinterpret_cast<double*>(smem);
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = wn * WTN + j * 32 + cq + e;
-                red[((0 * WGM + wm) * 8 + rq) * BN + c] = d1[j][e];
-                red[((1 * WGM + wm) * 8 + rq) * BN + c] = d2[j][e];
-            }
-        epi_lds_barrier();
-        const int tid = threadIdx.x;
-        if (tid < BN) {
-            double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-            for (int w = 0; w < WGM * 8; ++w) { t1 += red[w * BN + tid]; t2 += red[(WGM * 8 + w) * BN + tid]; }
-            double* o = part + ((long long)blk * Cout + n0 + tid) * 2;
-            o[0] = t1;
-            o[1] = t2 * (double)invstd[n0 + tid];
-        }
-    }
-
-    // the whole epilogue of the tile: rows, batch-statistics partial, BatchNorm-backward partial -- look-ahead row form where it applies, else
-    // the row-by-row form of rounds 1-4
+    // the whole epilogue of the tile's rows: look-ahead form where it applies, else the row-by-row form
     template <bool PRE = true>
-    __device__ __forceinline__ void finish(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[MI][NI], int mt, int bnr_blk, float* smem) {
+    __device__ __forceinline__ void finish(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[MI][NI], float (&s1)[NI], float (&s2)[NI],
+                                           double (&d1)[NI], double (&d2)[NI]) {
         if (!look) {
-            float s1[NI], s2[NI];
-            double bd1[NI], bd2[NI];
-            igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, bd1, bd2);
-            igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
-            igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, bnr_blk, n0, smem);
+            igemm_store_rows_impl<BM, BN, WGM, WGN, true>(p, c, acc, m0, n0, s1, s2, d1, d2);
             return;
         }
-        f32x4 s1[NI], s2[NI];
-        double d1[NI][4], d2[NI][4];
-        run<PRE>(acc, smem, s1, s2, d1, d2);
-        row_stats(p.stats, mt, smem, s1, s2);
-        row_bnr(p.bnr_part, p.bnr_invstd, bnr_blk, smem, d1, d2);
+        run<PRE>(acc, s1, s2, d1, d2);
     }
 };
 
@@ -541,14 +463,14 @@ __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Cl
 }
 
 // BatchNorm-backward partial of one M tile -> bnr_part[blk][Cout][2] = (S1, invstd * S2), summed in a fixed order
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&bd1)[BN / WGN / 32], const double (&bd2)[BN / WGN / 32], int blk, int n0,
                                                 float* smem) {
     constexpr int WTN = BN / WGN, NI = WTN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     if (!p.bnr_raw) return;
-    __syncthreads();   // all fragment reads of the last chunk are done: LDS is free
+    epi_lds_barrier();   // all fragment reads of the last chunk are done: LDS is free
     double* red = reinterpret_cast<double*>(smem);   // [WGM (wm)][BN][2]
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -560,7 +482,7 @@ __device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&b
             red[(wm * BN + c) * 2 + 1] = u2;
         }
     }
-    __syncthreads();
+    epi_lds_barrier();
     if (tid < BN) {
         double t1 = red[tid * 2 + 0], t2 = red[tid * 2 + 1];
 #pragma unroll
@@ -572,14 +494,14 @@ __device__ __forceinline__ void igemm_store_bnr(const ConvP& p, const double (&b
 }
 
 // per-channel (sum, sum of squares) partials of one M tile -> stats[mt][Cout][2]
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&s1)[BN / WGN / 32], const float (&s2)[BN / WGN / 32], int mt, int n0, float* smem) {
     constexpr int WTN = BN / WGN, NI = WTN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     if (p.stats) {
         // lanes l and l+32 hold the same channel; the M-waves are combined through LDS
-        __syncthreads();   // all fragment reads of the last chunk are done: LDS is free
+        epi_lds_barrier();   // all fragment reads of the last chunk are done: LDS is free
         float* red = smem;   // [WGM (wm)][BN][2]
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -591,7 +513,7 @@ __device__ __forceinline__ void igemm_store_stats(const ConvP& p, const float (&
                 red[(wm * BN + c) * 2 + 1] = u2;
             }
         }
-        __syncthreads();
+        epi_lds_barrier();
         if (tid < BN) {
             float* o = p.stats + ((long long)mt * p.Cout + n0 + tid) * 2;
             float t1 = red[tid * 2 + 0], t2 = red[tid * 2 + 1];

@@ -298,7 +298,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
     if (q < nchunks) chunk(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
     }
 
-    ep.finish(p, c, acc, mt, p.bnr_base[blockIdx.y] + mt, smem);
+    float s1[NI], s2[NI];
+    double bd1[NI], bd2[NI];
+    ep.finish(p, c, acc, s1, s2, bd1, bd2);
+    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
     clk_end(p, clk);
 }
 
@@ -510,7 +514,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
     }
     if (q < nsteps) step(stage, nstage, std::false_type{}, std::integral_constant<int, 0>{}, std::true_type{});
 
-    ep.finish(p, c, acc, mt, p.bnr_base[blockIdx.y] + mt, smem);
+    float s1[NI], s2[NI];
+    double bd1[NI], bd2[NI];
+    ep.finish(p, c, acc, s1, s2, bd1, bd2);
+    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
     clk_end(p, clk);
 }
 
@@ -626,14 +634,7 @@ int dispatch_x3_abl(const ConvP& p, int cfg, hipStream_t st) {
     }
 }
 
-int dispatch_x3(const ConvP& p0, int tile_cfg, hipStream_t st) {
-    ConvP p = p0;
-    // the row epilogue (conv_igemm.h) moves 16 bytes per lane: every tensor it touches must be 16-byte aligned (torch allocations are;
-    // a caller's odd view falls back to the row-by-row form, 4 bytes per lane)
-    if ((reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.res) | reinterpret_cast<uintptr_t>(p.bnr_raw) | reinterpret_cast<uintptr_t>(p.bnr_out) |
-         reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift) | reinterpret_cast<uintptr_t>(p.bnr_sc) | reinterpret_cast<uintptr_t>(p.bnr_sh) |
-         reinterpret_cast<uintptr_t>(p.bnr_mean)) & 15)
-        p.epi = 0;
+int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
     int bm, bn, kdim = 0;
     long long M = 0;
     for (int i = 0; i < p.ncls; ++i) {
