@@ -270,6 +270,9 @@ __device__ __forceinline__ void epi_static_for(F&& f) { epi_for16(f, std::make_i
 
 __device__ __attribute__((aligned(16))) const float k_epi_consts[2] = {0.f, 1.f};      // stand-ins for absent per-channel tensors (IgemmEpilogue::constants)
 
+#ifndef STRAPS_EPI_PF8
+#define STRAPS_EPI_PF8 1
+#endif
 struct EpiUnit {
     float rv[16];       // addend (p.res) of the lane's 16 rows
     float xr[16];       // BatchNorm input (p.bnr_raw)
@@ -282,7 +285,7 @@ struct EpiUnit {
 // compiler materialise the whole block in scratch.
 // (eight-wave workgroups share a SIMD's 512 registers between two waves: their four-unit tiles keep two units in flight, one of them early)
 template <int BM, int BN, int WGM, int WGN, int DEPTH = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 2 : (BM / WGM / 32) * (BN / WGN / 32),
-          int PF = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? 1 : DEPTH>
+          int PF = (WGM * WGN >= 8 && (BM / WGM / 32) * (BN / WGN / 32) > 2) ? STRAPS_EPI_PF8 : DEPTH>
 struct IgemmEpilogue {
     static constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32, NU = MI * NI;
     static_assert(DEPTH >= 1 && DEPTH <= NU && PF >= 1 && PF <= DEPTH, "look-ahead depth");
