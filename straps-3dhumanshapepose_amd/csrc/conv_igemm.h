@@ -392,7 +392,7 @@ struct IgemmEpilogue {
     // the units' registers would be live across every iteration.
     __device__ __forceinline__ void prefetch() {
         if (!look) return;
-        constants();
+        if constexpr (PF == DEPTH) constants();      // (the eight-wave four-unit tile has no registers to spare under its last chunk: it loads them behind the loop)
         epi_static_for<PF>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             issue(k / NI, k % NI, u[k]);
@@ -436,7 +436,7 @@ struct IgemmEpilogue {
             constexpr int k = decltype(kc)::value + (PRE ? PF : 0);
             issue(k / NI, k % NI, u[k]);
         });
-        if constexpr (!PRE) constants();
+        if constexpr (!PRE || PF != DEPTH) constants();
 #pragma unroll
         for (int j = 0; j < NI; ++j) { s1[j] = 0.f; s2[j] = 0.f; d1[j] = 0.0; d2[j] = 0.0; }
         epi_static_for<NU>([&](auto kc) {
