@@ -675,6 +675,9 @@ def main():
                     roof = {'bound': 'hbm', 'kernel': dominant, 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm['frac'],
                             'traffic': None, 'traffic_measured_in_run': False, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
                             'algorithmic_bytes_per_launch': B * per_body,
+                            # (`frac` divides by the kernels' own HIP-event time, `value` by the step time -- both here)
+                            'frac_by_step_time': round(B * per_body / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                            'achieved_by_step_time': round(B * per_body / (elapsed / args.steps) / 1e9, 1),
                             'mfma_side': {'pipe': 'fp16 MFMA, fp32 accumulate (split products)', 'issued': round(issued / secs / 1e12, 1), 'peak': 2500.0,
                                           'unit': 'TFLOP/s', 'frac': round(issued / secs / 1e12 / 2500.0, 4),
                                           'fp32_equivalent_tflops': round(ach, 2)}}

@@ -1,6 +1,6 @@
 """GPU: the gradient exchange on RCCL itself, as far as ONE GPU allows.
 
-gloo's blocking CPU collectives (tests/test_distributed_cpu.py, tests/test_gpu_00_two_ranks.py) prove the arithmetic of the exchange, not
+gloo's blocking CPU collectives (tests/test_distributed_cpu.py, tests/test_gpu_two_ranks.py) prove the arithmetic of the exchange, not
 its stream semantics.  Here the real thing runs, with a world of one rank (an all-reduce over one rank is the identity, but every call
 is a real RCCL call on RCCL's / the exchange's own stream):
   * the C-ABI exchange of include/straps_hip.h (straps_comm_* / straps_allreduce_grads) on its own;

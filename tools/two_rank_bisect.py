@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/two_rank_bisect.py -- tests/test_gpu_00_two_ranks.py::test_two_ranks_stay_in_sync_and_overlap_changes_nothing with the round's switches
+"""tools/two_rank_bisect.py -- tests/test_gpu_two_ranks.py::test_two_ranks_stay_in_sync_and_overlap_changes_nothing with the round's switches
 flipped through the environment (TWO_RANK_NO_BITS=1, TWO_RANK_TWO_PASS_PROXY=1, TWO_RANK_STEPS=n): eager vs split-graph + overlapped exchange."""
 import os
 import sys
