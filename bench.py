@@ -382,7 +382,6 @@ def main():
     ap.add_argument('--exchange-backend', default='torch', choices=['torch', 'rccl'],
                     help="gradient exchange through torch.distributed ('torch': the nccl backend == RCCL) or through the library's own C ABI "
                          "('rccl': straps_comm_* / straps_allreduce_grads on a dedicated stream)")
-    ap.add_argument('--no-pack-overlap', action='store_true', help='A/B: the per-step weight re-pack on the main stream in front of the stem (rounds 1-4) instead of beside it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
@@ -474,7 +473,7 @@ def main():
             ['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D'],
             init_loss_weights={'verts': 1.0, 'joints2D': 0.1, 'pose_params': 0.1, 'shape_params': 0.1, 'joints3D': 1.0}).to(dev)
         ts = TrainStep(reg, smpl, crit, B, lr=1e-4, rank=rank, world_size=world, seed=1234, mean_shape=mp['shape'], use_graph=not args.no_graph, overlap_wgrad=args.overlap_wgrad and not args.no_overlap,
-                       global_masked_mean=args.global_masked_mean, force_exchange=args.force_exchange, exchange_backend=args.exchange_backend, pack_overlap=not args.no_pack_overlap)
+                       global_masked_mean=args.global_masked_mean, force_exchange=args.force_exchange, exchange_backend=args.exchange_backend)
         step = ts.step
         workload = '%s: full synthetic OTF training step (augmentation + proxy construction + forward + multi-task loss ' \
                    '+ backward + Adam), %s, 18x256x256 proxy' % ('configs[3] per-GPU shape' if args.layers == 50 else 'configs[2]', net)
@@ -562,7 +561,6 @@ def main():
         if args.workload == 'train':
             ts.use_graph = False
             ts.side_stream = None          # one stream: kernels run back to back, so each event pair times ONE kernel alone
-            ts.pack_stream = None          # (... the weight re-pack too)
             ts.pipeline = False            # (and no next-batch generation running beside the timed kernels)
         step()
         torch.cuda.synchronize()

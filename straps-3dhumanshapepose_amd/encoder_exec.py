@@ -201,12 +201,10 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, kee
     return out, Ho, Wo
 
 
-def encoder_forward(net, x, tape=None, nzmask=None, before_stages=None):
+def encoder_forward(net, x, tape=None, nzmask=None):
     """net: resnet.ResNet; x: float32 [B,C,H,W] NCHW on the GPU.  Returns features [B, 512|2048].
     nzmask: optional non-zero map of x already computed by straps_stem_nzmask (the training step's data pipeline makes it next to
-    the input, off the critical path).
-    before_stages: optional callable run between the stem (+ pooling) and the first residual unit -- the first point at which the packed
-    convolution weights are read (the training step joins the stream that re-packs them there)."""
+    the input, off the critical path)."""
     hipabi.require_gpu_tensor(x, 'encoder input', torch.float32)
     if x.dim() != 4 or x.shape[1] != net.in_channels:
         raise RuntimeError('encoder expects [B,%d,H,W], got %s' % (net.in_channels, tuple(x.shape)))
@@ -216,7 +214,6 @@ def encoder_forward(net, x, tape=None, nzmask=None, before_stages=None):
     ctx = _Ctx(x.device, net.training, tape)
     ctx.net = net
     ctx.x3 = getattr(net, 'conv_precision', 'fp32') == 'bf16x3'
-    ctx.before_stages = before_stages
     if net.training:
         net._bn_epoch = getattr(net, '_bn_epoch', 0) + 1      # running statistics are about to change: folded-BN cache entries expire
     ctx.defer_nbt = getattr(net, '_nbt_flat', None) is not None
@@ -288,8 +285,6 @@ def encoder_forward(net, x, tape=None, nzmask=None, before_stages=None):
 
 def _residual_stages(ctx, net, y, B, H, W, tape):
     L = ctx.L
-    if getattr(ctx, 'before_stages', None) is not None:
-        ctx.before_stages()
     # ---- residual stages (:150-156) ----
     for li in range(1, 5):
         for unit in getattr(net, 'layer%d' % li):

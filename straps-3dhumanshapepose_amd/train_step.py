@@ -187,11 +187,8 @@ class TrainStep:
                  mean_shape=None, mean_cam_t=(0., 0.2, 42.), pose_pool=None, use_graph=False, overlap_wgrad=False,
                  renderer=None, track_metrics=False, comm_overlap=None, pipeline_data=True, smpl_augment_params=None,
                  cam_augment_params=None, bbox_augment_params=None, proxy_rep_augment_params=None, global_masked_mean=False,
-                 force_exchange=False, exchange_backend='torch', pack_overlap=True):
-        """pack_overlap (round 5): the per-step re-pack of every non-stem convolution weight (one batched launch, 75-150 us) runs on a stream of
-        its own beside the stem convolution -- which does not read those weights -- and is joined in front of the first residual unit; same
-        kernels, same results (A/B: bench.py --no-pack-overlap).
-        force_exchange / exchange_backend: see GradientExchange (force: run the exchange even when world_size == 1; backend 'rccl' = the
+                 force_exchange=False, exchange_backend='torch'):
+        """force_exchange / exchange_backend: see GradientExchange (force: run the exchange even when world_size == 1; backend 'rccl' = the
         library's own C-ABI all-reduce on a dedicated stream instead of torch.distributed).
         global_masked_mean (data parallel only; default off = the average of per-rank masked means): the joints2D task
         becomes the masked mean over the GLOBAL batch -- one extra 1-float sum all-reduce per step (each rank's visible-joint count,
@@ -205,7 +202,6 @@ class TrainStep:
                                'through the HIP library (no CPU fallback)')
         self.dev = p0.device
         self._force_exchange, self._exchange_backend = bool(force_exchange), exchange_backend
-        self.pack_stream = torch.cuda.Stream(device=self.dev) if pack_overlap else None
         with torch.cuda.device(self.dev):
             self._init(regressor, smpl, criterion, batch_size, lr, rank, world_size, seed, group, mean_shape, mean_cam_t, pose_pool, use_graph,
                        overlap_wgrad, renderer, track_metrics, comm_overlap, pipeline_data, smpl_augment_params, cam_augment_params,
@@ -437,20 +433,11 @@ class TrainStep:
         assert reg.training, 'TrainStep needs the regressor in .train() mode'
         hipabi.check(L.straps_memset_zero(hipabi.ptr(self.flat_g), self.flat_g.numel() * 4, st), 'straps_memset_zero(flat gradient)')
         enc_tape, ief_tape = {}, []
-        # every conv's forward + data-gradient weight layout, one launch -- beside the stem, which reads none of them (pack_overlap)
-        join_pack = None
-        if self.pack_stream is not None:
-            main = torch.cuda.current_stream()
-            self.pack_stream.wait_stream(main)                # (the weights were written by the last Adam launch on this stream)
-            with torch.cuda.stream(self.pack_stream):
-                reg.image_encoder.prepack(with_dgrad=True)
-            join_pack = lambda: main.wait_stream(self.pack_stream)
-        else:
-            reg.image_encoder.prepack(with_dgrad=True)
+        reg.image_encoder.prepack(with_dgrad=True)          # every conv's forward + data-gradient weight layout, one launch
         if self.nbt_flat is not None:
             # num_batches_tracked of every BatchNorm, one launch (encoder_exec defers to this)
             hipabi.check(L.straps_counter_add(hipabi.ptr(self.nbt_flat), self.nbt_flat.numel(), 1, st), 'straps_counter_add(num_batches_tracked)')
-        feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape, nzmask=batch.get('nzmask'), before_stages=join_pack)
+        feat = encoder_forward(reg.image_encoder, batch['input'], enc_tape, nzmask=batch.get('nzmask'))
         est = reg.ief_module.forward_estimate(feat, ief_tape)                      # [B,160]
         pose6d = est[:, 3:147]
         R = torch.empty(B, 24, 3, 3, device=d)

@@ -358,24 +358,6 @@ def test_last_outputs_follow_the_replayed_graph_parity():
     assert ts._last_by_parity[0]['verts'].data_ptr() != ts._last_by_parity[1]['verts'].data_ptr()
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
-def test_weight_repack_beside_the_stem_changes_nothing(use_graph):
-    """TrainStep(pack_overlap=True), the default since round 5: the per-step re-pack of the convolution weights runs on a stream of its own beside
-    the stem convolution and is joined in front of the first residual unit.  Same kernels on the same data: losses and parameters after six steps
-    equal the in-line form bit for bit, eagerly and under hipGraph replay (the fork / join is then part of the captured graph)."""
-    B = 4
-    outs = []
-    for overlap in (True, False):
-        dev, reg, smpl, crit = _setup(B, seed=6, conv_precision='bf16x3')
-        ts = TrainStep(reg, smpl, crit, B, lr=1e-3, mean_shape=MP['shape'], use_graph=use_graph, pack_overlap=overlap)
-        losses = [ts.step()[0:1].clone() for _ in range(6)]
-        torch.cuda.synchronize()
-        assert (ts.pack_stream is not None) == overlap and (ts.graph is not None) == use_graph
-        outs.append((torch.cat(losses).cpu(), ts.flat_p.clone().cpu(), ts.exp_avg.clone().cpu()))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-
-
 def test_set_data_state_with_captured_graphs_recaptures():
     """re-seating the data stream after the hipGraphs were captured drops them (they would consume the batch that was in flight)
     and the run continues exactly like an uninterrupted one."""
