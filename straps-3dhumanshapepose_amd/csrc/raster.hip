@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void lds_occupier_kernel(int microseconds, uns
 namespace {
 typedef __bf16 tool_bf16x8 __attribute__((ext_vector_type(8)));
 template <int MFMA>
-__global__ __launch_bounds__(256) void lds_frag_reader_kernel(unsigned* __restrict__ sink, int trips) {
+__device__ __forceinline__ void lds_frag_reader_body(unsigned* __restrict__ sink, int trips) {
     extern __shared__ __attribute__((aligned(16))) unsigned fr_lds[];      // 147 KB = 3 stages x 3 planes x (128 + 128) rows x 64 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 147 * 256; i += 256) fr_lds[i] = 0x3f803f80u ^ (unsigned)(i * 2654435761u >> 20);
@@ -272,7 +272,15 @@ __global__ __launch_bounds__(256) void lds_frag_reader_kernel(unsigned* __restri
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
     unsigned acc = 0;
     int stage = 0;
+    // MFMA == 2: the convolution kernel's register footprint as well -- 200 more registers kept live across the loop (no instruction touches
+    // them: the empty asm only pins them; the kernel may use all 512 registers), so that ONE wave per SIMD fits and registers spill over into AGPRs, as in the 128x128 kernel
+    float keep[MFMA == 2 ? 230 : 1];
+    for (int q = 0; q < (MFMA == 2 ? 230 : 1); ++q) keep[q] = (float)(lane + q);
     for (int t = 0; t < trips; ++t) {
+        if (MFMA == 2) {
+#pragma unroll
+            for (int q = 0; q < (MFMA == 2 ? 230 : 1); ++q) asm volatile("" : "+v"(keep[q]));
+        }
         const unsigned short* Ab = As + (stage * 3 * 256 + wm * 64) * 32;
         const unsigned short* Bb = As + (stage * 3 * 256 + 128 + wn * 64) * 32;
 #pragma unroll
@@ -307,12 +315,21 @@ __global__ __launch_bounds__(256) void lds_frag_reader_kernel(unsigned* __restri
         __builtin_amdgcn_s_barrier();
     }
     if (MFMA) acc += (unsigned)(c[0][0][0] + c[0][1][5] + c[1][0][15] + c[1][1][7] == 12345.678f);
+    if (MFMA == 2) { float sum = 0.f; for (int q = 0; q < 230; ++q) sum += keep[q]; acc += (unsigned)(sum == 12345.678f); }
     if (acc == 0x12345678u) sink[blockIdx.x] = acc;
+}
+template <int MFMA>
+__global__ __launch_bounds__(256) void lds_frag_reader_kernel(unsigned* __restrict__ sink, int trips) { lds_frag_reader_body<MFMA>(sink, trips); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lds_frag_reader_big_kernel(unsigned* __restrict__ sink, int trips) {
+    lds_frag_reader_body<2>(sink, trips);
 }
 }  // namespace
 extern "C" int straps_tool_lds_frag_reader(int mfma, int trips, int blocks, unsigned* sink, void* stream) {
     STRAPS_REQUIRE(trips > 0 && blocks > 0 && sink, "straps_tool_lds_frag_reader: bad arguments");
-    if (mfma) {
+    if (mfma == 2) {
+        STRAPS_RAISE_LDS(lds_frag_reader_big_kernel, 147 * 1024, "lds_frag_reader_big_kernel");
+        hipLaunchKernelGGL(lds_frag_reader_big_kernel, dim3(blocks), dim3(256), 147 * 1024, (hipStream_t)stream, sink, trips);
+    } else if (mfma) {
         STRAPS_RAISE_LDS(lds_frag_reader_kernel<1>, 147 * 1024, "lds_frag_reader_kernel");
         hipLaunchKernelGGL(lds_frag_reader_kernel<1>, dim3(blocks), dim3(256), 147 * 1024, (hipStream_t)stream, sink, trips);
     } else {

@@ -118,7 +118,7 @@ worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.envi
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
 other = os.environ.get('PROBE_LOAD', '1')
 lgraph = None
-if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum'):
+if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fragregs'):
     rend2 = NMRRenderer(8, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(dev)
     v2, _ = smpl.forward_arrays(torch.randn(8, 10, generator=g).to(dev), straps_amd.batch_rodrigues((torch.randn(8, 72, generator=g) * 0.4).to(dev).view(-1, 3)).view(8, 24, 3, 3).contiguous())
     ct2 = torch.tensor([0., 0.2, 42.], device=dev).expand(8, 3).contiguous()
@@ -148,19 +148,20 @@ if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum'):
         occ_sink = torch.zeros(4, device=dev, dtype=torch.int32)
         occ_kb = int(os.environ.get('PROBE_OCCUPY_KB', '147'))
 
-    if other in ('frag', 'fragsum'):
+    if other in ('frag', 'fragsum', 'fragregs'):
         import ctypes
         tl = ctypes.CDLL(hipabi.TOOLS_LIB_PATH)
         tl.straps_tool_lds_frag_reader.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         occ_sink = torch.zeros(4096, device=dev, dtype=torch.int32)
 
     def load_body():
-        if other in ('frag', 'fragsum'):
+        if other in ('frag', 'fragsum', 'fragregs'):
+            # (fragregs: + the convolution kernel's register footprint, 200 registers pinned: one wave per SIMD, accumulators in AGPRs)
             # (the convolution kernels' fragment reads alone, tools build: one 147 KB workgroup per CU, ~0.3 ms per launch)
             # PROBE_FRAG_TRIPS / PROBE_FRAG_BLOCKS: chunks per workgroup and workgroups per launch (400 x 256: one long-lived workgroup per CU;
             # 12 x 4096: short-lived ones, sixteen generations per CU and launch -- the convolution kernels' churn of LDS allocations)
             for _ in range(3):
-                rc = tl.straps_tool_lds_frag_reader(1 if other == 'frag' else 0, int(os.environ.get('PROBE_FRAG_TRIPS', '400')), int(os.environ.get('PROBE_FRAG_BLOCKS', '256')),
+                rc = tl.straps_tool_lds_frag_reader({'frag': 1, 'fragsum': 0, 'fragregs': 2}[other], int(os.environ.get('PROBE_FRAG_TRIPS', '400')), int(os.environ.get('PROBE_FRAG_BLOCKS', '256')),
                                                     occ_sink.data_ptr(), hipabi.stream_ptr())
                 assert rc == 0, L.straps_last_error()
         elif other == 'occupy':
