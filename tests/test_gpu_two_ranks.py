@@ -94,7 +94,22 @@ def _first_difference(ref, got):
     return None
 
 
+# TWO_RANK_REPEAT=n (environment, default 1): each comparison below is made n times -- the failure this file exists to catch showed up in one of seven
+# whole-suite runs of round 5 and never when the file ran alone; a hunt raises n instead of re-running the suite
+_REPEAT = int(os.environ.get('TWO_RANK_REPEAT', '1'))
+
+
 def test_two_ranks_stay_in_sync_and_overlap_changes_nothing():
+    for attempt in range(_REPEAT):
+        _two_ranks_stay_in_sync_and_overlap_changes_nothing(attempt)
+
+
+def test_two_ranks_with_the_global_masked_mean_option():
+    for attempt in range(_REPEAT):
+        _two_ranks_with_the_global_masked_mean_option(attempt)
+
+
+def _two_ranks_stay_in_sync_and_overlap_changes_nothing(attempt):
     """STRICT (round 5): two-bucket overlapped exchange + split hipGraphs == plain eager step, bit for bit, in EVERY stage of every step on both
     ranks; a failure names the first differing stage.  (Round 4 had loosened this to one-of-three attempts after unexplained failures
     inside whole-suite runs; DESIGN section 1 has the account.)"""
@@ -105,11 +120,11 @@ def test_two_ranks_stay_in_sync_and_overlap_changes_nothing():
     assert all(r[3] for r in got)
     assert all(r[6] and r[7] for r in got), 'the split hipGraph capture fell back to eager launches'
     why = _first_difference(ref, got)
-    assert why is None, why
+    assert why is None, 'attempt %d: %s' % (attempt, why)
     assert [r[5] for r in got] == [r[5] for r in ref] and got[0][4] == ref[0][4]
 
 
-def test_two_ranks_with_the_global_masked_mean_option():
+def _two_ranks_with_the_global_masked_mean_option(attempt):
     """TrainStep(global_masked_mean=True): the 1-float count exchange a step ahead of its batch (async, next to the data pipeline) under
     eager launches and under the split hipGraph replay -- replicas stay in sync, graphs == eager bit for bit in every stage (that the
     arithmetic is the global masked mean is tests/test_gpu_backward.py::test_global_masked_mean_loss_two_virtual_ranks_equal_the_global_batch)."""
@@ -118,7 +133,7 @@ def test_two_ranks_with_the_global_masked_mean_option():
     got = _run(overlap=True, use_graph=True, gm=True)
     assert all(r[3] for r in got) and all(r[6] and r[7] for r in got)
     why = _first_difference(ref, got)
-    assert why is None, why
+    assert why is None, 'attempt %d: %s' % (attempt, why)
     assert got[0][4] == ref[0][4] and [r[5] for r in got] == [r[5] for r in ref]
 
 
