@@ -485,8 +485,11 @@ class TrainStep:
                 if p.requires_grad:
                     self.gviews[p].copy_(dlv[k])
         encoder_backward(reg.image_encoder, enc_tape, dfeat, self.gviews, self.side_stream, after_layer3)
+        # (bwd: the backward chain's intermediate gradients, in the order they are produced -- tests/test_gpu_two_ranks.py digests them to name the
+        #  first kernel family whose output differs between two launch forms)
         self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed, rot=R, ief_tape=ief_tape,
-                         enc_tape=enc_tape if getattr(self, 'keep_enc_tape', False) else None)      # (keep_enc_tape: tests read the decisions taken)
+                         enc_tape=enc_tape if getattr(self, 'keep_enc_tape', False) else None,      # (keep_enc_tape: tests read the decisions taken)
+                         bwd=dict(dverts=dverts, djoints=djoints, dlv=dlv, dbetas=dbetas, drot_smpl=drot2, dest=dest, dfeat=dfeat))
         if self.metrics is not None:
             from .cam_utils import orthographic_project_torch
             pred = {'verts': verts, 'joints3D': joints.index_select(1, self._h36m14), 'shape_params': pred_shape,
