@@ -61,7 +61,24 @@ a = torch.randn(4096, 4096, device=dev)
 bad = torch.zeros(5, device=dev, dtype=torch.int64)
 
 
+if os.environ.get('PROBE_SMPL_BWD'):
+    # (round 5: the victim the two-rank test named -- straps_smpl_bwd on fixed inputs, 8 bodies, a fresh workspace per call)
+    import ctypes as _C
+    _gb = torch.Generator().manual_seed(3)
+    _b8 = torch.randn(8, 10, generator=_gb).to(dev)
+    _R8 = straps_amd.batch_rodrigues((torch.randn(8, 72, generator=_gb) * 0.4).to(dev).view(-1, 3)).view(8, 24, 3, 3).contiguous()
+    _dv8 = (torch.randn(8, 6890, 3, generator=_gb) * 1e-3).to(dev)
+    _dj8 = (torch.randn(8, 90, 3, generator=_gb) * 1e-3).to(dev)
+    _nws = L.straps_smpl_bwd_workspace_bytes(8, 0) // 4
+
+
 def stages():
+    if os.environ.get('PROBE_SMPL_BWD'):
+        ws = torch.empty(_nws, device=dev)
+        dbetas, drot = torch.empty(8, 10, device=dev), torch.empty(8, 24, 3, 3, device=dev)
+        hipabi.check(L.straps_smpl_bwd(_C.byref(smpl._model_struct()), hipabi.ptr(_b8), hipabi.ptr(_R8), hipabi.ptr(_dv8), hipabi.ptr(_dj8), hipabi.ptr(dbetas),
+                                       hipabi.ptr(drot), hipabi.ptr(ws), 8, 0, hipabi.stream_ptr()), 'straps_smpl_bwd')
+        return dbetas, drot, ws
     if os.environ.get('PROBE_SMPL'):
         # the SMPL forward of the data stream (target vertices and joints; reposed vertices): LDS operand rows read in its inner loops
         v1, j1 = smpl.forward_arrays(betas, R)
@@ -113,7 +130,7 @@ if train_load:
         ts.step()
     torch.cuda.synchronize()
 worst = ref[0].clone()
-worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.environ.get('PROBE_SMPL') else None
+worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.environ.get('PROBE_SMPL') and not os.environ.get('PROBE_SMPL_BWD') else None
 # other loads, each captured as a hipGraph and replayed on the main stream: PROBE_LOAD = raster (a second rasteriser on its own meshes),
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
 other = os.environ.get('PROBE_LOAD', '1')
@@ -227,7 +244,7 @@ if worst_z is not None:
         was = int(((rz[b_ * 65536:(b_ + 1) * 65536] & 0xffffffff) == fr).sum()) if kr != (1 << 64) - 1 else -1
         print('   body %d pixel (%3d, %3d): face %5d z-bits %08x  ->  %s ; the first face held %d pixels of this body before, holds %d now' % (
             b_, rem // 256, rem % 256, fr, kr >> 32, ('face %5d z-bits %08x' % (fw, kw >> 32)) if kw != (1 << 64) - 1 else 'EMPTY', was, still))
-d = (worst != ref[0]).nonzero()
+d = (worst != ref[0]).nonzero() if not os.environ.get('PROBE_SMPL_BWD') else torch.zeros(0)
 if d.numel():
     print('last differing part map: %d pixels differ; (body, row, col): first result -> this one' % d.shape[0])
     for b_, y_, x_ in d[:12].tolist():
@@ -235,7 +252,9 @@ if d.numel():
         print('   (%d, %3d, %3d): %g -> %g     3x3 neighbourhood in the first result: %s' % (b_, y_, x_, float(ref[0][b_, y_, x_]), float(worst[b_, y_, x_]), ' '.join('%g' % v for v in nb)))
 load = 'training step (graph) on the main stream' if train_load else load
 print('stages %s; ' % ('as ONE replayed hipGraph' if use_graph else 'as eager launches'), end='')
-if os.environ.get('PROBE_SMPL'):
+if os.environ.get('PROBE_SMPL_BWD'):
+    print('straps_smpl_bwd, 8 bodies, %d repetitions, background load %s: elements that ever differed from the first result -- dbetas %d, drotmats %d, workspace (F, A, partials) %d' % ((iters, load) + tuple(int(v) for v in bad.tolist()[:3])))
+elif os.environ.get('PROBE_SMPL'):
     print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- SMPL vertices %d, joints %d, reposed vertices %d' % ((B, iters, load) + tuple(int(v) for v in bad.tolist()[:3])))
 elif os.environ.get('PROBE_RASTER_PARTS'):
     print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- part map %d, z-buffer keys %d, projected vertices (as int64 pairs) %d'
