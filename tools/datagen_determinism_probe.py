@@ -135,7 +135,7 @@ worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.envi
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
 other = os.environ.get('PROBE_LOAD', '1')
 lgraph = None
-if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fragregs'):
+if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fragregs', 'smplbwd', 'datagen', 'fwdbwd', 'enc_fwd', 'ief', 'adam'):
     rend2 = NMRRenderer(8, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(dev)
     v2, _ = smpl.forward_arrays(torch.randn(8, 10, generator=g).to(dev), straps_amd.batch_rodrigues((torch.randn(8, 72, generator=g) * 0.4).to(dev).view(-1, 3)).view(8, 24, 3, 3).contiguous())
     ct2 = torch.tensor([0., 0.2, 42.], device=dev).expand(8, 3).contiguous()
@@ -171,8 +171,45 @@ if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fra
         tl.straps_tool_lds_frag_reader.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         occ_sink = torch.zeros(4096, device=dev, dtype=torch.int32)
 
+    if other in ('smplbwd', 'datagen', 'fwdbwd', 'enc_fwd', 'ief', 'adam'):
+        # (round 5: PARTS of a training step as the load -- which part disturbs the SMPL-backward victim that the whole step does disturb?)
+        import ctypes as _C2
+        from straps_amd.train_step import TrainStep
+        from straps_amd.encoder_exec import encoder_forward
+        MPp = straps_amd.synthetic_mean_params(0)
+        torch.manual_seed(6)
+        regp = straps_amd.SingleInputRegressor(18, 18, 3, mean_params=MPp).to(dev).train()
+        smp = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=4, precision='fp16x3_lbs').to(dev)
+        critp = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D']).to(dev)
+        tsp = TrainStep(regp, smp, critp, 4, lr=1e-4, mean_shape=MPp['shape'], use_graph=False, pipeline_data=False)
+        tsp.step(); tsp.step()
+        batchp = tsp.make_batch()
+        gb2 = torch.Generator().manual_seed(9)
+        b4 = torch.randn(4, 10, generator=gb2).to(dev)
+        R4 = straps_amd.batch_rodrigues((torch.randn(4, 72, generator=gb2) * 0.4).to(dev).view(-1, 3)).view(4, 24, 3, 3).contiguous()
+        dv4, dj4 = (torch.randn(4, 6890, 3, generator=gb2) * 1e-3).to(dev), (torch.randn(4, 90, 3, generator=gb2) * 1e-3).to(dev)
+        ws4 = torch.empty(L.straps_smpl_bwd_workspace_bytes(4, 0) // 4, device=dev)
+        db4, dr4 = torch.empty(4, 10, device=dev), torch.empty(4, 24, 3, 3, device=dev)
+
     def load_body():
-        if other in ('frag', 'fragsum', 'fragregs'):
+        if other == 'smplbwd':            # a second instance of the victim's own entry point, on buffers of its own
+            for _ in range(8):
+                hipabi.check(L.straps_smpl_bwd(_C2.byref(smp._model_struct()), hipabi.ptr(b4), hipabi.ptr(R4), hipabi.ptr(dv4), hipabi.ptr(dj4), hipabi.ptr(db4), hipabi.ptr(dr4),
+                                               hipabi.ptr(ws4), 4, 0, hipabi.stream_ptr()), 'smpl_bwd')
+        elif other == 'datagen':
+            tsp.make_batch(out=batchp)
+        elif other == 'fwdbwd':           # forward + loss + backward of the step, no Adam, no data generation
+            tsp.forward_backward(batchp)
+        elif other == 'enc_fwd':          # the encoder forward alone (stem, BatchNorm, convolutions)
+            regp.image_encoder.prepack(with_dgrad=True)
+            encoder_forward(regp.image_encoder, batchp['input'], {}, nzmask=batchp['nzmask'])
+        elif other == 'ief':
+            feat = torch.randn(4, 512, device=dev)
+            tape = []
+            regp.ief_module.forward_estimate(feat, tape)
+        elif other == 'adam':
+            tsp.optimise()
+        elif other in ('frag', 'fragsum', 'fragregs'):
             # (fragregs: + the convolution kernel's register footprint, 200 registers pinned: one wave per SIMD, accumulators in AGPRs)
             # (the convolution kernels' fragment reads alone, tools build: one 147 KB workgroup per CU, ~0.3 ms per launch)
             # PROBE_FRAG_TRIPS / PROBE_FRAG_BLOCKS: chunks per workgroup and workgroups per launch (400 x 256: one long-lived workgroup per CU;
