@@ -135,7 +135,7 @@ worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.envi
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
 other = os.environ.get('PROBE_LOAD', '1')
 lgraph = None
-if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fragregs', 'smplbwd', 'datagen', 'fwdbwd', 'enc_fwd', 'ief', 'adam'):
+if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fragregs', 'smplbwd', 'datagen', 'fwdbwd', 'enc_fwd', 'ief', 'adam', 'stem_only', 'pack'):
     rend2 = NMRRenderer(8, K, torch.eye(3), 256, rend_parts_seg=True, faces=smpl.faces, face_parts=smpl.face_parts).to(dev)
     v2, _ = smpl.forward_arrays(torch.randn(8, 10, generator=g).to(dev), straps_amd.batch_rodrigues((torch.randn(8, 72, generator=g) * 0.4).to(dev).view(-1, 3)).view(8, 24, 3, 3).contiguous())
     ct2 = torch.tensor([0., 0.2, 42.], device=dev).expand(8, 3).contiguous()
@@ -146,16 +146,17 @@ if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fra
         ccfg = {'x3': 0, 'halo': 512, 'abl1': 64, 'abl2': 128, 'abl3': 192, 'fp32': 0, 'fp32reg': 16, 'wgrad3': 0}.get(kind)
         if ccfg is None:                       # 'x3:<tile_cfg>' / 'fp32:<tile_cfg>'
             kind, ccfg = kind.split(':')[0], int(kind.split(':')[1])
-        xx = torch.randn(32, 32, 32, 256, device=dev)
-        ww = torch.randn(256, 256, 3, 3, device=dev) * 0.02
+        CB, CHW, CCH = int(os.environ.get('PROBE_CONV_B', '32')), int(os.environ.get('PROBE_CONV_HW', '32')), int(os.environ.get('PROBE_CONV_CH', '256'))
+        xx = torch.randn(CB, CHW, CHW, CCH, device=dev)
+        ww = torch.randn(CCH, CCH, 3, 3, device=dev) * 0.02
         x3, xps = split3(L, xx)
         w3, wps = weight_planes(L, ww)
-        yy = torch.empty(32, 32, 32, 256, device=dev)
-        nblk = L.straps_conv_x3_stat_blocks(32, 32, 32, 256, 256, 3, 3, 1, 1, ccfg & ~(64 | 128))
-        part = torch.empty(max(nblk, 1) * 256 * 2, device=dev)
-        wk = torch.randn(256, 3, 3, 256, device=dev) * 0.02                       # [cout][r][s][cin]: the fp32 kernel's packed weights
-        dwo = torch.empty(256, 256, 3, 3, device=dev)
-        wgws = torch.empty(max(L.straps_conv_wgrad_workspace_bytes(32, 32, 32, 256, 256, 3, 3, 1, 1), 16) // 4, device=dev)
+        yy = torch.empty(CB, CHW, CHW, CCH, device=dev)
+        nblk = L.straps_conv_x3_stat_blocks(CB, CHW, CHW, CCH, CCH, 3, 3, 1, 1, ccfg & ~(64 | 128))
+        part = torch.empty(max(nblk, 1) * CCH * 2, device=dev)
+        wk = torch.randn(CCH, 3, 3, CCH, device=dev) * 0.02                       # [cout][r][s][cin]: the fp32 kernel's packed weights
+        dwo = torch.empty(CCH, CCH, 3, 3, device=dev)
+        wgws = torch.empty(max(L.straps_conv_wgrad_workspace_bytes(CB, CHW, CHW, CCH, CCH, 3, 3, 1, 1), 16) // 4, device=dev)
         load_name = 'conv[%s]' % os.environ.get('PROBE_CONV_KIND', 'x3')
 
     if other == 'occupy':
@@ -171,7 +172,7 @@ if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fra
         tl.straps_tool_lds_frag_reader.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         occ_sink = torch.zeros(4096, device=dev, dtype=torch.int32)
 
-    if other in ('smplbwd', 'datagen', 'fwdbwd', 'enc_fwd', 'ief', 'adam'):
+    if other in ('smplbwd', 'datagen', 'fwdbwd', 'enc_fwd', 'ief', 'adam', 'stem_only', 'pack'):
         # (round 5: PARTS of a training step as the load -- which part disturbs the SMPL-backward victim that the whole step does disturb?)
         import ctypes as _C2
         from straps_amd.train_step import TrainStep
@@ -203,6 +204,22 @@ if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fra
         elif other == 'enc_fwd':          # the encoder forward alone (stem, BatchNorm, convolutions)
             regp.image_encoder.prepack(with_dgrad=True)
             encoder_forward(regp.image_encoder, batchp['input'], {}, nzmask=batchp['nzmask'])
+        elif other == 'pack':
+            regp.image_encoder.prepack(with_dgrad=True)
+        elif other == 'stem_only':        # stem convolution + its BatchNorm / ReLU / pooling tail, nothing behind it
+            class _Stop(Exception):
+                pass
+
+            def _stop(*a, **k):
+                raise _Stop()
+            from straps_amd import encoder_exec as _ee
+            _orig, _ee._residual_stages = _ee._residual_stages, _stop
+            try:
+                encoder_forward(regp.image_encoder, batchp['input'], {}, nzmask=batchp['nzmask'])
+            except _Stop:
+                pass
+            finally:
+                _ee._residual_stages = _orig
         elif other == 'ief':
             feat = torch.randn(4, 512, device=dev)
             tape = []
@@ -231,15 +248,15 @@ if other in ('raster', 'smpl', 'conv', 'fill', 'occupy', 'frag', 'fragsum', 'fra
             big.fill_(1.0)
         elif kind == 'wgrad3':
             for _ in range(6):
-                hipabi.check(L.straps_conv_wgrad_x3(None, None, hipabi.ptr(x3), xps, hipabi.ptr(x3), xps, hipabi.ptr(dwo), hipabi.ptr(wgws), 32, 32, 32, 256, 256, 3, 3, 1, 1, 0,
+                hipabi.check(L.straps_conv_wgrad_x3(None, None, hipabi.ptr(x3), xps, hipabi.ptr(x3), xps, hipabi.ptr(dwo), hipabi.ptr(wgws), CB, CHW, CHW, CCH, CCH, 3, 3, 1, 1, 0,
                                                     hipabi.stream_ptr()), 'wgrad3')
         elif kind in ('fp32', 'fp32reg'):
             for _ in range(4):
-                hipabi.check(L.straps_conv_fwd(hipabi.ptr(xx), hipabi.ptr(wk), None, None, None, 0, hipabi.ptr(yy), None, 32, 32, 32, 256, 256, 3, 3, 1, 1, ccfg,
+                hipabi.check(L.straps_conv_fwd(hipabi.ptr(xx), hipabi.ptr(wk), None, None, None, 0, hipabi.ptr(yy), None, CB, CHW, CHW, CCH, CCH, 3, 3, 1, 1, ccfg,
                                                hipabi.stream_ptr()), 'conv_fp32')
         else:
             for _ in range(8):
-                hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(yy), hipabi.ptr(part), 32, 32, 32, 256, 256, 3, 3, 1, 1, ccfg,
+                hipabi.check(L.straps_conv_fwd_x3(hipabi.ptr(x3), xps, hipabi.ptr(w3), wps, None, None, None, 0, hipabi.ptr(yy), hipabi.ptr(part), CB, CHW, CHW, CCH, CCH, 3, 3, 1, 1, ccfg,
                                                   hipabi.stream_ptr()), 'conv')
     load_body()
     torch.cuda.synchronize()
