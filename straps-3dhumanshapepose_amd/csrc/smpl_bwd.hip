@@ -432,7 +432,13 @@ extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* be
     if (btiles > 65535) { straps_set_error("straps_smpl_bwd: batch %lld exceeds one launch; split it", batch); return STRAPS_EUNSUPPORTED; }
     hipLaunchKernelGGL(smpl_verts_bwd_kernel, dim3(nch, (unsigned)btiles), dim3(256), lds, st, *model, F, Amat, dverts, djoints, dFp, dAp, batch, rpc);
     STRAPS_CHECK_LAUNCH("smpl_verts_bwd_kernel");
-    hipLaunchKernelGGL(smpl_pose_bwd_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, st, *model, betas, rotmats, dFp, dAp,
+    // 96 KB of dynamic LDS that the kernel never touches (round 5): this kernel moves data between lanes through the LDS unit
+    // (ds_bpermute), and such a kernel was found not bit-reproducible while it shares a compute unit with a bf16x3 implicit-GEMM workgroup
+    // (two processes on one GPU; one process with the step on two streams).  The smallest of those workgroups holds 72 KB, a CU has 160:
+    // with 96 KB reserved none fits beside this one.  Costs nothing (a few workgroups, 50 us); unexplained, hence fenced off rather than fixed.
+    constexpr size_t kLdsFence = 96 * 1024;
+    STRAPS_RAISE_LDS(smpl_pose_bwd_kernel, kLdsFence, "smpl_pose_bwd_kernel");
+    hipLaunchKernelGGL(smpl_pose_bwd_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), kLdsFence, st, *model, betas, rotmats, dFp, dAp,
                        djoints, dbetas, drotmats, batch, nch);
     STRAPS_CHECK_LAUNCH("smpl_pose_bwd_kernel");
     return STRAPS_OK;
