@@ -232,6 +232,65 @@ __global__ __launch_bounds__(256, 1) void smpl_verts_bwd_kernel(straps_smpl_mode
 }
 
 // ------------------------------------------------------------------------------------------
+// Lane exchanges of smpl_pose_bwd_kernel.  XCHG = 0 is the product: __shfl = ds_bpermute_b32, several in flight, waits placed by the compiler.
+// The other forms exist in the tools build only (round 5, DESIGN section 1: this kernel is not bit-reproducible beside a bf16x3 convolution
+// workgroup on its compute unit -- WHAT do the wrong values look like, and does the exchange have to go through the LDS unit for it?):
+//   1  v_readlane_b32 + select, 64 of them per exchange: no LDS-unit instruction in the kernel at all
+//   2  ds_bpermute_b32 TWICE, each followed by s_waitcnt lgkmcnt(0) (inline assembly: one in flight), both checked against form 1; mismatches logged
+//   4  ds_bpermute_b32 + s_waitcnt lgkmcnt(0), unchecked: is "one in flight" alone enough to make it reproducible?
+//   5  the product's __shfl (several in flight), checked against form 1 afterwards; mismatches logged
+#ifdef STRAPS_TOOLS
+__device__ unsigned g_xchg_log[4 + 8 * 4096];      // [0] mismatches seen, [1] exchanges checked (one count per wave-level call); records of 8 words
+#endif
+__device__ __forceinline__ int xchg_readlane(int v, int src) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const int t = __builtin_amdgcn_readlane(v, k);
+        r = (src == k) ? t : r;
+    }
+    return r;
+}
+__device__ __forceinline__ int xchg_bpermute_now(int v, int src) {
+    int r;
+    asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(src << 2), "v"(v) : "memory");
+    return r;
+}
+template <int XCHG>
+__device__ __forceinline__ float lane_get(float value, int src, int site, int trip, int& prev) {
+    if constexpr (XCHG == 0) {
+        return __shfl(value, src, 64);
+    } else {
+        const int v = __float_as_int(value);
+        src &= 63;
+        if constexpr (XCHG == 1) return __int_as_float(xchg_readlane(v, src));
+        if constexpr (XCHG == 4) return __int_as_float(xchg_bpermute_now(v, src));
+#ifdef STRAPS_TOOLS
+        int a, b;
+        if constexpr (XCHG == 2) { a = xchg_bpermute_now(v, src); b = xchg_bpermute_now(v, src); }
+        else { a = __float_as_int(__shfl(value, src, 64)); b = a; }
+        const int truth = xchg_readlane(v, src);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_xchg_log[1], 1u);
+        if (a != truth || b != truth) {
+            int from = -1;                            // does the wrong value belong to ANOTHER lane of the same register?
+            for (int k = 63; k >= 0; --k) from = (__builtin_amdgcn_readlane(v, k) == a) ? k : from;
+            const unsigned slot = atomicAdd(&g_xchg_log[0], 1u);
+            if (slot < 4096) {
+                unsigned* r = g_xchg_log + 4 + slot * 8;
+                r[0] = (unsigned)site | ((unsigned)trip << 8) | ((unsigned)(from & 0xff) << 16) | ((unsigned)(a != truth) << 24) | ((unsigned)(b != truth) << 25);
+                r[1] = threadIdx.x | (blockIdx.x << 16);
+                r[2] = (unsigned)src; r[3] = (unsigned)truth; r[4] = (unsigned)a; r[5] = (unsigned)b; r[6] = (unsigned)v; r[7] = (unsigned)prev;
+            }
+        }
+        prev = a;
+        return __int_as_float(a);
+#else
+        return value;
+#endif
+    }
+}
+
+template <int XCHG>
 __global__ __launch_bounds__(256) void smpl_pose_bwd_kernel(straps_smpl_model_t m, const float* __restrict__ betas,
                                                             const float* __restrict__ rotmats, const float* __restrict__ dFp,
                                                             const float* __restrict__ dAp, const float* __restrict__ djoints,
@@ -263,10 +322,11 @@ __global__ __launch_bounds__(256) void smpl_pose_bwd_kernel(straps_smpl_model_t 
     const int par = m.parents[jj];
     const int dep = vj ? m.depth[jj] : -1;
     const int src = base + (par < 0 ? 0 : par);
+    int xprev = 0;      // (tools forms: the value the previous exchange delivered to this lane)
     float rel[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float jp = __shfl(J[c], src, 64);
+        const float jp = lane_get<XCHG>(J[c], src, 0 + c, 0, xprev);
         rel[c] = (jj > 0) ? J[c] - jp : J[c];
     }
     // forward chain: G (own global transform) and P (parent's rotation), recomputed
@@ -280,7 +340,7 @@ __global__ __launch_bounds__(256) void smpl_pose_bwd_kernel(straps_smpl_model_t 
     for (int d = 1; d <= m.max_depth; ++d) {
         float P[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) P[e] = __shfl(G[e], src, 64);
+        for (int e = 0; e < 12; ++e) P[e] = lane_get<XCHG>(G[e], src, 8 + e, d, xprev);
         if (dep == d) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -351,7 +411,7 @@ __global__ __launch_bounds__(256) void smpl_pose_bwd_kernel(straps_smpl_model_t 
             const int cs = base + (ch < 0 ? 0 : ch);
             float in[15];
 #pragma unroll
-            for (int e = 0; e < 15; ++e) in[e] = __shfl(M[e], cs, 64);
+            for (int e = 0; e < 15; ++e) in[e] = lane_get<XCHG>(M[e], cs, 32 + cc * 16 + e, d, xprev);
             if (vj && ch >= 0) {       // in[] is zero unless that child is at depth d
 #pragma unroll
                 for (int e = 0; e < 9; ++e) gGR[e] += in[e];
@@ -386,8 +446,11 @@ __global__ __launch_bounds__(256) void smpl_pose_bwd_kernel(straps_smpl_model_t 
         float s = vj ? (m.j_shapedirs[(jj * 3 + 0) * 10 + l] * gJ[0] + m.j_shapedirs[(jj * 3 + 1) * 10 + l] * gJ[1] +
                         m.j_shapedirs[(jj * 3 + 2) * 10 + l] * gJ[2]) : 0.f;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const float direct = __shfl(gbeta_direct, base + l, 64);
+        for (int o = 16; o > 0; o >>= 1) {
+            if constexpr (XCHG == 0) s += __shfl_xor(s, o, 64);
+            else s += lane_get<XCHG>(s, lane ^ o, 96 + l, o, xprev);
+        }
+        const float direct = lane_get<XCHG>(gbeta_direct, base + l, 112 + l, 0, xprev);
         if (vb && j == l) dbetas[body * 10 + l] = s + direct;
     }
 }
@@ -437,9 +500,30 @@ extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* be
     // (two processes on one GPU; one process with the step on two streams).  The smallest of those workgroups holds 72 KB, a CU has 160:
     // with 96 KB reserved none fits beside this one.  Costs nothing (a few workgroups, 50 us); unexplained, hence fenced off rather than fixed.
     constexpr size_t kLdsFence = 96 * 1024;
-    STRAPS_RAISE_LDS(smpl_pose_bwd_kernel, kLdsFence, "smpl_pose_bwd_kernel");
-    hipLaunchKernelGGL(smpl_pose_bwd_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), kLdsFence, st, *model, betas, rotmats, dFp, dAp,
+    size_t fence = kLdsFence;
+    auto pose_bwd = smpl_pose_bwd_kernel<0>;
+#ifdef STRAPS_TOOLS
+    static const int xchg = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_XCHG", 0);        // (exchange forms, see lane_get)
+    static const int fenced = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_FENCE", 1);     // (0: the kernel as it was before the fence -- the reproducer's victim)
+    pose_bwd = xchg == 1 ? smpl_pose_bwd_kernel<1> : xchg == 2 ? smpl_pose_bwd_kernel<2> : xchg == 4 ? smpl_pose_bwd_kernel<4> : xchg == 5 ? smpl_pose_bwd_kernel<5> : pose_bwd;
+    if (!fenced) fence = 0;
+#endif
+    if (fence) STRAPS_RAISE_LDS(pose_bwd, fence, "smpl_pose_bwd_kernel");
+    hipLaunchKernelGGL(pose_bwd, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), fence, st, *model, betas, rotmats, dFp, dAp,
                        djoints, dbetas, drotmats, batch, nch);
     STRAPS_CHECK_LAUNCH("smpl_pose_bwd_kernel");
     return STRAPS_OK;
 }
+
+#ifdef STRAPS_TOOLS
+// tools build only: the exchange log of smpl_pose_bwd_kernel<2 | 5> copied to the host (words: 4 + 8 * 4096), then cleared when `reset`
+extern "C" int straps_tool_xchg_log(unsigned* host_words, int reset) {
+    STRAPS_REQUIRE(host_words, "straps_tool_xchg_log: null pointer");
+    static unsigned zeros[4 + 8 * 4096];
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(host_words, HIP_SYMBOL(g_xchg_log), sizeof(zeros));
+    if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(g_xchg_log), zeros, sizeof(zeros));
+    if (e != hipSuccess) { straps_set_error("straps_tool_xchg_log: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
+    return STRAPS_OK;
+}
+#endif

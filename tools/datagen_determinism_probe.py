@@ -316,6 +316,40 @@ elif os.environ.get('PROBE_RASTER_PARTS'):
 else:
     print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- rasteriser %d, crop + resize %d, '
           'augment_seg %d, network input %d, non-zero map %d' % ((B, iters, load) + tuple(int(v) for v in bad.tolist())))
+if os.environ.get('PROBE_SMPL_BWD') and os.environ.get('STRAPS_POSE_BWD_XCHG') in ('2', '5'):
+    # (tools build: smpl_pose_bwd_kernel checked every lane exchange against a v_readlane reference and logged the mismatches -- csrc/smpl_bwd.hip, lane_get)
+    import ctypes
+    import struct
+    words = (ctypes.c_uint * (4 + 8 * 4096))()
+    rc = ctypes.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_xchg_log(words, 1)
+    n, checked = words[0], words[1]
+    recs = [tuple(words[4 + 8 * k: 12 + 8 * k]) for k in range(min(n, 4096))]
+    f32 = lambda u: struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
+    site_name = lambda st: ('parent joint' if st < 8 else 'forward chain P[%d]' % (st - 8) if st < 32 else 'message of child %d, word %d' % ((st - 32) // 16, (st - 32) % 16)
+                            if st < 96 else 'beta reduction l=%d' % (st - 96) if st < 112 else 'direct beta l=%d' % (st - 112))
+    print('exchange log (rc %d): %d wave-level exchanges checked, %d lane results differ from the v_readlane reference' % (rc, checked, n))
+    if recs:
+        cls = dict(stale_previous_result=0, own_register=0, zero=0, another_lane_of_the_source_register=0, none_of_these=0)
+        first_bad, second_bad, sites, lanes_, waves = 0, 0, {}, {}, {}
+        for w0, w1, src, truth, a, b, own, prev in recs:
+            st, trip, frm = w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff
+            first_bad += (w0 >> 24) & 1
+            second_bad += (w0 >> 25) & 1
+            bad = a if (w0 >> 24) & 1 else b
+            key = ('stale_previous_result' if bad == prev else 'own_register' if bad == own else 'zero' if bad == 0 else
+                   'another_lane_of_the_source_register' if frm != 0xff and (w0 >> 24) & 1 else 'none_of_these')
+            cls[key] += 1
+            k = 'parent' if st < 8 else 'forward chain' if st < 32 else 'backward messages' if st < 96 else 'beta reduction' if st < 112 else 'direct beta'
+            sites[k] = sites.get(k, 0) + 1
+            lanes_[(w1 & 63)] = lanes_.get(w1 & 63, 0) + 1
+            waves[(w1 & 0xffff) >> 6] = waves.get((w1 & 0xffff) >> 6, 0) + 1
+        print('   first read wrong in %d records, the immediate second read (form 2) wrong in %d' % (first_bad, second_bad))
+        print('   what the wrong value is:', cls)
+        print('   where:', sites, '| waves', dict(sorted(waves.items())), '| distinct lanes %d' % len(lanes_))
+        for w0, w1, src, truth, a, b, own, prev in recs[:24]:
+            st, trip, frm = w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff
+            print('   %-28s trip %2d wave %d lane %2d <- lane %2d: expected %08x (%+.6e)  got %08x (%+.6e) then %08x | own %08x previous %08x | got == lane %s of the source' % (
+                site_name(st), trip, (w1 & 0xffff) >> 6, w1 & 63, src, truth, f32(truth), a, f32(a), b, own, prev, frm if frm != 0xff else '--'))
 if os.environ.get('PROBE_LOAD_REPORT'):      # (tools build with -DSTRAPS_RASTER_CHECK_LOADS)
     import ctypes
     rep = (ctypes.c_uint * 257)()
