@@ -82,7 +82,7 @@ __device__ __forceinline__ void rodrigues(float rx, float ry, float rz, float* o
 }
 
 // one thread per (body, slot): slots 0..23 = joints (rotation matrices), 24..33 = the ten shape coefficients
-__global__ __launch_bounds__(256) void augment_smpl_kernel(const float* __restrict__ pose_rows, long long n_rows, const float* __restrict__ u_index,
+__global__ __launch_bounds__(256) STRAPS_NO_PACKED_FP32 void augment_smpl_kernel(const float* __restrict__ pose_rows, long long n_rows, const float* __restrict__ u_index,
                                                            const float* __restrict__ orig_shape, const float* __restrict__ mean_shape,
                                                            const float* __restrict__ draws, int mode, const float* __restrict__ std_vector,
                                                            float range_lo, float range_scale, float* __restrict__ out_shape,

@@ -32,6 +32,18 @@ unsigned long long* straps_clk_acc_current();
         }                                                                                \
     } while (0)
 
+// Kernels in which the compiler would form a packed fp32 instruction whose LOW result reads the HIGH register of a source (VOP3P op_sel, e.g.
+// v_pk_fma_f32 d, a, b, c op_sel:[0,1,0]) are compiled WITHOUT packed fp32 instructions.  Round 5, DESIGN section 1: on MI355X such an instruction
+// returns a wrong low result in lanes 48..63 (the selected operand reads as zero: fma -> c, mul -> 0, add -> a) while a bf16x3 convolution workgroup
+// runs on the same compute unit -- measured with a victim of nothing but such instructions, each checked against the plain instruction on the same
+// registers (profiles/r05_packed_fp32_victim.txt: 0.8 % of the checks fail beside the convolution, none of 7.7 million alone; only the src1 select,
+// only the low half, only the last sixteen lanes).  tests/test_packed_fp32_audit.py disassembles the built library and fails if ANY kernel holds one.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STRAPS_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define STRAPS_NO_PACKED_FP32      // (the host pass does not know the feature)
+#endif
+
 // Dynamic-LDS limit of a kernel above the 64 KiB default.  Function attributes are per device: `done` is the caller's static bit mask
 // of the devices this kernel has been raised on (a process that drives several GPUs sets each once).
 inline hipError_t straps_raise_dynamic_lds(const void* fn, size_t bytes, unsigned long long& done) {

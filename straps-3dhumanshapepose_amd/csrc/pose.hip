@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void rot6d_kernel(const float* __restrict__ x6
     o[6] = b1z; o[7] = b2z; o[8] = b3z;
 }
 
-__global__ __launch_bounds__(256) void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ R, long long n) {
+__global__ __launch_bounds__(256) STRAPS_NO_PACKED_FP32 void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ R, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float rx = aa[i * 3 + 0], ry = aa[i * 3 + 1], rz = aa[i * 3 + 2];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ortho_project_bwd_kernel(const float* __r
 }
 
 // perspective: p = R x + t; p /= p_z; (u, v) = first two rows of K p.  K: one 3x3 (k_stride = 0) or one per body (k_stride = 9)
-__global__ __launch_bounds__(256) void persp_project_kernel(const float* __restrict__ pts, const float* __restrict__ rot, const float* __restrict__ tr,
+__global__ __launch_bounds__(256) STRAPS_NO_PACKED_FP32 void persp_project_kernel(const float* __restrict__ pts, const float* __restrict__ rot, const float* __restrict__ tr,
                                                             const float* __restrict__ K, int k_stride, float* __restrict__ out, long long B, int N) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= B * N) return;

@@ -23,7 +23,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void raster_project_kernel(const float* __restrict__ verts, const float* __restrict__ K,
+__global__ __launch_bounds__(256) STRAPS_NO_PACKED_FP32 void raster_project_kernel(const float* __restrict__ verts, const float* __restrict__ K,
                                                              const float* __restrict__ R, const float* __restrict__ t,
                                                              float* __restrict__ ndc, long long n, int nverts, int cam_per_body,
                                                              float orig, const float* __restrict__ noise_u, float noise_lo,
@@ -63,7 +63,7 @@ __device__ unsigned g_raster_report[1 + 4 * 64];
 #endif
 
 template <int G>      // lanes per face: they take the samples of its bounding box round-robin (the z-buffer minimum does not depend on who visits what)
-__global__ __launch_bounds__(256) void raster_face_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
+__global__ __launch_bounds__(256) STRAPS_NO_PACKED_FP32 void raster_face_kernel(const float* __restrict__ ndc, const int32_t* __restrict__ faces,
                                                           unsigned long long* __restrict__ zbuf, long long n, int nverts,
                                                           int nfaces, int wh, float near, float far) {
     // pixel-centre coordinates (2k + 1 - wh) / wh, computed per sample on purpose.  Rounds 2-4 read them from a table in LDS (filled per

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(straps_smpl_model_t m, c
 // does its skinning / stores on the VALU + LDS, so the two phases overlap in hardware (measured:
 // run back to back by one wave per SIMD they cost ~6 ms + ~6 ms at B = 65536).  No block barrier
 // inside the tile loop: each wave owns its stage slice.
-__global__ __launch_bounds__(NW * 64) void smpl_verts_kernel(straps_smpl_model_t m, const float* __restrict__ F,
+__global__ __launch_bounds__(NW * 64) STRAPS_NO_PACKED_FP32 void smpl_verts_kernel(straps_smpl_model_t m, const float* __restrict__ F,
                                                              const float* __restrict__ Amat, float* __restrict__ verts,
                                                              float* __restrict__ vout, long long B, int btiles,
                                                              int rounds, int rounds_per_chunk) {
@@ -311,7 +311,7 @@ constexpr float F_SCALE = 64.0f;          // 2^6
 __device__ __forceinline__ f32x16 mfma16h(half8 a, half8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <int PF>
-__global__ __launch_bounds__(NW * 64) void smpl_verts_h_kernel(straps_smpl_model_t m, const float* __restrict__ F,
+__global__ __launch_bounds__(NW * 64) STRAPS_NO_PACKED_FP32 void smpl_verts_h_kernel(straps_smpl_model_t m, const float* __restrict__ F,
                                                                const float* __restrict__ Amat, float* __restrict__ verts,
                                                                float* __restrict__ vout, long long B, int btiles,
                                                                int rounds, int rounds_per_chunk) {

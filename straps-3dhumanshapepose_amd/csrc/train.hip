@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void loss_grad_verts_kernel(const float* __res
 }
 
 // one wave per body: zero-fill + scatter of the head gradients
-__global__ __launch_bounds__(64) void loss_grad_heads_kernel(const float* __restrict__ joints, const float* __restrict__ est, int ld_est,
+__global__ __launch_bounds__(64) STRAPS_NO_PACKED_FP32 void loss_grad_heads_kernel(const float* __restrict__ joints, const float* __restrict__ est, int ld_est,
                                                              const float* __restrict__ prot, const float* __restrict__ tj2d,
                                                              const float* __restrict__ tj3d, const float* __restrict__ tshape,
                                                              const float* __restrict__ trot, const float* __restrict__ coef,

@@ -59,6 +59,7 @@ remove_prob = torch.full((6,), 0.1, device=dev)
 side = torch.cuda.Stream()
 a = torch.randn(4096, 4096, device=dev)
 bad = torch.zeros(5, device=dev, dtype=torch.int64)
+nans = torch.zeros(1, device=dev, dtype=torch.int64)      # (PROBE_SMPL_BWD with STRAPS_POSE_BWD_POISON=1: NaN results = partials read that this call never wrote)
 
 
 if os.environ.get('PROBE_SMPL_BWD'):
@@ -72,12 +73,28 @@ if os.environ.get('PROBE_SMPL_BWD'):
     _nws = L.straps_smpl_bwd_workspace_bytes(8, 0) // 4
 
 
+if os.environ.get('PROBE_PK_VICTIM'):
+    # (round 5, tools build: a victim of nothing but packed fp32 instructions, each checked against plain ones of the same registers -- csrc/smpl_bwd.hip, pk_victim_kernel)
+    import ctypes as _C
+    _pk_blocks, _pk_trips = int(os.environ.get('PROBE_PK_BLOCKS', '1')), int(os.environ.get('PROBE_PK_TRIPS', '64'))
+    _pk_in = torch.randn(256 * _pk_blocks * 6, generator=torch.Generator().manual_seed(5)).to(dev)
+    _pk_lib = _C.CDLL(hipabi.TOOLS_LIB_PATH)
+
+
 def stages():
+    if os.environ.get('PROBE_PK_VICTIM'):
+        out = torch.empty(256 * _pk_blocks, device=dev)
+        hipabi.check(_pk_lib.straps_tool_pk_victim(hipabi.ptr(_pk_in), hipabi.ptr(out), _pk_blocks, _pk_trips, hipabi.stream_ptr()), 'pk_victim')
+        return (out,)
     if os.environ.get('PROBE_SMPL_BWD'):
         ws = torch.empty(_nws, device=dev)
         dbetas, drot = torch.empty(8, 10, device=dev), torch.empty(8, 24, 3, 3, device=dev)
         hipabi.check(L.straps_smpl_bwd(_C.byref(smpl._model_struct()), hipabi.ptr(_b8), hipabi.ptr(_R8), hipabi.ptr(_dv8), hipabi.ptr(_dj8), hipabi.ptr(dbetas),
                                        hipabi.ptr(drot), hipabi.ptr(ws), 8, 0, hipabi.stream_ptr()), 'straps_smpl_bwd')
+        if os.environ.get('STRAPS_POSE_BWD_DBG'):      # (tools build: the kernel's intermediate values, [field][thread])
+            dbg = torch.empty(112, 256, device=dev)
+            hipabi.check(_C.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_pose_dbg(hipabi.ptr(dbg), hipabi.stream_ptr()), 'pose_dbg')
+            return dbetas, drot, ws, dbg
         return dbetas, drot, ws
     if os.environ.get('PROBE_SMPL'):
         # the SMPL forward of the data stream (target vertices and joints; reposed vertices): LDS operand rows read in its inner loops
@@ -130,6 +147,10 @@ if train_load:
         ts.step()
     torch.cuda.synchronize()
 worst = ref[0].clone()
+worst_rot = ref[1].clone() if os.environ.get('PROBE_SMPL_BWD') else None
+events = torch.zeros(1, device=dev, dtype=torch.int64)
+field_events = torch.zeros(112, device=dev, dtype=torch.int64)
+worst_dbg = ref[3].clone() if len(ref) > 3 and os.environ.get('PROBE_SMPL_BWD') else None
 worst_z = ref[1].clone() if os.environ.get('PROBE_RASTER_PARTS') and not os.environ.get('PROBE_SMPL') and not os.environ.get('PROBE_SMPL_BWD') else None
 # other loads, each captured as a hipGraph and replayed on the main stream: PROBE_LOAD = raster (a second rasteriser on its own meshes),
 # smpl (SMPL forward), conv (one bf16x3 convolution forward + data gradient), fill (1 GiB fill: pure cache pressure)
@@ -281,6 +302,15 @@ for i in range(iters):
             out = stages()
         for k, (o, r) in enumerate(zip(out, ref)):
             bad[k] += (o != r).sum()
+        if os.environ.get('PROBE_SMPL_BWD'):
+            nans += torch.isnan(out[0]).sum() + torch.isnan(out[1]).sum()
+            differs = (out[1] != ref[1]).any()
+            events += differs
+            worst_rot = torch.where(differs, out[1], worst_rot)               # (the last differing rotation gradient)
+            if len(out) > 3:
+                fm = (out[3] != ref[3]).any(1)
+                field_events += fm
+                worst_dbg = torch.where(fm.any(), out[3], worst_dbg)
         worst = torch.where((out[0] != ref[0]).any(), out[0], worst)          # (the last differing part map, selected on the device)
         if worst_z is not None:
             worst_z = torch.where((out[1] != ref[1]).any(), out[1], worst_z)
@@ -298,7 +328,7 @@ if worst_z is not None:
         was = int(((rz[b_ * 65536:(b_ + 1) * 65536] & 0xffffffff) == fr).sum()) if kr != (1 << 64) - 1 else -1
         print('   body %d pixel (%3d, %3d): face %5d z-bits %08x  ->  %s ; the first face held %d pixels of this body before, holds %d now' % (
             b_, rem // 256, rem % 256, fr, kr >> 32, ('face %5d z-bits %08x' % (fw, kw >> 32)) if kw != (1 << 64) - 1 else 'EMPTY', was, still))
-d = (worst != ref[0]).nonzero() if not os.environ.get('PROBE_SMPL_BWD') else torch.zeros(0)
+d = (worst != ref[0]).nonzero() if not (os.environ.get('PROBE_SMPL_BWD') or os.environ.get('PROBE_PK_VICTIM')) else torch.zeros(0)
 if d.numel():
     print('last differing part map: %d pixels differ; (body, row, col): first result -> this one' % d.shape[0])
     for b_, y_, x_ in d[:12].tolist():
@@ -316,6 +346,70 @@ elif os.environ.get('PROBE_RASTER_PARTS'):
 else:
     print('B = %d, %d repetitions, background load %s: elements that ever differed from the first result -- rasteriser %d, crop + resize %d, '
           'augment_seg %d, network input %d, non-zero map %d' % ((B, iters, load) + tuple(int(v) for v in bad.tolist())))
+if os.environ.get('PROBE_SMPL_BWD') and int(events):
+    dd = (worst_rot != ref[1])
+    print('calls whose rotation gradient differed: %d; the last of them differs in %d elements:' % (int(events), int(dd.sum())))
+    for b_ in range(8):
+        js = [(j_, int(dd[b_, j_].sum()), float(((worst_rot[b_, j_] - ref[1][b_, j_]).abs().max() / ref[1][b_, j_].abs().max().clamp_min(1e-30)))) for j_ in range(24) if bool(dd[b_, j_].any())]
+        if js:
+            print('   body %d: joints (differing of 9, max |difference| / max |value|): %s' % (b_, ' '.join('%d(%d, %.1e)' % t for t in js)))
+if worst_dbg is not None:
+    names = (['J[%d]' % c for c in range(3)] + ['rel[%d]' % c for c in range(3)] + ['R[%d]' % e for e in range(9)] + ['beta[0]', 'beta[9]', 'parent', 'depth'] +
+             ['G[%d]' % e for e in range(12)] + ['PR[%d]' % e for e in range(9)] + ['gA[%d]' % e for e in range(12)] + ['gGR0[%d]' % e for e in range(9)] +
+             ['gGt0[%d]' % c for c in range(3)] + ['gJ0[%d]' % c for c in range(3)] + ['child[%d]' % c for c in range(3)] + ['gGR[%d]' % e for e in range(9)] +
+             ['gR[%d]' % e for e in range(9)] + ['gGt[%d]' % c for c in range(3)] + ['gJ[%d]' % c for c in range(3)] + ['gR_out[%d]' % e for e in range(9)] + ['gbeta_direct'] +
+             ['shapedirs[c=0][%d] EARLY' % q for q in range(4)] + ['shapedirs[c=0][%d] LATE' % q for q in range(4)])
+    fe = field_events.tolist()
+    print('intermediate values of workgroup 0, calls in which a field differed from the first call (fields in program order): ' +
+          (', '.join('%s %d' % (names[k], fe[k]) for k in range(len(names)) if fe[k]) or 'none'))
+    dd = (worst_dbg != ref[3])
+    shown = 0
+    for k in range(len(names)):
+        if bool(dd[k].any()) and (shown < 6 or k >= 104):
+            shown += 1
+            idx = dd[k].nonzero().flatten().tolist()
+            print('   %-10s differs in threads %s: %s' % (names[k], ' '.join('%d(body %d joint %d)' % (t, t >> 5, t & 31) for t in idx[:8]),
+                                                        '  '.join('%.9g -> %.9g' % (float(ref[3][k, t]), float(worst_dbg[k, t])) for t in idx[:8])))
+if os.environ.get('PROBE_PK_VICTIM'):
+    import struct
+    words = (_C.c_uint * (4 + 8 * 4096))()
+    rc = _pk_lib.straps_tool_xchg_log(words, 1)
+    f32 = lambda u: struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
+    forms = ['pk_fma op_sel:[0,1,0]', 'pk_fma op_sel:[1,0,0]', 'pk_fma op_sel:[0,0,1]', 'pk_fma op_sel_hi:[1,0,1]', 'pk_fma (no selects)', 'pk_mul op_sel:[0,1]', 'pk_add op_sel:[0,1]']
+    print('packed fp32 victim, %d workgroup(s) x %d trips x 7 forms, %d launches beside %s (rc %d): %d wave-trips checked, %d lane results differ from the plain instructions' % (
+        _pk_blocks, _pk_trips, iters + 1, load, rc, words[1], words[0]))
+    by_form, by_quarter, by_trip, which = {}, {}, {}, dict(low=0, high=0)
+    for k in range(min(words[0], 4096)):
+        r = words[4 + 8 * k: 12 + 8 * k]
+        fm, trip = (r[0] & 0xffff) - 300, r[0] >> 16
+        by_form[forms[fm]] = by_form.get(forms[fm], 0) + 1
+        by_quarter[(r[1] & 63) >> 4] = by_quarter.get((r[1] & 63) >> 4, 0) + 1
+        by_trip[trip] = by_trip.get(trip, 0) + 1
+        which['low'] += r[2] != r[3]
+        which['high'] += r[4] != r[5]
+        if k < 12:
+            print('   %-26s trip %2d thread %3d (lane %2d): low %.9g, plain %.9g | high %.9g, plain %.9g | c = (%.9g, %.9g)' % (
+                forms[fm], trip, r[1] & 0xffff, r[1] & 63, f32(r[2]), f32(r[3]), f32(r[4]), f32(r[5]), f32(r[6]), f32(r[7])))
+    print('   by form:', by_form, '| by quarter of the wave (lanes 16q..16q+15):', dict(sorted(by_quarter.items())), '| half:', which)
+    print('   by trip:', dict(sorted(by_trip.items())))
+if os.environ.get('PROBE_SMPL_BWD') and os.environ.get('STRAPS_POSE_BWD_DBG') in ('4', '6'):
+    import ctypes
+    import struct
+    words = (ctypes.c_uint * (4 + 8 * 4096))()
+    rc = ctypes.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_xchg_log(words, 1)
+    f32 = lambda u: struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
+    print('v_pk_fma_f32 d, a, b, c op_sel:[0,1,0] against v_fma_f32 of the same registers (rc %d): %d waves checked, %d lane results differ' % (rc, words[1], words[0]))
+    lanes_ = {}
+    for k in range(min(words[0], 4096)):
+        r = words[4 + 8 * k: 12 + 8 * k]
+        lanes_[r[1] & 63] = lanes_.get(r[1] & 63, 0) + 1
+        if k < 16:
+            print('   thread %3d (lane %2d): a.lo %.9g  b.hi %.9g  c.lo %.9g -> packed low result %.9g, plain fma %.9g (packed high result %.9g)' % (
+                r[1] & 0xffff, r[1] & 63, f32(r[2]), f32(r[3]), f32(r[4]), f32(r[5]), f32(r[6]), f32(r[7])))
+    print('   lanes:', dict(sorted(lanes_.items())))
+if os.environ.get('PROBE_SMPL_BWD') and os.environ.get('STRAPS_POSE_BWD_POISON'):
+    print('partials poisoned with NaN before their producer: %d NaN among the results (dbetas, drotmats) of all calls; the reference call: %d' % (
+        int(nans), int(torch.isnan(ref[0]).sum() + torch.isnan(ref[1]).sum())))
 if os.environ.get('PROBE_SMPL_BWD') and os.environ.get('STRAPS_POSE_BWD_XCHG') in ('2', '5'):
     # (tools build: smpl_pose_bwd_kernel checked every lane exchange against a v_readlane reference and logged the mismatches -- csrc/smpl_bwd.hip, lane_get)
     import ctypes
