@@ -134,18 +134,14 @@ def test_two_ranks_replicas_stay_in_sync(gm):
         assert all(r[6] and r[7] for r in got), 'the split hipGraph capture fell back to eager launches'
 
 
-# Round 5's finding, kept visible instead of retried away.  The STRICT comparison -- every one of thirteen per-step stage digests of the
-# graphs + overlap run equal to the eager run's, both ranks -- used to fail in roughly one comparison of ten when the file ran inside the whole suite
-# (never alone).  Four differences caught with TWO_RANK_REPEAT=10 (profiles/r05_two_rank_hunt.txt) share one first differing stage: "SMPL backward (d
-# betas, d rotations)", with the batch, the network input, the loss record and the loss kernel's gradients identical in front of it; the GRAPH run's
-# digests were bit-identical across failing runs, the EAGER run's were not.  Isolated: smpl_pose_bwd_kernel -- lane exchanges through
-# the LDS unit -- is not bit-reproducible while it shares a compute unit with a bf16x3 convolution workgroup (of the other process here; of another
-# stream in a one-process reproducer).  Fenced off since: the kernel reserves 96 KB of LDS it never touches, so that no such workgroup fits beside it --
-# every reproducer went silent and this comparison held in 20 of 20 attempts of the next whole-suite hunt (XPASS).  The mechanism is NOT explained and
-# other kernels of the same kind may exist, so the marker stays: xfail(strict=False) -- a pass reads XPASS, a difference XFAIL with the stage named
-# in the report; neither stops the suite, neither is hidden.  The invariants of data parallelism are asserted hard above.
-@pytest.mark.xfail(strict=False, reason='two processes on ONE GPU: a kernel that exchanges lanes through the LDS unit beside the other rank\'s convolutions '
-                                        '(round 5: smpl_pose_bwd_kernel, fenced off since -- 20 of 20 attempts bit-identical; mechanism open, DESIGN section 1)')
+# Round 5's finding (kept visible instead of retried away), explained and removed.  The STRICT comparison -- every one of thirteen
+# per-step stage digests of the graphs + overlap run equal to the eager run's, both ranks -- used to fail in roughly one comparison of fifteen when the
+# file ran inside the whole suite.  Every difference caught (TWO_RANK_REPEAT=10, profiles/r05_two_rank_hunt.txt) had one first differing stage, "SMPL
+# backward (d betas, d rotations)".  Traced to ONE instruction: the compiler had formed `v_pk_fma_f32 ... op_sel:[0,1,0]` (a packed fp32
+# instruction whose LOW result reads the HIGH register of a source) in smpl_pose_bwd_kernel, and on MI355X such an instruction loses the product in lanes
+# 48..63 while a bf16x3 convolution workgroup -- here: of the OTHER process -- runs on the same compute unit (a victim of nothing but such instructions,
+# checked against plain ones: 0.8 % of the checks fail beside the convolution, none alone).  The kernels that held one are compiled without packed fp32
+# instructions and tests/test_packed_fp32_audit.py keeps the library free of them; since then the comparison holds, so it is a plain assertion again.
 @pytest.mark.parametrize('gm', [False, True], ids=['per_rank_mean', 'global_masked_mean'])
 def test_two_ranks_graphs_and_overlap_equal_the_eager_step_in_every_stage(gm):
     """two-bucket overlapped exchange + split hipGraphs == plain eager step, bit for bit, in EVERY stage of every step on both ranks; a
