@@ -641,18 +641,17 @@ extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* be
     if (btiles > 65535) { straps_set_error("straps_smpl_bwd: batch %lld exceeds one launch; split it", batch); return STRAPS_EUNSUPPORTED; }
     hipLaunchKernelGGL(smpl_verts_bwd_kernel, dim3(nch, (unsigned)btiles), dim3(256), lds, st, *model, F, Amat, dverts, djoints, dFp, dAp, batch, rpc);
     STRAPS_CHECK_LAUNCH("smpl_verts_bwd_kernel");
-    // 96 KB of dynamic LDS that the kernel never touches (round 5): this kernel moves data between lanes through the LDS unit
-    // (ds_bpermute), and such a kernel was found not bit-reproducible while it shares a compute unit with a bf16x3 implicit-GEMM workgroup
-    // (two processes on one GPU; one process with the step on two streams).  The smallest of those workgroups holds 72 KB, a CU has 160:
-    // with 96 KB reserved none fits beside this one.  Costs nothing (a few workgroups, 50 us); unexplained, hence fenced off rather than fixed.
-    constexpr size_t kLdsFence = 96 * 1024;
-    size_t fence = kLdsFence;
+    // (Round 5, DESIGN section 1: this kernel was the one whose results differed between two processes on one GPU.  Cause: a packed fp32 instruction with a
+    //  low-half operand select the compiler had formed in it -- the kernel is compiled without packed fp32 instructions now, see POSE_BWD_ATTR.  The mitigation
+    //  that came first, 96 KB of dynamic LDS the kernel never touches so that no bf16x3 convolution workgroup fits beside it on a compute unit, is kept as a
+    //  switch of the tools build for A/B runs -- STRAPS_POSE_BWD_FENCE=1 -- and is off everywhere else: profiles/r05_packed_fp32_fix.txt ran without it.)
+    size_t fence = 0;
     auto pose_bwd = smpl_pose_bwd_kernel<0, 0>;
 #ifdef STRAPS_TOOLS
     static const int xchg = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_XCHG", 0);        // (exchange forms, see lane_get)
-    static const int fenced = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_FENCE", 1);     // (0: the kernel as it was before the fence -- the reproducer's victim)
+    static const int fenced = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_FENCE", 0);     // (1: 96 KB of unused LDS, the first mitigation)
     pose_bwd = xchg == 1 ? smpl_pose_bwd_kernel<1> : xchg == 2 ? smpl_pose_bwd_kernel<2> : xchg == 4 ? smpl_pose_bwd_kernel<4> : xchg == 5 ? smpl_pose_bwd_kernel<5> : pose_bwd;
-    if (!fenced) fence = 0;
+    if (fenced) fence = 96 * 1024;
     static const int sc = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_SC", 0);            // (1: partials read past the caches)
     if (sc) pose_bwd = smpl_pose_bwd_kernel<0, 1>;
     static const int dbg = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_DBG", 0);          // (1: intermediate values dumped, straps_tool_pose_dbg fetches them)

@@ -40,7 +40,7 @@ from straps_amd.image_utils import batch_crop_and_resize  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 load = os.environ.get('PROBE_LOAD', '1') == '1'
-L = hipabi.use_library(hipabi.build(tools=True)) if os.environ.get('PROBE_TOOLS') else hipabi.load()
+L = (hipabi.use_library(os.environ.get('PROBE_TOOLS_LIB') or hipabi.build(tools=True))) if os.environ.get('PROBE_TOOLS') else hipabi.load()      # (PROBE_TOOLS_LIB: another tools build, e.g. one kept under tools/bin/)
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
 smpl = straps_amd.SMPL(straps_amd.synthetic_smpl_model(0), batch_size=1).to(dev)
