@@ -36,7 +36,7 @@ unsigned long long* straps_clk_acc_current();
 // v_pk_fma_f32 d, a, b, c op_sel:[0,1,0]) are compiled WITHOUT packed fp32 instructions.  Round 5, DESIGN section 1: on MI355X such an instruction
 // returns a wrong low result in lanes 48..63 (the selected operand reads as zero: fma -> c, mul -> 0, add -> a) while a bf16x3 convolution workgroup
 // runs on the same compute unit -- measured with a victim of nothing but such instructions, each checked against the plain instruction on the same
-// registers (profiles/r05_packed_fp32_victim.txt: 0.8 % of the checks fail beside the convolution, none of 7.7 million alone; only the src1 select,
+// registers (profiles/r05_packed_fp32_victim.txt: 0.12 % of the executions fail beside the convolution, none of 23 million alone; only the src1 select,
 // only the low half, only the last sixteen lanes).  tests/test_packed_fp32_audit.py disassembles the built library and fails if ANY kernel holds one.
 #if defined(__HIP_DEVICE_COMPILE__) && !(defined(STRAPS_TOOLS) && defined(STRAPS_ALLOW_PACKED_FP32))      // (tools build of a reproducer's victim: the kernels as they were)
 #define STRAPS_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))

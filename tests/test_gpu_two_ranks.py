@@ -140,7 +140,7 @@ def test_two_ranks_replicas_stay_in_sync(gm):
 # backward (d betas, d rotations)".  Traced to ONE instruction: the compiler had formed `v_pk_fma_f32 ... op_sel:[0,1,0]` (a packed fp32
 # instruction whose LOW result reads the HIGH register of a source) in smpl_pose_bwd_kernel, and on MI355X such an instruction loses the product in lanes
 # 48..63 while a bf16x3 convolution workgroup -- here: of the OTHER process -- runs on the same compute unit (a victim of nothing but such instructions,
-# checked against plain ones: 0.8 % of the checks fail beside the convolution, none alone).  The kernels that held one are compiled without packed fp32
+# checked against plain ones: 0.12 % of the executions fail beside the convolution, none alone).  The kernels that held one are compiled without packed fp32
 # instructions and tests/test_packed_fp32_audit.py keeps the library free of them; since then the comparison holds, so it is a plain assertion again.
 @pytest.mark.parametrize('gm', [False, True], ids=['per_rank_mean', 'global_masked_mean'])
 def test_two_ranks_graphs_and_overlap_equal_the_eager_step_in_every_stage(gm):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: the packed-fp32 victim (0.8 % of its checks fail beside the bf16x3 convolution) as a DETECTOR: which neighbour does it take?
+# round 5: the packed-fp32 victim (0.12 % of its vulnerable instructions fail beside the bf16x3 convolution) as a DETECTOR: which neighbour does it take?
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export STRAPS_TOOLS_NO_BUILD=1 PROBE_TOOLS=1 PROBE_PK_VICTIM=1 PROBE_CONV_B=4 PROBE_CONV_HW=16 PROBE_CONV_CH=256
