@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run when smpl_pose_bwd_kernel still held packed fp32 instructions; to repeat: build the tools library with STRAPS_TOOLS_SMPL_BWD_FLAGS=-DSTRAPS_POSE_BWD_PACKED first)
 # round 5: WHAT goes wrong in smpl_pose_bwd_kernel beside a bf16x3 convolution workgroup?  The reproducer of DESIGN section 1 (fence off) with the
 # kernel's lane exchanges in five forms (csrc/smpl_bwd.hip, lane_get; tools build): 0 the product's __shfl, 1 v_readlane only (no LDS-unit instruction),
 # 4 ds_bpermute with one in flight, 5 the product's __shfl checked against v_readlane, 2 ds_bpermute twice, one in flight, both checked

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run when smpl_pose_bwd_kernel still held packed fp32 instructions; to repeat: build the tools library with STRAPS_TOOLS_SMPL_BWD_FLAGS=-DSTRAPS_POSE_BWD_PACKED first)
 # round 5: the exchanges are NOT it (tools/r05_gpu_xchg.sh: 3.1 million checked, none wrong, and the readlane-only kernel differs too).  What the kernel
 # READS, then: the chunk partials its producer (smpl_verts_bwd_kernel, the launch in front of it on the same stream) wrote.  Tools-build switches:
 #   STRAPS_POSE_BWD_POISON=1  partials filled with NaN before the producer runs: a NaN result read what this call never wrote

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run when smpl_pose_bwd_kernel still held packed fp32 instructions; to repeat: build the tools library with STRAPS_TOOLS_SMPL_BWD_FLAGS=-DSTRAPS_POSE_BWD_PACKED first)
 # round 5: WHICH elements of the rotation gradient differ in an event (every event so far changed exactly 114 of them)?
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

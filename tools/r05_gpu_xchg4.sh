@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run when smpl_pose_bwd_kernel still held packed fp32 instructions; to repeat: build the tools library with STRAPS_TOOLS_SMPL_BWD_FLAGS=-DSTRAPS_POSE_BWD_PACKED first)
 # round 5: the FIRST intermediate value of smpl_pose_bwd_kernel that differs in an event (tools build, STRAPS_POSE_BWD_DBG=1: workgroup 0 dumps them)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

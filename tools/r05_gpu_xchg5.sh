@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run when smpl_pose_bwd_kernel still held packed fp32 instructions; to repeat: build the tools library with STRAPS_TOOLS_SMPL_BWD_FLAGS=-DSTRAPS_POSE_BWD_PACKED first)
 # round 5: the first wrong value is J[0] short of its l = 1 term = the SECOND dword of one global_load_dwordx4, lanes 48..63.  The load written out in assembly and
 # awaited on the spot (tools build, STRAPS_POSE_BWD_DBG=2; =3: ~500 cycles of sleep behind the wait): its four result registers copied early and late
 cd "$(dirname "$0")/.."

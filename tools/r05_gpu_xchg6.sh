@@ -1,4 +1,5 @@
 #!/bin/bash
+# (run when smpl_pose_bwd_kernel still held packed fp32 instructions; to repeat: build the tools library with STRAPS_TOOLS_SMPL_BWD_FLAGS=-DSTRAPS_POSE_BWD_PACKED first)
 # round 5: ONE instruction.  The l = 1 step of (J[0], J[1]) is v_pk_fma_f32 ... op_sel:[0,1,0]; its LOW result comes out short of the product in lanes 48..63.
 # STRAPS_POSE_BWD_DBG=4: the instruction written out, followed by a plain v_fma_f32 of the same registers; differences logged with the operands.
 # =6: the same with every load awaited and a sleep in front.  =5: the compiler's code, loads awaited and a sleep before the first arithmetic.
