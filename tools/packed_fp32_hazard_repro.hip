@@ -1,0 +1,212 @@
+// tools/packed_fp32_hazard_repro.hip -- round 5, DESIGN section 1: the packed-fp32 operand-select finding as ONE stand-alone HIP program (no torch, no Python,
+// and in its default mode no code of this repository's library either).
+//
+// VICTIM: one 256-thread workgroup, no LDS; every trip runs seven forms of v_pk_{fma,mul,add}_f32, each followed by plain v_fma / v_mul / v_add of the SAME
+// registers, and counts on the device the lanes whose packed result differs from the plain one (by form, by quarter of the wave, by half).
+// AGGRESSOR, replayed as a hipGraph of eight launches on a second stream (argv[2]):
+//   3 (default)  synthetic: 64 workgroups of four waves, 72 KB of LDS, 72 "chunks" of twelve v_mfma_f32_32x32x16_bf16 per wave between barriers, their operand
+//                fragments read out of LDS (ds_read_b128) in front of them -- the SHAPE of the library's bf16x3 convolution on 64 x 64 tiles, nothing else of it
+//   2 / 4 / 5    the same with register operands only (MFMAs + barriers) / plus a 16-byte global -> LDS copy per thread and chunk / form 4 on 256 workgroups
+//   1            the library's own kernel through its C ABI (straps_conv_fwd_x3 at 4 bodies x 16 x 16 x 256 -> 256 channels, 3 x 3; libstraps_hip.so is opened
+//                at run time: STRAPS_LIB=/path/to/libstraps_hip.so, default straps-3dhumanshapepose_amd/csrc/libstraps_hip.so under the current directory)
+//   0            none
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/packed_fp32_hazard_repro.hip -o tools/bin/packed_fp32_hazard_repro -ldl
+//   tools/bin/packed_fp32_hazard_repro [launches = 8000] [aggressor = 3]
+//
+// Measured on MI355X (profiles/r05_packed_fp32_hazard_repro.txt), wrong lane results in 6 000 launches = 2.7 million executions of each form: library kernel
+// 49 458; synthetic 3: 14 086; 2: 320; 4: 416; 5: 2 352; none: 0 -- always and only the three forms with a low-half select on src1, lanes 48..63, low half.
+// Exit status: 1 if any lane differed.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK_HIP(call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e__ = (call);                                                                          \
+        if (e__ != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e__)); exit(2); }   \
+    } while (0)
+#define CHECK_STRAPS(call)                                                                                \
+    do {                                                                                                  \
+        int r__ = (call);                                                                                 \
+        if (r__ != 0) { fprintf(stderr, "%s: %d %s\n", #call, r__, lib_last_error()); exit(2); }          \
+    } while (0)
+
+// the three entry points of libstraps_hip.so that aggressor 1 uses (include/straps_hip.h), resolved at run time
+typedef int (*conv_fwd_x3_t)(const unsigned short*, long long, const unsigned short*, long long, const float*, const float*, const float*, int, float*, float*, int, int, int,
+                             int, int, int, int, int, int, int, void*);
+typedef int (*stat_blocks_t)(int, int, int, int, int, int, int, int, int, int);
+typedef const char* (*last_error_t)(void);
+static conv_fwd_x3_t lib_conv_fwd_x3;
+static stat_blocks_t lib_stat_blocks;
+static last_error_t lib_last_error;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// counters: [0] wave-trips run, [1 + form] differing lanes of that form (7), [8 + quarter] by quarter of the wave (4), [12] low half, [13] high half
+#define PK_CHECK(form, PK_ASM, LO_ASM, HI_ASM)                                                                              \
+    do {                                                                                                                    \
+        f2 d; float lo, hi;                                                                                                 \
+        asm volatile(PK_ASM "\n\t" LO_ASM "\n\t" HI_ASM : "=&v"(d), "=&v"(lo), "=&v"(hi)                                    \
+                     : "v"(a), "v"(b), "v"(c), "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "v"(c.x), "v"(c.y));                 \
+        const bool bad_lo = __float_as_uint(d.x) != __float_as_uint(lo), bad_hi = __float_as_uint(d.y) != __float_as_uint(hi); \
+        if (bad_lo || bad_hi) {                                                                                             \
+            atomicAdd(&counters[1 + (form)], 1ull);                                                                         \
+            atomicAdd(&counters[8 + ((threadIdx.x & 63) >> 4)], 1ull);                                                      \
+            if (bad_lo) atomicAdd(&counters[12], 1ull);                                                                     \
+            if (bad_hi) atomicAdd(&counters[13], 1ull);                                                                     \
+        }                                                                                                                   \
+        sum += d.x + d.y;                                                                                                   \
+    } while (0)
+
+// asm operands: %3 a, %4 b, %5 c (register pairs); %6 a.lo %7 a.hi %8 b.lo %9 b.hi %10 c.lo %11 c.hi
+__global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ counters, int trips) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    f2 a = {in[t * 6 + 0], in[t * 6 + 1]}, b = {in[t * 6 + 2], in[t * 6 + 3]}, c = {in[t * 6 + 4], in[t * 6 + 5]};
+    float sum = 0.f;
+    for (int trip = 0; trip < trips; ++trip) {
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counters[0], 1ull);
+        PK_CHECK(0, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,1,0]", "v_fma_f32 %1, %6, %9, %10", "v_fma_f32 %2, %7, %9, %11");
+        PK_CHECK(1, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[1,0,0]", "v_fma_f32 %1, %7, %8, %10", "v_fma_f32 %2, %7, %9, %11");
+        PK_CHECK(2, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,0,1]", "v_fma_f32 %1, %6, %8, %11", "v_fma_f32 %2, %7, %9, %11");
+        PK_CHECK(3, "v_pk_fma_f32 %0, %3, %4, %5 op_sel_hi:[1,0,1]", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %8, %11");
+        PK_CHECK(4, "v_pk_fma_f32 %0, %3, %4, %5", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %9, %11");
+        PK_CHECK(5, "v_pk_mul_f32 %0, %3, %4 op_sel:[0,1]", "v_mul_f32 %1, %6, %9", "v_mul_f32 %2, %7, %9");
+        PK_CHECK(6, "v_pk_add_f32 %0, %3, %4 op_sel:[0,1]", "v_add_f32 %1, %6, %9", "v_add_f32 %2, %7, %9");
+        a.x += 0.001f; b.y -= 0.002f; c.x += 0.003f;
+    }
+    out[t] = sum;
+}
+
+// Synthetic aggressors (aggressor = 2..5): the convolution kernel's SHAPE re-implemented here -- 64 workgroups of four waves, 72 KB of LDS, 72 "chunks" of twelve
+// v_mfma_f32_32x32x16_bf16 per wave between barriers -- 2: MFMAs on register operands + barriers; 3: operand fragments read out of LDS (ds_read_b128) in front of
+// them; 4: plus a 16-byte global -> LDS copy per thread and chunk; 5: form 4 on 256 workgroups.  Does any of them do what the library's kernel does to the victim?
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __launch_bounds__(256) void synthetic_aggressor_kernel(const unsigned short* __restrict__ g, float* __restrict__ sink, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];      // 72 KB: 3 stages x 3 planes x 128 rows x 32 bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 36864; i += 256) lds[i] = (unsigned short)(0x3c00 + (i * 7 & 255));
+    __syncthreads();
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    bf16x8 a[3], b[3];
+    for (int pl = 0; pl < 3; ++pl) {
+        a[pl] = *reinterpret_cast<const bf16x8*>(lds + (pl * 128 + (lane & 31)) * 32 + (lane >> 5) * 8);
+        b[pl] = *reinterpret_cast<const bf16x8*>(lds + (pl * 128 + 64 + (lane & 31)) * 32 + (lane >> 5) * 8);
+    }
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int stage = ch % 3;
+        if (MODE >= 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(g + (((size_t)(blockIdx.x & 63) * 72 + (ch % 72)) * 256 + tid) * 8);
+            *reinterpret_cast<uint4*>(lds + stage * 12288 + tid * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (MODE >= 3) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[pl] = *reinterpret_cast<const bf16x8*>(lds + stage * 12288 + (pl * 128 + (wave >> 1) * 32 + (lane & 31)) * 32 + ((kk * 2 + (lane >> 5)) ^ ((lane >> 3) & 3)) * 8);
+                    b[pl] = *reinterpret_cast<const bf16x8*>(lds + stage * 12288 + (pl * 128 + 64 + (wave & 1) * 32 + (lane & 31)) * 32 + ((kk * 2 + (lane >> 5)) ^ ((lane >> 3) & 3)) * 8);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[TB[q]], acc, 0, 0, 0);
+        }
+        if (MODE == 2) asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+    }
+    float t = 0.f;
+    for (int r = 0; r < 16; ++r) t += acc[r];
+    if (t == 123.456f) sink[tid] = t;
+}
+
+int main(int argc, char** argv) {
+    const int launches = argc > 1 ? atoi(argv[1]) : 8000;
+    const int aggressor = argc > 2 ? atoi(argv[2]) : 3;
+    const int B = 4, HW = 16, C = 256, trips = 64;
+    const long long rows = (long long)B * HW * HW, xn = rows * C, wn = (long long)C * 9 * C;
+    hipStream_t sa, sv;
+    CHECK_HIP(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    CHECK_HIP(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+
+    // aggressor 1's operands: finite bf16 bit patterns (0x3c3c = 0.0115), any values do
+    unsigned short *x3 = nullptr, *w3 = nullptr;
+    float *y = nullptr, *part = nullptr;
+    if (aggressor == 1) {
+        const char* path = getenv("STRAPS_LIB") ? getenv("STRAPS_LIB") : "straps-3dhumanshapepose_amd/csrc/libstraps_hip.so";
+        void* lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { fprintf(stderr, "aggressor 1 needs the library: %s\n", dlerror()); return 2; }
+        lib_conv_fwd_x3 = (conv_fwd_x3_t)dlsym(lib, "straps_conv_fwd_x3");
+        lib_stat_blocks = (stat_blocks_t)dlsym(lib, "straps_conv_x3_stat_blocks");
+        lib_last_error = (last_error_t)dlsym(lib, "straps_last_error");
+        if (!lib_conv_fwd_x3 || !lib_stat_blocks || !lib_last_error) { fprintf(stderr, "entry points missing in %s\n", path); return 2; }
+        CHECK_HIP(hipMalloc(&x3, 3 * xn * sizeof(unsigned short)));
+        CHECK_HIP(hipMalloc(&w3, 3 * wn * sizeof(unsigned short)));
+        CHECK_HIP(hipMemset(x3, 0x3c, 3 * xn * sizeof(unsigned short)));
+        CHECK_HIP(hipMemset(w3, 0x3c, 3 * wn * sizeof(unsigned short)));
+        const int nblk = lib_stat_blocks(B, HW, HW, C, C, 3, 3, 1, 1, 0);
+        CHECK_HIP(hipMalloc(&y, rows * C * sizeof(float)));
+        CHECK_HIP(hipMalloc(&part, (size_t)(nblk > 0 ? nblk : 1) * C * 2 * sizeof(float)));
+    }
+
+    // victim operands
+    std::vector<float> h(256 * 6);
+    unsigned seed = 12345u;
+    for (float& v : h) { seed = seed * 1664525u + 1013904223u; v = ((int)(seed >> 8) % 4000 - 2000) * 1e-3f; }
+    float *vin, *vout;
+    unsigned long long* counters;
+    CHECK_HIP(hipMalloc(&vin, h.size() * sizeof(float)));
+    CHECK_HIP(hipMalloc(&vout, 256 * sizeof(float)));
+    CHECK_HIP(hipMalloc(&counters, 16 * sizeof(unsigned long long)));
+    CHECK_HIP(hipMemcpy(vin, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemset(counters, 0, 16 * sizeof(unsigned long long)));
+
+    hipGraphExec_t exec = nullptr;
+    if (aggressor >= 2) {
+        auto kern = aggressor == 2 ? synthetic_aggressor_kernel<2> : aggressor == 3 ? synthetic_aggressor_kernel<3> : synthetic_aggressor_kernel<4>;
+        CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+        unsigned short* g;
+        float* sink;
+        CHECK_HIP(hipMalloc(&g, (size_t)64 * 72 * 256 * 8 * sizeof(unsigned short)));
+        CHECK_HIP(hipMemset(g, 0x3c, (size_t)64 * 72 * 256 * 8 * sizeof(unsigned short)));
+        CHECK_HIP(hipMalloc(&sink, 256 * sizeof(float)));
+        hipGraph_t graph;
+        CHECK_HIP(hipStreamBeginCapture(sa, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(kern, dim3(aggressor == 5 ? 256 : 64), dim3(256), 73728, sa, g, sink, 72);
+        CHECK_HIP(hipStreamEndCapture(sa, &graph));
+        CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    } else if (aggressor) {
+        CHECK_STRAPS(lib_conv_fwd_x3(x3, xn, w3, wn, nullptr, nullptr, nullptr, 0, y, part, B, HW, HW, C, C, 3, 3, 1, 1, 0, sa));      // (first call outside the capture: attribute set-up)
+        CHECK_HIP(hipStreamSynchronize(sa));
+        hipGraph_t graph;
+        CHECK_HIP(hipStreamBeginCapture(sa, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < 8; ++k) CHECK_STRAPS(lib_conv_fwd_x3(x3, xn, w3, wn, nullptr, nullptr, nullptr, 0, y, part, B, HW, HW, C, C, 3, 3, 1, 1, 0, sa));
+        CHECK_HIP(hipStreamEndCapture(sa, &graph));
+        CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < launches; ++i) {
+        if (exec) CHECK_HIP(hipGraphLaunch(exec, sa));
+        hipLaunchKernelGGL(pk_victim_kernel, dim3(1), dim3(256), 0, sv, vin, vout, counters, trips);
+        if ((i & 63) == 63) { CHECK_HIP(hipStreamSynchronize(sv)); CHECK_HIP(hipStreamSynchronize(sa)); }
+    }
+    CHECK_HIP(hipDeviceSynchronize());
+    unsigned long long c[16];
+    CHECK_HIP(hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost));
+    const char* forms[7] = {"pk_fma op_sel:[0,1,0]", "pk_fma op_sel:[1,0,0]", "pk_fma op_sel:[0,0,1]", "pk_fma op_sel_hi:[1,0,1]", "pk_fma (no selects)", "pk_mul op_sel:[0,1]", "pk_add op_sel:[0,1]"};
+    unsigned long long total = 0;
+    for (int f = 0; f < 7; ++f) total += c[1 + f];
+    printf("packed fp32 victim, %d launches x %d trips x 7 forms, %s: %llu wave-trips, %llu lane results differ from the plain instructions\n", launches, trips,
+           aggressor == 1 ? "beside straps_conv_fwd_x3 (4 x 16 x 16 x 256 -> 256, 3 x 3)" : aggressor == 0 ? "alone" : aggressor == 2 ? "beside the synthetic aggressor 2 (MFMAs + barriers)"
+           : aggressor == 3 ? "beside the synthetic aggressor 3 (+ fragment reads)" : aggressor == 4 ? "beside the synthetic aggressor 4 (+ global -> LDS copies)" : "beside the synthetic aggressor 5 (form 4, 256 workgroups)", c[0], total);
+    for (int f = 0; f < 7; ++f) printf("   %-26s %llu\n", forms[f], c[1 + f]);
+    printf("   by quarter of the wave (lanes 0-15, 16-31, 32-47, 48-63): %llu %llu %llu %llu | low half %llu, high half %llu\n", c[8], c[9], c[10], c[11], c[12], c[13]);
+    return total ? 1 : 0;
+}
