@@ -7,6 +7,7 @@
 //   3 (default)  synthetic: 64 workgroups of four waves, 72 KB of LDS, 72 "chunks" of twelve v_mfma_f32_32x32x16_bf16 per wave between barriers, their operand
 //                fragments read out of LDS (ds_read_b128) in front of them -- the SHAPE of the library's bf16x3 convolution on 64 x 64 tiles, nothing else of it
 //   2 / 4 / 5    the same with register operands only (MFMAs + barriers) / plus a 16-byte global -> LDS copy per thread and chunk / form 4 on 256 workgroups
+//   6 / 7 / 8    form 3 with fp32 MFMAs (v_mfma_f32_32x32x2_f32) / with NO matrix instruction (the VALU consumes the fragments) / with v_mfma_f32_16x16x32_bf16
 //   1            the library's own kernel through its C ABI (straps_conv_fwd_x3 at 4 bodies x 16 x 16 x 256 -> 256 channels, 3 x 3; libstraps_hip.so is opened
 //                at run time: STRAPS_LIB=/path/to/libstraps_hip.so, default straps-3dhumanshapepose_amd/csrc/libstraps_hip.so under the current directory)
 //   0            none
@@ -15,7 +16,7 @@
 //   tools/bin/packed_fp32_hazard_repro [launches = 8000] [aggressor = 3]
 //
 // Measured on MI355X (profiles/r05_packed_fp32_hazard_repro.txt), wrong lane results in 6 000 launches = 1.5 million executions of each form: library kernel
-// 49 458; synthetic 3: 14 086; 2: 320; 4: 416; 5: 2 352; none: 0 -- always and only the three forms with a low-half select on src1, lanes 48..63, low half.
+// 49 458; synthetic 3: 14 086 - 22 410; 2: 320; 4: 416; 5: 2 352; 6 (fp32 MFMAs): 0; 7 (no matrix instruction): 0; 8 (16x16x32 bf16): 16; none: 0 -- always and only the three forms with a low-half select on src1, lanes 48..63, low half.
 // Exit status: 1 if any lane differed.
 #include <hip/hip_runtime.h>
 
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256) void synthetic_aggressor_kernel(const unsigned
     __syncthreads();
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
     bf16x8 a[3], b[3];
     for (int pl = 0; pl < 3; ++pl) {
         a[pl] = *reinterpret_cast<const bf16x8*>(lds + (pl * 128 + (lane & 31)) * 32 + (lane >> 5) * 8);
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void synthetic_aggressor_kernel(const unsigned
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
     for (int ch = 0; ch < chunks; ++ch) {
         const int stage = ch % 3;
-        if (MODE >= 4) {
+        if (MODE == 4) {
             const uint4 v = *reinterpret_cast<const uint4*>(g + (((size_t)(blockIdx.x & 63) * 72 + (ch % 72)) * 256 + tid) * 8);
             *reinterpret_cast<uint4*>(lds + stage * 12288 + tid * 8) = v;
         }
@@ -118,12 +121,23 @@ __global__ __launch_bounds__(256) void synthetic_aggressor_kernel(const unsigned
                     b[pl] = *reinterpret_cast<const bf16x8*>(lds + stage * 12288 + (pl * 128 + 64 + (wave & 1) * 32 + (lane & 31)) * 32 + ((kk * 2 + (lane >> 5)) ^ ((lane >> 3) & 3)) * 8);
                 }
             }
+            if (MODE == 6) {            // fp32 MFMAs (v_mfma_f32_32x32x2_f32) behind the same fragment reads
 #pragma unroll
-            for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[TB[q]], acc, 0, 0, 0);
+                for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a[TA[q]][0], (float)b[TB[q]][0], acc, 0, 0, 0);
+            } else if (MODE == 7) {     // NO matrix instruction: the fragments are consumed by the VALU
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc[q] += (float)a[TA[q]][q] * (float)b[TB[q]][q + 1];
+            } else if (MODE == 8) {     // the 16 x 16 x 32 bf16 MFMA
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[TA[q]], b[TB[q]], acc4, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[TB[q]], acc, 0, 0, 0);
+            }
         }
         if (MODE == 2) asm volatile("" : "+v"(a[0]), "+v"(b[0]));
     }
-    float t = 0.f;
+    float t = acc4[0] + acc4[1] + acc4[2] + acc4[3];
     for (int r = 0; r < 16; ++r) t += acc[r];
     if (t == 123.456f) sink[tid] = t;
 }
@@ -171,7 +185,8 @@ int main(int argc, char** argv) {
 
     hipGraphExec_t exec = nullptr;
     if (aggressor >= 2) {
-        auto kern = aggressor == 2 ? synthetic_aggressor_kernel<2> : aggressor == 3 ? synthetic_aggressor_kernel<3> : synthetic_aggressor_kernel<4>;
+        auto kern = aggressor == 2 ? synthetic_aggressor_kernel<2> : aggressor == 3 ? synthetic_aggressor_kernel<3> : aggressor == 6 ? synthetic_aggressor_kernel<6> : aggressor == 7 ? synthetic_aggressor_kernel<7>
+                  : aggressor == 8 ? synthetic_aggressor_kernel<8> : synthetic_aggressor_kernel<4>;
         CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
         unsigned short* g;
         float* sink;
@@ -205,7 +220,8 @@ int main(int argc, char** argv) {
     for (int f = 0; f < 7; ++f) total += c[1 + f];
     printf("packed fp32 victim, %d launches x %d trips x 7 forms, %s: %llu wave-trips, %llu lane results differ from the plain instructions\n", launches, trips,
            aggressor == 1 ? "beside straps_conv_fwd_x3 (4 x 16 x 16 x 256 -> 256, 3 x 3)" : aggressor == 0 ? "alone" : aggressor == 2 ? "beside the synthetic aggressor 2 (MFMAs + barriers)"
-           : aggressor == 3 ? "beside the synthetic aggressor 3 (+ fragment reads)" : aggressor == 4 ? "beside the synthetic aggressor 4 (+ global -> LDS copies)" : "beside the synthetic aggressor 5 (form 4, 256 workgroups)", c[0], total);
+           : aggressor == 3 ? "beside the synthetic aggressor 3 (+ fragment reads)" : aggressor == 6 ? "beside the synthetic aggressor 6 (form 3 with fp32 MFMAs)"
+           : aggressor == 7 ? "beside the synthetic aggressor 7 (form 3 WITHOUT matrix instructions)" : aggressor == 8 ? "beside the synthetic aggressor 8 (form 3 with 16x16x32 bf16 MFMAs)" : aggressor == 4 ? "beside the synthetic aggressor 4 (+ global -> LDS copies)" : "beside the synthetic aggressor 5 (form 4, 256 workgroups)", c[0], total);
     for (int f = 0; f < 7; ++f) printf("   %-26s %llu\n", forms[f], c[1 + f]);
     printf("   by quarter of the wave (lanes 0-15, 16-31, 32-47, 48-63): %llu %llu %llu %llu | low half %llu, high half %llu\n", c[8], c[9], c[10], c[11], c[12], c[13]);
     return total ? 1 : 0;
