@@ -16,7 +16,7 @@ import tempfile
 
 LLVM_BIN = os.environ.get('STRAPS_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
 MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
-PACKED = re.compile(r'\bv_pk_(?:fma|mul|add)_f32\b')
+PACKED = re.compile(r'\bv_pk_(?:(?:fma|mul|add)_f32|mov_b32)\b')      # (v_pk_mov_b32: the 64-bit sibling with the same operand selects -- not measured, not wanted either)
 OP_SEL = re.compile(r'\bop_sel:\[([01,]+)\]')
 
 
