@@ -7,7 +7,8 @@
 //   3 (default)  synthetic: 64 workgroups of four waves, 72 KB of LDS, 72 "chunks" of twelve v_mfma_f32_32x32x16_bf16 per wave between barriers, their operand
 //                fragments read out of LDS (ds_read_b128) in front of them -- the SHAPE of the library's bf16x3 convolution on 64 x 64 tiles, nothing else of it
 //   2 / 4 / 5    the same with register operands only (MFMAs + barriers) / plus a 16-byte global -> LDS copy per thread and chunk / form 4 on 256 workgroups
-//   6 / 7 / 8    form 3 with fp32 MFMAs (v_mfma_f32_32x32x2_f32) / with NO matrix instruction (the VALU consumes the fragments) / with v_mfma_f32_16x16x32_bf16
+//   6 / 7 / 8 / 9  form 3 with fp32 MFMAs (v_mfma_f32_32x32x2_f32) / with NO matrix instruction (the VALU consumes the fragments) / with v_mfma_f32_16x16x32_bf16 /
+//                with v_mfma_f32_32x32x16_f16
 //   1            the library's own kernel through its C ABI (straps_conv_fwd_x3 at 4 bodies x 16 x 16 x 256 -> 256 channels, 3 x 3; libstraps_hip.so is opened
 //                at run time: STRAPS_LIB=/path/to/libstraps_hip.so, default straps-3dhumanshapepose_amd/csrc/libstraps_hip.so under the current directory)
 //   0            none
@@ -16,7 +17,7 @@
 //   tools/bin/packed_fp32_hazard_repro [launches = 8000] [aggressor = 3]
 //
 // Measured on MI355X (profiles/r05_packed_fp32_hazard_repro.txt), wrong lane results in 6 000 launches = 1.5 million executions of each form: library kernel
-// 49 458; synthetic 3: 14 086 - 22 410; 2: 320; 4: 416; 5: 2 352; 6 (fp32 MFMAs): 0; 7 (no matrix instruction): 0; 8 (16x16x32 bf16): 16; none: 0 -- always and only the three forms with a low-half select on src1, lanes 48..63, low half.
+// 49 458; synthetic 3: 14 086 - 22 410; 2: 320; 4: 416; 5: 2 352; 6 (fp32 MFMAs): 0; 7 (no matrix instruction): 0; 8 (16x16x32 bf16): 16; 9 (32x32x16 fp16): 16 135; none: 0 -- always and only the three forms with a low-half select on src1, lanes 48..63, low half.
 // Exit status: 1 if any lane differed.
 #include <hip/hip_runtime.h>
 
@@ -127,6 +128,10 @@ __global__ __launch_bounds__(256) void synthetic_aggressor_kernel(const unsigned
             } else if (MODE == 7) {     // NO matrix instruction: the fragments are consumed by the VALU
 #pragma unroll
                 for (int q = 0; q < 6; ++q) acc[q] += (float)a[TA[q]][q] * (float)b[TB[q]][q + 1];
+            } else if (MODE == 9) {     // the fp16 MFMA of the same shape (v_mfma_f32_32x32x16_f16)
+                typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[TA[q]]), __builtin_bit_cast(half8, b[TB[q]]), acc, 0, 0, 0);
             } else if (MODE == 8) {     // the 16 x 16 x 32 bf16 MFMA
 #pragma unroll
                 for (int q = 0; q < 6; ++q) acc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[TA[q]], b[TB[q]], acc4, 0, 0, 0);
@@ -186,7 +191,7 @@ int main(int argc, char** argv) {
     hipGraphExec_t exec = nullptr;
     if (aggressor >= 2) {
         auto kern = aggressor == 2 ? synthetic_aggressor_kernel<2> : aggressor == 3 ? synthetic_aggressor_kernel<3> : aggressor == 6 ? synthetic_aggressor_kernel<6> : aggressor == 7 ? synthetic_aggressor_kernel<7>
-                  : aggressor == 8 ? synthetic_aggressor_kernel<8> : synthetic_aggressor_kernel<4>;
+                  : aggressor == 8 ? synthetic_aggressor_kernel<8> : aggressor == 9 ? synthetic_aggressor_kernel<9> : synthetic_aggressor_kernel<4>;
         CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
         unsigned short* g;
         float* sink;
@@ -221,7 +226,7 @@ int main(int argc, char** argv) {
     printf("packed fp32 victim, %d launches x %d trips x 7 forms, %s: %llu wave-trips, %llu lane results differ from the plain instructions\n", launches, trips,
            aggressor == 1 ? "beside straps_conv_fwd_x3 (4 x 16 x 16 x 256 -> 256, 3 x 3)" : aggressor == 0 ? "alone" : aggressor == 2 ? "beside the synthetic aggressor 2 (MFMAs + barriers)"
            : aggressor == 3 ? "beside the synthetic aggressor 3 (+ fragment reads)" : aggressor == 6 ? "beside the synthetic aggressor 6 (form 3 with fp32 MFMAs)"
-           : aggressor == 7 ? "beside the synthetic aggressor 7 (form 3 WITHOUT matrix instructions)" : aggressor == 8 ? "beside the synthetic aggressor 8 (form 3 with 16x16x32 bf16 MFMAs)" : aggressor == 4 ? "beside the synthetic aggressor 4 (+ global -> LDS copies)" : "beside the synthetic aggressor 5 (form 4, 256 workgroups)", c[0], total);
+           : aggressor == 7 ? "beside the synthetic aggressor 7 (form 3 WITHOUT matrix instructions)" : aggressor == 8 ? "beside the synthetic aggressor 8 (form 3 with 16x16x32 bf16 MFMAs)" : aggressor == 9 ? "beside the synthetic aggressor 9 (form 3 with 32x32x16 fp16 MFMAs)" : aggressor == 4 ? "beside the synthetic aggressor 4 (+ global -> LDS copies)" : "beside the synthetic aggressor 5 (form 4, 256 workgroups)", c[0], total);
     for (int f = 0; f < 7; ++f) printf("   %-26s %llu\n", forms[f], c[1 + f]);
     printf("   by quarter of the wave (lanes 0-15, 16-31, 32-47, 48-63): %llu %llu %llu %llu | low half %llu, high half %llu\n", c[8], c[9], c[10], c[11], c[12], c[13]);
     return total ? 1 : 0;
