@@ -38,6 +38,10 @@ int straps_selftest_mfma_peak(const float* seed512, float* out, int blocks, int 
  * operand-like data (out = blocks*256 floats; clk2 optional: shader / wall ticks of workgroup 0).  Timed, it gives the rate the pipe
  * SUSTAINS under the board's power budget -- the ceiling of the bf16x3 convolution kernels (bench.py: roofline.sustained_*). */
 int straps_selftest_mfma_bf16(float* out, unsigned long long* clk2, int blocks, int iters, void* stream);
+/* the same with a DENSE issue stream (round 6): eight independent accumulators per wave, two waves per SIMD at blocks = 512; `blocks` x 4 waves each
+ * issue iters x 96 MFMAs; data = 0: all-zero operands (no power limit on the pipe's data path), 1: operand-like bit patterns as above.  bench.py
+ * reports both (`roofline.sustained_mfma`), with MfmaUtil from its counter pass. */
+int straps_selftest_mfma_bf16_dense(float* out, unsigned long long* clk2, int blocks, int iters, int data, void* stream);
 const char* straps_last_error(void);
 /* number of visible HIP devices (0 => the product path must refuse to run) */
 int straps_device_count(void);

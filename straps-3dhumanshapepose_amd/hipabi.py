@@ -39,13 +39,20 @@ def build(force=False, verbose=False, tools=False):
     srcs = _existing_sources()
     lib_path = TOOLS_LIB_PATH if tools else LIB_PATH
     if tools and not force and os.environ.get('STRAPS_TOOLS_NO_BUILD') == '1' and os.path.isfile(lib_path):
-        return lib_path      # (GPU-box runs of the tools: use the library that travelled with the snapshot, whatever the copy did to the time stamps)
+        # (GPU-box runs of the tools: use the library that travelled with the snapshot, whatever the copy did to the time stamps -- and say which one)
+        import sys
+        import time
+        print('hipabi.build(tools=True): STRAPS_TOOLS_NO_BUILD=1 -- reusing %s (built %s)' % (lib_path, time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(os.path.getmtime(lib_path)))),
+              file=sys.stderr)
+        return lib_path
     # every header under csrc/ (common.h, conv_igemm.h, ...) and the public header: a change in any of them rebuilds every object --
     # translation units that share a struct (ConvP) can never be linked from different versions of it
     import glob
     hdrs = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [HEADER]
     deps = srcs + hdrs
     if not force and os.path.isfile(lib_path) and all(os.path.getmtime(lib_path) > os.path.getmtime(d) for d in deps):
+        if not tools:
+            _audit(lib_path, 'hipabi.build (library up to date)')
         return lib_path
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DSTRAPS_TOOLS'] if tools else [])
@@ -75,7 +82,24 @@ def build(force=False, verbose=False, tools=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
+    if not tools:
+        # the packed-operand-select hazard of DESIGN section 1 is a BUILD failure (round 6): the library just linked is disassembled, and one such
+        # instruction in any kernel raises (the file is moved aside).  The tools library is exempt: it holds the reproducers' victims on purpose.
+        _audit(lib_path, 'hipabi.build', fresh=True)
     return lib_path
+
+
+def _audit(lib_path, what, fresh=False):
+    """ISA audit of a product library (isa_audit.py): trusted when its stamp matches, run otherwise; raises on a finding, warns when the LLVM tools
+    that it needs are not installed."""
+    from . import isa_audit
+    if not fresh and isa_audit.stamp_ok(lib_path):
+        return
+    if not isa_audit.enforce(lib_path, what):
+        import warnings
+        warnings.warn('%s: llvm-objdump not found under %s -- the packed-operand-select audit of %s (DESIGN section 1: wrong results in lanes 48..63 on '
+                      'MI355X) did NOT run; set STRAPS_LLVM_BIN or audit the library where it was built (tools/audit_packed_fp32.py)'
+                      % (what, isa_audit.LLVM_BIN, lib_path), RuntimeWarning, stacklevel=3)
 
 
 class SmplModelStruct(C.Structure):
@@ -126,6 +150,7 @@ SIGNATURES = {
     'straps_set_clock_accumulator': (_I, [_P]),
     'straps_selftest_mfma_peak': (_I, [_P, _P, _I, _I, _P]),
     'straps_selftest_mfma_bf16': (_I, [_P, _P, _I, _I, _P]),
+    'straps_selftest_mfma_bf16_dense': (_I, [_P, _P, _I, _I, _I, _P]),
     'straps_pack_conv_weight': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weight_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'straps_pack_conv_weights_batched': (_I, [_P, _I, _L, _P]),
@@ -238,6 +263,8 @@ def load(path=None):
     if not os.path.isfile(p):
         raise RuntimeError('libstraps_hip.so is not built (%s missing): run `python -c "import __graft_entry__ as g; '
                            'g.build()"` -- this package has no CPU fallback' % p)
+    if os.path.abspath(p) != os.path.abspath(TOOLS_LIB_PATH):
+        _audit(p, 'hipabi.load')      # (a library without a matching audit stamp is audited before it is opened; a finding raises)
     lib = C.CDLL(p)
     if hasattr(lib, 'straps_abi_version'):
         lib.straps_abi_version.restype = C.c_int

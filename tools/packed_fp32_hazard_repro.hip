@@ -49,7 +49,8 @@ static last_error_t lib_last_error;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// counters: [0] wave-trips run, [1 + form] differing lanes of that form (7), [8 + quarter] by quarter of the wave (4), [12] low half, [13] high half
+// counters: [0] wave-trips run, [1 + form] differing lanes of that form (NFORMS <= 16), [17 + quarter] by quarter of the wave (4), [21] low half, [22] high half
+#define NFORMS 13
 #define PK_CHECK(form, PK_ASM, LO_ASM, HI_ASM)                                                                              \
     do {                                                                                                                    \
         f2 d; float lo, hi;                                                                                                 \
@@ -58,20 +59,70 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         const bool bad_lo = __float_as_uint(d.x) != __float_as_uint(lo), bad_hi = __float_as_uint(d.y) != __float_as_uint(hi); \
         if (bad_lo || bad_hi) {                                                                                             \
             atomicAdd(&counters[1 + (form)], 1ull);                                                                         \
-            atomicAdd(&counters[8 + ((threadIdx.x & 63) >> 4)], 1ull);                                                      \
-            if (bad_lo) atomicAdd(&counters[12], 1ull);                                                                     \
-            if (bad_hi) atomicAdd(&counters[13], 1ull);                                                                     \
+            atomicAdd(&counters[17 + ((threadIdx.x & 63) >> 4)], 1ull);                                                      \
+            if (bad_lo) atomicAdd(&counters[21], 1ull);                                                                     \
+            if (bad_hi) atomicAdd(&counters[22], 1ull);                                                                     \
         }                                                                                                                   \
         sum += d.x + d.y;                                                                                                   \
     } while (0)
 
+
+// ---- round 6: the other VOP3P forms with operand selects a compiler may emit -------------------------------------------
+// v_pk_mov_b32 (two 64-bit sources, each result half picks one 32-bit register of "its" source by op_sel): the reference is chosen among the four
+// source registers by what LANE 0 observes (the finding never touched lanes 0..47), so the check does not depend on this file's reading of the
+// select semantics; lanes that disagree with lane 0's choice are counted.
+#define PKMOV_CHECK(form, PK_ASM)                                                                                           \
+    do {                                                                                                                    \
+        f2 d;                                                                                                               \
+        asm volatile(PK_ASM : "=&v"(d) : "v"(a), "v"(b));                                                                   \
+        const unsigned cand[4] = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y)};  \
+        int slo = -1, shi = -1;                                                                                             \
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(__float_as_uint(d.x)), d1 = __builtin_amdgcn_readfirstlane(__float_as_uint(d.y)); \
+        for (int q = 0; q < 4; ++q) {                                                                                       \
+            const unsigned c0 = __builtin_amdgcn_readfirstlane(cand[q]);                                                    \
+            if (c0 == d0 && slo < 0) slo = q;                                                                               \
+            if (c0 == d1 && shi < 0) shi = q;                                                                               \
+        }                                                                                                                   \
+        const bool bad_lo = slo < 0 || __float_as_uint(d.x) != cand[slo < 0 ? 0 : slo];                                     \
+        const bool bad_hi = shi < 0 || __float_as_uint(d.y) != cand[shi < 0 ? 0 : shi];                                     \
+        if (bad_lo || bad_hi) {                                                                                             \
+            atomicAdd(&counters[1 + (form)], 1ull);                                                                         \
+            atomicAdd(&counters[17 + ((threadIdx.x & 63) >> 4)], 1ull);                                                     \
+            if (bad_lo) atomicAdd(&counters[21], 1ull);                                                                     \
+            if (bad_hi) atomicAdd(&counters[22], 1ull);                                                                     \
+        }                                                                                                                   \
+        if ((threadIdx.x & 63) == 0 && trip == 0) { sel_seen[(form) * 2] = slo; sel_seen[(form) * 2 + 1] = shi; }           \
+        sum += d.x + d.y;                                                                                                   \
+    } while (0)
+// packed 16-bit forms: one 32-bit register = (hi16 << 16 | lo16) per source; the references are the scalar-half instructions on halves moved into
+// the low 16 bits by plain shifts (no operand select anywhere in the reference).  %0 packed result, %1 / %2 low / high reference (low 16 bits),
+// %3 a, %4 b, %5 c, %6 a >> 16, %7 b >> 16, %8 c >> 16
+#define PK16_CHECK(form, PK_ASM, LO_ASM, HI_ASM)                                                                            \
+    do {                                                                                                                    \
+        unsigned d, lo, hi;                                                                                                 \
+        asm volatile(PK_ASM "\n\t" LO_ASM "\n\t" HI_ASM : "=&v"(d), "=&v"(lo), "=&v"(hi)                                    \
+                     : "v"(ha), "v"(hb), "v"(hc), "v"(ha >> 16), "v"(hb >> 16), "v"(hc >> 16));                             \
+        const bool bad_lo = (d & 0xffffu) != (lo & 0xffffu), bad_hi = (d >> 16) != (hi & 0xffffu);                          \
+        if (bad_lo || bad_hi) {                                                                                             \
+            atomicAdd(&counters[1 + (form)], 1ull);                                                                         \
+            atomicAdd(&counters[17 + ((threadIdx.x & 63) >> 4)], 1ull);                                                     \
+            if (bad_lo) atomicAdd(&counters[21], 1ull);                                                                     \
+            if (bad_hi) atomicAdd(&counters[22], 1ull);                                                                     \
+        }                                                                                                                   \
+        isum += d;                                                                                                          \
+    } while (0)
+
 // asm operands: %3 a, %4 b, %5 c (register pairs); %6 a.lo %7 a.hi %8 b.lo %9 b.hi %10 c.lo %11 c.hi
-__global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ counters, int trips) {
+__global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ counters, int trips, int* __restrict__ sel_seen) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     f2 a = {in[t * 6 + 0], in[t * 6 + 1]}, b = {in[t * 6 + 2], in[t * 6 + 3]}, c = {in[t * 6 + 4], in[t * 6 + 5]};
     float sum = 0.f;
+    // packed fp16 / u16 operands: halves are small exact fp16 numbers (as u16 they are just integers)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 fa = {(_Float16)a.x, (_Float16)a.y}, fb = {(_Float16)b.x, (_Float16)b.y}, fc = {(_Float16)c.x, (_Float16)c.y};
+    unsigned ha = __builtin_bit_cast(unsigned, fa), hb = __builtin_bit_cast(unsigned, fb), hc = __builtin_bit_cast(unsigned, fc), isum = 0;
     for (int trip = 0; trip < trips; ++trip) {
-        asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(ha), "+v"(hb), "+v"(hc));
         if ((threadIdx.x & 63) == 0) atomicAdd(&counters[0], 1ull);
         PK_CHECK(0, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,1,0]", "v_fma_f32 %1, %6, %9, %10", "v_fma_f32 %2, %7, %9, %11");
         PK_CHECK(1, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[1,0,0]", "v_fma_f32 %1, %7, %8, %10", "v_fma_f32 %2, %7, %9, %11");
@@ -80,9 +131,16 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict_
         PK_CHECK(4, "v_pk_fma_f32 %0, %3, %4, %5", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %9, %11");
         PK_CHECK(5, "v_pk_mul_f32 %0, %3, %4 op_sel:[0,1]", "v_mul_f32 %1, %6, %9", "v_mul_f32 %2, %7, %9");
         PK_CHECK(6, "v_pk_add_f32 %0, %3, %4 op_sel:[0,1]", "v_add_f32 %1, %6, %9", "v_add_f32 %2, %7, %9");
+        PKMOV_CHECK(7, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]");
+        PKMOV_CHECK(8, "v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]");
+        PK16_CHECK(9, "v_pk_fma_f16 %0, %3, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]", "v_fma_f16 %1, %3, %7, %5", "v_fma_f16 %2, %6, %7, %8");
+        PK16_CHECK(10, "v_pk_add_f16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_add_f16 %1, %3, %7", "v_add_f16 %2, %6, %7");
+        PK16_CHECK(11, "v_pk_mul_f16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_mul_f16 %1, %3, %7", "v_mul_f16 %2, %6, %7");
+        PK16_CHECK(12, "v_pk_add_u16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_add_u16 %1, %3, %7", "v_add_u16 %2, %6, %7");
         a.x += 0.001f; b.y -= 0.002f; c.x += 0.003f;
+        ha += 0x00010000u; hb ^= 0x00000400u;
     }
-    out[t] = sum;
+    out[t] = sum + (float)(isum & 1u);
 }
 
 // Synthetic aggressors (aggressor = 2..5): the convolution kernel's SHAPE re-implemented here -- 64 workgroups of four waves, 72 KB of LDS, 72 "chunks" of twelve
@@ -184,9 +242,12 @@ int main(int argc, char** argv) {
     unsigned long long* counters;
     CHECK_HIP(hipMalloc(&vin, h.size() * sizeof(float)));
     CHECK_HIP(hipMalloc(&vout, 256 * sizeof(float)));
-    CHECK_HIP(hipMalloc(&counters, 16 * sizeof(unsigned long long)));
+    CHECK_HIP(hipMalloc(&counters, 32 * sizeof(unsigned long long)));
+    int* sel_seen;
+    CHECK_HIP(hipMalloc(&sel_seen, 64 * sizeof(int)));
+    CHECK_HIP(hipMemset(sel_seen, 0xff, 64 * sizeof(int)));
     CHECK_HIP(hipMemcpy(vin, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-    CHECK_HIP(hipMemset(counters, 0, 16 * sizeof(unsigned long long)));
+    CHECK_HIP(hipMemset(counters, 0, 32 * sizeof(unsigned long long)));
 
     hipGraphExec_t exec = nullptr;
     if (aggressor >= 2) {
@@ -214,20 +275,25 @@ int main(int argc, char** argv) {
     }
     for (int i = 0; i < launches; ++i) {
         if (exec) CHECK_HIP(hipGraphLaunch(exec, sa));
-        hipLaunchKernelGGL(pk_victim_kernel, dim3(1), dim3(256), 0, sv, vin, vout, counters, trips);
+        hipLaunchKernelGGL(pk_victim_kernel, dim3(1), dim3(256), 0, sv, vin, vout, counters, trips, sel_seen);
         if ((i & 63) == 63) { CHECK_HIP(hipStreamSynchronize(sv)); CHECK_HIP(hipStreamSynchronize(sa)); }
     }
     CHECK_HIP(hipDeviceSynchronize());
-    unsigned long long c[16];
+    unsigned long long c[32];
+    int sel[64];
+    CHECK_HIP(hipMemcpy(sel, sel_seen, sizeof(sel), hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost));
-    const char* forms[7] = {"pk_fma op_sel:[0,1,0]", "pk_fma op_sel:[1,0,0]", "pk_fma op_sel:[0,0,1]", "pk_fma op_sel_hi:[1,0,1]", "pk_fma (no selects)", "pk_mul op_sel:[0,1]", "pk_add op_sel:[0,1]"};
+    const char* forms[NFORMS] = {"pk_fma op_sel:[0,1,0]", "pk_fma op_sel:[1,0,0]", "pk_fma op_sel:[0,0,1]", "pk_fma op_sel_hi:[1,0,1]", "pk_fma (no selects)", "pk_mul op_sel:[0,1]", "pk_add op_sel:[0,1]",
+                                 "pk_mov_b32 op_sel:[1,0]", "pk_mov_b32 op_sel:[0,1]", "pk_fma_f16 op_sel:[0,1,0]", "pk_add_f16 op_sel:[0,1]", "pk_mul_f16 op_sel:[0,1]", "pk_add_u16 op_sel:[0,1]"};
     unsigned long long total = 0;
-    for (int f = 0; f < 7; ++f) total += c[1 + f];
-    printf("packed fp32 victim, %d launches x %d trips x 7 forms, %s: %llu wave-trips, %llu lane results differ from the plain instructions\n", launches, trips,
+    for (int f = 0; f < NFORMS; ++f) total += c[1 + f];
+    printf("packed fp32 victim, %d launches x %d trips x 13 forms, %s: %llu wave-trips, %llu lane results differ from the plain instructions\n", launches, trips,
            aggressor == 1 ? "beside straps_conv_fwd_x3 (4 x 16 x 16 x 256 -> 256, 3 x 3)" : aggressor == 0 ? "alone" : aggressor == 2 ? "beside the synthetic aggressor 2 (MFMAs + barriers)"
            : aggressor == 3 ? "beside the synthetic aggressor 3 (+ fragment reads)" : aggressor == 6 ? "beside the synthetic aggressor 6 (form 3 with fp32 MFMAs)"
            : aggressor == 7 ? "beside the synthetic aggressor 7 (form 3 WITHOUT matrix instructions)" : aggressor == 8 ? "beside the synthetic aggressor 8 (form 3 with 16x16x32 bf16 MFMAs)" : aggressor == 9 ? "beside the synthetic aggressor 9 (form 3 with 32x32x16 fp16 MFMAs)" : aggressor == 4 ? "beside the synthetic aggressor 4 (+ global -> LDS copies)" : "beside the synthetic aggressor 5 (form 4, 256 workgroups)", c[0], total);
-    for (int f = 0; f < 7; ++f) printf("   %-26s %llu\n", forms[f], c[1 + f]);
-    printf("   by quarter of the wave (lanes 0-15, 16-31, 32-47, 48-63): %llu %llu %llu %llu | low half %llu, high half %llu\n", c[8], c[9], c[10], c[11], c[12], c[13]);
+    for (int f = 0; f < NFORMS; ++f) printf("   %-26s %llu\n", forms[f], c[1 + f]);
+    const char* regs[5] = {"(none matched)", "src0.lo", "src0.hi", "src1.lo", "src1.hi"};
+    for (int f = 7; f < 9; ++f) printf("   %-26s as lane 0 saw it: result.lo = %s, result.hi = %s\n", forms[f], regs[sel[f * 2] + 1], regs[sel[f * 2 + 1] + 1]);
+    printf("   by quarter of the wave (lanes 0-15, 16-31, 32-47, 48-63): %llu %llu %llu %llu | low half %llu, high half %llu\n", c[17], c[18], c[19], c[20], c[21], c[22]);
     return total ? 1 : 0;
 }
