@@ -364,6 +364,32 @@ int straps_split3_bf16_cm(const float* x, unsigned short* planes, long long rows
 /* statistics partials of straps_conv_fwd_x3 for this geometry: [blocks][cout][2]                          */
 int straps_conv_x3_stat_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride,
                                int pad, int tile_cfg);
+
+/* ---- 1x1 convolutions with the A operand read from the fp32 tensor (round 6; csrc/conv_x3f.hip) -------------------------------------
+ * models/resnet.py:34-36 (conv1x1) as used by the bottleneck units :80-121 and the shortcut convolutions :172-177.  Same arithmetic as
+ * the plane entry points above (three bf16 parts per fp32 value, six products per term, fp32 accumulate -- the two routes give the same
+ * bits on the same values), but the kernel splits the activation / gradient itself: the producer writes (and this reads) 4 bytes per
+ * element instead of 6-10, and the BatchNorm + ReLU in front of the convolution can ride in the operand path (a_scale / a_shift).       */
+/* 1 if straps_conv_fwd_x3f / straps_conv_dgrad_x3f / straps_conv_wgrad_x3f cover the geometry (1x1, pad 0, stride 1 | 2, channels % 64) */
+int straps_conv_x3f_supported(int cin, int cout, int kh, int kw, int stride, int pad);
+/* y = conv1x1(act(x)) [* scale + shift] [+ residual] [relu]; x: fp32 NHWC [batch][h][w][cin].  a_scale / a_shift ([cin], 16-byte aligned;
+ * both or neither): act(x) = x * a_scale + a_shift per channel, then ReLU if a_relu -- x is then the RAW output of the previous
+ * convolution and the normalised activation is never materialised; NULL: act(x) = x.  w3: the weights' planes as for
+ * straps_conv_fwd_x3.  stats_partial (training): [straps_conv_x3f_stat_blocks][cout][2] partial (sum, sum of squares) of y.            */
+int straps_conv_fwd_x3f(const float* x, const float* a_scale, const float* a_shift, int a_relu, const unsigned short* w3,
+                        long long w_plane_stride, const float* scale, const float* shift, const float* residual, int relu,
+                        float* y, float* stats_partial, int batch, int h, int w, int cin, int cout, int kh, int kw, int stride,
+                        int pad, int tile_cfg, void* stream);
+int straps_conv_x3f_stat_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg);
+/* dx = dgrad1x1(dy) [+ addend, masked by addend_bits]; dy: fp32 [batch][ho][wo][cout] (no planes of it need exist).  Optional, as in
+ * straps_conv_dgrad_x3_bn_bits: the two BatchNorm-backward sums of the BatchNorm (+ ReLU) whose output the convolution read (bn_raw !=
+ * NULL; mask = bn_out_bits, else relu'(bn_raw * bn_mask_scale + bn_mask_shift)) into bn_partials [straps_conv_dgrad_x3f_bn_blocks][cin][2]. */
+int straps_conv_dgrad_x3f(const float* dy, const unsigned short* w3_crsk, long long w_plane_stride, const float* addend,
+                          const unsigned* addend_bits, float* dx, int batch, int h, int w, int cin, int cout, int kh, int kw,
+                          int stride, int pad, int tile_cfg, const float* bn_raw, const unsigned* bn_out_bits,
+                          const float* bn_mask_scale, const float* bn_mask_shift, const float* bn_mean, const float* bn_invstd,
+                          double* bn_partials, void* stream);
+int straps_conv_dgrad_x3f_bn_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg);
 int straps_conv_fwd_x3(const unsigned short* x3, long long x_plane_stride,
                        const unsigned short* w3_krsc, long long w_plane_stride, const float* scale,
                        const float* shift, const float* residual, int relu, float* y_nhwc,
