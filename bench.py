@@ -325,6 +325,16 @@ def instrument(timer):
         def straps_conv_dgrad_x3_bits(self, *a):
             return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3_bits(*a), 1.5 * conv_bytes(*a[6:15]), geo('dgrad', *a[6:15]))
 
+        # the fp32-operand route of the long 1x1 layers (csrc/conv_x3f.hip, round 6): the same matrix work, counted under the same kernel key (class
+        # names carry "f32"); algorithmic bytes = the fp32 tensors (the plane route's operands are 1.5x that)
+        def straps_conv_fwd_x3f(self, *a):
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[12:21]), lambda: L.straps_conv_fwd_x3f(*a), conv_bytes(*a[12:21]),
+                              geo('fwd f32+bn' if a[1] is not None and getattr(a[1], 'value', a[1]) else 'fwd f32', *a[12:21]))
+
+        def straps_conv_dgrad_x3f(self, *a):
+            return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3f(*a), conv_bytes(*a[6:15]),
+                              geo('dgrad+bn f32' if a[16] is not None and getattr(a[16], 'value', a[16]) else 'dgrad f32', *a[6:15]))
+
         def straps_conv_wgrad(self, *a):
             return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a), 0.0, geo('wgrad', *a[4:13]))
 
@@ -386,6 +396,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
     ap.add_argument('--no-overlap', action='store_true', help='(default now) weight-gradient kernels stay on the main stream')
+    ap.add_argument('--no-x3f', action='store_true', help="A/B: the long 1x1 layers on the plane route (rounds 2-5) instead of the fp32-operand route (csrc/conv_x3f.hip)")
     ap.add_argument('--no-relu-bits', action='store_true', help="A/B: a residual unit's ReLU decisions reach the backward pass as fp32 tensors (rounds 1-3) instead of bits")
     ap.add_argument('--no-stem-ab', action='store_true', help='skip the dense-stem A/B steps after the timed region (profiling runs: keeps the kernel stats clean)')
     ap.add_argument('--overlap-wgrad', action='store_true', help='A/B: run the weight-gradient kernels on a side stream (0.1 ms slower since the data pipeline)')
@@ -407,6 +418,9 @@ def main():
     if args.no_relu_bits:
         from straps_amd import encoder_exec as _ee
         _ee._RELU_BITS = False
+    if args.no_x3f:
+        from straps_amd import encoder_exec as _ee2
+        _ee2.X3F_MIN_ROWS = 0
     if args.config:
         args.workload = {1: 'fwd', 2: 'train', 3: 'train', 4: 'smpl'}[args.config]
         if args.config == 3:

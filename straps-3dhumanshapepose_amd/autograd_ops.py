@@ -149,6 +149,29 @@ def _conv_dgrad(L, net, rec, draw, addend, planes_sink=None, bn_next=None, adden
     conv = rec['conv']
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
     dx = torch.empty(B, H, W, Cin, device=draw.device, dtype=torch.float32)
+    if rec.get('fmode'):
+        # the fp32-operand route (csrc/conv_x3f.hip): the gradient is read as the fp32 tensor -- no planes of it were written (encoder_exec.x3f_mode)
+        if not draw.numel():
+            raise RuntimeError('fp32-operand data gradient: the fp32 gradient was not materialised')
+        w3, wps = net._packed_weight_x3(conv, dgrad=True)
+        raw = nbits = msc = msh = mean = invstd = part = None
+        if bn_next is not None and _FUSE_BN_SUMS:
+            ssn = bn_next['stats']
+            from_raw = bn_next.get('residual') is None
+            nbits = None if from_raw else bn_next.get('bits')
+            if from_raw or nbits is not None:          # (a residual unit's BatchNorm without bits -- _RELU_BITS off -- keeps the plane route's fp32-mask form below)
+                nblk = L.straps_conv_dgrad_x3f_bn_blocks(B, H, W, Cin, Cout, k, k, stride, pad, 0)
+                part = torch.empty(nblk, Cin, 2, device=dx.device, dtype=torch.float64)
+                raw, mean, invstd = bn_next['raw'], ssn[2], ssn[3]
+                if from_raw:
+                    msc, msh = ssn[0], ssn[1]
+        if bn_next is None or not _FUSE_BN_SUMS or part is not None:
+            hipabi.check(L.straps_conv_dgrad_x3f(hipabi.ptr(draw), hipabi.ptr(w3), wps, hipabi.ptr(addend), hipabi.ptr(addend_bits), hipabi.ptr(dx), B, H, W, Cin, Cout,
+                                                 k, k, stride, pad, 0, hipabi.ptr(raw), hipabi.ptr(nbits), hipabi.ptr(msc), hipabi.ptr(msh), hipabi.ptr(mean),
+                                                 hipabi.ptr(invstd), hipabi.ptr(part), hipabi.stream_ptr()), 'straps_conv_dgrad_x3f')
+            if part is not None:
+                bn_next['bwd_partials'] = (part, nblk, dx)
+            return dx
     if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
         if not draw.numel() and (planes_sink is None or planes_sink.get(id(draw)) is None):
             raise RuntimeError('data gradient: neither the fp32 gradient nor its planes exist')
@@ -205,6 +228,9 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
     side = _SideStream(side_stream)
     sink = {} if getattr(net, 'conv_precision', 'fp32') == 'bf16x3' else None      # planes of the gradients the data-gradient kernels read
 
+    def sink_of(rec):   # planes of this layer's output gradient: not on the fp32-operand route (its data and weight gradient read the fp32 tensor)
+        return None if rec.get('fmode') else sink
+
     def keep(rec):      # does anything read the fp32 gradient of this layer's raw output?  (its weight gradient, unless that runs on planes)
         if sink is None or rec.get('x3') is None:
             return True
@@ -225,14 +251,14 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
             dskip_bits = None
             if ubits is not None:
                 # no masked copy dz of the incoming gradient: whoever needs relu'(out) * dy reads dy and the bits
-                draw, _ = _bn_bwd(L, rec, dy, True, False, grads, sink, keep(rec))
+                draw, _ = _bn_bwd(L, rec, dy, True, False, grads, sink_of(rec), keep(rec))
                 dz = dy
             else:
-                draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink, keep(rec))    # ReLU(out) mask; dz feeds the skip connection
+                draw, dz = _bn_bwd(L, rec, dy, True, True, grads, sink_of(rec), keep(rec))    # ReLU(out) mask; dz feeds the skip connection
             side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             if unit.downsample is not None:
                 recd = tape[id(unit.downsample[0])]
-                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink, keep(recd), mask_bits=ubits)
+                drawd, _ = _bn_bwd(L, recd, dz, False, False, grads, sink_of(recd), keep(recd), mask_bits=ubits)
                 side.run(lambda recd=recd, drawd=drawd: _conv_wgrad(L, recd, drawd, grads, sink), drawd)
                 dskip = _conv_dgrad(L, net, recd, drawd, None, sink)
             else:
@@ -241,7 +267,7 @@ def encoder_backward(net, tape, dfeat, views=None, side_stream=None, after_layer
                 rec_prev = tape[id(pairs[ci - 1][0])]
                 dt = _conv_dgrad(L, net, tape[id(pairs[ci][0])], draw, None, sink, bn_next=rec_prev if sink is not None else None)
                 rec = rec_prev
-                draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink, keep(rec))
+                draw, _ = _bn_bwd(L, rec, dt, True, False, grads, sink_of(rec), keep(rec))
                 side.run(lambda rec=rec, draw=draw: _conv_wgrad(L, rec, draw, grads, sink), draw)
             # (+ skip gradient fused in the epilogue; the result is dy of the PREVIOUS unit's last BatchNorm, whose sums ride along)
             dy = _conv_dgrad(L, net, tape[id(pairs[0][0])], draw, dskip, sink, bn_next=prev_last if sink is not None else None,

@@ -48,6 +48,7 @@ struct ConvP {
     const float* a_scale;
     const float* a_shift;
     int a_relu;
+    int abl;                        // tools build only (STRAPS_X3F_ABL: ablations of conv_x3f.hip's kernels, wrong results by design); 0 in the product
     // measurement aid (straps_set_clock_accumulator; NULL in library use): workgroup 0 of every launch adds the shader-clock and the
     // constant-rate wall-clock ticks it lived for to clk[0] / clk[1] -- their ratio is the clock the kernel really ran at
     unsigned long long* clk;
@@ -539,7 +540,7 @@ inline int conv_fwd_problem(ConvP& p, const float* scale, const float* shift, co
     p.scale = scale; p.shift = shift; p.res = residual; p.y = y; p.stats = stats_partial;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr; p.bnr_bits = p.res_bits = nullptr;
     p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current(); p.epi = STRAPS_TOOL_ENV_INT("STRAPS_EPI", 1);
-    p.a_scale = p.a_shift = nullptr; p.a_relu = 0;
+    p.a_scale = p.a_shift = nullptr; p.a_relu = 0; p.abl = 0;
     p.H = h; p.W = wdt; p.Cin = cin; p.Cout = cout; p.relu = relu; p.stride = stride;
     ConvP::Class& c = p.cls[0];
     p.ncls = 1;
@@ -567,7 +568,7 @@ inline int conv_dgrad_problem(ConvP& p, const float* addend, float* dx, int batc
     p.scale = nullptr; p.shift = nullptr; p.res = addend; p.y = dx; p.stats = nullptr;
     p.bnr_raw = p.bnr_out = p.bnr_sc = p.bnr_sh = p.bnr_mean = p.bnr_invstd = nullptr; p.bnr_part = nullptr; p.bnr_bits = p.res_bits = nullptr;
     p.yplanes = nullptr; p.yps = 0; p.clk = straps_clk_acc_current(); p.epi = STRAPS_TOOL_ENV_INT("STRAPS_EPI", 1);
-    p.a_scale = p.a_shift = nullptr; p.a_relu = 0;
+    p.a_scale = p.a_shift = nullptr; p.a_relu = 0; p.abl = 0;
     p.H = ho; p.W = wo; p.Cin = cout; p.Cout = cin; p.relu = 0; p.stride = 1;
     p.OH = h; p.OW = wdt; p.wtaps = kh * kw;
     p.omul = stride;

@@ -53,8 +53,165 @@ __device__ __forceinline__ void lds_write_b64(unsigned addr, const u32x2& v) {
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 
+// ---- lean epilogues (round 6) -------------------------------------------------------------------------------------------------------
+// The shared epilogue of conv_igemm.h is one code path for every fused form (eval scale / shift / residual / ReLU, plane outputs, addend with
+// fp32 or bit masks, BatchNorm sums with three mask forms), selected by wave-uniform RUN-TIME flags per value: 40-60 instructions per 64
+// results.  Behind a K = 576 ... 4608 reduction that is noise; behind the K = 64 ... 256 reductions of the layers this file exists for it is
+// the kernel: the counters of the 64 -> 256 forward at resnet50's layer1 size (tools/r06_gpu_5.sh, profiles/r06_x3f_pmc.txt) show ~1 300
+// instructions per wave and 64-row tile against 48 MFMAs, two waves per SIMD issuing one instruction per 4 cycles each -- with every memory
+// access and every MFMA ablated the launch still takes 48 of its 75 us.  The two forms a TRAINING step uses on these layers are therefore
+// written out with compile-time structure:
+//   EPI = 1  forward: raw result + per-channel (sum, sum of squares) partials -- per value one add, one fma, one store whose address is a
+//            wave-uniform row base (scalar registers, scalar ALU) + one per-lane 32-bit offset;
+//   EPI = 2  data gradient: + addend (optionally masked by ReLU bits) and the fused BatchNorm-backward sums (mask from bits or re-derived from
+//            raw).  A row's bit word is wave-uniform per half-wave: the two words of a register's rows are read into scalar registers
+//            (v_readlane of one coalesced load per 32 rows) and used directly as the LANE MASK of a v_cndmask; the two sums are accumulated
+//            in fp32 over the 16 values of a unit and added to the lane's double accumulators once per unit (2 + 3 fp64 operations per unit
+//            instead of 5 per value: the double accumulation exists for the cancellation across ~10^5 values of a channel, not across 16).
+// Same per-lane summation order for EPI = 1 as the shared epilogue (bit-identical statistics); EPI = 2's sums differ from it by rounding only.
+// Full tiles take the unpredicated form; the one ragged tile of a launch predicates per lane.  Everything else (eval forms, remapped parity
+// classes of a stride-2 gradient) stays on EPI = 0, the shared epilogue.
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void lean_epilogue_fwd(const ConvP& p, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0, int M,
+                                                  float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32]) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = __builtin_amdgcn_readfirstlane(wave / WGN), wn = __builtin_amdgcn_readfirstlane(wave % WGN);
+    const int Cout = p.Cout;
+    const int half4 = 4 * (lane >> 5);
+    const int loff = half4 * Cout + (lane & 31);                 // the lane's part of an element offset (32-bit)
+    float* const yb = p.y + (n0 + wn * WTN);
+    const bool full = m0 + BM <= M;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mrow = m0 + wm * WTM + i * 32;               // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* const rowp = yb + (long long)(mrow + (r & 3) + 8 * (r >> 2)) * Cout;      // wave-uniform base
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const float v = acc[i][j][r];
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
+                    rowp[loff + j * 32] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mrow = m0 + wm * WTM + i * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                float* const rowp = yb + (long long)(mrow + rr) * Cout;
+                const bool ok = mrow + rr + half4 < M;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const float v = acc[i][j][r];
+                    if (ok) {
+                        s1[j] += v;
+                        s2[j] = fmaf(v, v, s2[j]);
+                        rowp[loff + j * 32] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// v = mask bit of this lane ? a : 0, the 64-bit lane mask in scalar registers: v_cndmask_b32 with the mask as its select operand.  Through the
+// builtin, not inline assembly: gfx950 needs two wait states between a VALU write of a scalar register (the v_readlane that fetched the mask)
+// and a VALU read of it -- the compiler's hazard recogniser inserts them, assembly text is invisible to it (the first form of this function
+// was an asm statement and selected with stale masks).
+__device__ __forceinline__ float lane_masked(float a, unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? a : 0.f; }
+
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void lean_epilogue_dgrad(const ConvP& p, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0, int M,
+                                                    double (&d1)[BN / WGN / 32], double (&d2)[BN / WGN / 32]) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = __builtin_amdgcn_readfirstlane(wave / WGN), wn = __builtin_amdgcn_readfirstlane(wave % WGN);
+    const int Cout = p.Cout, CW = Cout >> 5;
+    const int half4 = 4 * (lane >> 5);
+    const int loff = half4 * Cout + (lane & 31);
+    const int cb = n0 + wn * WTN;                                  // first channel of the wave's columns (wave-uniform)
+    const bool full = m0 + BM <= M;
+    const bool has_add = p.res != nullptr, has_abits = p.res_bits != nullptr, bnr = p.bnr_raw != nullptr, has_obits = p.bnr_bits != nullptr;
+    float bmu[NI], bsc[NI], bsh[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = cb + j * 32 + (lane & 31);
+        bmu[j] = bnr ? p.bnr_mean[n] : 0.f;
+        bsc[j] = (bnr && !has_obits) ? p.bnr_sc[n] : 0.f;
+        bsh[j] = (bnr && !has_obits) ? p.bnr_sh[n] : 0.f;
+        d1[j] = 0.0;
+        d2[j] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int mrow = m0 + wm * WTM + i * 32;                   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            // ---- the unit's operands, every load in front of its first store
+            float rv[16], xr[16];
+            unsigned aw = 0xffffffffu, ow = 0xffffffffu;            // lane k (and k + 32): the bit word of row mrow + k of this column group
+            {
+                int rk = mrow + (lane & 31);
+                rk = rk < M ? rk : M - 1;
+                const long long wi = (long long)rk * CW + ((cb + j * 32) >> 5);
+                if (has_abits) aw = p.res_bits[wi];
+                if (has_obits) ow = p.bnr_bits[wi];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = mrow + (r & 3) + 8 * (r >> 2);
+                if (!full) row = row + half4 < M ? row : M - 1 - half4 < 0 ? 0 : M - 1 - half4;      // (ragged tile: rows behind the end re-read a valid one)
+                const long long o = (long long)row * Cout + cb + j * 32;
+                rv[r] = has_add ? p.res[o + loff] : 0.f;
+                xr[r] = bnr ? p.bnr_raw[o + loff] : 0.f;
+            }
+            float sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                // lane masks of this register's two rows (lanes 0-31: row rr, lanes 32-63: row rr + 4)
+                const unsigned long long am = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw, rr) |
+                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw, rr + 4) << 32);
+                float v = acc[i][j][r] + lane_masked(rv[r], am);
+                if (bnr) {
+                    float g;
+                    if (has_obits) {
+                        const unsigned long long om = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow, rr) |
+                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow, rr + 4) << 32);
+                        g = lane_masked(v, om);
+                    } else {
+                        g = fmaf(xr[r], bsc[j], bsh[j]) > 0.f ? v : 0.f;
+                    }
+                    if (!full && mrow + rr + half4 >= M) g = 0.f;
+                    sg += g;
+                    sgx = fmaf(g, xr[r] - bmu[j], sgx);
+                }
+                if (full || mrow + rr + half4 < M) p.y[(long long)(mrow + rr) * Cout + cb + j * 32 + loff] = v;
+            }
+            d1[j] += (double)sg;
+            d2[j] += (double)sgx;
+        }
+    }
+}
+
+// tools build: STRAPS_X3F_ABL = 1 no result stores, 2 no A loads (constants instead), 4 no MFMAs, 8 no statistics partials (any sum; wrong results)
+inline void x3f_ablate(ConvP& p) {
+    p.abl = STRAPS_TOOL_ENV_INT("STRAPS_X3F_ABL", 0);
+    if (p.abl & 1) p.y = nullptr;
+    if (p.abl & 8) p.stats = nullptr;
+}
+
 // ABN: the producer's BatchNorm (+ ReLU) in the operand path (p.a_scale / p.a_shift / p.a_relu)
-template <int BM, int BN, int WGM, int WGN, int NST, bool ABN>
+template <int BM, int BN, int WGM, int WGN, int NST, bool ABN, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_x3f_kernel(ConvP p) {
     const ConvP::Class& c = p.cls[blockIdx.y];
     const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT, cntaps = c.ntaps;
@@ -129,6 +286,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_x3f_kernel(ConvP
             bsc = *reinterpret_cast<const f32x4*>(p.a_scale + a_cc * 32 + aj * 4);
             bsh = *reinterpret_cast<const f32x4*>(p.a_shift + a_cc * 32 + aj * 4);
         }
+#ifdef STRAPS_TOOLS
+        if (p.abl & 2) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) areg[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+        } else
+#endif
 #pragma unroll
         for (int i = 0; i < AP; ++i) areg[i] = *reinterpret_cast<const f32x4*>(xg + a_off[i] + a_cc * 32);
         ++a_cc;
@@ -201,7 +364,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_x3f_kernel(ConvP
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // the last chunk: no copy wait follows -- the epilogue's first operands are fetched under this chunk's matrix work (conv_igemm.h)
-        if constexpr (decltype(last_c)::value) ep.prefetch();
+        if constexpr (decltype(last_c)::value && EPI == 0) ep.prefetch();
         if constexpr (MORE_A) load_a();
         const u16* Ab = As + (stage * 3 * BM + wm * WTM) * 32;
         const u16* Bb = Bs + (stage * 3 * BN + wn * WTN) * 32;
@@ -222,6 +385,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_x3f_kernel(ConvP
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
+#ifdef STRAPS_TOOLS
+                        if (!(p.abl & 4))
+#endif
                         acc[i][j] = mfma_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j]);
                         if (MORE_B && cnt % GAP == GAP - 1 && cnt / GAP < NPB) piece(nstage, cnt / GAP);
                         ++cnt;
@@ -259,13 +425,292 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_x3f_kernel(ConvP
 
     float s1[NI], s2[NI];
     double bd1[NI], bd2[NI];
-    ep.finish(p, c, acc, s1, s2, bd1, bd2);
-    igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
-    igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
+    if constexpr (EPI == 1) {
+        lean_epilogue_fwd<BM, BN, WGM, WGN>(p, acc, m0, n0, cM, s1, s2);
+        igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+    } else if constexpr (EPI == 2) {
+        lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, acc, m0, n0, cM, bd1, bd2);
+        igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
+    } else {
+        ep.finish(p, c, acc, s1, s2, bd1, bd2);
+        igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
+        igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
+    }
     clk_end(p, clk);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, bool ABN>
+// ---- the STREAMING form for the byte-bound layers (a small reduction extent against a long pixel axis: layer1 / layer2 of resnet50) ----------
+// What the tile kernel above costs on those: K = 64 is two chunks, so a workgroup lives for two exposed memory latencies (chunk 0's loads, chunk
+// 1's loads), a few hundred MFMA cycles and its stores -- ~10 us per workgroup at ~2 us of work, with two or three of them per CU to overlap
+// (tools/sweep_conv_x3f_cold.py: 82 us for the 64 -> 256 forward on 32 x 64 x 64 pixels, whose bytes are 34 us at 5 TB/s).
+// Here a workgroup is PERSISTENT: it owns ONE tile of the output channels and walks over M tiles; its A operand is a continuous stream of
+// (tile, chunk) steps that runs TWO steps ahead of the matrix work in two register sets -- the loads of step s + 2 are issued during step s and
+// converted during step s + 1 -- straight across tile boundaries: the next tile's first chunks are in flight while a tile's epilogue stores
+// its results, and after the first step no memory latency is exposed.
+//   BRES: the weight tile -- ALL of K for BN output channels, K x BN <= 16 384: 96 KB of planes -- stays resident in LDS (one LDS-DMA sweep at the
+//         start, no weight traffic afterwards; one workgroup per CU).  With BN = all output channels (64 -> 256) every A element is read and
+//         converted exactly once.
+//   else: the weights go through a two-stage ring (one chunk per step, copied under the previous step's matrix work); with 128 x 64 tiles two
+//         workgroups share a CU.
+// One class only (a stride-1 problem, or a forward 1x1 of any stride); K a multiple of 64 (the two register sets alternate with the chunk
+// parity, and a tile's epilogue -- the tile kernel's, with the same partial blocks as its 128-row tiles -- is instantiated once, behind an odd chunk).
+template <int BM, int BN, int WGM, int WGN, bool ABN, bool BRES, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv1x1_stream_kernel(ConvP p) {
+    static_assert(EPI == 1 || EPI == 2, "the streaming kernel carries the lean epilogues only");
+    const ConvP::Class& c = p.cls[0];
+    const int cMh = c.Mh, cMw = c.Mw, cM = c.M, cMT = c.MT;
+    ClkSample clk;
+    clk_begin(p, clk);
+    constexpr int NW = WGM * WGN, NTH = 64 * NW, RPP = 16 * NW;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
+    constexpr int BP = BN / RPP;
+    constexpr int ARP = NTH / 8, AP = BM / ARP;
+    static_assert(BN % RPP == 0 && BM % ARP == 0 && WTM % 32 == 0 && WTN % 32 == 0 && ARP % 32 == 0 && AP >= 1, "tile / wave grid mismatch");
+    static_assert((2 * BM + ARP * (AP - 1)) * 64 + 8 < 65536, "ds_write offsets");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KC = p.Cin >> 5;                    // chunks of the reduction extent (even)
+    u16* As = reinterpret_cast<u16*>(smem);       // [2 stages][3 planes][BM][32]
+    u16* Ws = As + 2 * 3 * BM * 32;               // BRES: [3 planes][KC][BN][32]; else [3 planes][2 stages][BN][32]
+    const int wchunks = BRES ? KC : 2;
+    float* red = reinterpret_cast<float*>(Ws + 3 * wchunks * BN * 32);      // [WGM][BN][2] doubles: the epilogue's cross-wave sums (a region of its own: the operand images stay live)
+    float* bnc = red + WGM * BN * 4;              // [2][Cin]: the operand-path BatchNorm's scale | shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nt = blockIdx.x % p.NT, n0 = nt * BN;
+    const int mstep = gridDim.x / p.NT;            // (the launcher makes the grid a multiple of NT)
+    const int mt0 = blockIdx.x / p.NT;
+    const u16* wg = reinterpret_cast<const u16*>(p.w);
+    const float* xg = p.x;
+    const bool arelu = p.a_relu != 0;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // ---- the weights: thread's source row / K group as in the ring kernels; chunk cc of plane pl at + (cc * Cout) * 32 + pl * wps
+    const int lr = tid >> 2, lc = (tid & 3) ^ swz3(lr);
+    const u16* wsrc = wg + (n0 + lr) * 32 + lc * 8 + (long long)c.tap_w[0] * KC * p.Cout * 32;
+    auto w_chunk = [&](int cc, int slot) {        // chunk cc of the weights -> LDS slot `slot` (BRES: slot = cc; ring: the stage)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int r = 0; r < BP; ++r)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ((long long)cc * p.Cout + RPP * r) * 32 + pl * p.wps),
+                                                 (__attribute__((address_space(3))) void*)(Ws + ((pl * wchunks + slot) * BN + RPP * r + 16 * wave_u) * 32), 16, 0, 0);
+    };
+    if constexpr (BRES) {
+        for (int cc = 0; cc < KC; ++cc) w_chunk(cc, cc);
+    } else {
+        w_chunk(0, 0);
+    }
+    if constexpr (ABN) {
+        for (int k = tid; k < p.Cin; k += NTH) { bnc[k] = p.a_scale[k]; bnc[p.Cin + k] = p.a_shift[k]; }
+    }
+
+    // ---- the A stream: thread (ar, aj) owns channels 4 aj .. 4 aj + 3 of a chunk in rows ar + ARP i of a tile.  Requests behind the workgroup's
+    //      last tile re-read its last chunk (the in-order counter then always sees the same number of loads per step: the waits below are counts)
+    const int ar = tid >> 3, aj = tid & 7;
+    const int a_wo = ar * 32 + (((aj >> 1) ^ swz3(ar)) << 3) + (aj & 1) * 4;
+    int a_off[AP];
+    int ld_mt = mt0, ld_cc = 0;
+    auto set_rows = [&](int mt_) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            int m = mt_ * BM + ar + ARP * i;
+            m = m < cM ? m : cM - 1;
+            const int MhMw = cMh * cMw;
+            const int b = m / MhMw, rem = m - b * MhMw;
+            const int ho = rem / cMw, wo = rem - ho * cMw;
+            a_off[i] = ((b * p.H + ho * p.stride + c.tap_dh[0]) * p.W + wo * p.stride + c.tap_dw[0]) * p.Cin + aj * 4;
+        }
+    };
+    set_rows(ld_mt < cMT ? ld_mt : cMT - 1);
+    f32x4 areg[2][AP];
+    auto load_a = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+#ifdef STRAPS_TOOLS
+        if (p.abl & 2) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) areg[SET][i] = f32x4{1.f, 2.f, 3.f, 4.f};
+        } else
+#endif
+#pragma unroll
+        for (int i = 0; i < AP; ++i) areg[SET][i] = *reinterpret_cast<const f32x4*>(xg + a_off[i] + ld_cc * 32);
+        if (ld_mt < cMT && ++ld_cc == KC) {
+            ld_mt += mstep;
+            if (ld_mt < cMT) { ld_cc = 0; set_rows(ld_mt); } else ld_cc = KC - 1;
+        }
+    };
+    // conversion of the chunk held in register set SET (chunk number cc of its tile: the BatchNorm constants' index) into LDS stage SET
+    auto convert_store = [&](auto set_c, int cc) {
+        constexpr int SET = decltype(set_c)::value;
+        const unsigned dst = (unsigned)(SET * 3 * BM * 32 + a_wo) * 2;
+        f32x4 bsc, bsh;
+        if constexpr (ABN) {
+            bsc = *reinterpret_cast<const f32x4*>(bnc + cc * 32 + aj * 4);
+            bsh = *reinterpret_cast<const f32x4*>(bnc + p.Cin + cc * 32 + aj * 4);
+        }
+        epi_static_for<AP>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            f32x4 v = areg[SET][i];
+            if constexpr (ABN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(v[e], bsc[e], bsh[e]);
+                    v[e] = arelu ? fmaxf(v[e], 0.f) : v[e];
+                }
+            }
+            unsigned l1, l2, l3, h1, h2, h3;
+            split3_pair(v[0], v[1], l1, l2, l3);
+            split3_pair(v[2], v[3], h1, h2, h3);
+            const u32x2 q1 = {l1, h1}, q2 = {l2, h2}, q3 = {l3, h3};
+            lds_write_b64<(0 * BM + ARP * i) * 64>(dst, q1);
+            lds_write_b64<(1 * BM + ARP * i) * 64>(dst, q2);
+            lds_write_b64<(2 * BM + ARP * i) * 64>(dst, q3);
+        });
+    };
+
+    f32x16 acc[MI][NI];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+    int fo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fo[kk] = (lane & 31) * 32 + (((kk * 2 + (lane >> 5)) ^ swz3(lane & 31)) << 3);
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int TB[6] = {1, 2, 0, 1, 0, 0};
+
+    // prologue: steps 0 and 1 requested, the weights (and the constants) landed, step 0 converted
+    load_a(std::integral_constant<int, 0>{});
+    load_a(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");      // (everything older than step 1's request: the weights, the constants' loads, step 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // bnc is complete
+    asm volatile("" ::: "memory");
+    convert_store(std::integral_constant<int, 0>{}, 0);
+
+    // one step = the matrix work of chunk cc (parity P) of the current tile out of A stage P.  In front of it the barrier that publishes stage P;
+    // behind its first k step: the conversion of the NEXT step's chunk (register set 1 - P, requested during the previous step) into stage 1 - P,
+    // then the request of the step after that into set P (free: converted during the previous step).  Ring form: this step's weight chunk was copied
+    // under the previous step; the next one's copy is issued first thing (in front of the A request: the counter retires in order, so the wait
+    // for a step's weights may leave the younger A request outstanding).
+    auto step = [&](auto par_c, int cc) {
+        constexpr int P = decltype(par_c)::value;
+        if constexpr (BRES) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AP) : "memory");      // my copies of this step's weights have landed (the A request behind them may be in flight), my part of its A image is written ...
+        __builtin_amdgcn_s_barrier();                              // ... everybody's are, and every wave is done reading the stages refilled next
+        asm volatile("" ::: "memory");
+        if constexpr (!BRES) w_chunk(cc + 1 == KC ? 0 : cc + 1, 1 - P);
+        const u16* Ab = As + (P * 3 * BM + wm * WTM) * 32;
+        const u16* Bb = Ws + ((BRES ? cc : P) * BN + wn * WTN) * 32;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[MI][3], b[NI][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(Ab + (pl * BM + i * 32) * 32 + fo[kk]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + (pl * wchunks * BN + j * 32) * 32 + fo[kk]);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+#ifdef STRAPS_TOOLS
+                        if (!(p.abl & 4))
+#endif
+                        acc[i][j] = mfma_bf16(a[i][TA[t]], b[j][TB[t]], acc[i][j]);
+                    }
+            if (kk == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                convert_store(std::integral_constant<int, 1 - P>{}, cc + 1 == KC ? 0 : cc + 1);
+                load_a(std::integral_constant<int, P>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int mt = mt0; mt < cMT; mt += mstep) {
+        for (int cc = 0; cc < KC; cc += 2) {
+            step(std::integral_constant<int, 0>{}, cc);
+            step(std::integral_constant<int, 1>{}, cc + 1);
+        }
+        if constexpr (EPI == 1) {
+            float s1[NI], s2[NI];
+            lean_epilogue_fwd<BM, BN, WGM, WGN>(p, acc, mt * BM, n0, cM, s1, s2);
+            igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, red);
+        } else {
+            double bd1[NI], bd2[NI];
+            lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, acc, mt * BM, n0, cM, bd1, bd2);
+            igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[0] + mt, n0, red);
+        }
+        zero_acc();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the requests and copies issued ahead of the end)
+    clk_end(p, clk);
+}
+
+// which epilogue a problem takes: 1 = the lean forward form (raw result + statistics: a training step's forward), 2 = the lean data-gradient form
+// (one class, no remap: stride 1), 0 = the shared epilogue of conv_igemm.h (eval forms, parity classes of a stride-2 gradient)
+inline int x3f_epilogue(const ConvP& p) {
+    if (STRAPS_TOOL_ENV_INT("STRAPS_X3F_LEAN", 1) == 0) return 0;      // (tools: A/B against the shared epilogue)
+    const ConvP::Class& c = p.cls[0];
+    const bool remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
+    if (p.ncls != 1 || remap || p.yplanes || p.bnr_out || !p.y || c.ntaps != 1) return 0;
+    if (!p.scale && !p.res && !p.relu && !p.bnr_raw && !p.res_bits) return 1;
+    if (!p.scale && !p.relu && !p.stats && !p.a_scale && (p.res || p.bnr_raw) && (!p.res_bits || p.res)) return 2;
+    return 0;
+}
+// LDS of the streaming kernel for a reduction extent of cin channels
+template <int BM, int BN, int WGM, bool BRES>
+size_t stream_lds_bytes(int cin) {
+    return (size_t)2 * 3 * BM * 32 * 2 + (size_t)3 * (BRES ? cin / 32 : 2) * BN * 32 * 2 + (size_t)WGM * BN * 4 * 4 + (size_t)2 * cin * 4;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool ABN, bool BRES, int EPI>
+int launch_stream_abn(const ConvP& p0, hipStream_t st) {
+    ConvP p = p0;
+    p.NT = p.Cout / BN;
+    p.cls[0].MT = (p.cls[0].M + BM - 1) / BM;
+    p.bnr_base[0] = 0;
+    const size_t lds = stream_lds_bytes<BM, BN, WGM, BRES>(p.Cin);
+    STRAPS_REQUIRE(lds <= 160 * 1024, "conv1x1_stream_kernel: the operand images do not fit the LDS (cin=%d, BN=%d)", p.Cin, BN);
+    // as many workgroups as stay resident (LDS decides), at most one per M tile; a multiple of the N tiles (a workgroup keeps ONE weight tile)
+    const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
+    int wgs = 256 * per_cu / p.NT;
+    {
+        const int f = STRAPS_TOOL_ENV_INT("STRAPS_X3F_STREAM_WGS", 0);      // (tools: workgroups per N tile; a large number = one tile per workgroup, nothing persistent)
+        if (f > 0) wgs = f;
+    }
+    if (wgs > p.cls[0].MT) wgs = p.cls[0].MT;
+    if (wgs < 1) wgs = 1;
+    x3f_ablate(p);
+    STRAPS_RAISE_LDS((conv1x1_stream_kernel<BM, BN, WGM, WGN, ABN, BRES, EPI>), lds, "conv1x1_stream_kernel");
+    hipLaunchKernelGGL((conv1x1_stream_kernel<BM, BN, WGM, WGN, ABN, BRES, EPI>), dim3(wgs * p.NT), dim3(64 * WGM * WGN), lds, st, p);
+    STRAPS_CHECK_LAUNCH("conv1x1_stream_kernel");
+    return STRAPS_OK;
+}
+template <int BM, int BN, int WGM, int WGN, bool BRES>
+int launch_stream(const ConvP& p, hipStream_t st) {
+    if (x3f_epilogue(p) == 2) return launch_stream_abn<BM, BN, WGM, WGN, false, BRES, 2>(p, st);
+    return p.a_scale ? launch_stream_abn<BM, BN, WGM, WGN, true, BRES, 1>(p, st) : launch_stream_abn<BM, BN, WGM, WGN, false, BRES, 1>(p, st);
+}
+
+// width of the streaming kernel's output-channel tile for this problem, 0 = not eligible (several classes, a reduction extent that is not a
+// multiple of 64).  256 wide with resident weights where all of K fits beside it (K = 64), else 128 / 64 wide with the weight ring.
+inline int stream_bn(const ConvP& p) {
+    if (p.ncls != 1 || p.cls[0].ntaps != 1 || p.Cin % 64 != 0 || x3f_epilogue(p) == 0) return 0;
+    if (p.Cout % 256 == 0 && p.Cin <= 64) return 256;
+    return p.Cout % 128 == 0 && p.Cin < p.Cout ? 128 : 64;
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, bool ABN, int EPI>
 int launch_x3f_abn(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     p.NT = p.Cout / BN;
@@ -278,30 +723,38 @@ int launch_x3f_abn(const ConvP& p0, hipStream_t st) {
         base += p.cls[i].MT;
     }
     const size_t lds = (size_t)NST * 3 * (BM + BN) * 32 * sizeof(u16);
-    STRAPS_RAISE_LDS((conv_igemm_x3f_kernel<BM, BN, WGM, WGN, NST, ABN>), lds, "conv_igemm_x3f_kernel");
-    hipLaunchKernelGGL((conv_igemm_x3f_kernel<BM, BN, WGM, WGN, NST, ABN>), dim3(maxblk, p.ncls), dim3(64 * WGM * WGN), lds, st, p);
+    x3f_ablate(p);
+    STRAPS_RAISE_LDS((conv_igemm_x3f_kernel<BM, BN, WGM, WGN, NST, ABN, EPI>), lds, "conv_igemm_x3f_kernel");
+    hipLaunchKernelGGL((conv_igemm_x3f_kernel<BM, BN, WGM, WGN, NST, ABN, EPI>), dim3(maxblk, p.ncls), dim3(64 * WGM * WGN), lds, st, p);
     STRAPS_CHECK_LAUNCH("conv_igemm_x3f_kernel");
     return STRAPS_OK;
 }
 template <int BM, int BN, int WGM, int WGN, int NST>
 int launch_x3f(const ConvP& p, hipStream_t st) {
-    return p.a_scale ? launch_x3f_abn<BM, BN, WGM, WGN, NST, true>(p, st) : launch_x3f_abn<BM, BN, WGM, WGN, NST, false>(p, st);
+    switch (x3f_epilogue(p)) {
+        case 1: return p.a_scale ? launch_x3f_abn<BM, BN, WGM, WGN, NST, true, 1>(p, st) : launch_x3f_abn<BM, BN, WGM, WGN, NST, false, 1>(p, st);
+        case 2: return launch_x3f_abn<BM, BN, WGM, WGN, NST, false, 2>(p, st);
+        default: return p.a_scale ? launch_x3f_abn<BM, BN, WGM, WGN, NST, true, 0>(p, st) : launch_x3f_abn<BM, BN, WGM, WGN, NST, false, 0>(p, st);
+    }
 }
 
 // tile_cfg & 15: 0 = auto, 1 = 128x64 (4 waves, 2 stages: 72 KB of LDS, two workgroups per CU), 2 = 64x64 (4 waves, 2 stages: 48 KB, three per CU),
-// 3 = 128x128 (8 waves, 2 stages: 96 KB, one per CU), 4 = 256x128 (8 waves, 2 stages: 144 KB).
+// 5 = the streaming kernel (persistent workgroups, 128-row
+// tiles, resident weights) where the problem is eligible (stream_bn), else as 0.
 // The 1x1 layers this kernel exists for are byte-bound: what counts is that a CU always has a workgroup in its load phase beside one in its
 // store phase, i.e. SEVERAL workgroups per CU, not a large tile (rule below from tools/sweep_conv_x3f_cold.py, profiles/r06_x3f_cold_sweep.txt)
-inline int pick_tile_x3f(int cfg, long long M, int cout, int ncls, int& bm, int& bn) {
+inline int pick_tile_x3f(int cfg, long long M, int cout, int ncls, int& bm, int& bn, int sbn = 0) {
     cfg &= 15;
+    // the streaming kernel: explicitly (5), or by rule for long problems -- at least four 128-row tiles per workgroup
+    if ((cfg == 5 || (cfg == 0 && M >= 4 * 128 * (256 / (cout / (sbn ? sbn : cout))))) && sbn) { bm = sbn == 256 ? 64 : 128; bn = sbn; return 5; }
+    if (cfg == 5) cfg = 0;
     if (cfg == 0) {
         const long long t64 = ((M / ncls + 127) / 128) * (cout / 64);       // 128x64 tiles of a class
         cfg = t64 < 512 ? 2 : 1;
     }
-    if (cout % 128 != 0 && (cfg == 3 || cfg == 4)) cfg = 1;
-    if (cfg < 1 || cfg > 4) cfg = 1;
-    bm = cfg == 2 ? 64 : cfg == 4 ? 256 : 128;
-    bn = cfg <= 2 ? 64 : 128;
+    if (cfg < 1 || cfg > 2) cfg = 1;
+    bm = cfg == 2 ? 64 : 128;
+    bn = 64;
     return cfg;
 }
 
@@ -309,10 +762,12 @@ int dispatch_x3f(const ConvP& p, int tile_cfg, hipStream_t st) {
     int bm, bn;
     long long M = 0;
     for (int i = 0; i < p.ncls; ++i) M += p.cls[i].M;
-    switch (pick_tile_x3f(tile_cfg, M, p.Cout, p.ncls, bm, bn)) {
+    switch (pick_tile_x3f(tile_cfg, M, p.Cout, p.ncls, bm, bn, stream_bn(p))) {
+        case 5:
+            if (bn == 256) return launch_stream<64, 256, 2, 4, true>(p, st);
+            if (bn == 128) return launch_stream<128, 128, 2, 4, false>(p, st);
+            return launch_stream<128, 64, 2, 2, false>(p, st);
         case 2: return launch_x3f<64, 64, 2, 2, 2>(p, st);
-        case 3: return launch_x3f<128, 128, 4, 2, 2>(p, st);
-        case 4: return launch_x3f<256, 128, 4, 2, 2>(p, st);
         default: return launch_x3f<128, 64, 2, 2, 2>(p, st);
     }
 }
@@ -321,7 +776,7 @@ int x3f_blocks(const ConvP& p, int tile_cfg) {
     int bm, bn;
     long long M = 0;
     for (int i = 0; i < p.ncls; ++i) M += p.cls[i].M;
-    pick_tile_x3f(tile_cfg, M, p.Cout, p.ncls, bm, bn);
+    pick_tile_x3f(tile_cfg, M, p.Cout, p.ncls, bm, bn, stream_bn(p));
     int blocks = 0;
     for (int i = 0; i < p.ncls; ++i) blocks += (p.cls[i].M + bm - 1) / bm;
     return blocks;
@@ -366,6 +821,7 @@ extern "C" int straps_conv_x3f_stat_blocks(int batch, int h, int w, int cin, int
     ConvP p;
     p.x = nullptr; p.w = nullptr; p.xps = p.wps = 0;
     if (!x3f_geometry_ok(kh, kw, pad) || conv_fwd_problem(p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, batch, h, w, cin, cout, kh, kw, stride, pad) != STRAPS_OK) return -1;
+    p.y = reinterpret_cast<float*>(16);      // (stand-in, as above: a training forward)
     return x3f_blocks(p, tile_cfg);
 }
 
@@ -404,5 +860,6 @@ extern "C" int straps_conv_dgrad_x3f_bn_blocks(int batch, int h, int w, int cin,
     p.x = nullptr; p.w = nullptr; p.xps = p.wps = 0;
     if (!x3f_geometry_ok(kh, kw, pad) || !(stride == 1 || stride == 2)) return -1;
     if (conv_dgrad_problem(p, nullptr, nullptr, batch, h, w, cin, cout, kh, kw, stride, pad) != STRAPS_OK) return -1;
+    p.y = reinterpret_cast<float*>(16); p.bnr_raw = reinterpret_cast<const float*>(16);      // (stand-ins: the tile rule looks at WHICH operands a launch has -- x3f_epilogue)
     return x3f_blocks(p, tile_cfg);
 }

@@ -408,8 +408,9 @@ extern "C" int straps_bn_apply(const float* x, const float* scale, const float* 
 static int bn_apply_x3_impl(const char* who, const float* x, const float* scale, const float* shift, const float* residual, int relu, float* y,
                             unsigned short* y_planes, long long plane_stride, unsigned* relu_bits, long long rows, int c, void* stream) {
     // (the planes are chunk-major, common.h cm_index: 32-channel chunks outermost -- c % 32 != 0 would index past rows*c)
-    STRAPS_REQUIRE(x && scale && shift && y_planes && rows > 0 && c > 0 && (c & 31) == 0, "%s: bad arguments (c%%32 must be 0: chunk-major planes; c=%d)", who, c);
-    STRAPS_REQUIRE(plane_stride >= rows * c && plane_stride % 8 == 0, "%s: plane_stride must be >= rows*c and a multiple of 8", who);
+    // (round 6: y_planes may be NULL when every consumer reads the fp32 tensor -- the fp32-operand 1x1 route, conv_x3f.hip; then y is required)
+    STRAPS_REQUIRE(x && scale && shift && (y_planes || y) && rows > 0 && c > 0 && (c & 31) == 0, "%s: bad arguments (c%%32 must be 0: chunk-major planes; c=%d)", who, c);
+    STRAPS_REQUIRE(!y_planes || (plane_stride >= rows * c && plane_stride % 8 == 0), "%s: plane_stride must be >= rows*c and a multiple of 8", who);
     const long long n4 = rows * (c >> 2);
     const int tiled = straps_bn_tiled(rows, c >> 2);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(tiled ? straps_bn_tiled_grid(rows, c >> 2, tiled) : straps_grid256_rows(n4, c >> 2)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,

@@ -10,6 +10,27 @@ import torch
 from . import hipabi
 
 
+# The fp32-operand route of the 1x1 layers (csrc/conv_x3f.hip, round 6): a 1x1 convolution whose input has at least this many pixel rows reads the
+# fp32 activation itself (and its data gradient the fp32 gradient), so the tensors around it are produced without bf16 planes.  0 switches the
+# route off (A/B: bench.py --no-x3f; tests compare the two routes).  The byte-bound layers are the long ones: resnet50's layer1 / layer2 at 32 bodies.
+X3F_MIN_ROWS = 16384
+
+
+def x3f_mode(ctx, conv, B, H, W):
+    """does this convolution run on the fp32-operand route in a training step?  1x1 without padding, the bf16x3 route, a long pixel axis, and a weight
+    gradient that reads the fp32 tensors anyway (straps_conv_wgrad_x3_on_planes == 0: otherwise the planes have to exist and the plane route reads them)"""
+    if not ctx.x3 or not X3F_MIN_ROWS:
+        return False
+    Cout, Cin, k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
+    stride, pad = conv.stride[0], conv.padding[0]
+    if not ctx.L.straps_conv_x3f_supported(Cin, Cout, k, conv.weight.shape[3], stride, pad):
+        return False
+    Ho, Wo = _conv_out(H, k, stride, pad), _conv_out(W, k, stride, pad)
+    if B * Ho * Wo < X3F_MIN_ROWS:
+        return False
+    return not ctx.L.straps_conv_wgrad_x3_on_planes(B, H, W, Cin, Cout, k, k, stride, pad)
+
+
 # ReLU decisions of a residual unit as bits for the backward pass (straps_bn_apply_bits_x3 and the *_bits backward entry points); False = the
 # fp32-mask forms of rounds 1-3 (tests compare the two: identical gradients)
 _RELU_BITS = True
@@ -63,13 +84,15 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=
         if rec is not None:
             rec.update(raw=raw, stats=ss, out=None)
         return ss
-    if ctx.x3 and relu and planes:
+    if ctx.x3 and relu and (planes or (_RELU_BITS and residual is not None and rec is not None)):
         # bf16x3 route: every ReLU output of the residual stages feeds a convolution -- its planes are written here, not by a split pass.
         # keep_fp32 = False: nothing reads the fp32 activation (its only consumers, the next convolution and that layer's weight
         # gradient, run on the planes; the ReLU mask of the backward is re-derived from raw): it is not written -- y is then an
         # empty tensor that only carries the identity the planes are looked up by.
+        # planes = False (round 6): every consumer reads the fp32 tensor (1x1 layers on the fp32-operand route, the pooling): no planes are written
+        keep_fp32 = keep_fp32 or not planes
         y = torch.empty_like(raw) if keep_fp32 else raw.new_empty(0)
-        planes, ps = _new_planes(raw)
+        planes, ps = _new_planes(raw) if planes else (None, 0)
         if _RELU_BITS and residual is not None and rec is not None:
             # the last BatchNorm of a residual unit, with a backward to come: the unit's ReLU decisions also as bits -- the backward reads
             # them (1/32 of the bytes) wherever it would read this fp32 activation for its sign (autograd_ops._bn_bwd, _conv_dgrad)
@@ -77,7 +100,8 @@ def _bn_train_finish(ctx, bn, raw, part, nblk, rows, residual, relu, rec, apply=
             hipabi.check(L.straps_bn_apply_bits_x3(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual),
                                                    hipabi.ptr(y if keep_fp32 else None), hipabi.ptr(planes), ps, hipabi.ptr(bits), rows, C,
                                                    hipabi.stream_ptr()), 'straps_bn_apply_bits_x3')
-            ctx.planes[id(y)] = (y, planes, ps)
+            if planes is not None:
+                ctx.planes[id(y)] = (y, planes, ps)
             rec.update(raw=raw, stats=ss, out=y if keep_fp32 else None, bits=bits)
             return y
         hipabi.check(L.straps_bn_apply_x3(hipabi.ptr(raw), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(residual), int(relu),
@@ -133,12 +157,20 @@ def _planes_of(ctx, t):
     return hit[1], hit[2]
 
 
-def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile_cfg):
+def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile_cfg, fmode=False):
     """the convolution itself on the route net.conv_precision selects: 'fp32' = exact-fp32 MFMA chain (csrc/conv.hip),
-    'bf16x3' = three-plane bf16 operands, six products per term, fp32 accumulate (csrc/conv_x3.hip)."""
+    'bf16x3' = three-plane bf16 operands, six products per term, fp32 accumulate (csrc/conv_x3.hip); fmode: the same arithmetic with the A
+    operand read from the fp32 tensor (csrc/conv_x3f.hip: 1x1 layers, x3f_mode)."""
     L = ctx.L
     B, H, W, Cin, Cout, k, stride, pad = geom
     s0, s1 = (hipabi.ptr(ss[0]), hipabi.ptr(ss[1])) if ss is not None else (None, None)
+    if fmode:
+        if not x.numel():
+            raise RuntimeError('fp32-operand convolution: the fp32 activation was not materialised')
+        w3, wps = net._packed_weight_x3(conv)
+        hipabi.check(L.straps_conv_fwd_x3f(hipabi.ptr(x), None, None, 0, hipabi.ptr(w3), wps, s0, s1, hipabi.ptr(residual), int(relu), hipabi.ptr(y),
+                                           hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg, hipabi.stream_ptr()), 'straps_conv_fwd_x3f')
+        return
     if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
         x3, xps = _planes_of(ctx, x)
         w3, wps = net._packed_weight_x3(conv)
@@ -151,15 +183,18 @@ def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile
                      'straps_conv_fwd')
 
 
-def conv_stat_blocks(L, net, geom, Ho, Wo, tile_cfg):
+def conv_stat_blocks(L, net, geom, Ho, Wo, tile_cfg, fmode=False):
     B, H, W, Cin, Cout, k, stride, pad = geom
+    if fmode:
+        return L.straps_conv_x3f_stat_blocks(B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg)
     if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
         return L.straps_conv_x3_stat_blocks(B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg)
     return L.straps_conv_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
 
 
-def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, keep_fp32=True):
-    """x NHWC [B,H,W,Cin] -> NHWC [B,Ho,Wo,Cout] through conv + BatchNorm (+residual) (+ReLU)."""
+def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, keep_fp32=True, planes=True):
+    """x NHWC [B,H,W,Cin] -> NHWC [B,Ho,Wo,Cout] through conv + BatchNorm (+residual) (+ReLU).
+    keep_fp32 / planes: which forms of the OUTPUT activation its consumers read (training mode on the bf16x3 route)."""
     L = ctx.L
     Cout, Cin, k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
     stride, pad = conv.stride[0], conv.padding[0]
@@ -190,14 +225,16 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, kee
         _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, None, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
         return y, Ho, Wo
     # training mode, or eval mode with a tape (frozen statistics: no partials needed)
+    fmode = rec is not None and x3f_mode(ctx, conv, B, H, W) and x.numel() > 0
     nblk, part = 0, None
     if ctx.training:
-        nblk = conv_stat_blocks(L, net, (B, H, W, Cin, Cout, k, stride, pad), Ho, Wo, tile_cfg)
+        nblk = conv_stat_blocks(L, net, (B, H, W, Cin, Cout, k, stride, pad), Ho, Wo, tile_cfg, fmode)
         part = ctx.empty(nblk, Cout, 2)
-    _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg)
+    _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg, fmode)
     if rec is not None and ctx.x3:
         rec['x3'] = ctx.planes.get(id(x))          # (x, planes, plane stride): the weight gradient reads the same planes
-    out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec, keep_fp32=keep_fp32)
+        rec['fmode'] = fmode                        # the backward takes the same route (autograd_ops: fp32 gradient, no planes of it)
+    out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec, keep_fp32=keep_fp32, planes=planes)
     return out, Ho, Wo
 
 
@@ -257,7 +294,9 @@ def encoder_forward(net, x, tape=None, nzmask=None):
             Hp, Wp = _conv_out(H, 3, 2, 1), _conv_out(W, 3, 2, 1)
             p = ctx.empty(B, Hp, Wp, 64)
             idx = torch.empty(B, Hp, Wp, 64, device=x.device, dtype=torch.uint8)
-            if ctx.x3:
+            u0 = net.layer1[0]
+            cons = [u0.conv_bn_pairs()[0][0]] + ([u0.downsample[0]] if u0.downsample is not None else [])
+            if ctx.x3 and not all(x3f_mode(ctx, cv, B, Hp, Wp) for cv in cons):      # (planes of the pooled output unless every reader takes the fp32 tensor)
                 planes, pstride = _new_planes(p)
                 hipabi.check(L.straps_bn_relu_maxpool_fwd_x3(hipabi.ptr(y), hipabi.ptr(ss[0]), hipabi.ptr(ss[1]), hipabi.ptr(p), hipabi.ptr(idx),
                                                              hipabi.ptr(planes), pstride, B, H, W, 64, hipabi.stream_ptr()),
@@ -285,27 +324,41 @@ def encoder_forward(net, x, tape=None, nzmask=None):
 
 def _residual_stages(ctx, net, y, B, H, W, tape):
     L = ctx.L
+    train_tape = ctx.x3 and tape is not None
+    units = [u for li in range(1, 5) for u in getattr(net, 'layer%d' % li)]
+
+    def needs(t_conv, b, h, w):
+        """(fp32, planes) forms a training-mode activation must exist in for the convolution t_conv that reads it (and for that layer's weight gradient)"""
+        if x3f_mode(ctx, t_conv, b, h, w):
+            return True, False
+        k2, s2, p2 = t_conv.weight.shape[2], t_conv.stride[0], t_conv.padding[0]
+        return (not L.straps_conv_wgrad_x3_on_planes(b, h, w, t_conv.weight.shape[1], t_conv.weight.shape[0], k2, k2, s2, p2)), True
     # ---- residual stages (:150-156) ----
-    for li in range(1, 5):
-        for unit in getattr(net, 'layer%d' % li):
-            idt = y
-            if unit.downsample is not None:
-                idt, _, _ = conv_bn(ctx, net, y, B, H, W, unit.downsample[0], unit.downsample[1], relu=False)
-            pairs = unit.conv_bn_pairs()
-            t, h, w = y, H, W
-            for ci, (conv, bn) in enumerate(pairs):
-                last = ci == len(pairs) - 1
-                keep = True
-                if ctx.x3 and not ctx.training and tape is None:
-                    keep = last                     # inference: only a unit's output is read as fp32 (identity of the next unit, pooling)
-                if ctx.x3 and ctx.training and tape is not None and not last:
-                    # the fp32 activation between two convolutions of a unit is dead when the next layer's weight gradient reads planes
-                    nc = pairs[ci + 1][0]
-                    k2, s2, p2 = nc.weight.shape[2], nc.stride[0], nc.padding[0]
-                    ho2, wo2 = _conv_out(h, conv.weight.shape[2], conv.stride[0], conv.padding[0]), _conv_out(w, conv.weight.shape[2], conv.stride[0], conv.padding[0])
-                    keep = not L.straps_conv_wgrad_x3_on_planes(B, ho2, wo2, nc.weight.shape[1], nc.weight.shape[0], k2, k2, s2, p2)
-                t, h, w = conv_bn(ctx, net, t, B, h, w, conv, bn, relu=True, residual=idt if last else None, keep_fp32=keep)
-            y, H, W = t, h, w
+    for ui, unit in enumerate(units):
+        idt = y
+        if unit.downsample is not None:
+            idt, _, _ = conv_bn(ctx, net, y, B, H, W, unit.downsample[0], unit.downsample[1], relu=False)
+        pairs = unit.conv_bn_pairs()
+        t, h, w = y, H, W
+        for ci, (conv, bn) in enumerate(pairs):
+            last = ci == len(pairs) - 1
+            keep, planes = True, True
+            if ctx.x3 and not ctx.training and tape is None:
+                keep = last                     # inference: only a unit's output is read as fp32 (identity of the next unit, pooling)
+            ho2, wo2 = _conv_out(h, conv.weight.shape[2], conv.stride[0], conv.padding[0]), _conv_out(w, conv.weight.shape[2], conv.stride[0], conv.padding[0])
+            if train_tape and ctx.training and not last:
+                # the fp32 activation between two convolutions of a unit is dead when the next layer (and its weight gradient) reads planes; its planes
+                # are dead when that layer runs on the fp32-operand route
+                keep, planes = needs(pairs[ci + 1][0], B, ho2, wo2)
+            elif train_tape and ctx.training and last:
+                # a unit's output: fp32 for the identity / the pooling; planes only if a convolution of the next unit reads planes
+                planes = False
+                if ui + 1 < len(units):
+                    nxt = units[ui + 1]
+                    cons = [nxt.conv_bn_pairs()[0][0]] + ([nxt.downsample[0]] if nxt.downsample is not None else [])
+                    planes = any(needs(cv, B, ho2, wo2)[1] for cv in cons)
+            t, h, w = conv_bn(ctx, net, t, B, h, w, conv, bn, relu=True, residual=idt if last else None, keep_fp32=keep, planes=planes)
+        y, H, W = t, h, w
     # ---- global average pool + flatten (:213-214) ----
     Cf = y.shape[3]
     feat = ctx.empty(B, Cf)

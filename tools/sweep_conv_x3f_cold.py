@@ -79,8 +79,8 @@ for name, H, Cin, Cout, stride, full in SHAPES:
         row += ' c%d %5.1f' % (cfg, t)
     for bn in (0, 1):
         row += ' | x3f%s:' % ('+bn' if bn else '')
-        for cfg in (0, 1, 2, 3, 4):
-            if cfg in (3, 4) and Cout % 128:
+        for cfg in (0, 1, 2, 3, 5):
+            if cfg == 3 and Cout % 128:
                 continue
             nblk = L.straps_conv_x3f_stat_blocks(B, H, H, Cin, Cout, 1, 1, stride, 0, cfg)
             part = torch.empty(max(nblk, 1) * Cout * 2, device=dev)
@@ -104,8 +104,8 @@ for name, H, Cin, Cout, stride, full in SHAPES:
                                       'dgrad_x3_bn')
         row += ' c%d %5.1f' % (cfg, cold(fn))
     row += ' | x3f:'
-    for cfg in (0, 1, 2, 3, 4):
-        if cfg in (3, 4) and Cin % 128:
+    for cfg in (0, 1, 2, 3, 5):
+        if cfg == 3 and Cin % 128:
             continue
         nb = L.straps_conv_dgrad_x3f_bn_blocks(B, H, H, Cin, Cout, 1, 1, stride, 0, cfg)
         bp = torch.empty(max(nb, 1) * Cin * 2, device=dev, dtype=torch.float64)
