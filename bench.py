@@ -335,6 +335,9 @@ def instrument(timer):
             return timer.wrap('conv_igemm_x3_kernel', conv_flops(*a[6:15]), lambda: L.straps_conv_dgrad_x3f(*a), conv_bytes(*a[6:15]),
                               geo('dgrad+bn f32' if a[16] is not None and getattr(a[16], 'value', a[16]) else 'dgrad f32', *a[6:15]))
 
+        def straps_conv_wgrad_x3f(self, *a):
+            return timer.wrap('conv_wgrad_x3_kernel', conv_flops(*a[7:16]), lambda: L.straps_conv_wgrad_x3f(*a), 0.0, geo('wgrad f32', *a[7:16]))
+
         def straps_conv_wgrad(self, *a):
             return timer.wrap('conv_wgrad_kernel', conv_flops(*a[4:13]), lambda: L.straps_conv_wgrad(*a), 0.0, geo('wgrad', *a[4:13]))
 
@@ -396,6 +399,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--dense-stem', action='store_true', help='A/B: disable the exact zero skipping of the stem (treat every input cell as non-zero)')
     ap.add_argument('--no-overlap', action='store_true', help='(default now) weight-gradient kernels stay on the main stream')
+    ap.add_argument('--x3f-min-rows', type=int, default=-1, help="A/B: pixel rows from which a 1x1 layer takes the fp32-operand route (default: encoder_exec.X3F_MIN_ROWS)")
+    ap.add_argument('--no-x3f-operand-bn', action='store_true', help="A/B: the BatchNorm in front of a fp32-operand 1x1 layer as an apply pass instead of in the operand path")
     ap.add_argument('--no-x3f', action='store_true', help="A/B: the long 1x1 layers on the plane route (rounds 2-5) instead of the fp32-operand route (csrc/conv_x3f.hip)")
     ap.add_argument('--no-relu-bits', action='store_true', help="A/B: a residual unit's ReLU decisions reach the backward pass as fp32 tensors (rounds 1-3) instead of bits")
     ap.add_argument('--no-stem-ab', action='store_true', help='skip the dense-stem A/B steps after the timed region (profiling runs: keeps the kernel stats clean)')
@@ -421,6 +426,12 @@ def main():
     if args.no_x3f:
         from straps_amd import encoder_exec as _ee2
         _ee2.X3F_MIN_ROWS = 0
+    if args.x3f_min_rows >= 0:
+        from straps_amd import encoder_exec as _ee3
+        _ee3.X3F_MIN_ROWS = args.x3f_min_rows
+    if args.no_x3f_operand_bn:
+        from straps_amd import encoder_exec as _ee4
+        _ee4.X3F_OPERAND_BN = False
     if args.config:
         args.workload = {1: 'fwd', 2: 'train', 3: 'train', 4: 'smpl'}[args.config]
         if args.config == 3:

@@ -390,6 +390,14 @@ int straps_conv_dgrad_x3f(const float* dy, const unsigned short* w3_crsk, long l
                           const float* bn_mask_scale, const float* bn_mask_shift, const float* bn_mean, const float* bn_invstd,
                           double* bn_partials, void* stream);
 int straps_conv_dgrad_x3f_bn_blocks(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int tile_cfg);
+/* dW (OIHW [cout][cin][1][1]) of a 1x1 convolution with BOTH operands read from the fp32 tensors (csrc/conv_wgrad_x3f.hip): x [batch][h][w][cin]
+ * -- with a_scale / a_shift / a_relu as in straps_conv_fwd_x3f: x is then the RAW output of the previous convolution, the producer's
+ * BatchNorm (+ ReLU) is applied in the operand path -- and dy [batch][ho][wo][cout].  workspace: straps_conv_wgrad_x3f_workspace_bytes
+ * (split-K partials); accumulate: dW += instead of =.  Same six-product bf16 arithmetic as straps_conv_wgrad_x3.                        */
+size_t straps_conv_wgrad_x3f_workspace_bytes(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
+int straps_conv_wgrad_x3f(const float* x, const float* a_scale, const float* a_shift, int a_relu, const float* dy, float* dw_oihw,
+                          void* workspace, int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad,
+                          int accumulate, void* stream);
 int straps_conv_fwd_x3(const unsigned short* x3, long long x_plane_stride,
                        const unsigned short* w3_krsc, long long w_plane_stride, const float* scale,
                        const float* shift, const float* residual, int relu, float* y_nhwc,

@@ -124,8 +124,18 @@ def _bn_bwd(L, rec, dy, masked, want_dz, grads, planes_sink=None, keep_fp32=True
 def _conv_wgrad(L, rec, draw, grads, planes_sink=None):
     conv = rec['conv']
     B, H, W, Cin, Cout, k, stride, pad, Ho, Wo = rec['geom']
-    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=draw.device, dtype=torch.float32)
     dw = grads.buf(conv.weight)
+    if rec.get('fmode'):
+        # the fp32-operand route (csrc/conv_wgrad_x3f.hip): both operands are the fp32 tensors; an input that is a RAW convolution output gets its
+        # BatchNorm + ReLU in the operand path (rec['a_bn']: the activation was never materialised)
+        a_bn = rec.get('a_bn')
+        wsf = torch.empty(max(L.straps_conv_wgrad_x3f_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, 1), device=draw.device, dtype=torch.float32)
+        hipabi.check(L.straps_conv_wgrad_x3f(hipabi.ptr(rec['x']), hipabi.ptr(a_bn[0] if a_bn is not None else None), hipabi.ptr(a_bn[1] if a_bn is not None else None),
+                                             int(a_bn is not None), hipabi.ptr(draw), hipabi.ptr(dw), hipabi.ptr(wsf), B, H, W, Cin, Cout, k, k, stride, pad, 0,
+                                             hipabi.stream_ptr()), 'straps_conv_wgrad_x3f')
+        grads[conv.weight] = dw
+        return
+    ws = torch.empty(L.straps_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k, stride, pad) // 4, device=draw.device, dtype=torch.float32)
     fp = lambda t: hipabi.ptr(t if t is not None and t.numel() else None)      # (an empty tensor = "fp32 copy not materialised")
     xh = rec.get('x3')
     gh = planes_sink.get(id(draw)) if planes_sink is not None else None

@@ -1585,6 +1585,14 @@ inline int wgrad_splits(long long M, int tiles, bool big = false, bool x3 = fals
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
+// (library-internal, not part of the C ABI: conv_wgrad_x3f.hip reduces its split-K partials with the same fixed-order kernel)
+int straps_internal_wgrad_reduce(const float* part, float* dw_oihw, int splits, int cout, int cin, int taps, int accumulate, hipStream_t st) {
+    const long long n = (long long)cout * taps * cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, st, part, dw_oihw, splits, cout, cin, taps, accumulate);
+    STRAPS_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return STRAPS_OK;
+}
+
 // plan of the halo-patch kernel; returns false when the layer must use the per-tap kernel
 static bool wgrad3_plan(int batch, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, Wgrad3P* p, int* splits, int cp = 32) {
     if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1)) return false;

@@ -13,12 +13,16 @@ from . import hipabi
 # The fp32-operand route of the 1x1 layers (csrc/conv_x3f.hip, round 6): a 1x1 convolution whose input has at least this many pixel rows reads the
 # fp32 activation itself (and its data gradient the fp32 gradient), so the tensors around it are produced without bf16 planes.  0 switches the
 # route off (A/B: bench.py --no-x3f; tests compare the two routes).  The byte-bound layers are the long ones: resnet50's layer1 / layer2 at 32 bodies.
-X3F_MIN_ROWS = 16384
+X3F_MIN_ROWS = 16384      # (same-box A/B of the resnet50 step at 32 bodies, profiles/r06_x3f_step_ab.txt: 16384 and 4096 +9.7 %, 2048 +8.4 %, 65536 +6.3 % over the plane route)
+# the BatchNorm + ReLU in front of a 1x1 convolution on that route applied in the convolution's operand path (the normalised activation is never
+# materialised: straps_conv_fwd_x3f / straps_conv_wgrad_x3f with a_scale); False = an apply pass that writes the fp32 activation (A/B)
+X3F_OPERAND_BN = True
 
 
 def x3f_mode(ctx, conv, B, H, W):
-    """does this convolution run on the fp32-operand route in a training step?  1x1 without padding, the bf16x3 route, a long pixel axis, and a weight
-    gradient that reads the fp32 tensors anyway (straps_conv_wgrad_x3_on_planes == 0: otherwise the planes have to exist and the plane route reads them)"""
+    """does this convolution run on the fp32-operand route in a training step?  1x1 without padding on the bf16x3 route with a long enough pixel axis:
+    forward (straps_conv_fwd_x3f), data gradient (straps_conv_dgrad_x3f) and weight gradient (straps_conv_wgrad_x3f) then all read fp32 tensors, and no
+    planes of its input activation / output gradient are ever written"""
     if not ctx.x3 or not X3F_MIN_ROWS:
         return False
     Cout, Cin, k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
@@ -26,9 +30,7 @@ def x3f_mode(ctx, conv, B, H, W):
     if not ctx.L.straps_conv_x3f_supported(Cin, Cout, k, conv.weight.shape[3], stride, pad):
         return False
     Ho, Wo = _conv_out(H, k, stride, pad), _conv_out(W, k, stride, pad)
-    if B * Ho * Wo < X3F_MIN_ROWS:
-        return False
-    return not ctx.L.straps_conv_wgrad_x3_on_planes(B, H, W, Cin, Cout, k, k, stride, pad)
+    return B * Ho * Wo >= X3F_MIN_ROWS
 
 
 # ReLU decisions of a residual unit as bits for the backward pass (straps_bn_apply_bits_x3 and the *_bits backward entry points); False = the
@@ -157,7 +159,7 @@ def _planes_of(ctx, t):
     return hit[1], hit[2]
 
 
-def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile_cfg, fmode=False):
+def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile_cfg, fmode=False, a_bn=None):
     """the convolution itself on the route net.conv_precision selects: 'fp32' = exact-fp32 MFMA chain (csrc/conv.hip),
     'bf16x3' = three-plane bf16 operands, six products per term, fp32 accumulate (csrc/conv_x3.hip); fmode: the same arithmetic with the A
     operand read from the fp32 tensor (csrc/conv_x3f.hip: 1x1 layers, x3f_mode)."""
@@ -168,7 +170,8 @@ def _conv_launch(ctx, net, x, wpk, conv, ss, residual, relu, y, part, geom, tile
         if not x.numel():
             raise RuntimeError('fp32-operand convolution: the fp32 activation was not materialised')
         w3, wps = net._packed_weight_x3(conv)
-        hipabi.check(L.straps_conv_fwd_x3f(hipabi.ptr(x), None, None, 0, hipabi.ptr(w3), wps, s0, s1, hipabi.ptr(residual), int(relu), hipabi.ptr(y),
+        a0, a1 = (hipabi.ptr(a_bn[0]), hipabi.ptr(a_bn[1])) if a_bn is not None else (None, None)
+        hipabi.check(L.straps_conv_fwd_x3f(hipabi.ptr(x), a0, a1, int(a_bn is not None), hipabi.ptr(w3), wps, s0, s1, hipabi.ptr(residual), int(relu), hipabi.ptr(y),
                                            hipabi.ptr(part), B, H, W, Cin, Cout, k, k, stride, pad, tile_cfg, hipabi.stream_ptr()), 'straps_conv_fwd_x3f')
         return
     if getattr(net, 'conv_precision', 'fp32') == 'bf16x3':
@@ -192,9 +195,11 @@ def conv_stat_blocks(L, net, geom, Ho, Wo, tile_cfg, fmode=False):
     return L.straps_conv_stat_blocks(B, Ho, Wo, Cout, k * k * Cin, tile_cfg)
 
 
-def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, keep_fp32=True, planes=True):
+def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, keep_fp32=True, planes=True, a_bn=None, defer_apply=False):
     """x NHWC [B,H,W,Cin] -> NHWC [B,Ho,Wo,Cout] through conv + BatchNorm (+residual) (+ReLU).
-    keep_fp32 / planes: which forms of the OUTPUT activation its consumers read (training mode on the bf16x3 route)."""
+    keep_fp32 / planes: which forms of the OUTPUT activation its consumers read (training mode on the bf16x3 route).
+    a_bn = (scale, shift): x is the RAW output of the previous convolution and that layer's BatchNorm + ReLU is applied in this convolution's operand path
+    (fp32-operand route only).  defer_apply: return (raw output, (scale, shift, ...)) instead of the activation -- the consumer applies them that way."""
     L = ctx.L
     Cout, Cin, k = conv.weight.shape[0], conv.weight.shape[1], conv.weight.shape[2]
     stride, pad = conv.stride[0], conv.padding[0]
@@ -226,14 +231,20 @@ def conv_bn(ctx, net, x, B, H, W, conv, bn, relu, residual=None, tile_cfg=0, kee
         return y, Ho, Wo
     # training mode, or eval mode with a tape (frozen statistics: no partials needed)
     fmode = rec is not None and x3f_mode(ctx, conv, B, H, W) and x.numel() > 0
+    if a_bn is not None and not fmode:
+        raise RuntimeError('operand-path BatchNorm needs the fp32-operand route')
     nblk, part = 0, None
     if ctx.training:
         nblk = conv_stat_blocks(L, net, (B, H, W, Cin, Cout, k, stride, pad), Ho, Wo, tile_cfg, fmode)
         part = ctx.empty(nblk, Cout, 2)
-    _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg, fmode)
+    _conv_launch(ctx, net, x, wpk, conv, None, None, False, y, part, (B, H, W, Cin, Cout, k, stride, pad), tile_cfg, fmode, a_bn)
     if rec is not None and ctx.x3:
         rec['x3'] = ctx.planes.get(id(x))          # (x, planes, plane stride): the weight gradient reads the same planes
         rec['fmode'] = fmode                        # the backward takes the same route (autograd_ops: fp32 gradient, no planes of it)
+        rec['a_bn'] = a_bn                          # (x is raw: the weight gradient applies the same scale / shift / ReLU in its operand path)
+    if defer_apply:
+        ss = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, None, relu, rec, apply=False)
+        return (y, ss), Ho, Wo
     out = _bn_train_finish(ctx, bn, y, part, nblk, B * Ho * Wo, residual, relu, rec, keep_fp32=keep_fp32, planes=planes)
     return out, Ho, Wo
 
@@ -340,24 +351,31 @@ def _residual_stages(ctx, net, y, B, H, W, tape):
             idt, _, _ = conv_bn(ctx, net, y, B, H, W, unit.downsample[0], unit.downsample[1], relu=False)
         pairs = unit.conv_bn_pairs()
         t, h, w = y, H, W
+        a_bn = None
         for ci, (conv, bn) in enumerate(pairs):
             last = ci == len(pairs) - 1
             keep, planes = True, True
             if ctx.x3 and not ctx.training and tape is None:
                 keep = last                     # inference: only a unit's output is read as fp32 (identity of the next unit, pooling)
             ho2, wo2 = _conv_out(h, conv.weight.shape[2], conv.stride[0], conv.padding[0]), _conv_out(w, conv.weight.shape[2], conv.stride[0], conv.padding[0])
-            if train_tape and ctx.training and not last:
+            defer = False
+            if train_tape and not last:
                 # the fp32 activation between two convolutions of a unit is dead when the next layer (and its weight gradient) reads planes; its planes
-                # are dead when that layer runs on the fp32-operand route
+                # are dead when that layer runs on the fp32-operand route -- and then the BatchNorm + ReLU itself moves into that layer's operand path
                 keep, planes = needs(pairs[ci + 1][0], B, ho2, wo2)
-            elif train_tape and ctx.training and last:
+                defer = X3F_OPERAND_BN and keep and not planes
+            elif train_tape and last:
                 # a unit's output: fp32 for the identity / the pooling; planes only if a convolution of the next unit reads planes
                 planes = False
                 if ui + 1 < len(units):
                     nxt = units[ui + 1]
                     cons = [nxt.conv_bn_pairs()[0][0]] + ([nxt.downsample[0]] if nxt.downsample is not None else [])
                     planes = any(needs(cv, B, ho2, wo2)[1] for cv in cons)
-            t, h, w = conv_bn(ctx, net, t, B, h, w, conv, bn, relu=True, residual=idt if last else None, keep_fp32=keep, planes=planes)
+            t, h, w = conv_bn(ctx, net, t, B, h, w, conv, bn, relu=True, residual=idt if last else None, keep_fp32=keep, planes=planes, a_bn=a_bn,
+                              defer_apply=defer)
+            a_bn = None
+            if defer:
+                t, a_bn = t          # (raw output, its BatchNorm's scale / shift / mean / invstd)
         y, H, W = t, h, w
     # ---- global average pool + flatten (:213-214) ----
     Cf = y.shape[3]

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
-SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'conv_x3.hip', 'conv_x3f.hip', 'stem.hip', 'smpl.hip',
+SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'conv_x3.hip', 'conv_x3f.hip', 'conv_wgrad_x3f.hip', 'stem.hip', 'smpl.hip',
            'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip', 'raster.hip', 'exchange.hip']
 
 _lib = None
@@ -175,6 +175,8 @@ SIGNATURES = {
     'straps_conv_x3f_stat_blocks': (_I, [_I] * 10),
     'straps_conv_dgrad_x3f': (_I, [_P, _P, _L, _P, _P, _P] + [_I] * 10 + [_P] * 8),
     'straps_conv_dgrad_x3f_bn_blocks': (_I, [_I] * 10),
+    'straps_conv_wgrad_x3f_workspace_bytes': (_Z, [_I] * 9),
+    'straps_conv_wgrad_x3f': (_I, [_P, _P, _P, _I, _P, _P, _P] + [_I] * 10 + [_P]),
     'straps_bn_apply_x3': (_I, [_P, _P, _P, _P, _I, _P, _P, _L, _L, _I, _P]),
     'straps_bn_relu_maxpool_fwd_x3': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'straps_conv_wgrad_x3_on_planes': (_I, [_I] * 9),

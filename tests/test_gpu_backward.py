@@ -471,7 +471,11 @@ def test_relu_bits_backward_equals_the_fp32_mask_backward(dev, layers):
     downsample branch (resnet18), bottlenecks (resnet50)."""
     from straps_amd import encoder_exec
     outs = []
+    rows0 = encoder_exec.X3F_MIN_ROWS
     try:
+        # (a statement about the plane kernels' two mask forms: the fp32-operand route of the long 1x1 layers -- round 6 -- has bit forms only, and its lean
+        #  epilogue pre-sums 16 values in fp32, so it is switched off for both runs; its own parity: tests/test_gpu_conv_x3f.py)
+        encoder_exec.X3F_MIN_ROWS = 0
         for on in (True, False):
             encoder_exec._RELU_BITS = on
             reg, _ = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
@@ -484,6 +488,7 @@ def test_relu_bits_backward_equals_the_fp32_mask_backward(dev, layers):
                          {n: b.clone() for n, b in reg.named_buffers()}))
     finally:
         encoder_exec._RELU_BITS = True
+        encoder_exec.X3F_MIN_ROWS = rows0
     (ya, ga, ba), (yb, gb, bb) = outs
     assert torch.equal(ya, yb)
     assert all(bool(torch.isfinite(g).all()) for g in ga.values())
@@ -815,3 +820,36 @@ def test_adam_vs_reference_golden(dev):
         off += n
     np.testing.assert_allclose(da, small['adam_delta_abs'], rtol=1e-4)
     np.testing.assert_allclose(ds, small['adam_delta_sum'], rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize('layers,operand_bn', [(50, True), (50, False), (18, True)])
+def test_fp32_operand_route_equals_the_plane_route(dev, layers, operand_bn):
+    """round 6 (csrc/conv_x3f.hip, conv_wgrad_x3f.hip; encoder_exec.x3f_mode): the long 1x1 layers read the fp32 tensors -- forward with the producer's
+    BatchNorm in the operand path, data gradient with the lean epilogue, weight gradient from fp32 operands -- instead of bf16 planes.  Same arithmetic
+    (three bf16 parts per value, six products per term): the forward outputs agree to rounding of the batch statistics' partial sums (other block
+    shapes), every parameter gradient to 2e-4 of its norm (bar of the whole-step float64 tests for resnet50: tests/test_gpu_train_step.py)."""
+    from straps_amd import encoder_exec
+    outs = []
+    rows0, bn0 = encoder_exec.X3F_MIN_ROWS, encoder_exec.X3F_OPERAND_BN
+    try:
+        encoder_exec.X3F_OPERAND_BN = operand_bn
+        for rows in (1024, 0):          # (every 1x1 layer from 1024 pixel rows on: layer1-3 of this batch; 0 = the plane route everywhere)
+            encoder_exec.X3F_MIN_ROWS = rows
+            reg, _ = _load_det(straps_amd.SingleInputRegressor(18, layers, 3, mean_params=MP), layers, dev)
+            reg.train()
+            x = torch.from_numpy(det_uniform((4, 18, 256, 256), 83, 0.0, 1.0)).to(dev)
+            coef = torch.from_numpy(det_uniform((4, 157), 84)).to(dev)
+            cam, pose, shp = reg(x)
+            (torch.cat([cam, pose, shp], 1) * coef).sum().backward()
+            outs.append((torch.cat([cam, pose, shp], 1).detach().clone(), {n: p.grad.clone() for n, p in reg.named_parameters()}))
+    finally:
+        encoder_exec.X3F_MIN_ROWS, encoder_exec.X3F_OPERAND_BN = rows0, bn0
+    (ya, ga), (yb, gb) = outs
+    assert torch.allclose(ya, yb, rtol=2e-5, atol=2e-5), (ya - yb).abs().max().item()
+    worst = 0.0
+    for n in ga:
+        a, b = ga[n].double(), gb[n].double()
+        assert torch.isfinite(a).all(), n
+        rel = ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+        worst = max(worst, rel)
+        assert rel <= 2e-4, '%s: %.3e' % (n, rel)

@@ -295,3 +295,44 @@ def test_x3f_refuses_what_it_does_not_cover(dev):
                                  0, None) != 0
     assert b'1x1' in L.straps_last_error()
     assert L.straps_conv_x3f_stat_blocks(1, 8, 8, 64, 64, 3, 3, 1, 1, 0) == -1
+
+
+WGRAD_CASES = [
+    # B, Cin, Cout, H, W, stride, operand-path BatchNorm     (every channel block of csrc/conv_wgrad_x3f.hip; ragged pixel counts; stride 2)
+    (2, 64, 256, 16, 16, 1, 1), (2, 256, 64, 16, 16, 1, 0), (3, 128, 512, 8, 8, 1, 1), (2, 512, 128, 16, 16, 1, 0), (2, 64, 64, 16, 16, 1, 1),
+    (2, 128, 128, 8, 8, 1, 0), (5, 64, 256, 7, 9, 1, 1), (3, 256, 512, 9, 7, 2, 0), (1, 1024, 256, 8, 8, 1, 0), (2, 256, 1024, 8, 8, 1, 1),
+    (17, 64, 256, 48, 48, 1, 1), (2, 1024, 2048, 8, 8, 2, 0), (2, 512, 2048, 4, 4, 1, 1),
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,stride,bn', WGRAD_CASES)
+def test_conv_wgrad_x3f_vs_float64(dev, B, Cin, Cout, H, W, stride, bn):
+    """dW of a 1x1 convolution from the fp32 tensors, optionally with the producer's BatchNorm + ReLU in the operand path.  Bar: 2e-5 of the maximum
+    against float64 autograd -- the plane kernel's bar (tests/test_gpu_conv_x3.py::test_conv_wgrad_x3_vs_float64); accumulate adds"""
+    L = hipabi.lib()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.from_numpy(det_uniform((B, Cin, H, W), 1701, -1, 1))
+    dy = torch.from_numpy(det_uniform((B, Cout, Ho, Wo), 1702, -1, 1))
+    sc = torch.from_numpy(det_uniform((Cin,), 1703, 0.5, 1.5))
+    sh = torch.from_numpy(det_uniform((Cin,), 1704, -0.5, 0.5))
+    xd, dyd = _nhwc(x, dev), _nhwc(dy, dev)
+    scd, shd = sc.to(dev), sh.to(dev)
+    act = x.double()
+    if bn:
+        act = (x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double()      # (the fp32 fmaf's rounding is inside the bar)
+        act = act.clamp_min(0)
+    w = torch.zeros(Cout, Cin, 1, 1, dtype=torch.float64, requires_grad=True)
+    F.conv2d(act, w, stride=stride).backward(dy.double())
+    ref = w.grad
+    ws = torch.empty(max(L.straps_conv_wgrad_x3f_workspace_bytes(B, H, W, Cin, Cout, 1, 1, stride, 0) // 4, 1), device=dev)
+    dw = torch.full((Cout, Cin, 1, 1), float('nan'), device=dev)
+    hipabi.check(L.straps_conv_wgrad_x3f(hipabi.ptr(xd), hipabi.ptr(scd if bn else None), hipabi.ptr(shd if bn else None), int(bn), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws),
+                                         B, H, W, Cin, Cout, 1, 1, stride, 0, 0, None), 'conv_wgrad_x3f')
+    torch.cuda.synchronize()
+    got = dw.cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0), 'max err %.3e of %.3e' % ((got - ref).abs().max().item(), ref.abs().max().item())
+    hipabi.check(L.straps_conv_wgrad_x3f(hipabi.ptr(xd), hipabi.ptr(scd if bn else None), hipabi.ptr(shd if bn else None), int(bn), hipabi.ptr(dyd), hipabi.ptr(dw), hipabi.ptr(ws),
+                                         B, H, W, Cin, Cout, 1, 1, stride, 0, 1, None), 'conv_wgrad_x3f accumulate')
+    torch.cuda.synchronize()
+    assert (dw.cpu().double() - 2 * ref).abs().max().item() <= 4e-5 * max(ref.abs().max().item(), 1.0)
