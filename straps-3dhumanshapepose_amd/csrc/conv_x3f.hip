@@ -151,49 +151,58 @@ __device__ __forceinline__ void lean_epilogue_dgrad(const ConvP& p, const f32x16
         d1[j] = 0.0;
         d2[j] = 0.0;
     }
+    // ---- every unit's operands first (MI x NI units of 16 + 16 values and two bit words: all requests of the tile in flight before the first result
+    //      store -- loads and stores retire through one in-order counter, and a load behind a store waits for it), then the arithmetic
+    float rv[MI][NI][16], xr[MI][NI][16];
+    unsigned aw[MI][NI], ow[MI][NI];                           // lane k (and k + 32): the bit word of row mrow + k of the unit's column group
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int mrow = m0 + wm * WTM + i * 32;                   // wave-uniform
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            // ---- the unit's operands, every load in front of its first store
-            float rv[16], xr[16];
-            unsigned aw = 0xffffffffu, ow = 0xffffffffu;            // lane k (and k + 32): the bit word of row mrow + k of this column group
+            aw[i][j] = 0xffffffffu; ow[i][j] = 0xffffffffu;
             {
                 int rk = mrow + (lane & 31);
                 rk = rk < M ? rk : M - 1;
                 const long long wi = (long long)rk * CW + ((cb + j * 32) >> 5);
-                if (has_abits) aw = p.res_bits[wi];
-                if (has_obits) ow = p.bnr_bits[wi];
+                if (has_abits) aw[i][j] = p.res_bits[wi];
+                if (has_obits) ow[i][j] = p.bnr_bits[wi];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = mrow + (r & 3) + 8 * (r >> 2);
-                if (!full) row = row + half4 < M ? row : M - 1 - half4 < 0 ? 0 : M - 1 - half4;      // (ragged tile: rows behind the end re-read a valid one)
+                if (!full) row = row + half4 < M ? row : (M - 1 - half4 < 0 ? 0 : M - 1 - half4);      // (ragged tile: rows behind the end re-read a valid one)
                 const long long o = (long long)row * Cout + cb + j * 32;
-                rv[r] = has_add ? p.res[o + loff] : 0.f;
-                xr[r] = bnr ? p.bnr_raw[o + loff] : 0.f;
+                rv[i][j][r] = has_add ? p.res[o + loff] : 0.f;
+                xr[i][j][r] = bnr ? p.bnr_raw[o + loff] : 0.f;
             }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int mrow = m0 + wm * WTM + i * 32;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
             float sg = 0.f, sgx = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
                 // lane masks of this register's two rows (lanes 0-31: row rr, lanes 32-63: row rr + 4)
-                const unsigned long long am = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw, rr) |
-                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw, rr + 4) << 32);
-                float v = acc[i][j][r] + lane_masked(rv[r], am);
+                const unsigned long long am = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw[i][j], rr) |
+                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw[i][j], rr + 4) << 32);
+                const float v = acc[i][j][r] + lane_masked(rv[i][j][r], am);
                 if (bnr) {
                     float g;
                     if (has_obits) {
-                        const unsigned long long om = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow, rr) |
-                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow, rr + 4) << 32);
+                        const unsigned long long om = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow[i][j], rr) |
+                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow[i][j], rr + 4) << 32);
                         g = lane_masked(v, om);
                     } else {
-                        g = fmaf(xr[r], bsc[j], bsh[j]) > 0.f ? v : 0.f;
+                        g = fmaf(xr[i][j][r], bsc[j], bsh[j]) > 0.f ? v : 0.f;
                     }
                     if (!full && mrow + rr + half4 >= M) g = 0.f;
                     sg += g;
-                    sgx = fmaf(g, xr[r] - bmu[j], sgx);
+                    sgx = fmaf(g, xr[i][j][r] - bmu[j], sgx);
                 }
                 if (full || mrow + rr + half4 < M) p.y[(long long)(mrow + rr) * Cout + cb + j * 32 + loff] = v;
             }

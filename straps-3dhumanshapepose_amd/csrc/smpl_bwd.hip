@@ -285,6 +285,8 @@ __device__ __forceinline__ float lane_get(float value, int src, int site, int tr
         prev = a;
         return __int_as_float(a);
 #else
+        // (the checked forms 2 / 5 exist in the tools build only -- instantiating one in the product must not compile to "no exchange")
+        static_assert(XCHG == 0 || XCHG == 1 || XCHG == 4, "lane_get: the checked exchange forms (2, 5) need -DSTRAPS_TOOLS");
         return value;
 #endif
     }

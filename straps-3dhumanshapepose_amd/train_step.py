@@ -142,9 +142,14 @@ class GradientExchange:
             hipabi.check(hipabi.lib().straps_comm_destroy(comm), 'straps_comm_destroy')
 
     def __del__(self):
+        # (a safety net only -- callers close() explicitly: at interpreter shutdown the HIP runtime / RCCL may already be torn down, and a device
+        #  synchronisation or ncclCommDestroy there can hang or abort where no `except` reaches)
+        import sys
+        if sys.is_finalizing():
+            return
         try:
             self.close()
-        except Exception:      # noqa: BLE001 -- interpreter shutdown: the library or the device may already be gone
+        except Exception:      # noqa: BLE001
             pass
 
     def _rccl_allreduce(self, lo, hi):
@@ -489,7 +494,9 @@ class TrainStep:
         #  first kernel family whose output differs between two launch forms)
         self.last = dict(loss=loss, verts=verts, joints=joints, est=est, reposed=reposed, rot=R, ief_tape=ief_tape,
                          enc_tape=enc_tape if getattr(self, 'keep_enc_tape', False) else None,      # (keep_enc_tape: tests read the decisions taken)
-                         bwd=dict(dverts=dverts, djoints=djoints, dlv=dlv, dbetas=dbetas, drot_smpl=drot2, dest=dest, dfeat=dfeat))
+                         # (keep_bwd, like keep_enc_tape: off in production -- under hipGraph capture these references would pin the tensors in the private pool)
+                         bwd=dict(dverts=dverts, djoints=djoints, dlv=dlv, dbetas=dbetas, drot_smpl=drot2, dest=dest, dfeat=dfeat)
+                         if getattr(self, 'keep_bwd', False) else None)
         if self.metrics is not None:
             from .cam_utils import orthographic_project_torch
             pred = {'verts': verts, 'joints3D': joints.index_select(1, self._h36m14), 'shape_params': pred_shape,
@@ -692,6 +699,9 @@ class TrainStep:
             ex.close()
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():      # (see GradientExchange.__del__)
+            return
         try:
             self.close()
         except Exception:      # noqa: BLE001

@@ -54,6 +54,7 @@ def _worker(rank, world, port, overlap, use_graph, q, gm=False):
     crit = straps_amd.HomoscedasticUncertaintyWeightedMultiTaskLoss(['verts', 'shape_params', 'pose_params', 'joints2D', 'joints3D']).to(dev)
     ts = TrainStep(reg, smpl, crit, 8, lr=1e-3, rank=rank, world_size=world, seed=77, mean_shape=mp_['shape'], use_graph=use_graph,
                    comm_overlap=overlap, global_masked_mean=gm)
+    ts.keep_bwd = True          # (the stage digests read the backward chain's intermediates: TrainStep.last['bwd'], kept only on request)
     named = [(n, p) for n, p in list(reg.named_parameters()) + [('criterion.' + n, p) for n, p in crit.named_parameters()] if ts.gviews.get(p) is not None]
     losses, stages, pertensor = [], [], []
     for _ in range(6):

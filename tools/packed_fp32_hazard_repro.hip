@@ -14,7 +14,7 @@
 //   0            none
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/packed_fp32_hazard_repro.hip -o tools/bin/packed_fp32_hazard_repro -ldl
-//   tools/bin/packed_fp32_hazard_repro [launches = 8000] [aggressor = 3]
+//   tools/bin/packed_fp32_hazard_repro [launches = 8000] [aggressor = 3] [forms = 0x1fff: bit f = run form f]
 //
 // Measured on MI355X (profiles/r05_packed_fp32_hazard_repro.txt), wrong lane results in 6 000 launches = 1.5 million executions of each form: library kernel
 // 49 458; synthetic 3: 14 086 - 22 410; 2: 320; 4: 416; 5: 2 352; 6 (fp32 MFMAs): 0; 7 (no matrix instruction): 0; 8 (16x16x32 bf16): 16; 9 (32x32x16 fp16): 16 135; none: 0 -- always and only the three forms with a low-half select on src1, lanes 48..63, low half.
@@ -113,7 +113,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     } while (0)
 
 // asm operands: %3 a, %4 b, %5 c (register pairs); %6 a.lo %7 a.hi %8 b.lo %9 b.hi %10 c.lo %11 c.hi
-__global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ counters, int trips, int* __restrict__ sel_seen) {
+__global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned long long* __restrict__ counters, int trips, int* __restrict__ sel_seen, unsigned forms) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     f2 a = {in[t * 6 + 0], in[t * 6 + 1]}, b = {in[t * 6 + 2], in[t * 6 + 3]}, c = {in[t * 6 + 4], in[t * 6 + 5]};
     float sum = 0.f;
@@ -124,19 +124,19 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict_
     for (int trip = 0; trip < trips; ++trip) {
         asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(ha), "+v"(hb), "+v"(hc));
         if ((threadIdx.x & 63) == 0) atomicAdd(&counters[0], 1ull);
-        PK_CHECK(0, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,1,0]", "v_fma_f32 %1, %6, %9, %10", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(1, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[1,0,0]", "v_fma_f32 %1, %7, %8, %10", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(2, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,0,1]", "v_fma_f32 %1, %6, %8, %11", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(3, "v_pk_fma_f32 %0, %3, %4, %5 op_sel_hi:[1,0,1]", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %8, %11");
-        PK_CHECK(4, "v_pk_fma_f32 %0, %3, %4, %5", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(5, "v_pk_mul_f32 %0, %3, %4 op_sel:[0,1]", "v_mul_f32 %1, %6, %9", "v_mul_f32 %2, %7, %9");
-        PK_CHECK(6, "v_pk_add_f32 %0, %3, %4 op_sel:[0,1]", "v_add_f32 %1, %6, %9", "v_add_f32 %2, %7, %9");
-        PKMOV_CHECK(7, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]");
-        PKMOV_CHECK(8, "v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]");
-        PK16_CHECK(9, "v_pk_fma_f16 %0, %3, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]", "v_fma_f16 %1, %3, %7, %5", "v_fma_f16 %2, %6, %7, %8");
-        PK16_CHECK(10, "v_pk_add_f16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_add_f16 %1, %3, %7", "v_add_f16 %2, %6, %7");
-        PK16_CHECK(11, "v_pk_mul_f16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_mul_f16 %1, %3, %7", "v_mul_f16 %2, %6, %7");
-        PK16_CHECK(12, "v_pk_add_u16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_add_u16 %1, %3, %7", "v_add_u16 %2, %6, %7");
+        if (forms & (1u << 0)) PK_CHECK(0, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,1,0]", "v_fma_f32 %1, %6, %9, %10", "v_fma_f32 %2, %7, %9, %11");
+        if (forms & (1u << 1)) PK_CHECK(1, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[1,0,0]", "v_fma_f32 %1, %7, %8, %10", "v_fma_f32 %2, %7, %9, %11");
+        if (forms & (1u << 2)) PK_CHECK(2, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,0,1]", "v_fma_f32 %1, %6, %8, %11", "v_fma_f32 %2, %7, %9, %11");
+        if (forms & (1u << 3)) PK_CHECK(3, "v_pk_fma_f32 %0, %3, %4, %5 op_sel_hi:[1,0,1]", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %8, %11");
+        if (forms & (1u << 4)) PK_CHECK(4, "v_pk_fma_f32 %0, %3, %4, %5", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %9, %11");
+        if (forms & (1u << 5)) PK_CHECK(5, "v_pk_mul_f32 %0, %3, %4 op_sel:[0,1]", "v_mul_f32 %1, %6, %9", "v_mul_f32 %2, %7, %9");
+        if (forms & (1u << 6)) PK_CHECK(6, "v_pk_add_f32 %0, %3, %4 op_sel:[0,1]", "v_add_f32 %1, %6, %9", "v_add_f32 %2, %7, %9");
+        if (forms & (1u << 7)) PKMOV_CHECK(7, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]");
+        if (forms & (1u << 8)) PKMOV_CHECK(8, "v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]");
+        if (forms & (1u << 9)) PK16_CHECK(9, "v_pk_fma_f16 %0, %3, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]", "v_fma_f16 %1, %3, %7, %5", "v_fma_f16 %2, %6, %7, %8");
+        if (forms & (1u << 10)) PK16_CHECK(10, "v_pk_add_f16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_add_f16 %1, %3, %7", "v_add_f16 %2, %6, %7");
+        if (forms & (1u << 11)) PK16_CHECK(11, "v_pk_mul_f16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_mul_f16 %1, %3, %7", "v_mul_f16 %2, %6, %7");
+        if (forms & (1u << 12)) PK16_CHECK(12, "v_pk_add_u16 %0, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]", "v_add_u16 %1, %3, %7", "v_add_u16 %2, %6, %7");
         a.x += 0.001f; b.y -= 0.002f; c.x += 0.003f;
         ha += 0x00010000u; hb ^= 0x00000400u;
     }
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void synthetic_aggressor_kernel(const unsigned
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 8000;
     const int aggressor = argc > 2 ? atoi(argv[2]) : 3;
+    const unsigned forms = argc > 3 ? (unsigned)strtoul(argv[3], nullptr, 0) : 0x1fffu;      // bit f = run form f (a shorter victim loop meets the aggressor more often per form)
     const int B = 4, HW = 16, C = 256, trips = 64;
     const long long rows = (long long)B * HW * HW, xn = rows * C, wn = (long long)C * 9 * C;
     hipStream_t sa, sv;
@@ -275,7 +276,7 @@ int main(int argc, char** argv) {
     }
     for (int i = 0; i < launches; ++i) {
         if (exec) CHECK_HIP(hipGraphLaunch(exec, sa));
-        hipLaunchKernelGGL(pk_victim_kernel, dim3(1), dim3(256), 0, sv, vin, vout, counters, trips, sel_seen);
+        hipLaunchKernelGGL(pk_victim_kernel, dim3(1), dim3(256), 0, sv, vin, vout, counters, trips, sel_seen, forms);
         if ((i & 63) == 63) { CHECK_HIP(hipStreamSynchronize(sv)); CHECK_HIP(hipStreamSynchronize(sa)); }
     }
     CHECK_HIP(hipDeviceSynchronize());
@@ -283,17 +284,17 @@ int main(int argc, char** argv) {
     int sel[64];
     CHECK_HIP(hipMemcpy(sel, sel_seen, sizeof(sel), hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(c, counters, sizeof(c), hipMemcpyDeviceToHost));
-    const char* forms[NFORMS] = {"pk_fma op_sel:[0,1,0]", "pk_fma op_sel:[1,0,0]", "pk_fma op_sel:[0,0,1]", "pk_fma op_sel_hi:[1,0,1]", "pk_fma (no selects)", "pk_mul op_sel:[0,1]", "pk_add op_sel:[0,1]",
+    const char* names[NFORMS] = {"pk_fma op_sel:[0,1,0]", "pk_fma op_sel:[1,0,0]", "pk_fma op_sel:[0,0,1]", "pk_fma op_sel_hi:[1,0,1]", "pk_fma (no selects)", "pk_mul op_sel:[0,1]", "pk_add op_sel:[0,1]",
                                  "pk_mov_b32 op_sel:[1,0]", "pk_mov_b32 op_sel:[0,1]", "pk_fma_f16 op_sel:[0,1,0]", "pk_add_f16 op_sel:[0,1]", "pk_mul_f16 op_sel:[0,1]", "pk_add_u16 op_sel:[0,1]"};
     unsigned long long total = 0;
     for (int f = 0; f < NFORMS; ++f) total += c[1 + f];
-    printf("packed fp32 victim, %d launches x %d trips x 13 forms, %s: %llu wave-trips, %llu lane results differ from the plain instructions\n", launches, trips,
+    printf("packed fp32 victim, %d launches x %d trips, forms 0x%x, %s: %llu wave-trips, %llu lane results differ from the plain instructions\n", launches, trips, forms,
            aggressor == 1 ? "beside straps_conv_fwd_x3 (4 x 16 x 16 x 256 -> 256, 3 x 3)" : aggressor == 0 ? "alone" : aggressor == 2 ? "beside the synthetic aggressor 2 (MFMAs + barriers)"
            : aggressor == 3 ? "beside the synthetic aggressor 3 (+ fragment reads)" : aggressor == 6 ? "beside the synthetic aggressor 6 (form 3 with fp32 MFMAs)"
            : aggressor == 7 ? "beside the synthetic aggressor 7 (form 3 WITHOUT matrix instructions)" : aggressor == 8 ? "beside the synthetic aggressor 8 (form 3 with 16x16x32 bf16 MFMAs)" : aggressor == 9 ? "beside the synthetic aggressor 9 (form 3 with 32x32x16 fp16 MFMAs)" : aggressor == 4 ? "beside the synthetic aggressor 4 (+ global -> LDS copies)" : "beside the synthetic aggressor 5 (form 4, 256 workgroups)", c[0], total);
-    for (int f = 0; f < NFORMS; ++f) printf("   %-26s %llu\n", forms[f], c[1 + f]);
+    for (int f = 0; f < NFORMS; ++f) printf("   %-26s %s%llu\n", names[f], (forms >> f) & 1 ? "" : "(not run) ", c[1 + f]);
     const char* regs[5] = {"(none matched)", "src0.lo", "src0.hi", "src1.lo", "src1.hi"};
-    for (int f = 7; f < 9; ++f) printf("   %-26s as lane 0 saw it: result.lo = %s, result.hi = %s\n", forms[f], regs[sel[f * 2] + 1], regs[sel[f * 2 + 1] + 1]);
+    for (int f = 7; f < 9; ++f) printf("   %-26s as lane 0 saw it: result.lo = %s, result.hi = %s\n", names[f], regs[sel[f * 2] + 1], regs[sel[f * 2 + 1] + 1]);
     printf("   by quarter of the wave (lanes 0-15, 16-31, 32-47, 48-63): %llu %llu %llu %llu | low half %llu, high half %llu\n", c[17], c[18], c[19], c[20], c[21], c[22]);
     return total ? 1 : 0;
 }
