@@ -291,6 +291,10 @@ typedef struct {
  * products K-packed; the large-batch kernel), _NARROW = 32 bodies per workgroup, two waves per SIMD (small batches).               */
 #define STRAPS_SMPL_KERNEL_WIDE 0x100
 #define STRAPS_SMPL_KERNEL_NARROW 0x200
+/* _WIDE_BUILTIN (with _WIDE; round 6): the 64-body kernel with its skinning chains issued through the compiler's MFMA builtin (AGPR results, every
+ * hazard resolved by the compiler) instead of the hand-placed VGPR-result assembly statements of the product form -- the reference instantiation the
+ * product form is compared with bit for bit (tests/test_gpu_forward.py): same arithmetic, ~5 % slower.  Plain-fp16x3_lbs mode only.            */
+#define STRAPS_SMPL_KERNEL_WIDE_BUILTIN 0x400
 /* arithmetic of the blend contraction (v_template + shapedirs + posedirs, K = 218) in straps_smpl_fwd */
 #define STRAPS_SMPL_EXACT_F32 0 /* fp32-input MFMA: exact fmaf chains (the reference's fp32 arithmetic)                  */
 /* three fp16-MFMA products of two-term splits, fp32 accumulate: ~7e-7 relative per product at 16x the matrix rate;

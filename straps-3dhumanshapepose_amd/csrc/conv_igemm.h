@@ -464,6 +464,206 @@ struct IgemmEpilogue {
     }
 };
 
+// ---- lean epilogues (round 6) -------------------------------------------------------------------------------------------------------
+// The shared epilogue above is one code path for every fused form (eval scale / shift / residual / ReLU, plane outputs, addend with fp32 or bit
+// masks, BatchNorm sums with three mask forms), selected by wave-uniform RUN-TIME flags per value: 40-60 instructions per 64 results.  Behind a
+// long reduction that is a few per cent; behind the K = 64 ... 256 reductions of resnet50's 1x1 layers it was the kernel (counters of the 64 -> 256
+// forward at layer1's size, tools/r06_gpu_5.sh / profiles/r06_x3f_pmc.txt: ~1 300 instructions per wave and 64-row tile against 48 MFMAs, two
+// waves per SIMD issuing one instruction per 4 cycles each -- with every memory access and every MFMA ablated the launch still took 48 of its
+// 75 us).  The two forms a TRAINING step uses are therefore written out with compile-time structure:
+//   EPI = 1  forward: raw result + per-channel (sum, sum of squares) partials -- per value one add, one fma, one store whose address is a
+//            wave-uniform row base (scalar registers, scalar ALU) + one per-lane 32-bit offset;
+//   EPI = 2  data gradient: + addend (optionally masked by ReLU bits) and the fused BatchNorm-backward sums (mask from bits or re-derived from
+//            raw).  A row's bit word is wave-uniform per half-wave: the two words of a register's rows are read into scalar registers
+//            (v_readlane of one coalesced load per 32 rows) and used directly as the LANE MASK of a v_cndmask; the two sums are accumulated in
+//            fp32 over the 16 values of a unit and added to the lane's double accumulators once per unit (2 + 3 fp64 operations per unit
+//            instead of 5 per value: the double accumulation exists for the cancellation across ~10^5 values of a channel, not across 16);
+//            every operand of UG units is requested before the first result store (loads and stores retire through one in-order counter).
+// Same per-lane summation order for EPI = 1 as the shared epilogue (bit-identical statistics); EPI = 2's sums differ from it by rounding only.
+// Full tiles take the unpredicated form; the one ragged tile of a launch predicates per lane; remapped outputs (the parity classes of a
+// stride-2 data gradient) find their physical pixels per lane as the shared epilogue does.  Everything else (eval forms, fp32 masks, plane
+// outputs) stays on EPI = 0.
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void lean_epilogue_fwd(const ConvP& p, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0, int M,
+                                                  float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32]) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = __builtin_amdgcn_readfirstlane(wave / WGN), wn = __builtin_amdgcn_readfirstlane(wave % WGN);
+    const int Cout = p.Cout;
+    const int half4 = 4 * (lane >> 5);
+    const int loff = half4 * Cout + (lane & 31);                 // the lane's part of an element offset (32-bit)
+    float* const yb = p.y + (n0 + wn * WTN);
+    const bool full = m0 + BM <= M;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mrow = m0 + wm * WTM + i * 32;               // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* const rowp = yb + (long long)(mrow + (r & 3) + 8 * (r >> 2)) * Cout;      // wave-uniform base
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const float v = acc[i][j][r];
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
+                    rowp[loff + j * 32] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mrow = m0 + wm * WTM + i * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                float* const rowp = yb + (long long)(mrow + rr) * Cout;
+                const bool ok = mrow + rr + half4 < M;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const float v = acc[i][j][r];
+                    if (ok) {
+                        s1[j] += v;
+                        s2[j] = fmaf(v, v, s2[j]);
+                        rowp[loff + j * 32] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// v = mask bit of this lane ? a : 0, the 64-bit lane mask in scalar registers: v_cndmask_b32 with the mask as its select operand.  Through the
+// builtin, not inline assembly: gfx950 needs two wait states between a VALU write of a scalar register (the v_readlane that fetched the mask)
+// and a VALU read of it -- the compiler's hazard recogniser inserts them, assembly text is invisible to it (the first form of this function
+// was an asm statement and selected with stale masks).
+__device__ __forceinline__ float lane_masked(float a, unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? a : 0.f; }
+
+// UG: units (32 x 32 accumulator blocks: 16 + 16 operand values per lane) whose operands are in flight together; default two (all of a two-unit wave tile)
+template <int BM, int BN, int WGM, int WGN, int UG = ((BM / WGM / 32) * (BN / WGN / 32) > 2 ? 2 : (BM / WGM / 32) * (BN / WGN / 32))>
+__device__ __forceinline__ void lean_epilogue_dgrad(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0,
+                                                    double (&d1)[BN / WGN / 32], double (&d2)[BN / WGN / 32]) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32, NU = MI * NI;
+    static_assert(UG >= 1 && NU % UG == 0, "unit groups");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = __builtin_amdgcn_readfirstlane(wave / WGN), wn = __builtin_amdgcn_readfirstlane(wave % WGN);
+    const int M = c.M, Cout = p.Cout, CW = Cout >> 5;
+    const int half4 = 4 * (lane >> 5);
+    const int cb = n0 + wn * WTN;                                  // first channel of the wave's columns (wave-uniform)
+    const bool full = m0 + BM <= M;
+    const bool remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
+    const bool has_add = p.res != nullptr, has_abits = p.res_bits != nullptr, bnr = p.bnr_raw != nullptr, has_obits = p.bnr_bits != nullptr;
+    float bmu[NI], bsc[NI], bsh[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = cb + j * 32 + (lane & 31);
+        bmu[j] = bnr ? p.bnr_mean[n] : 0.f;
+        bsc[j] = (bnr && !has_obits) ? p.bnr_sc[n] : 0.f;
+        bsh[j] = (bnr && !has_obits) ? p.bnr_sh[n] : 0.f;
+        d1[j] = 0.0;
+        d2[j] = 0.0;
+    }
+    // physical pixel of logical row m (a parity class of a stride-2 data gradient lands on every other pixel of the output; else the row itself)
+    auto pixel = [&](int m) {
+        m = m < M ? m : M - 1;                                     // (ragged tile: rows behind the end re-read a valid one; their results are masked out)
+        if (!remap) return m;
+        const int MhMw = c.Mh * c.Mw;
+        const int b_ = m / MhMw, rem = m - b_ * MhMw;
+        const int ho_ = rem / c.Mw, wo_ = rem - ho_ * c.Mw;
+        return (b_ * p.OH + ho_ * p.omul + c.oah) * p.OW + wo_ * p.omul + c.oaw;
+    };
+#pragma unroll
+    for (int g = 0; g < NU / UG; ++g) {
+        float rv[UG][16], xr[UG][16];
+        unsigned aw[UG], ow[UG];                                   // lane k (and k + 32): the bit word of row mrow + k of the unit's column group
+        int po[UG][16];                                            // element offset (32-bit) of the lane's 16 results of a unit
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int i = (g * UG + u) / NI, j = (g * UG + u) % NI;
+            const int mrow = m0 + wm * WTM + i * 32;               // wave-uniform
+            aw[u] = 0xffffffffu; ow[u] = 0xffffffffu;
+            {
+                const long long wi = (long long)pixel(mrow + (lane & 31)) * CW + ((cb + j * 32) >> 5);
+                if (has_abits) aw[u] = p.res_bits[wi];
+                if (has_obits) ow[u] = p.bnr_bits[wi];
+            }
+            const int coff = cb + j * 32 + (lane & 31);
+            if (!remap && full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) po[u][r] = (mrow + (r & 3) + 8 * (r >> 2) + half4) * Cout + coff;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) po[u][r] = pixel(mrow + (r & 3) + 8 * (r >> 2) + half4) * Cout + coff;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                rv[u][r] = has_add ? p.res[po[u][r]] : 0.f;
+                xr[u][r] = bnr ? p.bnr_raw[po[u][r]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int i = (g * UG + u) / NI, j = (g * UG + u) % NI;
+            const int mrow = m0 + wm * WTM + i * 32;
+            float sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                // lane masks of this register's two rows (lanes 0-31: row rr, lanes 32-63: row rr + 4)
+                const unsigned long long am = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw[u], rr) |
+                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw[u], rr + 4) << 32);
+                const float v = acc[i][j][r] + lane_masked(rv[u][r], am);
+                const bool ok = full || mrow + rr + half4 < M;
+                if (bnr) {
+                    float gq;
+                    if (has_obits) {
+                        const unsigned long long om = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow[u], rr) |
+                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow[u], rr + 4) << 32);
+                        gq = lane_masked(v, om);
+                    } else {
+                        gq = fmaf(xr[u][r], bsc[j], bsh[j]) > 0.f ? v : 0.f;
+                    }
+                    if (!ok) gq = 0.f;
+                    sg += gq;
+                    sgx = fmaf(gq, xr[u][r] - bmu[j], sgx);
+                }
+                if (ok) p.y[po[u][r]] = v;
+            }
+            d1[j] += (double)sg;
+            d2[j] += (double)sgx;
+        }
+    }
+}
+
+// which epilogue a problem takes: 1 = the lean forward form (raw result + statistics: a training step's forward; one class, no remap), 2 = the lean
+// data-gradient form (addend with optional ReLU bits, BatchNorm sums with bits or the re-derived mask; any class structure), 0 = the shared epilogue
+inline int lean_epilogue_choice(const ConvP& p) {
+    if (p.yplanes || p.bnr_out || !p.y || p.scale || p.relu) return 0;
+    const ConvP::Class& c = p.cls[0];
+    const bool remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
+    if (!p.res && !p.bnr_raw && !p.res_bits) return (p.ncls == 1 && !remap) ? 1 : 0;
+    if (!p.stats && (p.res || p.bnr_raw) && (!p.res_bits || p.res)) {
+        for (int i = 0; i < p.ncls; ++i)
+            if (p.cls[i].ntaps == 0) return 0;      // (the dead parity classes of a 1x1 / stride-2 gradient: dx = addend there -- the shared epilogue's row form)
+        return 2;
+    }
+    return 0;
+}
+
+// the epilogue object of the plane kernels (conv_x3_kernels.h): the look-ahead epilogue for EPI = 0, nothing for the lean forms
+template <int BM, int BN, int WGM, int WGN, int EPI>
+struct X3Epilogue {
+    __device__ __forceinline__ void init(const ConvP&, const ConvP::Class&, int, int) {}
+    __device__ __forceinline__ void prefetch() {}
+    template <bool PRE = true>
+    __device__ __forceinline__ void finish(const ConvP&, const ConvP::Class&, const f32x16 (&)[BM / WGM / 32][BN / WGN / 32], float (&)[BN / WGN / 32],
+                                           float (&)[BN / WGN / 32], double (&)[BN / WGN / 32], double (&)[BN / WGN / 32]) {}
+};
+template <int BM, int BN, int WGM, int WGN>
+struct X3Epilogue<BM, BN, WGM, WGN, 0> : IgemmEpilogue<BM, BN, WGM, WGN> {};
+
 template <int BM, int BN, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0,
                                                  float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32]) {

@@ -53,165 +53,6 @@ __device__ __forceinline__ void lds_write_b64(unsigned addr, const u32x2& v) {
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 
-// ---- lean epilogues (round 6) -------------------------------------------------------------------------------------------------------
-// The shared epilogue of conv_igemm.h is one code path for every fused form (eval scale / shift / residual / ReLU, plane outputs, addend with
-// fp32 or bit masks, BatchNorm sums with three mask forms), selected by wave-uniform RUN-TIME flags per value: 40-60 instructions per 64
-// results.  Behind a K = 576 ... 4608 reduction that is noise; behind the K = 64 ... 256 reductions of the layers this file exists for it is
-// the kernel: the counters of the 64 -> 256 forward at resnet50's layer1 size (tools/r06_gpu_5.sh, profiles/r06_x3f_pmc.txt) show ~1 300
-// instructions per wave and 64-row tile against 48 MFMAs, two waves per SIMD issuing one instruction per 4 cycles each -- with every memory
-// access and every MFMA ablated the launch still takes 48 of its 75 us.  The two forms a TRAINING step uses on these layers are therefore
-// written out with compile-time structure:
-//   EPI = 1  forward: raw result + per-channel (sum, sum of squares) partials -- per value one add, one fma, one store whose address is a
-//            wave-uniform row base (scalar registers, scalar ALU) + one per-lane 32-bit offset;
-//   EPI = 2  data gradient: + addend (optionally masked by ReLU bits) and the fused BatchNorm-backward sums (mask from bits or re-derived from
-//            raw).  A row's bit word is wave-uniform per half-wave: the two words of a register's rows are read into scalar registers
-//            (v_readlane of one coalesced load per 32 rows) and used directly as the LANE MASK of a v_cndmask; the two sums are accumulated
-//            in fp32 over the 16 values of a unit and added to the lane's double accumulators once per unit (2 + 3 fp64 operations per unit
-//            instead of 5 per value: the double accumulation exists for the cancellation across ~10^5 values of a channel, not across 16).
-// Same per-lane summation order for EPI = 1 as the shared epilogue (bit-identical statistics); EPI = 2's sums differ from it by rounding only.
-// Full tiles take the unpredicated form; the one ragged tile of a launch predicates per lane.  Everything else (eval forms, remapped parity
-// classes of a stride-2 gradient) stays on EPI = 0, the shared epilogue.
-template <int BM, int BN, int WGM, int WGN>
-__device__ __forceinline__ void lean_epilogue_fwd(const ConvP& p, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0, int M,
-                                                  float (&s1)[BN / WGN / 32], float (&s2)[BN / WGN / 32]) {
-    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = __builtin_amdgcn_readfirstlane(wave / WGN), wn = __builtin_amdgcn_readfirstlane(wave % WGN);
-    const int Cout = p.Cout;
-    const int half4 = 4 * (lane >> 5);
-    const int loff = half4 * Cout + (lane & 31);                 // the lane's part of an element offset (32-bit)
-    float* const yb = p.y + (n0 + wn * WTN);
-    const bool full = m0 + BM <= M;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    if (full) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int mrow = m0 + wm * WTM + i * 32;               // wave-uniform
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float* const rowp = yb + (long long)(mrow + (r & 3) + 8 * (r >> 2)) * Cout;      // wave-uniform base
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const float v = acc[i][j][r];
-                    s1[j] += v;
-                    s2[j] = fmaf(v, v, s2[j]);
-                    rowp[loff + j * 32] = v;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int mrow = m0 + wm * WTM + i * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                float* const rowp = yb + (long long)(mrow + rr) * Cout;
-                const bool ok = mrow + rr + half4 < M;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const float v = acc[i][j][r];
-                    if (ok) {
-                        s1[j] += v;
-                        s2[j] = fmaf(v, v, s2[j]);
-                        rowp[loff + j * 32] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// v = mask bit of this lane ? a : 0, the 64-bit lane mask in scalar registers: v_cndmask_b32 with the mask as its select operand.  Through the
-// builtin, not inline assembly: gfx950 needs two wait states between a VALU write of a scalar register (the v_readlane that fetched the mask)
-// and a VALU read of it -- the compiler's hazard recogniser inserts them, assembly text is invisible to it (the first form of this function
-// was an asm statement and selected with stale masks).
-__device__ __forceinline__ float lane_masked(float a, unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? a : 0.f; }
-
-template <int BM, int BN, int WGM, int WGN>
-__device__ __forceinline__ void lean_epilogue_dgrad(const ConvP& p, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0, int M,
-                                                    double (&d1)[BN / WGN / 32], double (&d2)[BN / WGN / 32]) {
-    constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = __builtin_amdgcn_readfirstlane(wave / WGN), wn = __builtin_amdgcn_readfirstlane(wave % WGN);
-    const int Cout = p.Cout, CW = Cout >> 5;
-    const int half4 = 4 * (lane >> 5);
-    const int loff = half4 * Cout + (lane & 31);
-    const int cb = n0 + wn * WTN;                                  // first channel of the wave's columns (wave-uniform)
-    const bool full = m0 + BM <= M;
-    const bool has_add = p.res != nullptr, has_abits = p.res_bits != nullptr, bnr = p.bnr_raw != nullptr, has_obits = p.bnr_bits != nullptr;
-    float bmu[NI], bsc[NI], bsh[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = cb + j * 32 + (lane & 31);
-        bmu[j] = bnr ? p.bnr_mean[n] : 0.f;
-        bsc[j] = (bnr && !has_obits) ? p.bnr_sc[n] : 0.f;
-        bsh[j] = (bnr && !has_obits) ? p.bnr_sh[n] : 0.f;
-        d1[j] = 0.0;
-        d2[j] = 0.0;
-    }
-    // ---- every unit's operands first (MI x NI units of 16 + 16 values and two bit words: all requests of the tile in flight before the first result
-    //      store -- loads and stores retire through one in-order counter, and a load behind a store waits for it), then the arithmetic
-    float rv[MI][NI][16], xr[MI][NI][16];
-    unsigned aw[MI][NI], ow[MI][NI];                           // lane k (and k + 32): the bit word of row mrow + k of the unit's column group
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int mrow = m0 + wm * WTM + i * 32;                   // wave-uniform
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            aw[i][j] = 0xffffffffu; ow[i][j] = 0xffffffffu;
-            {
-                int rk = mrow + (lane & 31);
-                rk = rk < M ? rk : M - 1;
-                const long long wi = (long long)rk * CW + ((cb + j * 32) >> 5);
-                if (has_abits) aw[i][j] = p.res_bits[wi];
-                if (has_obits) ow[i][j] = p.bnr_bits[wi];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = mrow + (r & 3) + 8 * (r >> 2);
-                if (!full) row = row + half4 < M ? row : (M - 1 - half4 < 0 ? 0 : M - 1 - half4);      // (ragged tile: rows behind the end re-read a valid one)
-                const long long o = (long long)row * Cout + cb + j * 32;
-                rv[i][j][r] = has_add ? p.res[o + loff] : 0.f;
-                xr[i][j][r] = bnr ? p.bnr_raw[o + loff] : 0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int mrow = m0 + wm * WTM + i * 32;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            float sg = 0.f, sgx = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                // lane masks of this register's two rows (lanes 0-31: row rr, lanes 32-63: row rr + 4)
-                const unsigned long long am = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw[i][j], rr) |
-                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)aw[i][j], rr + 4) << 32);
-                const float v = acc[i][j][r] + lane_masked(rv[i][j][r], am);
-                if (bnr) {
-                    float g;
-                    if (has_obits) {
-                        const unsigned long long om = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow[i][j], rr) |
-                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ow[i][j], rr + 4) << 32);
-                        g = lane_masked(v, om);
-                    } else {
-                        g = fmaf(xr[i][j][r], bsc[j], bsh[j]) > 0.f ? v : 0.f;
-                    }
-                    if (!full && mrow + rr + half4 >= M) g = 0.f;
-                    sg += g;
-                    sgx = fmaf(g, xr[i][j][r] - bmu[j], sgx);
-                }
-                if (full || mrow + rr + half4 < M) p.y[(long long)(mrow + rr) * Cout + cb + j * 32 + loff] = v;
-            }
-            d1[j] += (double)sg;
-            d2[j] += (double)sgx;
-        }
-    }
-}
-
 // tools build: STRAPS_X3F_ABL = 1 no result stores, 2 no A loads (constants instead), 4 no MFMAs, 8 no statistics partials (any sum; wrong results)
 inline void x3f_ablate(ConvP& p) {
     p.abl = STRAPS_TOOL_ENV_INT("STRAPS_X3F_ABL", 0);
@@ -438,7 +279,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_igemm_x3f_kernel(ConvP
         lean_epilogue_fwd<BM, BN, WGM, WGN>(p, acc, m0, n0, cM, s1, s2);
         igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
     } else if constexpr (EPI == 2) {
-        lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, acc, m0, n0, cM, bd1, bd2);
+        lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, c, acc, m0, n0, bd1, bd2);
         igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
     } else {
         ep.finish(p, c, acc, s1, s2, bd1, bd2);
@@ -656,7 +497,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv1x1_stream_kernel(ConvP
             igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, red);
         } else {
             double bd1[NI], bd2[NI];
-            lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, acc, mt * BM, n0, cM, bd1, bd2);
+            lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, c, acc, mt * BM, n0, bd1, bd2);
             igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[0] + mt, n0, red);
         }
         zero_acc();
@@ -665,17 +506,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv1x1_stream_kernel(ConvP
     clk_end(p, clk);
 }
 
-// which epilogue a problem takes: 1 = the lean forward form (raw result + statistics: a training step's forward), 2 = the lean data-gradient form
-// (one class, no remap: stride 1), 0 = the shared epilogue of conv_igemm.h (eval forms, parity classes of a stride-2 gradient)
+// which epilogue a problem takes (conv_igemm.h: lean_epilogue_choice); the tools build can switch the lean forms off for the A/B
 inline int x3f_epilogue(const ConvP& p) {
-    if (STRAPS_TOOL_ENV_INT("STRAPS_X3F_LEAN", 1) == 0) return 0;      // (tools: A/B against the shared epilogue)
-    const ConvP::Class& c = p.cls[0];
-    const bool remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
-    if (p.ncls != 1 || remap || p.yplanes || p.bnr_out || !p.y || c.ntaps != 1) return 0;
-    if (!p.scale && !p.res && !p.relu && !p.bnr_raw && !p.res_bits) return 1;
-    if (!p.scale && !p.relu && !p.stats && !p.a_scale && (p.res || p.bnr_raw) && (!p.res_bits || p.res)) return 2;
-    return 0;
+    if (STRAPS_TOOL_ENV_INT("STRAPS_X3F_LEAN", 1) == 0) return 0;
+    if (p.cls[0].ntaps != 1) return 0;
+    return lean_epilogue_choice(p);
 }
+
 // LDS of the streaming kernel for a reduction extent of cin channels
 template <int BM, int BN, int WGM, bool BRES>
 size_t stream_lds_bytes(int cin) {

