@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STRAPS_ABI_VERSION 8
+#define STRAPS_ABI_VERSION 9
 
 #define STRAPS_OK 0
 #define STRAPS_EINVAL 1       /* bad argument (shape, alignment, null pointer) */

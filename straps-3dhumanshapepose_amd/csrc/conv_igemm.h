@@ -637,6 +637,144 @@ __device__ __forceinline__ void lean_epilogue_dgrad(const ConvP& p, const ConvP:
     }
 }
 
+// The lean data-gradient epilogue with the shared epilogue's LOOK-AHEAD (plane kernels, conv_x3_lean.hip): two units' operands in flight, the first two
+// requested under the last K chunk's matrix work (prefetch(), called where the shared epilogue's is), unit k + 2 as soon as unit k is stored.  PRESUM =
+// false: the two BatchNorm sums are accumulated per value in double, in the shared epilogue's order -- bit-identical partials (the plane kernels'
+// bits-against-fp32-mask tests compare them bit for bit); true: fp32 over a unit's 16 values first (lean_epilogue_dgrad's arithmetic).
+template <int BM, int BN, int WGM, int WGN, bool PRESUM = false>
+struct LeanDgradEpilogue {
+    static constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32, NU = MI * NI, DEPTH = NU > 1 ? 2 : 1;
+    static constexpr int PF = (WGM * WGN >= 8 && NU > 2) ? 1 : DEPTH;      // (eight-wave tiles: one unit under the last chunk, as the shared epilogue)
+    struct Unit { float rv[16], xr[16]; unsigned aw, ow; };
+    Unit u[DEPTH];
+    int m0, n0, lane, wm, wn, M, Cout, half4, cb;
+    bool full, remap, has_add, has_abits, bnr, has_obits, pre;
+    const float *g_res, *g_raw;
+    const unsigned *g_abits, *g_obits;
+    float* g_y;
+    int cMh, cMw, OH, OW, omul, oah, oaw;
+
+    __device__ __forceinline__ void init(const ConvP& p, const ConvP::Class& c, int m0_, int n0_) {
+        const int wave = threadIdx.x >> 6;
+        m0 = m0_; n0 = n0_; lane = threadIdx.x & 63;
+        wm = __builtin_amdgcn_readfirstlane(wave / WGN); wn = __builtin_amdgcn_readfirstlane(wave % WGN);
+        M = c.M; Cout = p.Cout; half4 = 4 * (lane >> 5); cb = n0 + wn * WTN;
+        full = m0 + BM <= M;
+        remap = p.omul != 1 || c.oah != 0 || c.oaw != 0 || p.OH != c.Mh || p.OW != c.Mw;
+        has_add = p.res != nullptr; has_abits = p.res_bits != nullptr; bnr = p.bnr_raw != nullptr; has_obits = p.bnr_bits != nullptr;
+        g_res = p.res; g_raw = p.bnr_raw; g_abits = p.res_bits; g_obits = p.bnr_bits; g_y = p.y;
+        cMh = c.Mh; cMw = c.Mw; OH = p.OH; OW = p.OW; omul = p.omul; oah = c.oah; oaw = c.oaw;
+        pre = false;
+    }
+    __device__ __forceinline__ int pixel(int m) const {
+        m = m < M ? m : M - 1;
+        if (!remap) return m;
+        const int MhMw = cMh * cMw;
+        const int b_ = m / MhMw, rem = m - b_ * MhMw;
+        const int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
+        return (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
+    }
+    __device__ __forceinline__ void issue(int k, Unit& un) const {
+        const int i = k / NI, j = k % NI;
+        const int mrow = m0 + wm * WTM + i * 32;
+        un.aw = 0xffffffffu; un.ow = 0xffffffffu;
+        {
+            const long long wi = (long long)pixel(mrow + (lane & 31)) * (Cout >> 5) + ((cb + j * 32) >> 5);
+            if (has_abits) un.aw = g_abits[wi];
+            if (has_obits) un.ow = g_obits[wi];
+        }
+        const int coff = cb + j * 32 + (lane & 31);
+        int pix[16];
+        pixels(mrow, pix);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            un.rv[r] = has_add ? g_res[pix[r] * Cout + coff] : 0.f;
+            un.xr[r] = bnr ? g_raw[pix[r] * Cout + coff] : 0.f;
+        }
+    }
+    // physical pixels of the lane's 16 rows of the block row at mrow (rows mrow + half4 + (r & 3) + 8 (r >> 2)); remapped classes: one division, then a walk
+    __device__ __forceinline__ void pixels(int mrow, int (&pix)[16]) const {
+        const int mb = mrow + half4;
+        if (!remap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int m = mb + (r & 3) + 8 * (r >> 2); pix[r] = (full || m < M) ? m : M - 1; }
+        } else {
+            const int MhMw = cMh * cMw;
+            int mm = mb < M ? mb : M - 1;
+            int b_ = mm / MhMw;
+            const int rem = mm - b_ * MhMw;
+            int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pix[r] = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
+                wo_ += (r & 3) == 3 ? 5 : 1;
+                while (wo_ >= cMw) {
+                    wo_ -= cMw;
+                    if (++ho_ == cMh) { ho_ = 0; ++b_; }
+                }
+            }
+        }
+    }
+    // under the last chunk's matrix work (the kernels call this exactly where they call the shared epilogue's prefetch)
+    __device__ __forceinline__ void prefetch() {
+        epi_static_for<PF>([&](auto kc) { issue(decltype(kc)::value, u[decltype(kc)::value]); });
+        pre = true;
+    }
+    template <bool PRE = true>
+    __device__ __forceinline__ void finish(const ConvP& p, const ConvP::Class&, const f32x16 (&acc)[MI][NI], float (&)[NI], float (&)[NI], double (&d1)[NI],
+                                           double (&d2)[NI]) {
+        float bmu[NI], bsc[NI], bsh[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = cb + j * 32 + (lane & 31);
+            bmu[j] = bnr ? p.bnr_mean[n] : 0.f;
+            bsc[j] = (bnr && !has_obits) ? p.bnr_sc[n] : 0.f;
+            bsh[j] = (bnr && !has_obits) ? p.bnr_sh[n] : 0.f;
+            d1[j] = 0.0;
+            d2[j] = 0.0;
+        }
+        if (!pre) epi_static_for<PF>([&](auto kc) { issue(decltype(kc)::value, u[decltype(kc)::value]); });      // (a class without taps never reaches a last chunk)
+        epi_static_for<DEPTH - PF>([&](auto kc) { issue(decltype(kc)::value + PF, u[decltype(kc)::value + PF]); });
+        epi_static_for<NU>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, i = k / NI, j = k % NI;
+            Unit& un = u[k % DEPTH];
+            const int mrow = m0 + wm * WTM + i * 32;
+            const int coff = cb + j * 32 + (lane & 31);
+            int pix[16];
+            pixels(mrow, pix);
+            float sg = 0.f, sgx = 0.f;
+            epi_static_for<16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value, rr = (r & 3) + 8 * (r >> 2);
+                const unsigned long long am = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)un.aw, rr) |
+                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)un.aw, rr + 4) << 32);
+                const float v = acc[i][j][r] + lane_masked(un.rv[r], am);
+                const bool ok = full || mrow + rr + half4 < M;
+                if (bnr) {
+                    float gq;
+                    if (has_obits) {
+                        const unsigned long long om = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)un.ow, rr) |
+                                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)un.ow, rr + 4) << 32);
+                        gq = lane_masked(v, om);
+                    } else {
+                        gq = fmaf(un.xr[r], bsc[j], bsh[j]) > 0.f ? v : 0.f;
+                    }
+                    if (!ok) gq = 0.f;
+                    if constexpr (PRESUM) {
+                        sg += gq;
+                        sgx = fmaf(gq, un.xr[r] - bmu[j], sgx);
+                    } else {
+                        d1[j] += (double)gq;
+                        d2[j] += (double)gq * ((double)un.xr[r] - (double)bmu[j]);
+                    }
+                }
+                if (ok) g_y[pix[r] * Cout + coff] = v;
+            });
+            if constexpr (PRESUM) { d1[j] += (double)sg; d2[j] += (double)sgx; }
+            if constexpr (k + DEPTH < NU) issue(k + DEPTH, un);
+        });
+    }
+};
+
 // which epilogue a problem takes: 1 = the lean forward form (raw result + statistics: a training step's forward; one class, no remap), 2 = the lean
 // data-gradient form (addend with optional ReLU bits, BatchNorm sums with bits or the re-derived mask; any class structure), 0 = the shared epilogue
 inline int lean_epilogue_choice(const ConvP& p) {
@@ -663,6 +801,8 @@ struct X3Epilogue {
 };
 template <int BM, int BN, int WGM, int WGN>
 struct X3Epilogue<BM, BN, WGM, WGN, 0> : IgemmEpilogue<BM, BN, WGM, WGN> {};
+template <int BM, int BN, int WGM, int WGN>
+struct X3Epilogue<BM, BN, WGM, WGN, 2> : LeanDgradEpilogue<BM, BN, WGM, WGN, false> {};
 
 template <int BM, int BN, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void igemm_store_rows(const ConvP& p, const ConvP::Class& c, const f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32], int m0, int n0,

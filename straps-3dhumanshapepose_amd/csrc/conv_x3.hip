@@ -95,12 +95,14 @@ int dispatch_x3(const ConvP& p, int tile_cfg, hipStream_t st) {
         if (p.cls[i].ntaps * p.Cin > kdim) kdim = p.cls[i].ntaps * p.Cin;
     }
     const int halo = halo_choice(p, tile_cfg);
-    // the lean forward epilogue (conv_igemm.h; conv_x3_lean.hip holds the instantiations): a training step's forward -- raw result + statistics -- on the
-    // automatic tiles.  (The lean DATA-GRADIENT epilogue stays with the 1x1 kernels of conv_x3f.hip: behind these kernels' long reductions the shared
-    // epilogue's look-ahead -- operands requested under the last chunk's matrix work -- is worth what its instruction count costs: same-box A/B of both
-    // forms on the resnet18 classes, profiles/r06_lean_epilogue_ab.txt.)
+    // the lean epilogues (conv_igemm.h; conv_x3_lean.hip holds the instantiations) on the automatic tiles: a training step's forward -- raw result +
+    // statistics: +3.2 % / +2.8 % on the resnet18 / resnet50 step -- and its data gradients (LeanDgradEpilogue: the same look-ahead as the shared
+    // epilogue -- two units' operands requested under the last chunk's matrix work -- with the lean arithmetic, per-value double sums in the shared
+    // epilogue's order: bit-identical results, +0.2 ... +1 % on the steps; without the look-ahead the lean form was a wash behind these kernels' long
+    // reductions: profiles/r06_lean_epilogue_ab.txt)
     if ((tile_cfg & 15) == 0 && !(tile_cfg & (64 | 128)) && STRAPS_TOOL_ENV_INT("STRAPS_X3_LEAN", 1)) {
-        const int epi = lean_epilogue_choice(p) == 1 ? 1 : 0;
+        int epi = lean_epilogue_choice(p);
+        if (epi == 2 && !STRAPS_TOOL_ENV_INT("STRAPS_X3_LEAN_DGRAD", 1)) epi = 0;      // (tools: A/B of the data-gradient form alone)
         if (epi) {
             const int cfg = halo ? 0 : pick_tile_x3(tile_cfg, M, p.Cout, kdim, bm, bn, p.ncls, kdim == p.Cin);
             if (halo == 1 || halo == 3 || (!halo && (cfg == 3 || cfg == 5 || cfg == 7 || cfg == 9 || cfg == 11 || cfg == 12)))

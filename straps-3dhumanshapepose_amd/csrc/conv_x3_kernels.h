@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3_kernel(ConvP p) 
         lean_epilogue_fwd<BM, BN, WGM, WGN>(p, acc, m0, n0, c.M, s1, s2);
         igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
     } else if constexpr (EPI == 2) {
-        lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, c, acc, m0, n0, bd1, bd2);
+        ep.finish(p, c, acc, s1, s2, bd1, bd2);      // (LeanDgradEpilogue: its first two units were requested under the last chunk)
         igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
     } else {
         ep.finish(p, c, acc, s1, s2, bd1, bd2);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_x3h_kernel(ConvP p)
         lean_epilogue_fwd<BM, BN, WGM, WGN>(p, acc, m0, n0, c.M, s1, s2);
         igemm_store_stats<BM, BN, WGM, WGN>(p, s1, s2, mt, n0, smem);
     } else if constexpr (EPI == 2) {
-        lean_epilogue_dgrad<BM, BN, WGM, WGN>(p, c, acc, m0, n0, bd1, bd2);
+        ep.finish(p, c, acc, s1, s2, bd1, bd2);      // (LeanDgradEpilogue: its first two units were requested under the last chunk)
         igemm_store_bnr<BM, BN, WGM, WGN>(p, bd1, bd2, p.bnr_base[blockIdx.y] + mt, n0, smem);
     } else {
         ep.finish(p, c, acc, s1, s2, bd1, bd2);

@@ -1,6 +1,7 @@
-// conv_x3_lean.hip -- the bf16x3 implicit-GEMM kernels of conv_x3_kernels.h instantiated with the LEAN forward epilogue of conv_igemm.h (round 6): EPI = 1,
-// a training step's forward (raw result + statistics partials, bit-identical to the shared epilogue's) -- on the tiles the automatic rule of conv_x3.hip
-// picks.  (EPI = 2, the lean data-gradient form, is used by conv_x3f.hip's 1x1 kernels only: see conv_x3.hip, dispatch_x3.)  A translation unit of its own so that the two sets of
+// conv_x3_lean.hip -- the bf16x3 implicit-GEMM kernels of conv_x3_kernels.h instantiated with the LEAN epilogues of conv_igemm.h (round 6): EPI = 1, a
+// training step's forward (raw result + statistics partials), EPI = 2, its data gradients (LeanDgradEpilogue: addend with optional ReLU bits, fused
+// BatchNorm-backward sums, parity classes of a stride-2 gradient; look-ahead under the last chunk) -- both bit-identical to the shared epilogue's results,
+// on the tiles the automatic rule of conv_x3.hip picks.  A translation unit of its own so that the two sets of
 // instantiations compile in parallel; conv_x3.hip's dispatch_x3 decides (lean_epilogue_choice) and calls in here.
 #include "conv_x3_kernels.h"
 
@@ -27,9 +28,5 @@ int dispatch_lean(const ConvP& p, int halo, int cfg, hipStream_t st) {
 
 int straps_internal_dispatch_x3_lean(const void* pv, int halo, int cfg, int epi, hipStream_t st) {
     const ConvP& p = *static_cast<const ConvP*>(pv);
-    if (epi != 1) {
-        straps_set_error("conv_x3_lean: only the forward form (EPI = 1) is instantiated for the plane kernels");
-        return STRAPS_EUNSUPPORTED;
-    }
-    return dispatch_lean<1>(p, halo, cfg, st);
+    return epi == 1 ? dispatch_lean<1>(p, halo, cfg, st) : dispatch_lean<2>(p, halo, cfg, st);
 }

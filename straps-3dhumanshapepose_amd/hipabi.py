@@ -141,7 +141,7 @@ def gemm_multi(descs):
 _P, _I, _L, _F, _Z, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); must list every symbol of include/straps_hip.h (tests/test_abi.py checks)
-ABI_VERSION = 8      # == STRAPS_ABI_VERSION of include/straps_hip.h (tests/test_abi.py compares the two); load() refuses a library of another version
+ABI_VERSION = 9      # == STRAPS_ABI_VERSION of include/straps_hip.h (tests/test_abi.py compares the two); load() refuses a library of another version
 SIGNATURES = {
     'straps_abi_version': (_I, []),
     'straps_last_error': (C.c_char_p, []),

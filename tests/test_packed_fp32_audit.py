@@ -41,3 +41,31 @@ def test_the_auditor_sees_the_instruction_when_there_is_one(tmp_path):
         seen[name] = audit_packed_fp32.audit(str(lib))[0]
     assert any('op_sel:[0,1,0]' in ins for _, ins in seen['plain']), seen['plain']
     assert not seen['marked'], seen['marked']
+
+
+@needs_llvm
+def test_a_library_with_a_planted_instruction_cannot_pass_the_build_audit_or_be_loaded(tmp_path):
+    """round 6: the audit is part of hipabi.build() / hipabi.load() (isa_audit.enforce): a library that holds the instruction raises
+    and is moved aside; a clean one gets a stamp that load() trusts; a stale stamp (the file changed) is not trusted."""
+    from straps_amd import isa_audit
+    src = tmp_path / 'k.hip'
+    src.write_text(textwrap.dedent('''
+        #include <hip/hip_runtime.h>
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        __global__ ATTR void k(const f2* a, const f2* b, f2* c) { int i = threadIdx.x; f2 x = a[i], y = b[i]; c[i] = x * y.y + c[i]; }
+    '''))
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    planted, clean = tmp_path / 'planted.so', tmp_path / 'clean.so'
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-DATTR=', str(src), '-o', str(planted)], check=True, capture_output=True)
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-DATTR=__attribute__((target("no-packed-fp32-ops")))', str(src), '-o', str(clean)],
+                   check=True, capture_output=True)
+    # load(): no stamp -> audited -> refused (before dlopen), and the file is gone from its path
+    with pytest.raises(RuntimeError, match='low-half operand select'):
+        hipabi.load(str(planted))
+    assert not planted.exists() and (tmp_path / 'planted.so.rejected').exists()
+    # the build-side call on a clean library: passes, leaves the stamp; the stamp is bound to the file's content
+    assert isa_audit.enforce(str(clean), 'test') is True
+    assert isa_audit.stamp_ok(str(clean))
+    with open(clean, 'ab') as f:
+        f.write(b'\\0')
+    assert not isa_audit.stamp_ok(str(clean))
