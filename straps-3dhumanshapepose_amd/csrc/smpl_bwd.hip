@@ -232,91 +232,15 @@ __global__ __launch_bounds__(256, 1) STRAPS_NO_PACKED_FP32 void smpl_verts_bwd_k
 }
 
 // ------------------------------------------------------------------------------------------
-// Lane exchanges of smpl_pose_bwd_kernel.  XCHG = 0 is the product: __shfl = ds_bpermute_b32, several in flight, waits placed by the compiler.
-// The other forms exist in the tools build only (round 5, DESIGN section 1: this kernel is not bit-reproducible beside a bf16x3 convolution
-// workgroup on its compute unit -- WHAT do the wrong values look like, and does the exchange have to go through the LDS unit for it?):
-//   1  v_readlane_b32 + select, 64 of them per exchange: no LDS-unit instruction in the kernel at all
-//   2  ds_bpermute_b32 TWICE, each followed by s_waitcnt lgkmcnt(0) (inline assembly: one in flight), both checked against form 1; mismatches logged
-//   4  ds_bpermute_b32 + s_waitcnt lgkmcnt(0), unchecked: is "one in flight" alone enough to make it reproducible?
-//   5  the product's __shfl (several in flight), checked against form 1 afterwards; mismatches logged
-#ifdef STRAPS_TOOLS
-__device__ unsigned g_xchg_log[4 + 8 * 4096];      // [0] mismatches seen, [1] exchanges checked (one count per wave-level call); records of 8 words
-#endif
-__device__ __forceinline__ int xchg_readlane(int v, int src) {
-    int r = 0;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        const int t = __builtin_amdgcn_readlane(v, k);
-        r = (src == k) ? t : r;
-    }
-    return r;
-}
-__device__ __forceinline__ int xchg_bpermute_now(int v, int src) {
-    int r;
-    asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(src << 2), "v"(v) : "memory");
-    return r;
-}
-template <int XCHG>
-__device__ __forceinline__ float lane_get(float value, int src, int site, int trip, int& prev) {
-    if constexpr (XCHG == 0) {
-        return __shfl(value, src, 64);
-    } else {
-        const int v = __float_as_int(value);
-        src &= 63;
-        if constexpr (XCHG == 1) return __int_as_float(xchg_readlane(v, src));
-        if constexpr (XCHG == 4) return __int_as_float(xchg_bpermute_now(v, src));
-#ifdef STRAPS_TOOLS
-        int a, b;
-        if constexpr (XCHG == 2) { a = xchg_bpermute_now(v, src); b = xchg_bpermute_now(v, src); }
-        else { a = __float_as_int(__shfl(value, src, 64)); b = a; }
-        const int truth = xchg_readlane(v, src);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_xchg_log[1], 1u);
-        if (a != truth || b != truth) {
-            int from = -1;                            // does the wrong value belong to ANOTHER lane of the same register?
-            for (int k = 63; k >= 0; --k) from = (__builtin_amdgcn_readlane(v, k) == a) ? k : from;
-            const unsigned slot = atomicAdd(&g_xchg_log[0], 1u);
-            if (slot < 4096) {
-                unsigned* r = g_xchg_log + 4 + slot * 8;
-                r[0] = (unsigned)site | ((unsigned)trip << 8) | ((unsigned)(from & 0xff) << 16) | ((unsigned)(a != truth) << 24) | ((unsigned)(b != truth) << 25);
-                r[1] = threadIdx.x | (blockIdx.x << 16);
-                r[2] = (unsigned)src; r[3] = (unsigned)truth; r[4] = (unsigned)a; r[5] = (unsigned)b; r[6] = (unsigned)v; r[7] = (unsigned)prev;
-            }
-        }
-        prev = a;
-        return __int_as_float(a);
-#else
-        // (the checked forms 2 / 5 exist in the tools build only -- instantiating one in the product must not compile to "no exchange")
-        static_assert(XCHG == 0 || XCHG == 1 || XCHG == 4, "lane_get: the checked exchange forms (2, 5) need -DSTRAPS_TOOLS");
-        return value;
-#endif
-    }
-}
-
-// SC = 1 (tools build): the chunk partials are read with system-scope loads (sc0 sc1: past the L1 and the L2) -- does a stale cache line explain it?
-template <int SC>
-__device__ __forceinline__ float partial_load(const float* p) {
-    if constexpr (SC) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else return *p;
-}
-#ifdef STRAPS_TOOLS
-__global__ void pose_bwd_gap_kernel() {}
-// DBG = 1: workgroup 0 dumps its intermediate values, field-major ([field][thread], 256 threads), for the probe to name the FIRST quantity that differs
-constexpr int POSE_DBG_FIELDS = 112;
-__device__ float g_pose_dbg[POSE_DBG_FIELDS * 256];
-#define POSE_DBG(field, value) do { if constexpr (DBG) { if (blockIdx.x == 0) g_pose_dbg[(field) * 256 + threadIdx.x] = (value); } } while (0)
-#else
-#define POSE_DBG(field, value) do { } while (0)
-#endif
-
-// The kernel as it was (packed fp32 instructions allowed: the reproducer's victim, and the forms that write one out in assembly) exists in a tools build made with
-// STRAPS_TOOLS_SMPL_BWD_FLAGS=-DSTRAPS_POSE_BWD_PACKED only; every other build compiles it without packed fp32 instructions (common.h, STRAPS_NO_PACKED_FP32).
-#if defined(STRAPS_TOOLS) && defined(STRAPS_POSE_BWD_PACKED)
-#define POSE_BWD_ATTR
-#else
-#define POSE_BWD_ATTR STRAPS_NO_PACKED_FP32
-#endif
-template <int XCHG, int SC = 0, int DBG = 0>
-__global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps_smpl_model_t m, const float* __restrict__ betas,
+// smpl_pose_bwd_kernel is compiled WITHOUT packed fp32 instructions (common.h, STRAPS_NO_PACKED_FP32): round 5 traced its irreproducible results beside a
+// bf16x3 convolution workgroup to ONE instruction the compiler had formed in it, v_pk_fma_f32 ... op_sel:[0,1,0].  The instrumented forms
+// of the kernel that found it -- checked lane exchanges, value dumps, the instruction written out next to a plain v_fma_f32 -- were removed in round 6: the
+// stand-alone reproducer tools/packed_fp32_hazard_repro.hip carries the finding, profiles/r05_packed_fp32_* the measurements, and the kernel below is the
+// product's only form (the removal left its instruction stream alone: same opcode counts but for two integer instructions, registers renumbered --
+// compared on the disassembly).
+// (a lane exchange of the kernel below: ds_bpermute_b32, several in flight, waits placed by the compiler)
+__device__ __forceinline__ float lane_get(float value, int src) { return __shfl(value, src, 64); }
+__global__ __launch_bounds__(256) STRAPS_NO_PACKED_FP32 void smpl_pose_bwd_kernel(straps_smpl_model_t m, const float* __restrict__ betas,
                                                             const float* __restrict__ rotmats, const float* __restrict__ dFp,
                                                             const float* __restrict__ dAp, const float* __restrict__ djoints,
                                                             float* __restrict__ dbetas, float* __restrict__ drot, long long B,
@@ -337,126 +261,22 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
 #pragma unroll
     for (int e = 0; e < 9; ++e) R[e] = rotmats[(bb * 24 + jj) * 9 + e];
     float J[3];
-    [[maybe_unused]] int par_early = 0, dep_early = 0;
-    typedef float pose_f4 __attribute__((ext_vector_type(4)));
-    [[maybe_unused]] pose_f4 sd_first = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (DBG == 2 || DBG == 3) {
-        // (tools build; the first value that differs in an event is J[0], short of its l = 1 term in lanes 48..63.  Here the joint's first four shape
-        //  coefficients are loaded by ONE dwordx4 load written out in assembly and awaited on the spot (vmcnt(0)); its four result registers are copied
-        //  right away ("early") and again at the kernel's end ("late": the same registers read ~10^4 cycles later) -- was the value never written, or
-        //  written after the counter said so?  DBG = 3 sleeps ~500 cycles between the wait and the early copy)
-        const float* ap = m.j_shapedirs + jj * 30;
-        if constexpr (DBG == 3) asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)\n\ts_sleep 8" : "=&v"(sd_first) : "v"(ap) : "memory");
-        else asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(sd_first) : "v"(ap) : "memory");
-        float e0, e1, e2, e3;
-        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7" : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
-                     : "v"(sd_first.x), "v"(sd_first.y), "v"(sd_first.z), "v"(sd_first.w));
-        POSE_DBG(104, e0); POSE_DBG(105, e1); POSE_DBG(106, e2); POSE_DBG(107, e3);
-        float sd[30];
 #pragma unroll
-        for (int q = 4; q < 30; ++q) sd[q] = m.j_shapedirs[jj * 30 + q];
-        sd[0] = e0; sd[1] = e1; sd[2] = e2; sd[3] = e3;
+    for (int c = 0; c < 3; ++c) {
+        float s = m.j_template[jj * 3 + c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float s = m.j_template[jj * 3 + c];
-#pragma unroll
-            for (int l = 0; l < 10; ++l) s = fmaf(sd[c * 10 + l], beta[l], s);
-            J[c] = s;
-        }
+        for (int l = 0; l < 10; ++l) s = fmaf(m.j_shapedirs[(jj * 3 + c) * 10 + l], beta[l], s);
+        J[c] = s;
     }
-#if defined(STRAPS_TOOLS) && defined(STRAPS_POSE_BWD_PACKED)
-    else if constexpr (DBG == 4 || DBG == 5 || DBG == 6) {
-        // (tools build.  The wrong J[0] is the result of ONE instruction: the l = 1 step of the (J[0], J[1]) pair, v_pk_fma_f32 ... op_sel:[0,1,0] -- the only step
-        //  whose LOW half takes the HIGH register of a source.  DBG = 4: that instruction written out, and the same product-sum computed again by a plain
-        //  v_fma_f32 from the same registers right behind it; a difference is logged with the operands.  DBG = 5: the kernel's usual code, but every load
-        //  of the prologue awaited (and ~250 cycles slept) before the first arithmetic instruction: no load result arrives while the packed instructions run)
-        float sd[30], t[3];
-#pragma unroll
-        for (int q = 0; q < 30; ++q) sd[q] = m.j_shapedirs[jj * 30 + q];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) t[c] = m.j_template[jj * 3 + c];
-        par_early = m.parents[jj];
-        dep_early = m.depth[jj];
-        if constexpr (DBG == 5) {
-#pragma unroll
-            for (int q = 0; q < 30; ++q) asm volatile("" : "+v"(sd[q]));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(t[c]));
-#pragma unroll
-            for (int l = 0; l < 10; ++l) asm volatile("" : "+v"(beta[l]));
-#pragma unroll
-            for (int e = 0; e < 9; ++e) asm volatile("" : "+v"(R[e]));
-            asm volatile("" : "+v"(par_early), "+v"(dep_early));
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_sleep 4" ::: "memory");
-            // (pinned again BEHIND the sleep: volatile statements keep their order, and the arithmetic below depends on these)
-#pragma unroll
-            for (int q = 0; q < 30; ++q) asm volatile("" : "+v"(sd[q]));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(t[c]));
-#pragma unroll
-            for (int l = 0; l < 10; ++l) asm volatile("" : "+v"(beta[l]));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float s = t[c];
-#pragma unroll
-                for (int l = 0; l < 10; ++l) s = fmaf(sd[c * 10 + l], beta[l], s);
-                J[c] = s;
-            }
-        } else {
-            typedef float pose_f2 __attribute__((ext_vector_type(2)));
-            pose_f2 acc = {fmaf(sd[0], beta[0], t[0]), fmaf(sd[10], beta[0], t[1])};
-            pose_f2 a = {sd[1], sd[11]}, b = {beta[0], beta[1]}, d;
-            float plain;
-            asm volatile("" : "+v"(a), "+v"(b), "+v"(acc));      // (the three register pairs exist as pairs from here on: the plain v_fma_f32 reads their halves)
-            if constexpr (DBG == 6)      // (DBG = 6: the same pair of instructions with every load of the wave awaited and ~250 cycles slept in front of them)
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_sleep 4\n\tv_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,1,0]\n\tv_fma_f32 %1, %5, %6, %7"
-                             : "=&v"(d), "=&v"(plain) : "v"(a), "v"(b), "v"(acc), "v"(a.x), "v"(b.y), "v"(acc.x) : "memory");
-            else
-                asm volatile("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,1,0]\n\tv_fma_f32 %1, %5, %6, %7"
-                             : "=&v"(d), "=&v"(plain) : "v"(a), "v"(b), "v"(acc), "v"(a.x), "v"(b.y), "v"(acc.x));
-            if ((threadIdx.x & 63) == 0) atomicAdd(&g_xchg_log[1], 1u);
-            if (__float_as_uint(d.x) != __float_as_uint(plain)) {
-                const unsigned slot = atomicAdd(&g_xchg_log[0], 1u);
-                if (slot < 4096) {
-                    unsigned* r = g_xchg_log + 4 + slot * 8;
-                    r[0] = 200; r[1] = threadIdx.x | (blockIdx.x << 16); r[2] = __float_as_uint(a.x); r[3] = __float_as_uint(b.y); r[4] = __float_as_uint(acc.x);
-                    r[5] = __float_as_uint(d.x); r[6] = __float_as_uint(plain); r[7] = __float_as_uint(d.y);
-                }
-            }
-            float s0 = d.x, s1 = d.y, s2 = t[2];
-#pragma unroll
-            for (int l = 2; l < 10; ++l) { s0 = fmaf(sd[l], beta[l], s0); s1 = fmaf(sd[10 + l], beta[l], s1); }
-#pragma unroll
-            for (int l = 0; l < 10; ++l) s2 = fmaf(sd[20 + l], beta[l], s2);
-            J[0] = s0; J[1] = s1; J[2] = s2;
-        }
-    }
-#endif
-    else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float s = m.j_template[jj * 3 + c];
-#pragma unroll
-            for (int l = 0; l < 10; ++l) s = fmaf(m.j_shapedirs[(jj * 3 + c) * 10 + l], beta[l], s);
-            J[c] = s;
-        }
-    }
-#if !(defined(STRAPS_TOOLS) && defined(STRAPS_POSE_BWD_PACKED))
-    static_assert(DBG < 4, "forms 4..6 need -DSTRAPS_POSE_BWD_PACKED");
-#endif
-    const int par = (DBG >= 4) ? par_early : m.parents[jj];
-    const int dep = vj ? ((DBG >= 4) ? dep_early : m.depth[jj]) : -1;
+    const int par = m.parents[jj];
+    const int dep = vj ? m.depth[jj] : -1;
     const int src = base + (par < 0 ? 0 : par);
-    int xprev = 0;      // (tools forms: the value the previous exchange delivered to this lane)
     float rel[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float jp = lane_get<XCHG>(J[c], src, 0 + c, 0, xprev);
+        const float jp = lane_get(J[c], src);
         rel[c] = (jj > 0) ? J[c] - jp : J[c];
     }
-    for (int c = 0; c < 3; ++c) { POSE_DBG(0 + c, J[c]); POSE_DBG(3 + c, rel[c]); }
-    for (int e = 0; e < 9; ++e) POSE_DBG(6 + e, R[e]);
-    POSE_DBG(15, beta[0]); POSE_DBG(16, beta[9]); POSE_DBG(17, (float)par); POSE_DBG(18, (float)dep);
     // forward chain: G (own global transform) and P (parent's rotation), recomputed
     float G[12], PR[9];
 #pragma unroll
@@ -468,7 +288,7 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
     for (int d = 1; d <= m.max_depth; ++d) {
         float P[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) P[e] = lane_get<XCHG>(G[e], src, 8 + e, d, xprev);
+        for (int e = 0; e < 12; ++e) P[e] = lane_get(G[e], src);
         if (dep == d) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -481,8 +301,6 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
             }
         }
     }
-    for (int e = 0; e < 12; ++e) POSE_DBG(19 + e, G[e]);
-    for (int e = 0; e < 9; ++e) POSE_DBG(31 + e, PR[e]);
     // gradient arriving at A_j (sum of chunk partials) and at the posed joint
     float gA[12];
 #pragma unroll
@@ -491,7 +309,7 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
         for (int c = 0; c < chunks; ++c) {
             const float* p = dAp + (((long long)c * B + body) * 24 + j) * 12;
 #pragma unroll
-            for (int e = 0; e < 12; ++e) gA[e] += partial_load<SC>(p + e);
+            for (int e = 0; e < 12; ++e) gA[e] += p[e];
         }
     float gGR[9], gGt[3], gJ[3];
 #pragma unroll
@@ -505,13 +323,9 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
 #pragma unroll
     for (int c = 0; c < 3; ++c) gJ[c] = -(G[0 * 4 + c] * gA[3] + G[1 * 4 + c] * gA[7] + G[2 * 4 + c] * gA[11]);
 
-    for (int e = 0; e < 12; ++e) POSE_DBG(40 + e, gA[e]);
-    for (int e = 0; e < 9; ++e) POSE_DBG(52 + e, gGR[e]);
-    for (int c = 0; c < 3; ++c) { POSE_DBG(61 + c, gGt[c]); POSE_DBG(64 + c, gJ[c]); }
     int child[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) child[c] = m.children[jj * 3 + c];
-    for (int c = 0; c < 3; ++c) POSE_DBG(67 + c, (float)child[c]);
     float gR[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) gR[e] = 0.f;
@@ -545,7 +359,7 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
             const int cs = base + (ch < 0 ? 0 : ch);
             float in[15];
 #pragma unroll
-            for (int e = 0; e < 15; ++e) in[e] = lane_get<XCHG>(M[e], cs, 32 + cc * 16 + e, d, xprev);
+            for (int e = 0; e < 15; ++e) in[e] = lane_get(M[e], cs);
             if (vj && ch >= 0) {       // in[] is zero unless that child is at depth d
 #pragma unroll
                 for (int e = 0; e < 9; ++e) gGR[e] += in[e];
@@ -554,8 +368,6 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
             }
         }
     }
-    for (int e = 0; e < 9; ++e) { POSE_DBG(70 + e, gGR[e]); POSE_DBG(79 + e, gR[e]); }
-    for (int c = 0; c < 3; ++c) { POSE_DBG(88 + c, gGt[c]); POSE_DBG(91 + c, gJ[c]); }
     if (j == 0) {   // root: G = [R | J]
 #pragma unroll
         for (int e = 0; e < 9; ++e) gR[e] = gGR[e];
@@ -569,20 +381,12 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
             const float* p = dFp + ((long long)c * B + body) * KP;
             if (j >= 1) {
 #pragma unroll
-                for (int e = 0; e < 9; ++e) gR[e] += partial_load<SC>(p + 11 + (j - 1) * 9 + e);
+                for (int e = 0; e < 9; ++e) gR[e] += p[11 + (j - 1) * 9 + e];
             }
-            if (j < 10) gbeta_direct += partial_load<SC>(p + 1 + j);
+            if (j < 10) gbeta_direct += p[1 + j];
         }
 #pragma unroll
         for (int e = 0; e < 9; ++e) drot[(body * 24 + j) * 9 + e] = gR[e];
-    }
-    for (int e = 0; e < 9; ++e) POSE_DBG(94 + e, gR[e]);
-    POSE_DBG(103, gbeta_direct);
-    if constexpr (DBG == 2 || DBG == 3) {
-        float l0, l1, l2, l3;
-        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7" : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
-                     : "v"(sd_first.x), "v"(sd_first.y), "v"(sd_first.z), "v"(sd_first.w));
-        POSE_DBG(108, l0); POSE_DBG(109, l1); POSE_DBG(110, l2); POSE_DBG(111, l3);
     }
     // dbeta[l] = dF[1+l] + sum_j sum_c Js[j][c][l] * gJ_j[c]
 #pragma unroll
@@ -590,11 +394,8 @@ __global__ __launch_bounds__(256) POSE_BWD_ATTR void smpl_pose_bwd_kernel(straps
         float s = vj ? (m.j_shapedirs[(jj * 3 + 0) * 10 + l] * gJ[0] + m.j_shapedirs[(jj * 3 + 1) * 10 + l] * gJ[1] +
                         m.j_shapedirs[(jj * 3 + 2) * 10 + l] * gJ[2]) : 0.f;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            if constexpr (XCHG == 0) s += __shfl_xor(s, o, 64);
-            else s += lane_get<XCHG>(s, lane ^ o, 96 + l, o, xprev);
-        }
-        const float direct = lane_get<XCHG>(gbeta_direct, base + l, 112 + l, 0, xprev);
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float direct = lane_get(gbeta_direct, base + l);
         if (vb && j == l) dbetas[body * 10 + l] = s + direct;
     }
 }
@@ -635,111 +436,14 @@ extern "C" int straps_smpl_bwd(const straps_smpl_model_t* model, const float* be
     if (rc != STRAPS_OK) return rc;
     const size_t lds = (size_t)(BT * AS + 4 * BT * SS) * sizeof(float);
     STRAPS_RAISE_LDS((smpl_verts_bwd_kernel), lds, "smpl_verts_bwd_kernel");
-#ifdef STRAPS_TOOLS
-    static const int poison = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_POISON", 0);    // (1: the partials are NaN before their producer runs -- a result that is NaN read what this call never wrote)
-    if (poison && hipMemsetAsync(dFp, 0xff, (size_t)nch * batch * (KP + 288) * sizeof(float), st) != hipSuccess) { straps_set_error("straps_smpl_bwd: poison failed"); return STRAPS_EHIP; }
-#endif
     const long long btiles = (batch + BT - 1) / BT;
     if (btiles > 65535) { straps_set_error("straps_smpl_bwd: batch %lld exceeds one launch; split it", batch); return STRAPS_EUNSUPPORTED; }
     hipLaunchKernelGGL(smpl_verts_bwd_kernel, dim3(nch, (unsigned)btiles), dim3(256), lds, st, *model, F, Amat, dverts, djoints, dFp, dAp, batch, rpc);
     STRAPS_CHECK_LAUNCH("smpl_verts_bwd_kernel");
     // (Round 5, DESIGN section 1: this kernel was the one whose results differed between two processes on one GPU.  Cause: a packed fp32 instruction with a
-    //  low-half operand select the compiler had formed in it -- the kernel is compiled without packed fp32 instructions now, see POSE_BWD_ATTR.  The mitigation
-    //  that came first, 96 KB of dynamic LDS the kernel never touches so that no bf16x3 convolution workgroup fits beside it on a compute unit, is kept as a
-    //  switch of the tools build for A/B runs -- STRAPS_POSE_BWD_FENCE=1 -- and is off everywhere else: profiles/r05_packed_fp32_fix.txt ran without it.)
-    size_t fence = 0;
-    auto pose_bwd = smpl_pose_bwd_kernel<0, 0>;
-#ifdef STRAPS_TOOLS
-    static const int xchg = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_XCHG", 0);        // (exchange forms, see lane_get)
-    static const int fenced = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_FENCE", 0);     // (1: 96 KB of unused LDS, the first mitigation)
-    pose_bwd = xchg == 1 ? smpl_pose_bwd_kernel<1> : xchg == 2 ? smpl_pose_bwd_kernel<2> : xchg == 4 ? smpl_pose_bwd_kernel<4> : xchg == 5 ? smpl_pose_bwd_kernel<5> : pose_bwd;
-    if (fenced) fence = 96 * 1024;
-    static const int sc = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_SC", 0);            // (1: partials read past the caches)
-    if (sc) pose_bwd = smpl_pose_bwd_kernel<0, 1>;
-    static const int dbg = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_DBG", 0);          // (1: intermediate values dumped, straps_tool_pose_dbg fetches them)
-#ifdef STRAPS_POSE_BWD_PACKED
-    if (dbg >= 4) pose_bwd = dbg == 4 ? smpl_pose_bwd_kernel<0, 0, 4> : dbg == 5 ? smpl_pose_bwd_kernel<0, 0, 5> : smpl_pose_bwd_kernel<0, 0, 6>;
-    else
-#endif
-    if (dbg) pose_bwd = dbg == 2 ? smpl_pose_bwd_kernel<0, 0, 2> : dbg == 3 ? smpl_pose_bwd_kernel<0, 0, 3> : xchg == 1 ? smpl_pose_bwd_kernel<1, 0, 1> : smpl_pose_bwd_kernel<0, 0, 1>;
-    static const int gap = STRAPS_TOOL_ENV_INT("STRAPS_POSE_BWD_GAP", 0);          // (1: an empty kernel between the producer of the partials and this kernel)
-    if (gap) hipLaunchKernelGGL(pose_bwd_gap_kernel, dim3(1), dim3(64), 0, st);
-#endif
-    if (fence) STRAPS_RAISE_LDS(pose_bwd, fence, "smpl_pose_bwd_kernel");
-    hipLaunchKernelGGL(pose_bwd, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), fence, st, *model, betas, rotmats, dFp, dAp,
+    //  low-half operand select the compiler had formed in it -- the kernel is compiled without packed fp32 instructions, STRAPS_NO_PACKED_FP32.)
+    hipLaunchKernelGGL(smpl_pose_bwd_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, st, *model, betas, rotmats, dFp, dAp,
                        djoints, dbetas, drotmats, batch, nch);
     STRAPS_CHECK_LAUNCH("smpl_pose_bwd_kernel");
     return STRAPS_OK;
 }
-
-#ifdef STRAPS_TOOLS
-// tools build only: the intermediate values smpl_pose_bwd_kernel<.., .., 1> dumped, copied device -> device on `stream` ([112][256] floats)
-extern "C" int straps_tool_pose_dbg(float* device_dst, void* stream) {
-    STRAPS_REQUIRE(device_dst, "straps_tool_pose_dbg: null pointer");
-    const hipError_t e = hipMemcpyFromSymbolAsync(device_dst, HIP_SYMBOL(g_pose_dbg), sizeof(float) * POSE_DBG_FIELDS * 256, 0, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-    if (e != hipSuccess) { straps_set_error("straps_tool_pose_dbg: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-    return STRAPS_OK;
-}
-// tools build only: the exchange log of smpl_pose_bwd_kernel<2 | 5> copied to the host (words: 4 + 8 * 4096), then cleared when `reset`
-extern "C" int straps_tool_xchg_log(unsigned* host_words, int reset) {
-    STRAPS_REQUIRE(host_words, "straps_tool_xchg_log: null pointer");
-    static unsigned zeros[4 + 8 * 4096];
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpyFromSymbol(host_words, HIP_SYMBOL(g_xchg_log), sizeof(zeros));
-    if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(g_xchg_log), zeros, sizeof(zeros));
-    if (e != hipSuccess) { straps_set_error("straps_tool_xchg_log: %s", hipGetErrorString(e)); return STRAPS_EHIP; }
-    return STRAPS_OK;
-}
-#endif
-
-#ifdef STRAPS_TOOLS
-// tools build only (round 5): a victim of nothing but packed fp32 instructions.  One workgroup-sized launch like smpl_pose_bwd_kernel's (no LDS,
-// a few loads, then arithmetic); every trip runs seven forms of v_pk_{fma,mul,add}_f32, each followed by plain v_fma / v_mul / v_add of the SAME registers, and logs
-// every lane whose packed result differs (g_xchg_log: form | trip << 16, thread, operands, both results).  Which operand-select forms lose their product beside a
-// bf16x3 convolution workgroup -- only "low result from a HIGH register" (op_sel), or others too -- and only in a wave's first instructions, or any time?
-namespace {
-typedef float tool_f2 __attribute__((ext_vector_type(2)));
-#define PK_CHECK(form, PK_ASM, LO_ASM, HI_ASM)                                                                                          \
-    do {                                                                                                                                \
-        tool_f2 d; float lo, hi;                                                                                                        \
-        asm volatile(PK_ASM "\n\t" LO_ASM "\n\t" HI_ASM : "=&v"(d), "=&v"(lo), "=&v"(hi)                                               \
-                     : "v"(a), "v"(b), "v"(c), "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "v"(c.x), "v"(c.y));                             \
-        if (__float_as_uint(d.x) != __float_as_uint(lo) || __float_as_uint(d.y) != __float_as_uint(hi)) {                               \
-            const unsigned slot = atomicAdd(&g_xchg_log[0], 1u);                                                                        \
-            if (slot < 4096) {                                                                                                          \
-                unsigned* r = g_xchg_log + 4 + slot * 8;                                                                                \
-                r[0] = 300u + (form) + ((unsigned)trip << 16); r[1] = threadIdx.x | (blockIdx.x << 16);                                 \
-                r[2] = __float_as_uint(d.x); r[3] = __float_as_uint(lo); r[4] = __float_as_uint(d.y); r[5] = __float_as_uint(hi);       \
-                r[6] = __float_as_uint(c.x); r[7] = __float_as_uint(c.y);                                                               \
-            }                                                                                                                           \
-        }                                                                                                                               \
-        sum += d.x + d.y;                                                                                                               \
-    } while (0)
-// operands: %3 a, %4 b, %5 c (pairs); %6 a.lo %7 a.hi %8 b.lo %9 b.hi %10 c.lo %11 c.hi
-__global__ __launch_bounds__(256) void pk_victim_kernel(const float* __restrict__ in, float* __restrict__ out, int trips) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    tool_f2 a = {in[t * 6 + 0], in[t * 6 + 1]}, b = {in[t * 6 + 2], in[t * 6 + 3]}, c = {in[t * 6 + 4], in[t * 6 + 5]};
-    float sum = 0.f;
-    for (int trip = 0; trip < trips; ++trip) {
-        asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_xchg_log[1], 1u);
-        PK_CHECK(0, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,1,0]", "v_fma_f32 %1, %6, %9, %10", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(1, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[1,0,0]", "v_fma_f32 %1, %7, %8, %10", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(2, "v_pk_fma_f32 %0, %3, %4, %5 op_sel:[0,0,1]", "v_fma_f32 %1, %6, %8, %11", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(3, "v_pk_fma_f32 %0, %3, %4, %5 op_sel_hi:[1,0,1]", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %8, %11");
-        PK_CHECK(4, "v_pk_fma_f32 %0, %3, %4, %5", "v_fma_f32 %1, %6, %8, %10", "v_fma_f32 %2, %7, %9, %11");
-        PK_CHECK(5, "v_pk_mul_f32 %0, %3, %4 op_sel:[0,1]", "v_mul_f32 %1, %6, %9", "v_mul_f32 %2, %7, %9");
-        PK_CHECK(6, "v_pk_add_f32 %0, %3, %4 op_sel:[0,1]", "v_add_f32 %1, %6, %9", "v_add_f32 %2, %7, %9");
-        a.x += 0.001f; b.y -= 0.002f; c.x += 0.003f;
-    }
-    out[t] = sum;
-}
-#undef PK_CHECK
-}  // namespace
-extern "C" int straps_tool_pk_victim(const float* in, float* out, int blocks, int trips, void* stream) {
-    STRAPS_REQUIRE(in && out && blocks > 0 && trips > 0, "straps_tool_pk_victim: bad argument");
-    hipLaunchKernelGGL(pk_victim_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, trips);
-    STRAPS_CHECK_LAUNCH("pk_victim_kernel");
-    return STRAPS_OK;
-}
-#endif

@@ -59,7 +59,7 @@ def build(force=False, verbose=False, tools=False):
     extra = dict(EXTRA_FLAGS)
     if tools and os.environ.get('STRAPS_TOOLS_SMPL_FLAGS'):      # (build-time A/B of compiler flags for one source: tools library only)
         extra['smpl.hip'] = extra.get('smpl.hip', []) + os.environ['STRAPS_TOOLS_SMPL_FLAGS'].split()
-    if tools and os.environ.get('STRAPS_TOOLS_SMPL_BWD_FLAGS'):      # (-DSTRAPS_POSE_BWD_PACKED: smpl_pose_bwd_kernel WITH packed fp32 instructions, the round-5 victim)
+    if tools and os.environ.get('STRAPS_TOOLS_SMPL_BWD_FLAGS'):      # (-DSTRAPS_ALLOW_PACKED_FP32: the kernels WITH packed fp32 instructions, as round 5 found them: csrc/common.h)
         extra['smpl_bwd.hip'] = extra.get('smpl_bwd.hip', []) + os.environ['STRAPS_TOOLS_SMPL_BWD_FLAGS'].split()
     if tools and os.environ.get('STRAPS_TOOLS_RASTER_FLAGS'):
         extra['raster.hip'] = extra.get('raster.hip', []) + os.environ['STRAPS_TOOLS_RASTER_FLAGS'].split()

@@ -56,10 +56,16 @@ useg = torch.rand(B * 9, generator=g).to(dev)
 j2d = (torch.rand(B, 17, 2, generator=g) * 150 + 50).to(dev)
 remove_prob = torch.full((6,), 0.1, device=dev)
 
+_REMOVED = [k for k in ('PROBE_PK_VICTIM', 'STRAPS_POSE_BWD_DBG', 'STRAPS_POSE_BWD_XCHG', 'STRAPS_POSE_BWD_SC', 'STRAPS_POSE_BWD_POISON', 'STRAPS_POSE_BWD_GAP', 'STRAPS_POSE_BWD_FENCE')
+            if os.environ.get(k)]
+if _REMOVED:
+    raise SystemExit('%s: the instrumented forms of smpl_pose_bwd_kernel and the in-library packed-fp32 victim were removed in round 6 (their findings: DESIGN section 1, '
+                     'profiles/r05_packed_fp32_*); the stand-alone reproducer is tools/packed_fp32_hazard_repro.hip' % ', '.join(_REMOVED))
+
 side = torch.cuda.Stream()
 a = torch.randn(4096, 4096, device=dev)
 bad = torch.zeros(5, device=dev, dtype=torch.int64)
-nans = torch.zeros(1, device=dev, dtype=torch.int64)      # (PROBE_SMPL_BWD with STRAPS_POSE_BWD_POISON=1: NaN results = partials read that this call never wrote)
+nans = torch.zeros(1, device=dev, dtype=torch.int64)
 
 
 if os.environ.get('PROBE_SMPL_BWD'):
@@ -73,28 +79,12 @@ if os.environ.get('PROBE_SMPL_BWD'):
     _nws = L.straps_smpl_bwd_workspace_bytes(8, 0) // 4
 
 
-if os.environ.get('PROBE_PK_VICTIM'):
-    # (round 5, tools build: a victim of nothing but packed fp32 instructions, each checked against plain ones of the same registers -- csrc/smpl_bwd.hip, pk_victim_kernel)
-    import ctypes as _C
-    _pk_blocks, _pk_trips = int(os.environ.get('PROBE_PK_BLOCKS', '1')), int(os.environ.get('PROBE_PK_TRIPS', '64'))
-    _pk_in = torch.randn(256 * _pk_blocks * 6, generator=torch.Generator().manual_seed(5)).to(dev)
-    _pk_lib = _C.CDLL(hipabi.TOOLS_LIB_PATH)
-
-
 def stages():
-    if os.environ.get('PROBE_PK_VICTIM'):
-        out = torch.empty(256 * _pk_blocks, device=dev)
-        hipabi.check(_pk_lib.straps_tool_pk_victim(hipabi.ptr(_pk_in), hipabi.ptr(out), _pk_blocks, _pk_trips, hipabi.stream_ptr()), 'pk_victim')
-        return (out,)
     if os.environ.get('PROBE_SMPL_BWD'):
         ws = torch.empty(_nws, device=dev)
         dbetas, drot = torch.empty(8, 10, device=dev), torch.empty(8, 24, 3, 3, device=dev)
         hipabi.check(L.straps_smpl_bwd(_C.byref(smpl._model_struct()), hipabi.ptr(_b8), hipabi.ptr(_R8), hipabi.ptr(_dv8), hipabi.ptr(_dj8), hipabi.ptr(dbetas),
                                        hipabi.ptr(drot), hipabi.ptr(ws), 8, 0, hipabi.stream_ptr()), 'straps_smpl_bwd')
-        if os.environ.get('STRAPS_POSE_BWD_DBG'):      # (tools build: the kernel's intermediate values, [field][thread])
-            dbg = torch.empty(112, 256, device=dev)
-            hipabi.check(_C.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_pose_dbg(hipabi.ptr(dbg), hipabi.stream_ptr()), 'pose_dbg')
-            return dbetas, drot, ws, dbg
         return dbetas, drot, ws
     if os.environ.get('PROBE_SMPL'):
         # the SMPL forward of the data stream (target vertices and joints; reposed vertices): LDS operand rows read in its inner loops
@@ -328,7 +318,7 @@ if worst_z is not None:
         was = int(((rz[b_ * 65536:(b_ + 1) * 65536] & 0xffffffff) == fr).sum()) if kr != (1 << 64) - 1 else -1
         print('   body %d pixel (%3d, %3d): face %5d z-bits %08x  ->  %s ; the first face held %d pixels of this body before, holds %d now' % (
             b_, rem // 256, rem % 256, fr, kr >> 32, ('face %5d z-bits %08x' % (fw, kw >> 32)) if kw != (1 << 64) - 1 else 'EMPTY', was, still))
-d = (worst != ref[0]).nonzero() if not (os.environ.get('PROBE_SMPL_BWD') or os.environ.get('PROBE_PK_VICTIM')) else torch.zeros(0)
+d = (worst != ref[0]).nonzero() if not os.environ.get('PROBE_SMPL_BWD') else torch.zeros(0)
 if d.numel():
     print('last differing part map: %d pixels differ; (body, row, col): first result -> this one' % d.shape[0])
     for b_, y_, x_ in d[:12].tolist():
@@ -353,103 +343,3 @@ if os.environ.get('PROBE_SMPL_BWD') and int(events):
         js = [(j_, int(dd[b_, j_].sum()), float(((worst_rot[b_, j_] - ref[1][b_, j_]).abs().max() / ref[1][b_, j_].abs().max().clamp_min(1e-30)))) for j_ in range(24) if bool(dd[b_, j_].any())]
         if js:
             print('   body %d: joints (differing of 9, max |difference| / max |value|): %s' % (b_, ' '.join('%d(%d, %.1e)' % t for t in js)))
-if worst_dbg is not None:
-    names = (['J[%d]' % c for c in range(3)] + ['rel[%d]' % c for c in range(3)] + ['R[%d]' % e for e in range(9)] + ['beta[0]', 'beta[9]', 'parent', 'depth'] +
-             ['G[%d]' % e for e in range(12)] + ['PR[%d]' % e for e in range(9)] + ['gA[%d]' % e for e in range(12)] + ['gGR0[%d]' % e for e in range(9)] +
-             ['gGt0[%d]' % c for c in range(3)] + ['gJ0[%d]' % c for c in range(3)] + ['child[%d]' % c for c in range(3)] + ['gGR[%d]' % e for e in range(9)] +
-             ['gR[%d]' % e for e in range(9)] + ['gGt[%d]' % c for c in range(3)] + ['gJ[%d]' % c for c in range(3)] + ['gR_out[%d]' % e for e in range(9)] + ['gbeta_direct'] +
-             ['shapedirs[c=0][%d] EARLY' % q for q in range(4)] + ['shapedirs[c=0][%d] LATE' % q for q in range(4)])
-    fe = field_events.tolist()
-    print('intermediate values of workgroup 0, calls in which a field differed from the first call (fields in program order): ' +
-          (', '.join('%s %d' % (names[k], fe[k]) for k in range(len(names)) if fe[k]) or 'none'))
-    dd = (worst_dbg != ref[3])
-    shown = 0
-    for k in range(len(names)):
-        if bool(dd[k].any()) and (shown < 6 or k >= 104):
-            shown += 1
-            idx = dd[k].nonzero().flatten().tolist()
-            print('   %-10s differs in threads %s: %s' % (names[k], ' '.join('%d(body %d joint %d)' % (t, t >> 5, t & 31) for t in idx[:8]),
-                                                        '  '.join('%.9g -> %.9g' % (float(ref[3][k, t]), float(worst_dbg[k, t])) for t in idx[:8])))
-if os.environ.get('PROBE_PK_VICTIM'):
-    import struct
-    words = (_C.c_uint * (4 + 8 * 4096))()
-    rc = _pk_lib.straps_tool_xchg_log(words, 1)
-    f32 = lambda u: struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
-    forms = ['pk_fma op_sel:[0,1,0]', 'pk_fma op_sel:[1,0,0]', 'pk_fma op_sel:[0,0,1]', 'pk_fma op_sel_hi:[1,0,1]', 'pk_fma (no selects)', 'pk_mul op_sel:[0,1]', 'pk_add op_sel:[0,1]']
-    print('packed fp32 victim, %d workgroup(s) x %d trips x 7 forms, %d launches beside %s (rc %d): %d wave-trips checked, %d lane results differ from the plain instructions' % (
-        _pk_blocks, _pk_trips, iters + 1, load, rc, words[1], words[0]))
-    by_form, by_quarter, by_trip, which = {}, {}, {}, dict(low=0, high=0)
-    for k in range(min(words[0], 4096)):
-        r = words[4 + 8 * k: 12 + 8 * k]
-        fm, trip = (r[0] & 0xffff) - 300, r[0] >> 16
-        by_form[forms[fm]] = by_form.get(forms[fm], 0) + 1
-        by_quarter[(r[1] & 63) >> 4] = by_quarter.get((r[1] & 63) >> 4, 0) + 1
-        by_trip[trip] = by_trip.get(trip, 0) + 1
-        which['low'] += r[2] != r[3]
-        which['high'] += r[4] != r[5]
-        if k < 12:
-            print('   %-26s trip %2d thread %3d (lane %2d): low %.9g, plain %.9g | high %.9g, plain %.9g | c = (%.9g, %.9g)' % (
-                forms[fm], trip, r[1] & 0xffff, r[1] & 63, f32(r[2]), f32(r[3]), f32(r[4]), f32(r[5]), f32(r[6]), f32(r[7])))
-    print('   by form:', by_form, '| by quarter of the wave (lanes 16q..16q+15):', dict(sorted(by_quarter.items())), '| half:', which)
-    print('   by trip:', dict(sorted(by_trip.items())))
-if os.environ.get('PROBE_SMPL_BWD') and os.environ.get('STRAPS_POSE_BWD_DBG') in ('4', '6'):
-    import ctypes
-    import struct
-    words = (ctypes.c_uint * (4 + 8 * 4096))()
-    rc = ctypes.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_xchg_log(words, 1)
-    f32 = lambda u: struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
-    print('v_pk_fma_f32 d, a, b, c op_sel:[0,1,0] against v_fma_f32 of the same registers (rc %d): %d waves checked, %d lane results differ' % (rc, words[1], words[0]))
-    lanes_ = {}
-    for k in range(min(words[0], 4096)):
-        r = words[4 + 8 * k: 12 + 8 * k]
-        lanes_[r[1] & 63] = lanes_.get(r[1] & 63, 0) + 1
-        if k < 16:
-            print('   thread %3d (lane %2d): a.lo %.9g  b.hi %.9g  c.lo %.9g -> packed low result %.9g, plain fma %.9g (packed high result %.9g)' % (
-                r[1] & 0xffff, r[1] & 63, f32(r[2]), f32(r[3]), f32(r[4]), f32(r[5]), f32(r[6]), f32(r[7])))
-    print('   lanes:', dict(sorted(lanes_.items())))
-if os.environ.get('PROBE_SMPL_BWD') and os.environ.get('STRAPS_POSE_BWD_POISON'):
-    print('partials poisoned with NaN before their producer: %d NaN among the results (dbetas, drotmats) of all calls; the reference call: %d' % (
-        int(nans), int(torch.isnan(ref[0]).sum() + torch.isnan(ref[1]).sum())))
-if os.environ.get('PROBE_SMPL_BWD') and os.environ.get('STRAPS_POSE_BWD_XCHG') in ('2', '5'):
-    # (tools build: smpl_pose_bwd_kernel checked every lane exchange against a v_readlane reference and logged the mismatches -- csrc/smpl_bwd.hip, lane_get)
-    import ctypes
-    import struct
-    words = (ctypes.c_uint * (4 + 8 * 4096))()
-    rc = ctypes.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_xchg_log(words, 1)
-    n, checked = words[0], words[1]
-    recs = [tuple(words[4 + 8 * k: 12 + 8 * k]) for k in range(min(n, 4096))]
-    f32 = lambda u: struct.unpack('<f', struct.pack('<I', u & 0xffffffff))[0]
-    site_name = lambda st: ('parent joint' if st < 8 else 'forward chain P[%d]' % (st - 8) if st < 32 else 'message of child %d, word %d' % ((st - 32) // 16, (st - 32) % 16)
-                            if st < 96 else 'beta reduction l=%d' % (st - 96) if st < 112 else 'direct beta l=%d' % (st - 112))
-    print('exchange log (rc %d): %d wave-level exchanges checked, %d lane results differ from the v_readlane reference' % (rc, checked, n))
-    if recs:
-        cls = dict(stale_previous_result=0, own_register=0, zero=0, another_lane_of_the_source_register=0, none_of_these=0)
-        first_bad, second_bad, sites, lanes_, waves = 0, 0, {}, {}, {}
-        for w0, w1, src, truth, a, b, own, prev in recs:
-            st, trip, frm = w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff
-            first_bad += (w0 >> 24) & 1
-            second_bad += (w0 >> 25) & 1
-            bad = a if (w0 >> 24) & 1 else b
-            key = ('stale_previous_result' if bad == prev else 'own_register' if bad == own else 'zero' if bad == 0 else
-                   'another_lane_of_the_source_register' if frm != 0xff and (w0 >> 24) & 1 else 'none_of_these')
-            cls[key] += 1
-            k = 'parent' if st < 8 else 'forward chain' if st < 32 else 'backward messages' if st < 96 else 'beta reduction' if st < 112 else 'direct beta'
-            sites[k] = sites.get(k, 0) + 1
-            lanes_[(w1 & 63)] = lanes_.get(w1 & 63, 0) + 1
-            waves[(w1 & 0xffff) >> 6] = waves.get((w1 & 0xffff) >> 6, 0) + 1
-        print('   first read wrong in %d records, the immediate second read (form 2) wrong in %d' % (first_bad, second_bad))
-        print('   what the wrong value is:', cls)
-        print('   where:', sites, '| waves', dict(sorted(waves.items())), '| distinct lanes %d' % len(lanes_))
-        for w0, w1, src, truth, a, b, own, prev in recs[:24]:
-            st, trip, frm = w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff
-            print('   %-28s trip %2d wave %d lane %2d <- lane %2d: expected %08x (%+.6e)  got %08x (%+.6e) then %08x | own %08x previous %08x | got == lane %s of the source' % (
-                site_name(st), trip, (w1 & 0xffff) >> 6, w1 & 63, src, truth, f32(truth), a, f32(a), b, own, prev, frm if frm != 0xff else '--'))
-if os.environ.get('PROBE_LOAD_REPORT'):      # (tools build with -DSTRAPS_RASTER_CHECK_LOADS)
-    import ctypes
-    rep = (ctypes.c_uint * 257)()
-    rc = ctypes.CDLL(hipabi.TOOLS_LIB_PATH).straps_tool_raster_report(rep)
-    print('raster_face_kernel re-read its vertex coordinates at the end of every lane (rc %d): %d differ from what the lane computed with' % (rc, rep[0]))
-    f32 = lambda u: ctypes.c_float.from_buffer(ctypes.c_uint(u)).value
-    for k in range(min(rep[0], 16)):
-        print('   workgroup %6d thread %3d coordinate %d of face %5d: used 0x%08x (%.7g), memory holds 0x%08x (%.7g)' % (
-            rep[1 + 4 * k], rep[2 + 4 * k] & 0xffff, (rep[2 + 4 * k] >> 16) & 15, rep[2 + 4 * k] >> 20, rep[3 + 4 * k], f32(rep[3 + 4 * k]), rep[4 + 4 * k], f32(rep[4 + 4 * k])))

@@ -45,7 +45,7 @@ def victim(label, garbage):
     import ctypes as C
     import straps_amd
     from straps_amd import hipabi
-    L = hipabi.use_library(hipabi.build(tools=True)) if os.environ.get('PROBE_TOOLS') else hipabi.load()      # (tools library: STRAPS_POSE_BWD_FENCE=0 takes the LDS fence off)
+    L = hipabi.use_library(hipabi.build(tools=True)) if os.environ.get('PROBE_TOOLS') else hipabi.load()      # (PROBE_TOOLS: through the tools build of the library)
     dev = torch.device('cuda:0')
     B = 8
     g = torch.Generator().manual_seed(3)
