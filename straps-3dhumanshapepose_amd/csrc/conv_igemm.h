@@ -704,9 +704,12 @@ struct LeanDgradEpilogue {
             int b_ = mm / MhMw;
             const int rem = mm - b_ * MhMw;
             int ho_ = rem / cMw, wo_ = rem - ho_ * cMw;
+            // ragged last tile: a row behind the end re-reads the class's LAST pixel (its result is masked out) -- the walk below would carry it past the
+            // tensor, and an operand read there (whatever the memory holds: a NaN times a zero gradient is a NaN in the BatchNorm sums) is not masked
+            const int plast = full ? 0 : pixel(M - 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pix[r] = (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw;
+                pix[r] = (full || mb + (r & 3) + 8 * (r >> 2) < M) ? (b_ * OH + ho_ * omul + oah) * OW + wo_ * omul + oaw : plast;
                 wo_ += (r & 3) == 3 ? 5 : 1;
                 while (wo_ >= cMw) {
                     wo_ -= cMw;

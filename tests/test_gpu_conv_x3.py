@@ -319,7 +319,9 @@ def test_conv_wgrad_x3_vs_float64(dev, B, Cin, Cout, H, W, k, stride):
 
 @pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,cfg,from_out', [
     (2, 64, 64, 16, 16, 3, 1, 0, False), (2, 64, 128, 16, 16, 3, 2, 0, True), (64, 256, 256, 16, 16, 3, 1, 0, False), (3, 128, 128, 8, 8, 3, 1, 5, True),
-    (2, 64, 128, 16, 16, 1, 2, 0, False), (5, 128, 128, 24, 24, 3, 1, 12, True), (2, 128, 256, 9, 14, 3, 2, 1, False), (4, 128, 64, 32, 32, 3, 1, 512, False)])
+    (2, 64, 128, 16, 16, 1, 2, 0, False), (5, 128, 128, 24, 24, 3, 1, 12, True), (2, 128, 256, 9, 14, 3, 2, 1, False), (4, 128, 64, 32, 32, 3, 1, 512, False),
+    # ragged last tiles of a stride-2 gradient's parity classes on the AUTOMATIC tiles (the lean data-gradient epilogue, round 6), odd maps
+    (2, 128, 256, 9, 14, 3, 2, 0, False), (3, 64, 128, 15, 11, 3, 2, 0, False), (2, 64, 128, 30, 22, 3, 2, 0, False), (5, 64, 64, 7, 7, 3, 1, 0, False)])
 def test_dgrad_x3_with_fused_batchnorm_sums(dev, B, Cin, Cout, H, W, k, stride, cfg, from_out):
     """straps_conv_dgrad_x3_bn: dx as straps_conv_dgrad_x3 writes it (bit for bit), and the per-tile partials of the next BatchNorm
     backward's sums S1 = sum mask*dy, S2 = invstd * sum mask*dy*(raw - mean) (double) -- every tile configuration in use, the four parity
@@ -332,8 +334,13 @@ def test_dgrad_x3_with_fused_batchnorm_sums(dev, B, Cin, Cout, H, W, k, stride, 
     g = torch.from_numpy(det_uniform((B, Ho, Wo, Cout), 3, -1, 1)).to(dev) * 1e-3
     g3, gps = _split(g)
     w3, wps = _wsplit(dev, w, dgrad=True)
-    add = torch.from_numpy(det_uniform((B, H, W, Cin), 4, -1, 1)).to(dev) * 1e-3
-    raw = torch.from_numpy(det_uniform((B, H, W, Cin), 5, -2, 2)).to(dev)
+    # (the addend and raw sit in the middle of NaN-filled buffers: an operand read past a tensor's end -- a ragged tile's rows behind the last pixel -- shows
+    #  up as a NaN in the sums instead of depending on what the allocator left there)
+    n_el = B * H * W * Cin
+    poison_a, poison_r = torch.full((3 * n_el,), float('nan'), device=dev), torch.full((3 * n_el,), float('nan'), device=dev)
+    add, raw = poison_a[n_el:2 * n_el].view(B, H, W, Cin), poison_r[n_el:2 * n_el].view(B, H, W, Cin)
+    add.copy_(torch.from_numpy(det_uniform((B, H, W, Cin), 4, -1, 1)).to(dev) * 1e-3)
+    raw.copy_(torch.from_numpy(det_uniform((B, H, W, Cin), 5, -2, 2)).to(dev))
     mean = raw.mean(dim=(0, 1, 2)).contiguous()
     invstd = (raw.var(dim=(0, 1, 2), unbiased=False) + 1e-5).rsqrt().contiguous()
     msc = torch.from_numpy(det_uniform((Cin,), 6, 0.5, 1.5)).to(dev)
