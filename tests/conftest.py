@@ -18,3 +18,26 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_free_memory(request):
+    """GPU tests run on POISONED free memory (round 6): before each test the caching allocator's free blocks are filled with NaN, so that a kernel
+    that reads what it never wrote -- a ragged tile's rows behind the last pixel, a workspace it assumed zero -- turns a result into NaN instead of
+    depending on what an earlier test left behind.  (The defect this was written for: DESIGN section 3, lean data-gradient epilogue; it showed as a
+    NaN gradient only behind tests that had freed NaN-filled tensors.)"""
+    if request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        try:
+            # 4 GB in 64 MB blocks, 256 MB in 1 MB blocks (the allocator's large pool), 32 MB in 64 KB blocks (its small pool): filled, then freed --
+            # the allocator serves later requests from these cached blocks before it asks the driver for new (zeroed) memory
+            held = [torch.full((n // 4,), float('nan'), device='cuda') for n, k in ((64 << 20, 64), (1 << 20, 256), (64 << 10, 512)) for _ in range(k)]
+            del held
+            torch.cuda.synchronize()
+        except RuntimeError:
+            torch.cuda.empty_cache()
+    yield
