@@ -16,6 +16,7 @@ no torch operator does arithmetic inside the step (a few `clone()` / `zeros` of 
 hipGraph capture and `torch.distributed`.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 import torch
@@ -144,8 +145,7 @@ class GradientExchange:
     def __del__(self):
         # (a safety net only -- callers close() explicitly: at interpreter shutdown the HIP runtime / RCCL may already be torn down, and a device
         #  synchronisation or ncclCommDestroy there can hang or abort where no `except` reaches)
-        import sys
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():      # (module globals are cleared late in shutdown: `sys` itself may be gone; an import here would raise)
             return
         try:
             self.close()
@@ -699,8 +699,7 @@ class TrainStep:
             ex.close()
 
     def __del__(self):
-        import sys
-        if sys.is_finalizing():      # (see GradientExchange.__del__)
+        if sys is None or sys.is_finalizing():      # (see GradientExchange.__del__)
             return
         try:
             self.close()
