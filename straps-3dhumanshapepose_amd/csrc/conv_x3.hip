@@ -42,7 +42,7 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
         // fewer than 128 128x128-tile equivalents per class: 128x64 tiles would leave half the CUs without a workgroup -- 64x64 (round 4, from the
         // COLD sweep tools/sweep_conv_x3_cold.py: resnet50's layer4 at 32 bodies, 2 048 pixels x 512 channels: 3x3 96 -> 74 us, 1x1 2048 -> 512
         // 55 -> 41 us; resnet18's 256 -> 512 stride-2 data gradient 80 -> 66 us)
-        else if (t128 / ncls < 128) cfg = 3;
+        else if (t128 / ncls < STRAPS_TOOL_ENV_INT("STRAPS_X3_SMALL_T128", 128)) cfg = 3;      // (tools: the threshold of the 64x64 rule, for A/B runs)
         else if (ncls > 1) cfg = t128 / ncls >= 512 ? 12 : t128 / ncls >= 256 ? (one_tap ? 9 : 12) : 11;
         else cfg = t128 >= 512 ? 12 : t128 >= 256 ? 5 : 7;       // (11 / 12: the pipelined loop pays with two-stage rings: -7 %)
     }
