@@ -45,6 +45,10 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
         else if (t128 / ncls < STRAPS_TOOL_ENV_INT("STRAPS_X3_SMALL_T128", 128)) cfg = 3;      // (tools: the threshold of the 64x64 rule, for A/B runs)
         else if (ncls > 1) cfg = t128 / ncls >= 512 ? 12 : t128 / ncls >= 256 ? (one_tap ? 9 : 12) : 11;
         else cfg = t128 >= 512 ? 12 : t128 >= 256 ? 5 : 7;       // (11 / 12: the pipelined loop pays with two-stage rings: -7 %)
+        {   // (tools: one configuration for every class the three size rules above decide -- A/B runs of the rule itself with the lean epilogues in place)
+            const int f = STRAPS_TOOL_ENV_INT("STRAPS_X3_RULE_CFG", 0);
+            if (f > 0 && cout % 128 == 0 && t128 / ncls >= 128) cfg = f;
+        }
     }
     if (cout % 128 != 0 && cfg != 3 && cfg != 7 && cfg != 10 && cfg != 11) cfg = 2;
     bm = (cfg == 4 || cfg == 6 || cfg == 12) ? 256 : cfg == 3 ? 64 : 128;
