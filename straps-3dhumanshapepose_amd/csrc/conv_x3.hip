@@ -48,6 +48,8 @@ inline int pick_tile_x3(int cfg, long long M, int cout, int kdim, int& bm, int& 
         {   // (tools: one configuration for every class the three size rules above decide -- A/B runs of the rule itself with the lean epilogues in place)
             const int f = STRAPS_TOOL_ENV_INT("STRAPS_X3_RULE_CFG", 0);
             if (f > 0 && cout % 128 == 0 && t128 / ncls >= 128) cfg = f;
+            const int lo = STRAPS_TOOL_ENV_INT("STRAPS_X3_LOW_CFG", 0);      // (... and for the smallest of the three buckets alone: 128 <= tiles < 256)
+            if (lo > 0 && ncls == 1 && cout % 128 == 0 && t128 >= 128 && t128 < 256) cfg = lo;
         }
     }
     if (cout % 128 != 0 && cfg != 3 && cfg != 7 && cfg != 10 && cfg != 11) cfg = 2;
